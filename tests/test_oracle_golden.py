@@ -1,0 +1,34 @@
+"""Pins the CPU oracle (oracle/orl_oracle.c) to the reference: every golden trace captured by
+importing the reference (oracle/gen_golden.py) must be reproduced bit-for-bit — integers with ==,
+float64 values with == as well (the oracle uses the same libm and the same operation order)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleBatch
+from tests.helpers import golden_names, load_golden, replay
+
+
+def _make(meta):
+    kw = dict(meta["kwargs"])
+    seed = kw.pop("seed")
+    return OracleBatch(meta["env"], meta["topology"], [seed], **kw)
+
+
+def _exact(name):
+    def check(t, what, got, exp):
+        if got is None:
+            return
+        got, exp = np.asarray(got), np.asarray(exp)
+        if got.dtype.kind == "f" or exp.dtype.kind == "f":
+            ok = np.array_equal(got.astype(np.float64), exp.astype(np.float64), equal_nan=True)
+        else:
+            ok = np.array_equal(got, exp)
+        assert ok, "%s: step %d: %s differs\n got %r\n exp %r" % (name, t, what, got, exp)
+    return check
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_reproduces_reference_trace(name):
+    g = load_golden(name)
+    env = _make(g["meta"])
+    replay(env, g, _exact(name))
