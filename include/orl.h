@@ -1,0 +1,160 @@
+/*
+ * orl.h — C ABI of liborlgpu.so: batched optical-network RL environments on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE hot path of optical-rl-gym: the per-env
+ * reset()/step()/observation()/heuristic loop of RWAEnv / RMSAEnv / DeepRMSAEnv / RMCSAEnv.
+ * The reference is pure Python (no FFI of its own); each entry point below names the
+ * reference interface it stands in for (file:line relative to the reference repo).  The
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and implemented in
+ * optical_rl_gym_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ORL_E_* code; orl_last_error() gives text
+ *   - nothing throws across the ABI; no torch / HIP types appear in any signature
+ *   - host buffers are caller-owned, C-contiguous, valid only for the duration of the call
+ *   - device memory is owned by the handles; one batch lives on ONE GPU (multi-GPU = one process and
+ *     one batch per GPU; envs are independent, there is no collective)
+ *   - a handle is not thread-safe: one host thread drives it (the reference env is single-threaded too)
+ *   - `n_envs` independent envs; env i behaves exactly like a reference env constructed with seed_i
+ */
+#ifndef ORL_H
+#define ORL_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORL_ABI_VERSION 1
+
+#define ORL_OK 0
+#define ORL_E_INVALID (-1)   /* bad argument / unsupported configuration */
+#define ORL_E_HIP (-2)       /* HIP runtime error (no GPU, out of memory, launch failure) */
+#define ORL_E_ACTION (-3)    /* an action was out of the action space (reference: IndexError, rmsa_env.py:167) */
+#define ORL_E_OVERFLOW (-4)  /* an env exceeded its pending-release capacity */
+
+/* env families (optical_rl_gym/__init__.py:3-26 registry ids) */
+#define ORL_ENV_RMSA 0      /* "RMSA-v0"      optical_rl_gym/envs/rmsa_env.py:18 */
+#define ORL_ENV_DEEPRMSA 1  /* "DeepRMSA-v0"  optical_rl_gym/envs/deeprmsa_env.py:9 */
+#define ORL_ENV_RWA 2       /* "RWA-v0"       optical_rl_gym/envs/rwa_env.py:15 */
+#define ORL_ENV_RMCSA 3     /* "RMCSA-v0"     optical_rl_gym/envs/rmcsa_env.py:18 */
+
+/* on-device heuristics.  RMSA: rmsa_env.py:747-803; DeepRMSA: deeprmsa_env.py:135-155 (SP=0, SAP=1);
+ * RWA: rwa_env.py:425-502; RMCSA: rmcsa_env.py:882-911 (id 1). */
+#define ORL_POLICY_SP_FF 0
+#define ORL_POLICY_SAP_FF 1 /* k-shortest-path first-fit (KSP-FF) */
+#define ORL_POLICY_LLP_FF 2
+#define ORL_POLICY_SAP_LF 3 /* RWA only */
+
+/* Flattened topology: what the reference keeps in topology.graph["ksp"] / ["modulations"] and in the
+ * networkx edge attributes (examples/create_topology.py:96-147).  All arrays are copied. */
+typedef struct {
+  int32_t n_nodes, n_links, k_paths, max_hops, n_modulations;
+  const int32_t* n_paths;         /* [n_nodes*n_nodes]            paths available for (src,dst) */
+  const int32_t* path_hops;       /* [n_nodes*n_nodes*k]          Path.hops */
+  const int32_t* path_links;      /* [n_nodes*n_nodes*k*max_hops] edge "index" per hop, -1 padded */
+  const double* path_length;      /* [n_nodes*n_nodes*k]          Path.length (km) */
+  const int32_t* path_modulation; /* [n_nodes*n_nodes*k]          index of the modulation the heuristics use */
+  const int32_t* edge_iter_order; /* [n_links]                    link index of the i-th edge of topology.edges() */
+} orl_topology_desc;
+
+/* Traffic + environment parameters: the reference constructors' kwargs after their own derivations
+ * (optical_network_env.py:14-94, rmsa_env.py:29-161, deeprmsa_env.py:10-46, rwa_env.py:19-94,
+ * rmcsa_env.py:29-207).  Float tables are computed on the host with the reference's own expressions. */
+typedef struct {
+  int32_t env_type;            /* ORL_ENV_* */
+  int32_t num_spectrum_resources;
+  int32_t num_spatial_resources; /* cores; 1 unless RMCSA */
+  int32_t episode_length;
+  int32_t allow_rejection;
+  int32_t j;                   /* DeepRMSA: blocks per path */
+  int32_t bit_rate_mode;       /* 0 = continuous randint(lo, hi), 1 = discrete choices(bit_rates, probs) */
+  int32_t bit_rate_lo, bit_rate_hi;
+  int32_t n_bit_rates;         /* rows of the bit-rate tables: hi-lo+1 (continuous) or len(bit_rates) */
+  int32_t event_capacity;      /* pending releases per env (0 = derive from load) */
+  int32_t reserved;
+  double lambda_arrival;       /* 1 / mean_service_inter_arrival_time  (rmsa_env.py:548-550) */
+  double lambda_holding;       /* 1 / mean_service_holding_time        (rmsa_env.py:553) */
+  const double* cum_src;       /* [n_nodes]          accumulate(node_request_probabilities) */
+  const double* cum_dst;       /* [n_nodes*n_nodes]  per src: accumulate(probs with src zeroed, renormalised) */
+  const int32_t* bit_rates;    /* [n_bit_rates]      bit rate of table row i */
+  const double* cum_bit_rate;  /* [n_bit_rates]      discrete mode: accumulate(bit_rate_probabilities) */
+  const uint8_t* n_slots;      /* [n_bit_rates*n_modulations] get_number_slots (rmsa_env.py:610-621) */
+  const double* lmax_snr;      /* [n_modulations*n_bit_rates] RMCSA reach limit, eq.(1) (rmcsa_env.py:366-375); may be NULL */
+  const double* lmax_xt;       /* [n_modulations]             RMCSA reach limit, eq.(2) (rmcsa_env.py:377-379); may be NULL */
+} orl_env_config;
+
+typedef struct orl_topology orl_topology;
+typedef struct orl_batch orl_batch;
+
+/* per-env integer counters, in this order (optical_network_env.py:29-34, rmsa_env.py:73-76) */
+#define ORL_N_COUNTERS 8
+/* current service record: arrival_time, holding_time, source_id, destination_id, bit_rate, service_id */
+#define ORL_N_SERVICE 6
+
+typedef struct {
+  double ms_total;   /* wall time of the whole call on the device (HIP events) */
+  double ms_policy;  /* average duration of one slot-scan (policy) launch */
+  double ms_step;    /* average duration of one step launch */
+  int64_t launches;  /* kernel launches issued */
+} orl_run_stats;
+
+int orl_abi_version(void);
+const char* orl_last_error(void);
+int orl_device_count(void);
+
+int orl_topology_create(const orl_topology_desc* desc, int device_id, orl_topology** out);
+void orl_topology_destroy(orl_topology* t);
+
+/* n_envs envs on device `device_id`.  mt_state: [n_envs][625] uint32 = random.Random(seed_i).getstate()[1]
+ * (624 state words + index), i.e. optical_network_env.py:205-210 done by the caller.  Construction ends with
+ * the reference's reset(only_episode_counters=False) (rmsa_env.py:160-161): every env holds its first service. */
+int orl_batch_create(const orl_env_config* cfg, const orl_topology* topo, int64_t n_envs, const uint32_t* mt_state,
+                     orl_batch** out);
+void orl_batch_destroy(orl_batch* b);
+
+int orl_batch_info_dim(const orl_batch* b); /* floats per env in the info row */
+int orl_batch_obs_dim(const orl_batch* b);  /* DeepRMSA observation length, else 0 */
+
+/* reset(only_episode_counters = !full) (rmsa_env.py:284-359, rwa_env.py:164-208, rmcsa_env.py:386-483).
+ * env_mask: NULL = all envs, else [n_envs] bytes. */
+int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask);
+
+/* Heuristic decision for the pending service of every env.  actions_out: [n_envs][4] int32 or NULL to keep the
+ * result on the device for the next orl_batch_step(actions = NULL).
+ * Columns: RMSA/RWA (path, slot, -, -); DeepRMSA (action, -, -, -); RMCSA (path, modulation, core, slot). */
+int orl_batch_policy(orl_batch* b, int policy_id, int32_t* actions_out);
+
+/* step() for every env (rmsa_env.py:163-282, deeprmsa_env.py:48-58, rwa_env.py:101-162, rmcsa_env.py:209-339).
+ * actions: [n_envs][4] int32, or NULL = use the device-resident result of the last orl_batch_policy().
+ * auto_reset != 0: an env that returns done is soft-reset right away (what SB3's VecEnv does).
+ * Any output pointer may be NULL (result stays on the device).  reward_out/[n_envs] double, done_out/[n_envs] u8,
+ * info_out/[n_envs][info_dim] double, obs_out/[n_envs][obs_dim] double (DeepRMSA).
+ * Synchronous on return when any output pointer is given. */
+int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, double* reward_out,
+                   uint8_t* done_out, double* info_out);
+
+/* DeepRMSAEnv.observation() for the pending service (deeprmsa_env.py:60-121). */
+int orl_batch_observation(orl_batch* b, double* obs_out);
+
+/* n_steps x { policy ; step(auto_reset) } entirely on the device (the loop of utils.evaluate_heuristic,
+ * utils.py:113-128, with VecEnv-style auto reset).  time_kernels != 0 brackets every launch with HIP events. */
+int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels, orl_run_stats* stats);
+
+int orl_batch_sync(orl_batch* b);
+
+/* state read-back (parity tests, Python attribute surface) */
+int orl_batch_get_counters(orl_batch* b, int64_t* out /*[n_envs][ORL_N_COUNTERS]*/);
+int orl_batch_get_services(orl_batch* b, double* out /*[n_envs][ORL_N_SERVICE]*/);
+int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out /*[cores][links][slots] 0/1*/);
+int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out /*[4][links]: utilization, external_fragmentation, compactness, last_update*/);
+int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out /*[4]: throughput, compactness, last_update, current_time*/);
+int orl_batch_get_active(orl_batch* b, int32_t* out /*[n_envs] pending releases*/);
+int orl_batch_get_flags(orl_batch* b, int32_t* out /*[n_envs] bit0 event overflow, bit1 bad action*/);
+/* summed over envs: services_processed, services_accepted (for throughput/blocking reports) */
+int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORL_H */

@@ -1,0 +1,7 @@
+"""optical_rl_gym_amd: batched RWA / RMSA / DeepRMSA / RMCSA optical-network environments whose
+reset()/step()/heuristic hot path runs as hand-written HIP kernels on AMD MI355X (gfx950)."""
+from .envs import (BatchedDeepRMSAEnv, BatchedOpticalEnv, BatchedRMCSAEnv, BatchedRMSAEnv, BatchedRWAEnv,  # noqa: F401
+                   make)
+from .topology import Modulation, Path, Topology, get_best_modulation_format  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,82 @@
+"""ctypes binding of the C ABI in include/orl.h.  Fails loudly when the HIP library is missing: there is no
+CPU fallback in the product."""
+import ctypes as C
+import os
+
+from . import _build
+
+_LIB = None
+
+
+class TopologyDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_links", "k_paths", "max_hops", "n_modulations")] + [
+        (n, C.c_void_p) for n in ("n_paths", "path_hops", "path_links", "path_length", "path_modulation", "edge_iter_order")]
+
+
+class EnvConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "env_type", "num_spectrum_resources", "num_spatial_resources", "episode_length", "allow_rejection", "j",
+        "bit_rate_mode", "bit_rate_lo", "bit_rate_hi", "n_bit_rates", "event_capacity", "reserved")] + [
+        ("lambda_arrival", C.c_double), ("lambda_holding", C.c_double)] + [
+        (n, C.c_void_p) for n in ("cum_src", "cum_dst", "bit_rates", "cum_bit_rate", "n_slots", "lmax_snr", "lmax_xt")]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_policy", C.c_double), ("ms_step", C.c_double), ("launches", C.c_int64)]
+
+
+EXPORTS = {
+    "orl_abi_version": (C.c_int, []),
+    "orl_last_error": (C.c_char_p, []),
+    "orl_device_count": (C.c_int, []),
+    "orl_topology_create": (C.c_int, [C.POINTER(TopologyDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "orl_topology_destroy": (None, [C.c_void_p]),
+    "orl_batch_create": (C.c_int, [C.POINTER(EnvConfig), C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "orl_batch_destroy": (None, [C.c_void_p]),
+    "orl_batch_info_dim": (C.c_int, [C.c_void_p]),
+    "orl_batch_obs_dim": (C.c_int, [C.c_void_p]),
+    "orl_batch_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "orl_batch_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "orl_batch_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orl_batch_observation": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(RunStats)]),
+    "orl_batch_sync": (C.c_int, [C.c_void_p]),
+    "orl_batch_get_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_get_services": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_get_slots": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "orl_batch_get_link_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "orl_batch_get_net_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "orl_batch_get_active": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_get_flags": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_totals": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+}
+
+
+class OrlError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (building if the sources are newer) liborlgpu.so."""
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB
+        if _build.stale():
+            path = _build.build()
+        if not os.path.exists(path):
+            raise OrlError("liborlgpu.so is missing and could not be built; the HIP path is the only path")
+        handle = C.CDLL(path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(handle, name)  # AttributeError = ABI mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if handle.orl_abi_version() != 1:
+            raise OrlError("ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().orl_last_error()
+        raise OrlError("liborlgpu: error %d: %s" % (rc, msg.decode() if msg else "?"))

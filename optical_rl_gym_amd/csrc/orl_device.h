@@ -1,0 +1,985 @@
+// orl_device.h — CDNA4 (gfx950) device code of the batched optical-network environments.
+//
+// Execution model: ONE 64-lane wavefront per environment instance.  Everything an env
+// decides is wave-uniform; lanes are spent on the naturally parallel axes of the state:
+//   * (path)           k-shortest-path availability AND-reduce + first-fit run search
+//   * (hop of a path)  slot provision / release and the per-link statistics that follow
+//   * (event slot)     pending-release scan (64 release times per load instruction)
+//   * (MT word)        32 Mersenne-Twister outputs per refill, twisted in place
+//   * (node), (link)   weighted node draw (cumulative-table ballot) and link means
+// The link x slot availability map is bit-packed (1 = free), W 64-bit words per link
+// row, and is staged through LDS once per kernel so that the per-path reductions and
+// the provision/release read-modify-writes never go back to HBM.
+//
+// Reference semantics restated here (file:line relative to the reference repo):
+//   optical_rl_gym/envs/rmsa_env.py        step 163-282, reset 284-359, _provision_path 364-415,
+//                                          _release_path 417-437, stats 439-543, _next_service 545-597,
+//                                          get_number_slots 610-621, is_path_free 623-636,
+//                                          get_available_blocks 667-697, compactness 699-744,
+//                                          heuristics 747-803
+//   optical_rl_gym/envs/deeprmsa_env.py    step 48-58, observation 60-121, reward 123-124, heuristics 135-155
+//   optical_rl_gym/envs/rwa_env.py         step 101-162, _next_service 258-288, stats 365-383, heuristics 403-502
+//   optical_rl_gym/envs/rmcsa_env.py       step 209-339, crosstalk 341-384, _next_service 690-739, heuristic 882-911
+//   optical_rl_gym/envs/optical_network_env.py  _add_release 143-154, _get_node_pair 156-173
+// plus CPython's random.Random (MT19937, random(), expovariate, choices, randint) and
+// numpy's pairwise float64 summation, which the reference calls on this path.
+//
+// Compile with -ffp-contract=off: every float64 expression below is written in the
+// reference's evaluation order and must not be fused.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "orl_log.h"
+
+namespace orl {
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef unsigned int u32;
+
+enum { ENV_RMSA = 0, ENV_DEEPRMSA = 1, ENV_RWA = 2, ENV_RMCSA = 3 };
+enum { POL_SP_FF = 0, POL_SAP_FF = 1, POL_LLP_FF = 2, POL_SAP_LF = 3 };
+
+// scalar-record slots (one 8-byte word each; 32 per env = one 256-B line, lane l owns word l)
+enum {
+  SC_NOW = 0, SC_AT, SC_HT, SC_GTHR, SC_GCOMP, SC_GLAST,
+  SC_SP, SC_SA, SC_ESP, SC_ESA, SC_BRQ, SC_BRP, SC_EBRQ, SC_EBRP, SC_SBR, SC_SNH,
+  SC_SRC_DST, SC_BR_IDX, SC_ID_MTPOS, SC_EV, SC_FLAGS, SC_COUNT
+};
+#define ORL_SCAL_WORDS 32
+#define ORL_FLAG_EV_OVERFLOW 1
+#define ORL_FLAG_BAD_ACTION 2
+
+struct DevParams {
+  int env_type, N, E, K, H, M, S, W, C, episode_length, allow_rejection, J;
+  int bit_rate_mode, br_lo, n_br, rand_n, rand_bits;
+  int ev_cap, bm_words, n_info, obs_dim, lds_bytes;
+  double lambda_a, lambda_h;
+  i64 B;
+  // shared, read-only (L2-resident) topology / traffic tables
+  const int* n_paths;               // [N*N]
+  const unsigned char* path_hops;   // [N*N*K]
+  const short* path_links;          // [N*N*K*H]
+  const unsigned char* path_mod;    // [N*N*K]  best modulation (index)
+  const double* path_length;        // [N*N*K]
+  const int* edge_iter_order;       // [E]
+  const double* cum_src;            // [N]      accumulate(node_request_probabilities)
+  const double* cum_dst;            // [N*N]    accumulate(renormalised probs with src zeroed)
+  const int* bit_rates;             // [n_br]   discrete mode values
+  const double* cum_br;             // [n_br]   accumulate(bit_rate_probabilities)
+  const unsigned char* nslots;      // [n_br*M] ceil(bit_rate/(se*channel_width))+1
+  const double* lmax_snr;           // [M*n_br] RMCSA reach limits
+  const double* lmax_xt;            // [M]
+  // per-env state (struct-of-arrays over envs)
+  u64* bitmap;      // [B][bm_words]      bm_words = C*E*W rounded up to a multiple of 2
+  double* ev_time;  // [B][ev_cap]        +inf = empty slot
+  u64* ev_info;     // [B][ev_cap]        packed {pair_path:24 | slot:12 | n:8 | core:5 | bit_rate:15}
+  u32* mt;          // [B][624]           update-behind MT19937 state
+  double* lstat;    // [B][4][E]          utilization, external_fragmentation, compactness, last_update
+  u64* scal;        // [B][32]
+  int* core_sums;   // [B][2*C]           per core: sum(lambda_max-lambda_min), sum(free blocks inside)
+  i64* br_hist;     // [B][2*n_br]        discrete mode: requested / provisioned histograms
+  i64* act_hist;    // [B][(K+1)+(S+1)]   RWA: marginals of actions_output
+  // I/O (device resident; the C-ABI copies to/from host buffers)
+  int* actions;            // [B][4]
+  double* reward;          // [B]
+  unsigned char* done;     // [B]
+  double* info;            // [B][n_info]
+  double* obs;             // [B][obs_dim]
+  double* term_obs;        // [B][obs_dim]  observation before the auto reset (same values: soft reset keeps the service)
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ u32 rdlane(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ u64 rdlane64(u64 v, int l) {
+  u32 lo = rdlane((u32)v, l), hi = rdlane((u32)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ double rdlane_f64(double v, int l) { return __longlong_as_double((i64)rdlane64((u64)__double_as_longlong(v), l)); }
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+// compiler-level ordering of LDS/global accesses between phases of one wave (no instructions emitted)
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// ---------------------------------------------------------------------------------------------
+// bit-packed slot rows: W 64-bit words, bit s of the row = slot s is free; bits >= S are always 0
+// ---------------------------------------------------------------------------------------------
+template <int W> struct Row { u64 w[W]; };
+
+template <int W> __device__ __forceinline__ Row<W> row_load(const u64* p) {
+  Row<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = p[i];
+  return r;
+}
+template <int W> __device__ __forceinline__ void row_store(u64* p, const Row<W>& r) {
+#pragma unroll
+  for (int i = 0; i < W; i++) p[i] = r.w[i];
+}
+template <int W> __device__ __forceinline__ Row<W> row_and(const Row<W>& a, const Row<W>& b) {
+  Row<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = a.w[i] & b.w[i];
+  return r;
+}
+template <int W> __device__ __forceinline__ Row<W> row_andn(const Row<W>& a, const Row<W>& b) {  // a & ~b
+  Row<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = a.w[i] & ~b.w[i];
+  return r;
+}
+template <int W> __device__ __forceinline__ Row<W> row_or(const Row<W>& a, const Row<W>& b) {
+  Row<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = a.w[i] | b.w[i];
+  return r;
+}
+template <int W> __device__ __forceinline__ bool row_any(const Row<W>& a) {
+  u64 o = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++) o |= a.w[i];
+  return o != 0;
+}
+template <int W> __device__ __forceinline__ int row_popc(const Row<W>& a) {
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++) c += __popcll(a.w[i]);
+  return c;
+}
+// index of the lowest set bit, 64*W if none
+template <int W> __device__ __forceinline__ int row_ctz(const Row<W>& a) {
+  int r = 64 * W;
+#pragma unroll
+  for (int i = W - 1; i >= 0; i--)
+    if (a.w[i]) r = 64 * i + (int)__builtin_ctzll(a.w[i]);
+  return r;
+}
+// index of the highest set bit + 1, 0 if none
+template <int W> __device__ __forceinline__ int row_bitlen(const Row<W>& a) {
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++)
+    if (a.w[i]) r = 64 * i + 64 - (int)__builtin_clzll(a.w[i]);
+  return r;
+}
+// bits [0, n)
+template <int W> __device__ __forceinline__ Row<W> row_mask_lo(int n) {
+  Row<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    int c = n - 64 * i;
+    r.w[i] = c >= 64 ? ~0ull : (c <= 0 ? 0ull : ((1ull << c) - 1ull));
+  }
+  return r;
+}
+// bits [s, s+n)
+template <int W> __device__ __forceinline__ Row<W> row_range(int s, int n) {
+  Row<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    int lo = s - 64 * i, hi = s + n - 64 * i;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 64 ? 64 : hi;
+    int c = hi - lo;
+    u64 m = c >= 64 ? ~0ull : (c <= 0 ? 0ull : ((1ull << c) - 1ull));
+    r.w[i] = c <= 0 ? 0ull : (m << lo);
+  }
+  return r;
+}
+// logical shift right by st, 0 < st < 64
+template <int W> __device__ __forceinline__ Row<W> row_shr_small(const Row<W>& a, int st) {
+  Row<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    u64 hi = (i + 1 < W) ? a.w[i + 1] : 0ull;
+    r.w[i] = (a.w[i] >> st) | (hi << (64 - st));
+  }
+  return r;
+}
+// x & ~(x << 1): one bit per run of ones (its first position)
+template <int W> __device__ __forceinline__ Row<W> row_starts(const Row<W>& a) {
+  Row<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    u64 carry = (i > 0) ? (a.w[i - 1] >> 63) : 0ull;
+    r.w[i] = a.w[i] & ~((a.w[i] << 1) | carry);
+  }
+  return r;
+}
+// bit s set iff slots s .. s+n-1 are all ones in m (1 <= n <= 64).  Log-step shift-AND.
+template <int W> __device__ __forceinline__ Row<W> row_runs_ge(const Row<W>& m, int n) {
+  Row<W> r = m;
+  int have = 1;
+  while (have < n) {
+    int st = n - have;
+    st = st < have ? st : have;
+    r = row_and<W>(r, row_shr_small<W>(r, st));
+    have += st;
+  }
+  return r;
+}
+// longest run of ones inside one 64-bit word (binary search on run length)
+__device__ __forceinline__ int word_longest_run(u64 x) {
+  if (!x) return 0;
+  int L = 1;
+  u64 r = x;
+  for (;;) {
+    u64 t = (L < 64) ? (r & (r >> L)) : 0ull;
+    if (!t) break;
+    r = t;
+    L <<= 1;
+  }
+  for (int st = L >> 1; st > 0; st >>= 1) {
+    u64 t = r & (r >> st);
+    if (t) { r = t; L += st; }
+  }
+  return L;
+}
+// longest run of ones across the row (runs continue across word boundaries)
+template <int W> __device__ __forceinline__ int row_longest_run(const Row<W>& a) {
+  int best = 0, carry = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    u64 x = a.w[i];
+    if (x == ~0ull) { carry += 64; continue; }
+    int lead = (int)__builtin_ctzll(~x);
+    int c = carry + lead;
+    best = c > best ? c : best;
+    int inner = word_longest_run(x);
+    best = inner > best ? inner : best;
+    carry = (x >> 63) ? (int)__builtin_clzll(~x) : 0;
+  }
+  return carry > best ? carry : best;
+}
+
+// Per-link integer summary that feeds the network spectrum compactness (rmsa_env.py:699-744):
+// if the row holds >= 2 used blocks: occ = lambda_max - lambda_min, fb = free blocks strictly inside.
+template <int W> __device__ __forceinline__ void link_summary(const Row<W>& a, int S, int& occ, int& fb) {
+  Row<W> used = row_andn<W>(row_mask_lo<W>(S), a);
+  occ = 0;
+  fb = 0;
+  if (row_popc<W>(row_starts<W>(used)) > 1) {
+    int lo = row_ctz<W>(used), hi = row_bitlen<W>(used);
+    occ = hi - lo;
+    Row<W> in = row_and<W>(a, row_range<W>(lo, hi - lo));
+    fb = row_popc<W>(row_starts<W>(in));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-wave working state (wave-uniform values; the compiler keeps most of it in SGPRs)
+// ---------------------------------------------------------------------------------------------
+struct Env {
+  double now, at, ht, g_thr, g_comp, g_last;
+  i64 sp, sa, esp, esa, brq, brp, ebrq, ebrp, s_br, s_nh;
+  int src, dst, bit_rate, br_idx, id, mt_pos, ev_hwm, ev_cnt, new_service, flags;
+  // freshly pushed release event of this kernel invocation (kept in registers: the store to
+  // ev_time is not guaranteed visible to the other lanes' loads within the same kernel)
+  double push_t;
+  int push_idx;
+  // pointers
+  u64* bm;        // LDS: [C*E*W]
+  double* ls;     // LDS: [4][E]
+  double* scratch;  // LDS: [E]
+  double* obs_l;  // LDS: [obs_dim]
+  int* cs;        // LDS: [2*C]
+  double* ev_time;
+  u64* ev_info;
+  u32* mt;
+  i64 env;
+};
+
+__device__ __forceinline__ void env_load(const DevParams& P, Env& e, i64 env, int lane) {
+  u64 v = (lane < ORL_SCAL_WORDS) ? P.scal[env * ORL_SCAL_WORDS + lane] : 0ull;
+#define F64(slot) __longlong_as_double((i64)rdlane64(v, slot))
+#define I64(slot) ((i64)rdlane64(v, slot))
+  e.now = F64(SC_NOW); e.at = F64(SC_AT); e.ht = F64(SC_HT);
+  e.g_thr = F64(SC_GTHR); e.g_comp = F64(SC_GCOMP); e.g_last = F64(SC_GLAST);
+  e.sp = I64(SC_SP); e.sa = I64(SC_SA); e.esp = I64(SC_ESP); e.esa = I64(SC_ESA);
+  e.brq = I64(SC_BRQ); e.brp = I64(SC_BRP); e.ebrq = I64(SC_EBRQ); e.ebrp = I64(SC_EBRP);
+  e.s_br = I64(SC_SBR); e.s_nh = I64(SC_SNH);
+  u64 t;
+  t = rdlane64(v, SC_SRC_DST); e.src = (int)(u32)t; e.dst = (int)(t >> 32);
+  t = rdlane64(v, SC_BR_IDX); e.bit_rate = (int)(u32)t; e.br_idx = (int)(t >> 32);
+  t = rdlane64(v, SC_ID_MTPOS); e.id = (int)(u32)t; e.mt_pos = (int)(t >> 32);
+  t = rdlane64(v, SC_EV); e.ev_hwm = (int)(u32)t; e.ev_cnt = (int)(t >> 32);
+  t = rdlane64(v, SC_FLAGS); e.new_service = (int)(u32)t; e.flags = (int)(t >> 32);
+#undef F64
+#undef I64
+  e.push_idx = -1;
+  e.push_t = 0.0;
+  e.env = env;
+  e.ev_time = P.ev_time + env * P.ev_cap;
+  e.ev_info = P.ev_info + env * P.ev_cap;
+  e.mt = P.mt + env * 624;
+}
+
+__device__ __forceinline__ u64 pack2(int lo, int hi) { return ((u64)(u32)hi << 32) | (u64)(u32)lo; }
+
+__device__ __forceinline__ void env_store(const DevParams& P, const Env& e, int lane) {
+  u64 v = 0;
+#define PUTF(slot, x) if (lane == slot) v = (u64)__double_as_longlong(x);
+#define PUTI(slot, x) if (lane == slot) v = (u64)(x);
+  PUTF(SC_NOW, e.now) PUTF(SC_AT, e.at) PUTF(SC_HT, e.ht) PUTF(SC_GTHR, e.g_thr) PUTF(SC_GCOMP, e.g_comp) PUTF(SC_GLAST, e.g_last)
+  PUTI(SC_SP, e.sp) PUTI(SC_SA, e.sa) PUTI(SC_ESP, e.esp) PUTI(SC_ESA, e.esa)
+  PUTI(SC_BRQ, e.brq) PUTI(SC_BRP, e.brp) PUTI(SC_EBRQ, e.ebrq) PUTI(SC_EBRP, e.ebrp)
+  PUTI(SC_SBR, e.s_br) PUTI(SC_SNH, e.s_nh)
+  PUTI(SC_SRC_DST, pack2(e.src, e.dst)) PUTI(SC_BR_IDX, pack2(e.bit_rate, e.br_idx))
+  PUTI(SC_ID_MTPOS, pack2(e.id, e.mt_pos)) PUTI(SC_EV, pack2(e.ev_hwm, e.ev_cnt)) PUTI(SC_FLAGS, pack2(e.new_service, e.flags))
+#undef PUTF
+#undef PUTI
+  if (lane < SC_COUNT) P.scal[e.env * ORL_SCAL_WORDS + lane] = v;
+}
+
+// stage the env's slot map, link statistics and per-core sums into this wave's LDS window
+__device__ __forceinline__ void stage_in(const DevParams& P, Env& e, u64* lds, int lane) {
+  e.bm = lds;
+  e.ls = (double*)(lds + P.bm_words);
+  e.scratch = e.ls + 4 * P.E;
+  e.obs_l = e.scratch + P.E;
+  e.cs = (int*)(e.obs_l + P.obs_dim);
+  const ulonglong2* g = (const ulonglong2*)(P.bitmap + e.env * P.bm_words);
+  ulonglong2* l = (ulonglong2*)lds;
+  for (int i = lane; i < P.bm_words / 2; i += 64) l[i] = g[i];
+  const double* gs = P.lstat + e.env * 4 * P.E;
+  for (int i = lane; i < 4 * P.E; i += 64) e.ls[i] = gs[i];
+  if (lane < 2 * P.C) e.cs[lane] = P.core_sums[e.env * 2 * P.C + lane];
+  wave_fence();
+}
+__device__ __forceinline__ void stage_out(const DevParams& P, Env& e, int lane) {
+  wave_fence();
+  ulonglong2* g = (ulonglong2*)(P.bitmap + e.env * P.bm_words);
+  const ulonglong2* l = (const ulonglong2*)e.bm;
+  for (int i = lane; i < P.bm_words / 2; i += 64) g[i] = l[i];
+  double* gs = P.lstat + e.env * 4 * P.E;
+  for (int i = lane; i < 4 * P.E; i += 64) gs[i] = e.ls[i];
+  if (lane < 2 * P.C) P.core_sums[e.env * 2 * P.C + lane] = e.cs[lane];
+}
+
+// ---------------------------------------------------------------------------------------------
+// MT19937, CPython-compatible stream, "update-behind" in-place form.
+//
+// CPython regenerates all 624 words at once when the index reaches 624
+// (Modules/_randommodule.c genrand_uint32).  Here array position i holds the NEXT generation's
+// word if i < pos and the current generation's word if i >= pos: right after word i is handed
+// out, its successor-generation value is computed from (M[i], M[i+1], M[i+397]) and written in
+// place — the same recurrence, evaluated lazily, so the output sequence is identical but a
+// refill is 32 lanes x (3 loads + 1 store) with no 2.5-KB regeneration burst.
+// ---------------------------------------------------------------------------------------------
+struct Rng {
+  u32 out;   // lane j < 32: tempered output number (consumed + j) of the stream
+  u32 nxt;   // lane j < 32: next-generation value for that array position
+  int used;  // words handed out from the current window
+};
+
+__device__ __forceinline__ void rng_fill(Env& e, Rng& r, int lane) {
+  int i = e.mt_pos + (lane & 31);
+  int i0 = i >= 624 ? i - 624 : i;
+  int i1 = i0 + 1 >= 624 ? i0 + 1 - 624 : i0 + 1;
+  int im = i0 + 397 >= 624 ? i0 + 397 - 624 : i0 + 397;
+  u32 cur = e.mt[i0], nx = e.mt[i1], far = e.mt[im];
+  u32 y = (cur & 0x80000000u) | (nx & 0x7fffffffu);
+  r.nxt = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  u32 t = cur;
+  t ^= (t >> 11);
+  t ^= (t << 7) & 0x9d2c5680u;
+  t ^= (t << 15) & 0xefc60000u;
+  t ^= (t >> 18);
+  r.out = t;
+  r.used = 0;
+}
+__device__ __forceinline__ void rng_commit(Env& e, Rng& r, int lane) {
+  if (lane < r.used) {
+    int i = e.mt_pos + lane;
+    e.mt[i >= 624 ? i - 624 : i] = r.nxt;
+  }
+  int p = e.mt_pos + r.used;
+  e.mt_pos = p >= 624 ? p - 624 : p;
+  r.used = 0;
+}
+__device__ __forceinline__ u32 rng_u32(Env& e, Rng& r, int lane) {
+  if (r.used == 32) {
+    rng_commit(e, r, lane);
+    rng_fill(e, r, lane);
+  }
+  u32 v = rdlane(r.out, r.used);
+  r.used++;
+  return v;
+}
+// random.random(): (a>>5, b>>6) -> 53-bit double
+__device__ __forceinline__ double rng_random(Env& e, Rng& r, int lane) {
+  u32 a = rng_u32(e, r, lane) >> 5, b = rng_u32(e, r, lane) >> 6;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+// random.expovariate(lambd) = -log(1.0 - random()) / lambd
+__device__ __forceinline__ double rng_expovariate(Env& e, Rng& r, int lane, double lambd) {
+  return -orl_log(1.0 - rng_random(e, r, lane)) / lambd;
+}
+// random.choices(pop, weights)[0] = bisect_right(cum, random() * (cum[-1] + 0.0), 0, n - 1)
+//  = number of i in [0, n-2] with cum[i] <= x (cum is non-decreasing)
+__device__ __forceinline__ int rng_choice(Env& e, Rng& r, int lane, const double* cum, int n) {
+  double x = rng_random(e, r, lane) * (cum[n - 1] + 0.0);
+  int cnt = 0;
+  for (int base = 0; base < n - 1; base += 64) {
+    int i = base + lane;
+    bool le = (i < n - 1) && (cum[i] <= x);
+    cnt += (int)__popcll(__ballot(le));
+  }
+  return cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared helpers on the env state
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pair_base(const DevParams& P, int src, int dst) { return (src * P.N + dst) * P.K; }
+
+// _get_network_compactness from the running integer sums
+__device__ __forceinline__ double net_compactness(const DevParams& P, const Env& e, int core) {
+  int occ = e.cs[2 * core], fb = e.cs[2 * core + 1];
+  if (fb > 0) return ((double)occ / (double)e.s_nh) * ((double)P.E / (double)fb);
+  return 1.0;
+}
+
+// _update_link_stats on the row `a` (already modified) of `link`; lane-private work
+template <int ENV, int W>
+__device__ __forceinline__ void link_stats_update(const DevParams& P, Env& e, int link, const Row<W>& a) {
+  const int E = P.E, S = P.S;
+  double last_update = e.ls[3 * E + link];
+  double time_diff = e.now - last_update;
+  if (e.now > 0) {
+    int free_ = row_popc<W>(a);
+    double cur_util = (double)(S - free_) / (double)S;
+    e.ls[link] = ((e.ls[link] * last_update) + (cur_util * time_diff)) / e.now;
+    if (ENV != ENV_RWA) {
+      double cur_frag = 0.0, cur_comp = 0.0;
+      if (free_ > 0) {
+        Row<W> used = row_andn<W>(row_mask_lo<W>(S), a);
+        int nf = row_popc<W>(row_starts<W>(a));
+        int nu = row_popc<W>(row_starts<W>(used));
+        bool edge_free = (a.w[0] & 1ull) && ((a.w[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull);
+        int max_empty = 0;
+        if (nf > 1 && !(nf == 2 && edge_free)) max_empty = row_longest_run<W>(a);
+        cur_frag = 1.0 - ((double)max_empty / (double)free_);
+        if (nu > 1) {
+          int lo = row_ctz<W>(used), hi = row_bitlen<W>(used);
+          cur_comp = ((double)(hi - lo) / (double)(S - free_)) * (1.0 / (double)nu);
+        } else {
+          cur_comp = 1.0;
+        }
+      }
+      e.ls[E + link] = ((e.ls[E + link] * last_update) + (cur_frag * time_diff)) / e.now;
+      e.ls[2 * E + link] = ((e.ls[2 * E + link] * last_update) + (cur_comp * time_diff)) / e.now;
+    }
+  }
+  e.ls[3 * E + link] = e.now;
+}
+
+// set (release) or clear (provision) slots [s0, s0+n) on every link of the path; lanes = hops.
+// Maintains the per-core integer sums and runs the per-link statistics, like the reference's
+// per-link loop in _provision_path / _release_path.
+template <int ENV, int W>
+__device__ __forceinline__ void path_apply(const DevParams& P, Env& e, int lane, int pidx, int core, int s0, int n, bool release) {
+  const int hops = P.path_hops[pidx];
+  int d_occ = 0, d_fb = 0;
+  if (lane < hops) {
+    int link = P.path_links[pidx * P.H + lane];
+    u64* rp = e.bm + (core * P.E + link) * W;
+    Row<W> a = row_load<W>(rp);
+    int occ0 = 0, fb0 = 0, occ1 = 0, fb1 = 0;
+    if (ENV != ENV_RWA) link_summary<W>(a, P.S, occ0, fb0);
+    Row<W> m = row_range<W>(s0, n);
+    a = release ? row_or<W>(a, m) : row_andn<W>(a, m);
+    row_store<W>(rp, a);
+    if (ENV != ENV_RWA) link_summary<W>(a, P.S, occ1, fb1);
+    d_occ = occ1 - occ0;
+    d_fb = fb1 - fb0;
+    link_stats_update<ENV, W>(P, e, link, a);
+  }
+  if (ENV != ENV_RWA) {
+    d_occ = wave_sum(d_occ);
+    d_fb = wave_sum(d_fb);
+    wave_fence();
+    if (lane == 0) {
+      e.cs[2 * core] += d_occ;
+      e.cs[2 * core + 1] += d_fb;
+    }
+  }
+  wave_fence();
+}
+
+// is_path_free: all links of the path free on [s0, s0+n)
+template <int W>
+__device__ __forceinline__ bool path_is_free(const DevParams& P, const Env& e, int lane, int pidx, int core, int s0, int n) {
+  if (s0 + n > P.S) return false;
+  const int hops = P.path_hops[pidx];
+  bool busy = false;
+  if (lane < hops) {
+    int link = P.path_links[pidx * P.H + lane];
+    Row<W> a = row_load<W>(e.bm + (core * P.E + link) * W);
+    Row<W> m = row_range<W>(s0, n);
+    busy = row_any<W>(row_andn<W>(m, a));
+  }
+  return __ballot(busy) == 0ull;
+}
+
+// AND of the link rows of a path (lane-private: every lane may call it with its own pidx/core)
+template <int W>
+__device__ __forceinline__ Row<W> path_and(const DevParams& P, const Env& e, int pidx, int core) {
+  Row<W> m = row_mask_lo<W>(P.S);
+  const int hops = P.path_hops[pidx];
+  for (int h = 0; h < hops; h++) {
+    int link = P.path_links[pidx * P.H + h];
+    m = row_and<W>(m, row_load<W>(e.bm + (core * P.E + link) * W));
+  }
+  return m;
+}
+
+// pending-release storage: unordered slots, +inf = empty.  Push = lowest empty slot.
+__device__ __forceinline__ void ev_push(const DevParams& P, Env& e, int lane, double t, u64 info) {
+  int idx = -1;
+  for (int base = 0; base < e.ev_hwm; base += 64) {
+    int i = base + lane;
+    bool empty = (i < e.ev_hwm) && (e.ev_time[i] == __builtin_inf());
+    u64 b = __ballot(empty);
+    if (b) { idx = base + (int)__builtin_ctzll(b); break; }
+  }
+  if (idx < 0) {
+    if (e.ev_hwm >= P.ev_cap) { e.flags |= ORL_FLAG_EV_OVERFLOW; return; }
+    idx = e.ev_hwm++;
+  }
+  if (lane == 0) { e.ev_time[idx] = t; e.ev_info[idx] = info; }
+  e.ev_cnt++;
+  e.push_idx = idx;
+  e.push_t = t;
+}
+
+__device__ __forceinline__ u64 ev_pack(int pidx, int s0, int n, int core, int bit_rate) {
+  return (u64)(u32)pidx | ((u64)(u32)s0 << 24) | ((u64)(u32)n << 36) | ((u64)(u32)core << 44) | ((u64)(u32)bit_rate << 49);
+}
+
+// release every pending service with release_time <= now, in increasing time order
+// (the reference pops its heap until the top is in the future: rmsa_env.py:590-597).
+// Each round finds the smallest (time, slot) strictly after the previous one, so the result
+// does not depend on whether this kernel's own ev_time stores are visible to the loads yet.
+template <int ENV, int W>
+__device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane) {
+  double prev_t = -__builtin_inf();
+  int prev_i = -1;
+  for (;;) {
+    double bt = __builtin_inf();
+    int bi = 0x7fffffff;
+    for (int base = 0; base < e.ev_hwm; base += 64) {
+      int i = base + lane;
+      if (i < e.ev_hwm) {
+        double t = (i == e.push_idx) ? e.push_t : e.ev_time[i];
+        bool after = (t > prev_t) || (t == prev_t && i > prev_i);
+        if (after && (t < bt || (t == bt && i < bi))) { bt = t; bi = i; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      double ot = __shfl_xor(bt, o, 64);
+      int oi = __shfl_xor(bi, o, 64);
+      if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; }
+    }
+    if (!(bt <= e.now)) break;
+    u64 info = e.ev_info[bi];
+    int pidx = (int)(info & 0xffffffu), s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
+    int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
+    if (lane == 0) e.ev_time[bi] = __builtin_inf();
+    if (bi == e.push_idx) e.push_t = __builtin_inf();
+    e.ev_cnt--;
+    path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
+    e.s_br -= br;
+    e.s_nh -= (i64)n * (int)P.path_hops[pidx];
+    prev_t = bt;
+    prev_i = bi;
+  }
+  // shrink the scan window when its tail is empty
+  while (e.ev_hwm > 0) {
+    int i = e.ev_hwm - 1;
+    double t = (i == e.push_idx) ? e.push_t : e.ev_time[i];
+    // entries released above read +inf or a stale finite time <= now; both mean "empty"
+    if (t == __builtin_inf() || t <= e.now) e.ev_hwm--; else break;
+  }
+}
+
+// _next_service
+template <int ENV, int W>
+__device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lane) {
+  if (e.new_service) return;
+  Rng r;
+  rng_fill(e, r, lane);
+  double at = e.now + rng_expovariate(e, r, lane, P.lambda_a);
+  e.now = at;
+  double ht = rng_expovariate(e, r, lane, P.lambda_h);
+  int src = rng_choice(e, r, lane, P.cum_src, P.N);
+  int dst = rng_choice(e, r, lane, P.cum_dst + src * P.N, P.N);
+  int bit_rate = 0, br_idx = 0;
+  if (ENV != ENV_RWA) {
+    if (P.bit_rate_mode == 0) {  // randint(lo, hi) = lo + _randbelow(hi + 1 - lo)
+      u32 v = rng_u32(e, r, lane) >> (32 - P.rand_bits);
+      while ((int)v >= P.rand_n) v = rng_u32(e, r, lane) >> (32 - P.rand_bits);
+      br_idx = (int)v;
+      bit_rate = P.br_lo + br_idx;
+    } else {
+      br_idx = rng_choice(e, r, lane, P.cum_br, P.n_br);
+      bit_rate = P.bit_rates[br_idx];
+    }
+  }
+  rng_commit(e, r, lane);
+  if (ENV == ENV_RWA || ENV == ENV_RMCSA) release_due<ENV, W>(P, e, lane);
+  e.id = (int)e.esp;
+  e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
+  e.new_service = 1;
+  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) { e.sp += 1; e.esp += 1; }
+  if (ENV != ENV_RWA) {
+    e.brq += bit_rate;
+    e.ebrq += bit_rate;
+    if (P.bit_rate_mode == 1 && lane == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;
+  }
+  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) release_due<ENV, W>(P, e, lane);
+}
+
+// soft reset (reset(only_episode_counters=True)): the pending service is counted again
+template <int ENV> __device__ __forceinline__ void soft_reset(Env& e) {
+  e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
+  if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
+}
+
+// get_available_blocks: the first `want` free runs of m with length >= n; returns how many were found
+template <int W>
+__device__ __forceinline__ int first_blocks(const Row<W>& m, int S, int n, int want, int* starts, int* lens) {
+  Row<W> r = row_runs_ge<W>(m, n);
+  Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
+  int found = 0;
+  while (found < want && row_any<W>(r)) {
+    int s = row_ctz<W>(r);
+    Row<W> z = row_andn<W>(zeros, row_mask_lo<W>(s));
+    int end = row_any<W>(z) ? row_ctz<W>(z) : S;
+    starts[found] = s;
+    lens[found] = end - s;
+    found++;
+    r = row_andn<W>(r, row_mask_lo<W>(end));
+  }
+  return found;
+}
+
+// DeepRMSAEnv.observation (deeprmsa_env.py:60-121); lanes = paths, lane 0 writes the header
+template <int W>
+__device__ __forceinline__ void deep_observation(const DevParams& P, const Env& e, int lane, double* obs_out, double* obs_out2) {
+  const int N = P.N, J = P.J, S = P.S, WD = 2 * J + 3;
+  double* obs = e.obs_l;  // assembled in LDS, written out coalesced
+  for (int i = lane; i < P.obs_dim; i += 64) obs[i] = (i >= 1 + 2 * N) ? -1.0 : 0.0;
+  wave_fence();
+  int mn = e.src < e.dst ? e.src : e.dst, mx = e.src < e.dst ? e.dst : e.src;
+  if (lane == 0) {
+    obs[0] = (double)e.bit_rate / 100;
+    obs[1 + mn] = 1.0;
+    obs[1 + N + mx] = 1.0;
+  }
+  int np_ = P.n_paths[e.src * N + e.dst];
+  if (lane < np_) {
+    int pidx = pair_base(P, e.src, e.dst) + lane;
+    Row<W> m = path_and<W>(P, e, pidx, 0);
+    int n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+    double* sp = obs + 1 + 2 * N + lane * WD;
+    Row<W> r = row_runs_ge<W>(m, n);
+    Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
+    for (int b = 0; b < J && row_any<W>(r); b++) {
+      int s = row_ctz<W>(r);
+      Row<W> z = row_andn<W>(zeros, row_mask_lo<W>(s));
+      int end = row_any<W>(z) ? row_ctz<W>(z) : S;
+      sp[2 * b] = 2 * ((double)s - 0.5 * (double)S) / (double)S;
+      sp[2 * b + 1] = (double)(end - s - 8) / 8;
+      r = row_andn<W>(r, row_mask_lo<W>(end));
+    }
+    sp[2 * J] = ((double)n - 5.5) / 3.5;
+    int tot = row_popc<W>(m);
+    sp[2 * J + 1] = 2 * ((double)tot - 0.5 * (double)S) / (double)S;
+    int nruns = row_popc<W>(row_starts<W>(m));
+    if (nruns > 0) sp[2 * J + 2] = ((double)tot / (double)nruns - 4) / 4;
+  }
+  wave_fence();
+  for (int i = lane; i < P.obs_dim; i += 64) {
+    double v = obs[i];
+    obs_out[i] = v;
+    if (obs_out2) obs_out2[i] = v;
+  }
+  wave_fence();
+}
+
+// np.mean over the per-link values taken in topology.edges() order: numpy pairwise sum then / E
+__device__ __forceinline__ double link_mean(const DevParams& P, const double* vals /*LDS [E]*/, double* scratch /*LDS [E]*/, int lane) {
+  const int E = P.E;
+  for (int i = lane; i < E; i += 64) scratch[i] = vals[P.edge_iter_order[i]];
+  wave_fence();
+  double res;
+  if (E < 8) {
+    res = 0.;
+    for (int i = 0; i < E; i++) res += scratch[i];
+  } else {  // E <= 128 (checked on the host)
+    double r = (lane < 8) ? scratch[lane] : 0.0;
+    int i;
+    for (i = 8; i < E - (E % 8); i += 8)
+      if (lane < 8) r += scratch[i + lane];
+    double r0 = rdlane_f64(r, 0), r1 = rdlane_f64(r, 1), r2 = rdlane_f64(r, 2), r3 = rdlane_f64(r, 3);
+    double r4 = rdlane_f64(r, 4), r5 = rdlane_f64(r, 5), r6 = rdlane_f64(r, 6), r7 = rdlane_f64(r, 7);
+    res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < E; i++) res += scratch[i];
+  }
+  wave_fence();
+  return res / (double)E;
+}
+
+// ---------------------------------------------------------------------------------------------
+// heuristics (the policy side): returns the action in a[0..3]
+// ---------------------------------------------------------------------------------------------
+template <int ENV, int W>
+__device__ __forceinline__ void policy(const DevParams& P, const Env& e, int lane, int pol, int* a) {
+  const int K = P.K, S = P.S;
+  const int np_ = P.n_paths[e.src * P.N + e.dst];
+  const int pb = pair_base(P, e.src, e.dst);
+  a[0] = a[1] = a[2] = a[3] = 0;
+  if (ENV == ENV_RMSA) {
+    // lanes = paths.  KSP first-fit incl. the reference's off-by-one: start slots 0 .. S-n-1 only
+    a[0] = K; a[1] = S;
+    int slot = -1, freec = 0;
+    int limit = (pol == POL_SP_FF) ? 1 : np_;
+    if (lane < limit) {
+      int pidx = pb + lane;
+      Row<W> m = path_and<W>(P, e, pidx, 0);
+      int n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+      Row<W> cand = row_and<W>(row_runs_ge<W>(m, n), row_mask_lo<W>(S - n));
+      if (row_any<W>(cand)) { slot = row_ctz<W>(cand); freec = row_popc<W>(m); }
+    }
+    u64 fit = __ballot(slot >= 0);
+    if (fit) {
+      int best = (int)__builtin_ctzll(fit);
+      if (pol == POL_LLP_FF) {  // most free slots on the AND-row, first path wins ties (strict >)
+        int mx = wave_max(slot >= 0 ? freec : -1);
+        best = (int)__builtin_ctzll(__ballot(slot >= 0 && freec == mx));
+        if (mx <= 0) best = -1;  // free_slots > max_free_slots with max_free_slots = 0 initially
+      }
+      if (best >= 0) { a[0] = best; a[1] = __shfl(slot, best, 64); }
+    }
+  } else if (ENV == ENV_DEEPRMSA) {
+    a[0] = K * P.J;
+    bool has = false;
+    int limit = (pol == POL_SP_FF) ? 1 : np_;
+    if (lane < limit) {
+      int pidx = pb + lane;
+      Row<W> m = path_and<W>(P, e, pidx, 0);
+      int n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+      has = row_any<W>(row_runs_ge<W>(m, n));
+    }
+    u64 fit = __ballot(has);
+    if (pol == POL_SP_FF) a[0] = (!P.allow_rejection || fit) ? 0 : K * P.J;
+    else if (fit) a[0] = (int)__builtin_ctzll(fit) * P.J;
+  } else if (ENV == ENV_RWA) {
+    a[0] = K; a[1] = S;
+    int slot = -1, cap = 0, hops = 0;
+    int limit = (pol == POL_SP_FF) ? 1 : np_;
+    if (lane < limit) {
+      int pidx = pb + lane;
+      Row<W> m = path_and<W>(P, e, pidx, 0);
+      hops = P.path_hops[pidx];
+      cap = row_popc<W>(m);
+      if (pol == POL_SAP_LF) {  // range(S-1, 0, -1): wavelength 0 is never tried
+        Row<W> c = row_andn<W>(m, row_mask_lo<W>(1));
+        if (row_any<W>(c)) slot = row_bitlen<W>(c) - 1;
+      } else if (row_any<W>(m)) {
+        slot = row_ctz<W>(m);
+      }
+    }
+    int best = -1;
+    if (pol == POL_SP_FF) {
+      best = (__ballot(slot >= 0) & 1ull) ? 0 : -1;
+    } else if (pol == POL_LLP_FF) {
+      // for idp: cap = capacity(path); if cap > best_load: (first-fit exists iff cap > 0) -> take it.
+      // best_load starts at -DBL_MAX, so a path with cap == 0 passes the test but finds no wavelength.
+      int mx = wave_max(slot >= 0 ? cap : -1);
+      if (mx > 0) best = (int)__builtin_ctzll(__ballot(slot >= 0 && cap == mx));
+    } else {
+      // fewest hops among the paths that have a free wavelength; earlier path wins ties (strict <)
+      int mh = -wave_max(slot >= 0 ? -hops : -(1 << 20));
+      u64 bb = __ballot(slot >= 0 && hops == mh);
+      if (bb) best = (int)__builtin_ctzll(bb);
+    }
+    if (best >= 0) { a[0] = best; a[1] = __shfl(slot, best, 64); }
+  } else if (ENV == ENV_RMCSA) {
+    // lanes = (path, core) pairs in the reference's loop order: path-major, then core
+    a[0] = K; a[1] = P.M; a[2] = P.C; a[3] = S;
+    int best = -1, bslot = 0;
+    for (int base = 0; base < np_ * P.C && best < 0; base += 64) {
+      int q = base + lane, slot = -1;
+      if (q < np_ * P.C) {
+        int pth = q / P.C, core = q - pth * P.C;
+        int pidx = pb + pth;
+        Row<W> m = path_and<W>(P, e, pidx, core);
+        int n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+        Row<W> cand = row_and<W>(row_runs_ge<W>(m, n), row_mask_lo<W>(S - n));
+        if (row_any<W>(cand)) slot = row_ctz<W>(cand);
+      }
+      u64 fit = __ballot(slot >= 0);
+      if (fit) { int l = (int)__builtin_ctzll(fit); best = base + l; bslot = __shfl(slot, l, 64); }
+    }
+    if (best >= 0) {
+      int pth = best / P.C;
+      a[0] = pth; a[1] = P.path_mod[pb + pth]; a[2] = best - pth * P.C; a[3] = bslot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step(): everything between receiving the action and handing back (reward, done, info)
+// ---------------------------------------------------------------------------------------------
+template <int ENV, int W>
+__device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const int* act, int auto_reset,
+                                     double* reward_out, unsigned char* done_out, double* info_out, double* obs_out,
+                                     double* term_obs_out) {
+  const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0;
+  int path, slot, mod = 0, core = 0;
+  bool bad = false;
+  if (ENV == ENV_DEEPRMSA) {  // deeprmsa_env.py:48-58
+    int aa = act[0];
+    path = K; slot = S;
+    if (aa >= 0 && aa < K * P.J) {
+      int route = aa / P.J, block = aa - route * P.J;
+      int starts[8], lens[8];
+      int pidx = pair_base(P, e.src, e.dst) + route;
+      int nb = 0;
+      if (route < P.n_paths[e.src * P.N + e.dst]) {
+        Row<W> m = path_and<W>(P, e, pidx, 0);
+        nb = first_blocks<W>(m, S, P.nslots[e.br_idx * P.M + P.path_mod[pidx]], block + 1, starts, lens);
+      }
+      if (block < nb) { path = route; slot = starts[block]; }
+    }
+  } else if (ENV == ENV_RMCSA) {
+    path = act[0]; mod = act[1]; core = act[2]; slot = act[3];
+    bad = path < 0 || path > K || mod < 0 || mod > P.M || core < 0 || core > P.C || slot < 0 || slot > S;
+  } else if (ENV == ENV_RWA) {
+    path = act[0]; slot = act[1];
+    bad = path < 0 || path >= K + rej || slot < 0 || slot >= S + rej;
+  } else {
+    path = act[0]; slot = act[1];
+    bad = path < 0 || path > K || slot < 0 || slot > S;
+  }
+  if (bad) {  // the reference raises IndexError on actions_output[...]; flag it and treat as a rejection
+    e.flags |= ORL_FLAG_BAD_ACTION;
+    path = K; slot = S; mod = P.M; core = P.C;
+  }
+  const int path0 = path, slot0 = slot;
+  double prev_comp = 0.0, cur_comp = 0.0;
+  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) prev_comp = net_compactness(P, e, 0);
+  bool accepted = false;
+  bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
+  if (in_range && path < P.n_paths[e.src * P.N + e.dst]) {
+    int pidx = pair_base(P, e.src, e.dst) + path;
+    int n = 1;
+    if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
+    else if (ENV != ENV_RWA) n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+    bool ok = path_is_free<W>(P, e, lane, pidx, core, slot, n);
+    if (ok && ENV == ENV_RMCSA) {  // _crosstalk_is_acceptable: two reach limits
+      double len = P.path_length[pidx];
+      ok = (len < P.lmax_xt[mod]) && (len < P.lmax_snr[mod * P.n_br + e.br_idx]);
+    }
+    if (ok) {
+      path_apply<ENV, W>(P, e, lane, pidx, core, slot, n, false);
+      e.s_br += e.bit_rate;
+      e.s_nh += (i64)n * (int)P.path_hops[pidx];
+      if (ENV != ENV_RWA) {  // _update_network_stats
+        double last_update = e.g_last, time_diff = e.now - last_update;
+        if (e.now > 0) {
+          double cur_thr = (double)e.s_br;
+          e.g_thr = ((e.g_thr * last_update) + (cur_thr * time_diff)) / e.now;
+          e.g_comp = ((e.g_comp * last_update) + (net_compactness(P, e, core) * time_diff)) / e.now;
+        }
+        e.g_last = e.now;
+        e.brp += e.bit_rate;
+        e.ebrp += e.bit_rate;
+        if (P.bit_rate_mode == 1 && lane == 0) P.br_hist[e.env * 2 * P.n_br + P.n_br + e.br_idx] += 1;
+      }
+      e.sa += 1;
+      e.esa += 1;
+      accepted = true;
+      ev_push(P, e, lane, e.at + e.ht, ev_pack(pidx, slot, n, core, e.bit_rate));
+    }
+  }
+  if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
+  if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
+  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) cur_comp = net_compactness(P, e, 0);
+
+  if (ENV == ENV_RWA) {
+    // actions_output marginals (rwa_env.py:103, 148-151).  Each lane owns histogram entries, applies this
+    // step's increment itself and derives its info value from the updated count (total = services_processed).
+    i64* h = P.act_hist + e.env * ((K + 1) + (S + 1));
+    const int npa = K + rej, nsa = S + rej;
+    for (int base = 0; base < npa + nsa; base += 64) {
+      int i = base + lane;
+      if (i < npa + nsa) {
+        int hi = (i < npa) ? i : (K + 1) + (i - npa);
+        bool hit = !bad && ((i < npa) ? (i == path0) : (i - npa == slot0));
+        i64 v = h[hi] + (hit ? 1 : 0);
+        if (hit) h[hi] = v;
+        if (info_out) info_out[2 + i] = (double)v / (double)e.sp;
+      }
+    }
+  }
+  double reward = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
+  if (info_out) {
+    double i0 = (double)(e.sp - e.sa) / (double)e.sp;
+    double i1 = (double)(e.esp - e.esa) / (double)e.esp;
+    if (lane == 0) { info_out[0] = i0; info_out[1] = i1; }
+    if (ENV != ENV_RWA) {
+      double i2 = (double)(e.brq - e.brp) / (double)e.brq;
+      double i3 = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
+      if (lane == 0) { info_out[2] = i2; info_out[3] = i3; }
+    }
+    if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
+      double* scratch = e.scratch;
+      double mc = link_mean(P, e.ls + 2 * P.E, scratch, lane);
+      double mu = link_mean(P, e.ls, scratch, lane);
+      if (lane == 0) { info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu; }
+      if (P.bit_rate_mode == 1 && lane == 0) {  // rmsa_env.py:217-227, 268-273
+        const i64* rq = P.br_hist + e.env * 2 * P.n_br;
+        const i64* pv = rq + P.n_br;
+        double mxv = -__builtin_inf(), mnv = __builtin_inf();
+        for (int i = 0; i < P.n_br; i++) {
+          double bl = 0.0;
+          if (rq[i] > 0) bl = (double)(rq[i] - pv[i]) / (double)rq[i];
+          info_out[8 + i] = bl;
+          mxv = bl > mxv ? bl : mxv;
+          mnv = bl < mnv ? bl : mnv;
+        }
+        info_out[8 + P.n_br] = mxv - mnv;
+      }
+    }
+  }
+  e.new_service = 0;
+  next_service<ENV, W>(P, e, lane);
+  bool done = (e.esp == (i64)P.episode_length);
+  if (ENV == ENV_DEEPRMSA && obs_out) {
+    deep_observation<W>(P, e, lane, obs_out, (done && term_obs_out) ? term_obs_out : nullptr);
+  }
+  if (done && auto_reset) soft_reset<ENV>(e);
+  if (lane == 0) {
+    if (reward_out) *reward_out = reward;
+    if (done_out) *done_out = done ? 1 : 0;
+  }
+}
+
+}  // namespace orl

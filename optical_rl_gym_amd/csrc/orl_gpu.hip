@@ -1,0 +1,625 @@
+// orl_gpu.hip — kernels + C ABI (include/orl.h) of liborlgpu.so.  gfx950 only.
+//
+// Kernels (one 64-lane wavefront = one workgroup = one env):
+//   k_init_mt   CPython MT19937 state -> in-place "update-behind" form (orl_device.h, Rng)
+//   k_reset     full reset (clear network, draw first service) or soft reset (episode counters)
+//   k_policy    slot-scan: AND the link rows of each of the k paths out of LDS, log-step run
+//               detection, first fit -> action            [the HBM-streaming kernel of the roofline]
+//   k_step      apply action, statistics, reward/info, next service (RNG, releases), observation
+//   k_obs       DeepRMSA observation of the pending service
+// Host side: plain HIP runtime, one stream per batch, no torch types.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/orl.h"
+#include "orl_device.h"
+
+using namespace orl;
+
+// =============================================================================================
+// kernels
+// =============================================================================================
+extern __shared__ __attribute__((aligned(16))) unsigned char orl_lds_raw[];
+
+__global__ void __launch_bounds__(64) k_init_mt(DevParams P, const u32* raw) {
+  const i64 env = blockIdx.x;
+  const int lane = lane_id();
+  u32* m = (u32*)orl_lds_raw;
+  const u32* src = raw + env * 625;
+  for (int i = lane; i < 624; i += 64) m[i] = src[i];
+  int p0 = (int)src[624];
+  if (p0 > 624) p0 = 624;
+  wave_fence();
+  // positions < p0 were already handed out by CPython: advance them to the next generation
+  for (int base = 0; base < p0; base += 64) {
+    int i = base + lane;
+    u32 nw = 0;
+    if (i < p0) {
+      int i1 = i + 1 >= 624 ? i + 1 - 624 : i + 1;
+      int im = i + 397 >= 624 ? i + 397 - 624 : i + 397;
+      u32 y = (m[i] & 0x80000000u) | (m[i1] & 0x7fffffffu);
+      nw = m[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    wave_fence();
+    if (i < p0) m[i] = nw;
+    wave_fence();
+  }
+  u32* dst = P.mt + env * 624;
+  for (int i = lane; i < 624; i += 64) dst[i] = m[i];
+  u64 v = 0;
+  if (lane == SC_ID_MTPOS) v = pack2(0, p0 >= 624 ? 0 : p0);
+  if (lane < ORL_SCAL_WORDS) P.scal[env * ORL_SCAL_WORDS + lane] = v;
+}
+
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsigned char* mask) {
+  const i64 env = blockIdx.x;
+  const int lane = lane_id();
+  if (mask && !mask[env]) return;
+  Env e;
+  env_load(P, e, env, lane);
+  if (!full) {
+    soft_reset<ENV>(e);
+    env_store(P, e, lane);
+    return;
+  }
+  u64* lds = (u64*)orl_lds_raw;
+  e.bm = lds;
+  e.ls = (double*)(lds + P.bm_words);
+  e.scratch = e.ls + 4 * P.E;
+  e.obs_l = e.scratch + P.E;
+  e.cs = (int*)(e.obs_l + P.obs_dim);
+  // available_slots = ones (rmsa_env.py:337-339); bits >= S stay 0
+  for (int i = lane; i < P.bm_words; i += 64) {
+    int w = i % W;
+    int c = P.S - 64 * w;
+    u64 v = c >= 64 ? ~0ull : (c <= 0 ? 0ull : ((1ull << c) - 1ull));
+    lds[i] = (i < P.C * P.E * W) ? v : 0ull;
+  }
+  for (int i = lane; i < 4 * P.E; i += 64) e.ls[i] = 0.0;
+  if (lane < 2 * P.C) e.cs[lane] = 0;
+  for (int i = lane; i < P.ev_cap; i += 64) e.ev_time[i] = __builtin_inf();
+  if (P.br_hist) for (int i = lane; i < 2 * P.n_br; i += 64) P.br_hist[env * 2 * P.n_br + i] = 0;
+  if (P.act_hist) for (int i = lane; i < (P.K + 1) + (P.S + 1); i += 64) P.act_hist[env * ((P.K + 1) + (P.S + 1)) + i] = 0;
+  wave_fence();
+  e.now = 0; e.at = 0; e.ht = 0; e.g_thr = 0; e.g_comp = 0; e.g_last = 0;
+  e.sp = e.sa = e.esp = e.esa = e.brq = e.brp = e.ebrq = e.ebrp = e.s_br = e.s_nh = 0;
+  e.src = e.dst = e.bit_rate = e.br_idx = e.id = 0;
+  e.ev_hwm = 0; e.ev_cnt = 0; e.new_service = 0; e.flags = 0;
+  next_service<ENV, W>(P, e, lane);
+  stage_out(P, e, lane);
+  env_store(P, e, lane);
+}
+
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) k_policy(DevParams P, int pol) {
+  const i64 env = blockIdx.x;
+  const int lane = lane_id();
+  Env e;
+  env_load(P, e, env, lane);
+  u64* lds = (u64*)orl_lds_raw;
+  e.bm = lds;
+  {
+    const ulonglong2* g = (const ulonglong2*)(P.bitmap + env * P.bm_words);
+    ulonglong2* l = (ulonglong2*)lds;
+    for (int i = lane; i < P.bm_words / 2; i += 64) l[i] = g[i];
+  }
+  wave_fence();
+  int a[4];
+  policy<ENV, W>(P, e, lane, pol, a);
+  if (lane == 0) *(int4*)(P.actions + env * 4) = make_int4(a[0], a[1], a[2], a[3]);
+}
+
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) k_step(DevParams P, int auto_reset, int want_info) {
+  const i64 env = blockIdx.x;
+  const int lane = lane_id();
+  Env e;
+  env_load(P, e, env, lane);
+  stage_in(P, e, (u64*)orl_lds_raw, lane);
+  int4 av = *(const int4*)(P.actions + env * 4);
+  int act[4] = {av.x, av.y, av.z, av.w};
+  step<ENV, W>(P, e, lane, act, auto_reset, P.reward + env, P.done + env,
+               want_info ? P.info + env * P.n_info : nullptr,
+               P.obs_dim ? P.obs + env * P.obs_dim : nullptr,
+               P.obs_dim ? P.term_obs + env * P.obs_dim : nullptr);
+  stage_out(P, e, lane);
+  env_store(P, e, lane);
+}
+
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) k_obs(DevParams P) {
+  const i64 env = blockIdx.x;
+  const int lane = lane_id();
+  Env e;
+  env_load(P, e, env, lane);
+  stage_in(P, e, (u64*)orl_lds_raw, lane);
+  if (ENV == ENV_DEEPRMSA) deep_observation<W>(P, e, lane, P.obs + env * P.obs_dim, nullptr);
+}
+
+// sums of services_processed / services_accepted over the batch (two atomics per wave)
+__global__ void k_totals(DevParams P, unsigned long long* out) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  i64 sp = 0, sa = 0;
+  if (i < P.B) { sp = (i64)P.scal[i * ORL_SCAL_WORDS + SC_SP]; sa = (i64)P.scal[i * ORL_SCAL_WORDS + SC_SA]; }
+  for (int o = 32; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); sa += __shfl_xor(sa, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(out, (unsigned long long)sp); atomicAdd(out + 1, (unsigned long long)sa); }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                                     \
+  do {                                                                                                \
+    hipError_t _e = (x);                                                                              \
+    if (_e != hipSuccess) return fail(ORL_E_HIP, "%s failed: %s", #x, hipGetErrorString(_e));         \
+  } while (0)
+
+struct orl_topology {
+  int device;
+  int N, E, K, H, M;
+  int* n_paths;
+  unsigned char* path_hops;
+  short* path_links;
+  unsigned char* path_mod;
+  double* path_length;
+  int* edge_iter_order;
+};
+
+struct orl_batch {
+  DevParams P;
+  int device, wt;
+  hipStream_t stream;
+  std::vector<void*> allocs;
+  hipEvent_t ev0, ev1;
+  unsigned long long* d_totals;
+};
+
+template <typename T, typename S>
+static int upload_conv(T** out, const S* src, size_t n, std::vector<void*>* track) {
+  std::vector<T> tmp(n);
+  for (size_t i = 0; i < n; i++) tmp[i] = (T)src[i];
+  HIPCHK(hipMalloc((void**)out, n * sizeof(T) + 16));
+  if (track) track->push_back(*out);
+  HIPCHK(hipMemcpy(*out, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int orl_abi_version(void) { return ORL_ABI_VERSION; }
+extern "C" const char* orl_last_error(void) { return g_err.c_str(); }
+extern "C" int orl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, orl_topology** out) {
+  if (!d || !out) return fail(ORL_E_INVALID, "null argument");
+  if (d->n_nodes < 2 || d->n_nodes > 512 || d->n_links < 1 || d->n_links > 128 || d->k_paths < 1 || d->k_paths > 64 ||
+      d->max_hops < 1 || d->max_hops > 64 || d->n_modulations < 1 || d->n_modulations > 255)
+    return fail(ORL_E_INVALID, "topology out of supported range (N<=512, E<=128, k<=64, hops<=64)");
+  HIPCHK(hipSetDevice(device_id));
+  orl_topology* t = new orl_topology();
+  memset(t, 0, sizeof *t);
+  t->device = device_id;
+  t->N = d->n_nodes; t->E = d->n_links; t->K = d->k_paths; t->H = d->max_hops; t->M = d->n_modulations;
+  size_t nn = (size_t)t->N * t->N, npk = nn * t->K;
+  for (size_t i = 0; i < npk; i++)
+    if (d->path_hops[i] > t->H || (d->path_modulation[i] >= t->M)) { delete t; return fail(ORL_E_INVALID, "bad path table entry %zu", i); }
+  for (size_t i = 0; i < npk * t->H; i++)
+    if (d->path_links[i] >= t->E) { delete t; return fail(ORL_E_INVALID, "bad link index in path table"); }
+  int rc = 0;
+  std::vector<int32_t> mod(npk);
+  for (size_t i = 0; i < npk; i++) mod[i] = d->path_modulation[i] < 0 ? 0 : d->path_modulation[i];
+  rc |= upload_conv(&t->n_paths, d->n_paths, nn, nullptr);
+  rc |= upload_conv(&t->path_hops, d->path_hops, npk, nullptr);
+  rc |= upload_conv(&t->path_links, d->path_links, npk * t->H, nullptr);
+  rc |= upload_conv(&t->path_mod, mod.data(), npk, nullptr);
+  rc |= upload_conv(&t->path_length, d->path_length, npk, nullptr);
+  rc |= upload_conv(&t->edge_iter_order, d->edge_iter_order, (size_t)t->E, nullptr);
+  if (rc) { delete t; return ORL_E_HIP; }
+  *out = t;
+  return ORL_OK;
+}
+
+extern "C" void orl_topology_destroy(orl_topology* t) {
+  if (!t) return;
+  hipSetDevice(t->device);
+  hipFree(t->n_paths); hipFree(t->path_hops); hipFree(t->path_links); hipFree(t->path_mod);
+  hipFree(t->path_length); hipFree(t->edge_iter_order);
+  delete t;
+}
+
+// ---- launch dispatch over (env family, words per row) ------------------------------------------
+#define ORL_FOR_W(CALL)                 \
+  switch (b->wt) {                      \
+    case 1: CALL(1); break;             \
+    case 2: CALL(2); break;             \
+    case 5: CALL(5); break;             \
+    default: CALL(8); break;            \
+  }
+#define ORL_FOR_ENV(MACRO)                                  \
+  switch (b->P.env_type) {                                  \
+    case ENV_RMSA: { MACRO(ENV_RMSA) } break;               \
+    case ENV_DEEPRMSA: { MACRO(ENV_DEEPRMSA) } break;       \
+    case ENV_RWA: { MACRO(ENV_RWA) } break;                 \
+    default: { MACRO(ENV_RMCSA) } break;                    \
+  }
+
+static void launch_reset(orl_batch* b, int full, const unsigned char* dmask) {
+  dim3 g((unsigned)b->P.B), blk(64);
+  size_t lds = b->P.lds_bytes;
+#define CALLW(WW) hipLaunchKernelGGL((k_reset<EE, WW>), g, blk, lds, b->stream, b->P, full, dmask)
+#define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
+  ORL_FOR_ENV(PER_ENV)
+#undef PER_ENV
+#undef CALLW
+}
+static void launch_policy(orl_batch* b, int pol) {
+  dim3 g((unsigned)b->P.B), blk(64);
+  size_t lds = (size_t)b->P.bm_words * 8;
+#define CALLW(WW) hipLaunchKernelGGL((k_policy<EE, WW>), g, blk, lds, b->stream, b->P, pol)
+#define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
+  ORL_FOR_ENV(PER_ENV)
+#undef PER_ENV
+#undef CALLW
+}
+static void launch_step(orl_batch* b, int auto_reset, int want_info) {
+  dim3 g((unsigned)b->P.B), blk(64);
+  size_t lds = b->P.lds_bytes;
+#define CALLW(WW) hipLaunchKernelGGL((k_step<EE, WW>), g, blk, lds, b->stream, b->P, auto_reset, want_info)
+#define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
+  ORL_FOR_ENV(PER_ENV)
+#undef PER_ENV
+#undef CALLW
+}
+static void launch_obs(orl_batch* b) {
+  dim3 g((unsigned)b->P.B), blk(64);
+  size_t lds = b->P.lds_bytes;
+#define CALLW(WW) hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, b->stream, b->P)
+  ORL_FOR_W(CALLW)
+#undef CALLW
+}
+
+template <typename T> static int dalloc(orl_batch* b, T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T) + 64));
+  b->allocs.push_back(*p);
+  return 0;
+}
+
+extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
+                                orl_batch** out) {
+  if (!c || !t || !out || !mt_state || n_envs < 1) return fail(ORL_E_INVALID, "null/invalid argument");
+  if (c->env_type < 0 || c->env_type > 3) return fail(ORL_E_INVALID, "unknown env_type %d", c->env_type);
+  const int S = c->num_spectrum_resources, C = c->num_spatial_resources;
+  if (S < 2 || S > 512) return fail(ORL_E_INVALID, "num_spectrum_resources must be in [2, 512]");
+  if (C < 1 || C > 31 || (c->env_type != ORL_ENV_RMCSA && C != 1)) return fail(ORL_E_INVALID, "bad num_spatial_resources");
+  if (c->env_type == ORL_ENV_DEEPRMSA && (c->j < 1 || c->j > 8)) return fail(ORL_E_INVALID, "j must be in [1, 8]");
+  if (c->n_bit_rates < 1 || c->n_bit_rates > 4096) return fail(ORL_E_INVALID, "bad n_bit_rates");
+  if (!c->cum_src || !c->cum_dst) return fail(ORL_E_INVALID, "node probability tables missing");
+  if (c->env_type != ORL_ENV_RWA && (!c->n_slots || !c->bit_rates)) return fail(ORL_E_INVALID, "bit-rate tables missing");
+  if (c->env_type == ORL_ENV_RMCSA && (!c->lmax_snr || !c->lmax_xt)) return fail(ORL_E_INVALID, "RMCSA reach tables missing");
+  if (c->bit_rate_mode == 1 && !c->cum_bit_rate) return fail(ORL_E_INVALID, "cum_bit_rate missing");
+  if (c->env_type != ORL_ENV_RWA) {
+    for (int i = 0; i < c->n_bit_rates * t->M; i++)
+      if (c->n_slots[i] < 1 || c->n_slots[i] > 64) return fail(ORL_E_INVALID, "n_slots entries must be in [1, 64]");
+    for (int i = 0; i < c->n_bit_rates; i++)
+      if (c->bit_rates[i] < 0 || c->bit_rates[i] > 32767) return fail(ORL_E_INVALID, "bit rates must be < 32768");
+  }
+  HIPCHK(hipSetDevice(t->device));
+  orl_batch* b = new orl_batch();
+  memset(&b->P, 0, sizeof b->P);
+  b->device = t->device;
+  b->d_totals = nullptr;
+  DevParams& P = b->P;
+  P.env_type = c->env_type;
+  P.N = t->N; P.E = t->E; P.K = t->K; P.H = t->H; P.M = t->M;
+  P.S = S; P.C = C;
+  b->wt = S <= 64 ? 1 : (S <= 128 ? 2 : (S <= 320 ? 5 : 8));
+  P.W = b->wt;
+  P.episode_length = c->episode_length;
+  P.allow_rejection = c->allow_rejection ? 1 : 0;
+  P.J = c->env_type == ORL_ENV_DEEPRMSA ? c->j : 1;
+  P.bit_rate_mode = c->bit_rate_mode;
+  P.br_lo = c->bit_rate_lo;
+  P.n_br = c->n_bit_rates;
+  P.rand_n = c->bit_rate_hi + 1 - c->bit_rate_lo;
+  P.rand_bits = 0;
+  for (int v = P.rand_n; v > 0; v >>= 1) P.rand_bits++;
+  if (c->bit_rate_mode == 0 && c->env_type != ORL_ENV_RWA && (P.rand_n < 1 || P.rand_n != c->n_bit_rates))
+    return fail(ORL_E_INVALID, "continuous mode needs n_bit_rates == hi - lo + 1");
+  P.lambda_a = c->lambda_arrival;
+  P.lambda_h = c->lambda_holding;
+  if (!(P.lambda_a > 0) || !(P.lambda_h > 0)) return fail(ORL_E_INVALID, "rates must be positive");
+  P.B = n_envs;
+  int cap = c->event_capacity;
+  if (cap <= 0) {
+    double load = P.lambda_a / P.lambda_h;
+    cap = (int)(load + 10.0 * sqrt(load) + 64.0);
+  }
+  P.ev_cap = (cap + 63) / 64 * 64;
+  int words = C * P.E * b->wt;
+  P.bm_words = (words + 1) & ~1;
+  int rej = P.allow_rejection;
+  if (c->env_type == ORL_ENV_RWA) P.n_info = 2 + (P.K + rej) + (S + rej);
+  else if (c->env_type == ORL_ENV_RMCSA) P.n_info = 4;
+  else P.n_info = 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
+  P.obs_dim = c->env_type == ORL_ENV_DEEPRMSA ? 1 + 2 * P.N + (2 * P.J + 3) * P.K : 0;
+  P.lds_bytes = ((P.bm_words + 4 * P.E + P.E + P.obs_dim) * 8 + 2 * C * 4 + 15) & ~15;
+  if (P.lds_bytes < 624 * 4) P.lds_bytes = 624 * 4;  // k_init_mt stages the MT state in the same window
+  if (P.lds_bytes > 64 * 1024) { delete b; return fail(ORL_E_INVALID, "per-env LDS window too large (%d B)", P.lds_bytes); }
+
+  P.n_paths = t->n_paths; P.path_hops = t->path_hops; P.path_links = t->path_links; P.path_mod = t->path_mod;
+  P.path_length = t->path_length; P.edge_iter_order = t->edge_iter_order;
+  int rc = 0;
+  {
+    double* p; int* q; unsigned char* u;
+    rc |= upload_conv(&p, c->cum_src, (size_t)P.N, &b->allocs); P.cum_src = p;
+    rc |= upload_conv(&p, c->cum_dst, (size_t)P.N * P.N, &b->allocs); P.cum_dst = p;
+    if (c->bit_rates) { rc |= upload_conv(&q, c->bit_rates, (size_t)P.n_br, &b->allocs); P.bit_rates = q; }
+    if (c->cum_bit_rate) { rc |= upload_conv(&p, c->cum_bit_rate, (size_t)P.n_br, &b->allocs); P.cum_br = p; }
+    if (c->n_slots) { rc |= upload_conv(&u, c->n_slots, (size_t)P.n_br * P.M, &b->allocs); P.nslots = u; }
+    if (c->lmax_snr) { rc |= upload_conv(&p, c->lmax_snr, (size_t)P.n_br * P.M, &b->allocs); P.lmax_snr = p; }
+    if (c->lmax_xt) { rc |= upload_conv(&p, c->lmax_xt, (size_t)P.M, &b->allocs); P.lmax_xt = p; }
+  }
+  size_t B = (size_t)n_envs;
+  rc |= dalloc(b, &P.bitmap, B * P.bm_words);
+  rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
+  rc |= dalloc(b, &P.ev_info, B * P.ev_cap);
+  rc |= dalloc(b, &P.mt, B * 624);
+  rc |= dalloc(b, &P.lstat, B * 4 * P.E);
+  rc |= dalloc(b, &P.scal, B * ORL_SCAL_WORDS);
+  rc |= dalloc(b, &P.core_sums, B * 2 * C);
+  if (c->bit_rate_mode == 1 && c->env_type != ORL_ENV_RWA) rc |= dalloc(b, &P.br_hist, B * 2 * P.n_br);
+  if (c->env_type == ORL_ENV_RWA) rc |= dalloc(b, &P.act_hist, B * ((P.K + 1) + (S + 1)));
+  rc |= dalloc(b, &P.actions, B * 4);
+  rc |= dalloc(b, &P.reward, B);
+  rc |= dalloc(b, &P.done, B);
+  rc |= dalloc(b, &P.info, B * P.n_info);
+  if (P.obs_dim) { rc |= dalloc(b, &P.obs, B * P.obs_dim); rc |= dalloc(b, &P.term_obs, B * P.obs_dim); }
+  rc |= dalloc(b, &b->d_totals, 2);
+  if (rc) { orl_batch_destroy(b); return ORL_E_HIP; }
+  HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&b->ev0));
+  HIPCHK(hipEventCreate(&b->ev1));
+  // MT state upload + conversion, then the constructor's full reset
+  u32* raw = nullptr;
+  HIPCHK(hipMalloc((void**)&raw, B * 625 * sizeof(u32)));
+  HIPCHK(hipMemcpyAsync(raw, mt_state, B * 625 * sizeof(u32), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemsetAsync(P.actions, 0, B * 4 * sizeof(int), b->stream));
+  hipLaunchKernelGGL(k_init_mt, dim3((unsigned)B), dim3(64), 624 * 4, b->stream, P, raw);
+  launch_reset(b, 1, nullptr);
+  if (P.obs_dim) launch_obs(b);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  hipFree(raw);
+  *out = b;
+  return ORL_OK;
+}
+
+extern "C" void orl_batch_destroy(orl_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  for (void* p : b->allocs) hipFree(p);
+  delete b;
+}
+
+extern "C" int orl_batch_info_dim(const orl_batch* b) { return b ? b->P.n_info : 0; }
+extern "C" int orl_batch_obs_dim(const orl_batch* b) { return b ? b->P.obs_dim : 0; }
+
+extern "C" int orl_batch_sync(orl_batch* b) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  unsigned char* dmask = nullptr;
+  if (env_mask) {
+    HIPCHK(hipMalloc((void**)&dmask, (size_t)b->P.B));
+    HIPCHK(hipMemcpyAsync(dmask, env_mask, (size_t)b->P.B, hipMemcpyHostToDevice, b->stream));
+  }
+  launch_reset(b, full ? 1 : 0, dmask);
+  if (b->P.obs_dim) launch_obs(b);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  if (dmask) hipFree(dmask);
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_policy(orl_batch* b, int policy_id, int32_t* actions_out) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  if (policy_id < 0 || policy_id > 3) return fail(ORL_E_INVALID, "unknown policy %d", policy_id);
+  HIPCHK(hipSetDevice(b->device));
+  launch_policy(b, policy_id);
+  if (actions_out) {
+    HIPCHK(hipMemcpyAsync(actions_out, b->P.actions, (size_t)b->P.B * 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+  }
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, double* reward_out,
+                              uint8_t* done_out, double* info_out) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t B = (size_t)b->P.B;
+  if (actions) HIPCHK(hipMemcpyAsync(b->P.actions, actions, B * 4 * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  launch_step(b, auto_reset ? 1 : 0, 1);
+  bool any = false;
+  if (reward_out) { HIPCHK(hipMemcpyAsync(reward_out, b->P.reward, B * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (done_out) { HIPCHK(hipMemcpyAsync(done_out, b->P.done, B, hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (info_out) { HIPCHK(hipMemcpyAsync(info_out, b->P.info, B * b->P.n_info * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (obs_out && b->P.obs_dim) { HIPCHK(hipMemcpyAsync(obs_out, b->P.obs, B * b->P.obs_dim * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (any || actions) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+  }
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_observation(orl_batch* b, double* obs_out) {
+  if (!b || !obs_out) return fail(ORL_E_INVALID, "null argument");
+  if (!b->P.obs_dim) return fail(ORL_E_INVALID, "this env family has no array observation");
+  HIPCHK(hipSetDevice(b->device));
+  launch_obs(b);
+  HIPCHK(hipMemcpyAsync(obs_out, b->P.obs, (size_t)b->P.B * b->P.obs_dim * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels, orl_run_stats* stats) {
+  if (!b || n_steps < 0) return fail(ORL_E_INVALID, "bad argument");
+  if (policy_id < 0 || policy_id > 3) return fail(ORL_E_INVALID, "unknown policy %d", policy_id);
+  HIPCHK(hipSetDevice(b->device));
+  std::vector<hipEvent_t> evs;
+  if (time_kernels) {
+    evs.resize((size_t)n_steps * 3);
+    for (auto& e : evs) HIPCHK(hipEventCreate(&e));
+  }
+  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  for (int64_t s = 0; s < n_steps; s++) {
+    if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s], b->stream));
+    launch_policy(b, policy_id);
+    if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s + 1], b->stream));
+    launch_step(b, 1, 0);
+    if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s + 2], b->stream));
+  }
+  HIPCHK(hipEventRecord(b->ev1, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  if (stats) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    stats->ms_total = ms;
+    stats->launches = 2 * n_steps;
+    stats->ms_policy = stats->ms_step = 0;
+    if (time_kernels && n_steps > 0) {
+      double sp = 0, ss = 0;
+      for (int64_t s = 0; s < n_steps; s++) {
+        float a = 0, c2 = 0;
+        HIPCHK(hipEventElapsedTime(&a, evs[3 * s], evs[3 * s + 1]));
+        HIPCHK(hipEventElapsedTime(&c2, evs[3 * s + 1], evs[3 * s + 2]));
+        sp += a; ss += c2;
+      }
+      stats->ms_policy = sp / (double)n_steps;
+      stats->ms_step = ss / (double)n_steps;
+    }
+  }
+  for (auto& e : evs) hipEventDestroy(e);
+  return ORL_OK;
+}
+
+// ---- read-back ----------------------------------------------------------------------------------
+static int fetch_scal(orl_batch* b, std::vector<u64>& host) {
+  host.resize((size_t)b->P.B * ORL_SCAL_WORDS);
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(host.data(), b->P.scal, host.size() * sizeof(u64), hipMemcpyDeviceToHost));
+  return 0;
+}
+static double as_f64(u64 v) { double d; memcpy(&d, &v, 8); return d; }
+
+extern "C" int orl_batch_get_counters(orl_batch* b, int64_t* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) {
+    const u64* s = &h[(size_t)i * ORL_SCAL_WORDS];
+    int64_t* o = out + i * ORL_N_COUNTERS;
+    o[0] = (int64_t)s[SC_SP]; o[1] = (int64_t)s[SC_SA]; o[2] = (int64_t)s[SC_ESP]; o[3] = (int64_t)s[SC_ESA];
+    o[4] = (int64_t)s[SC_BRQ]; o[5] = (int64_t)s[SC_BRP]; o[6] = (int64_t)s[SC_EBRQ]; o[7] = (int64_t)s[SC_EBRP];
+  }
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_services(orl_batch* b, double* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) {
+    const u64* s = &h[(size_t)i * ORL_SCAL_WORDS];
+    double* o = out + i * ORL_N_SERVICE;
+    o[0] = as_f64(s[SC_AT]); o[1] = as_f64(s[SC_HT]);
+    o[2] = (double)(int)(u32)s[SC_SRC_DST]; o[3] = (double)(int)(s[SC_SRC_DST] >> 32);
+    o[4] = (double)(int)(u32)s[SC_BR_IDX]; o[5] = (double)(int)(u32)s[SC_ID_MTPOS];
+  }
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_active(orl_batch* b, int32_t* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) out[i] = (int32_t)(h[(size_t)i * ORL_SCAL_WORDS + SC_EV] >> 32);
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_flags(orl_batch* b, int32_t* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) out[i] = (int32_t)(h[(size_t)i * ORL_SCAL_WORDS + SC_FLAGS] >> 32);
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out) {
+  if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  std::vector<u64> h((size_t)b->P.bm_words);
+  HIPCHK(hipMemcpy(h.data(), b->P.bitmap + env * b->P.bm_words, h.size() * 8, hipMemcpyDeviceToHost));
+  const int W = b->wt, S = b->P.S, rows = b->P.C * b->P.E;
+  for (int r = 0; r < rows; r++)
+    for (int s = 0; s < S; s++) out[(size_t)r * S + s] = (uint8_t)((h[(size_t)r * W + (s >> 6)] >> (s & 63)) & 1ull);
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out) {
+  if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out, b->P.lstat + env * 4 * b->P.E, (size_t)4 * b->P.E * 8, hipMemcpyDeviceToHost));
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out) {
+  if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  u64 s[ORL_SCAL_WORDS];
+  HIPCHK(hipMemcpy(s, b->P.scal + env * ORL_SCAL_WORDS, sizeof s, hipMemcpyDeviceToHost));
+  out[0] = as_f64(s[SC_GTHR]); out[1] = as_f64(s[SC_GCOMP]); out[2] = as_f64(s[SC_GLAST]); out[3] = as_f64(s[SC_NOW]);
+  return ORL_OK;
+}
+extern "C" int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemsetAsync(b->d_totals, 0, 16, b->stream));
+  unsigned blocks = (unsigned)((b->P.B + 255) / 256);
+  hipLaunchKernelGGL(k_totals, dim3(blocks), dim3(256), 0, b->stream, b->P, b->d_totals);
+  unsigned long long h[2];
+  HIPCHK(hipMemcpyAsync(h, b->d_totals, 16, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (processed) *processed = (int64_t)h[0];
+  if (accepted) *accepted = (int64_t)h[1];
+  return ORL_OK;
+}

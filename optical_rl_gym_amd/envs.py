@@ -1,0 +1,389 @@
+"""Batched optical-network environments on MI355X: host-side mirror of the reference's env classes.
+
+Each class takes the reference constructor's kwargs (same names, same defaults, same derivations) plus
+`num_envs`, `seeds` and `device_id`, flattens them into the tables of include/orl.h and drives the HIP
+library through ctypes.  Env i of a batch behaves exactly like a reference env built with seed=seeds[i].
+
+reference constructors: optical_network_env.py:14-94, rmsa_env.py:29-161, deeprmsa_env.py:10-46,
+rwa_env.py:19-94, rmcsa_env.py:29-207.
+"""
+import ctypes as C
+import itertools
+import math
+import random
+
+import numpy as np
+
+from . import _lib
+from .topology import Topology
+
+POLICIES = {"SP_FF": 0, "SAP_FF": 1, "KSP_FF": 1, "LLP_FF": 2, "SAP_LF": 3, "SP": 0, "SAP": 1, "SAP_BM_FC_FF": 1}
+
+RMSA_INFO_KEYS = ["service_blocking_rate", "episode_service_blocking_rate", "bit_rate_blocking_rate",
+                  "episode_bit_rate_blocking_rate", "network_compactness", "network_compactness_difference",
+                  "avg_link_compactness", "avg_link_utilization"]
+COUNTER_NAMES = ["services_processed", "services_accepted", "episode_services_processed",
+                 "episode_services_accepted", "bit_rate_requested", "bit_rate_provisioned",
+                 "episode_bit_rate_requested", "episode_bit_rate_provisioned"]
+
+
+def mt_states(seeds):
+    """optical_network_env.py:205-210: rng = random.Random(seed or 41) -> [n][625] uint32 MT19937 state."""
+    out = np.empty((len(seeds), 625), np.uint32)
+    for i, s in enumerate(seeds):
+        out[i] = random.Random(41 if s is None else int(s)).getstate()[1]
+    return out
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class BatchedOpticalEnv:
+    """Common machinery; use one of the four family classes below."""
+
+    ENV_TYPE = None
+    N_ACTION = 2
+
+    # ---- construction --------------------------------------------------------------------------
+    def _setup(self, topology, num_envs, seeds, device_id, *, episode_length, load, mean_service_holding_time,
+               num_spectrum_resources, allow_rejection, node_request_probabilities, channel_width,
+               bit_rate_selection="continuous", bit_rates=(10, 40, 100), bit_rate_probabilities=None,
+               bit_rate_lower_bound=25, bit_rate_higher_bound=100, j=1, num_spatial_resources=1,
+               modulations=None, worst_xt=None, event_capacity=0):
+        self.lib = _lib.lib()
+        self.topology = Topology.load(topology) if isinstance(topology, str) else topology
+        t = self.topology
+        self.num_envs = int(num_envs)
+        if seeds is None:
+            seeds = [None] * self.num_envs
+        elif np.isscalar(seeds):
+            seeds = [int(seeds) + i for i in range(self.num_envs)]
+        assert len(seeds) == self.num_envs
+        self.seeds = list(seeds)
+        self.device_id = device_id
+        self.episode_length = episode_length
+        self.allow_rejection = bool(allow_rejection)
+        self.reject_action = 1 if allow_rejection else 0
+        self.num_spectrum_resources = num_spectrum_resources
+        self.num_spatial_resources = num_spatial_resources
+        self.k_paths = t.k_paths
+        self.channel_width = channel_width
+        self.j = j
+        # set_load (optical_network_env.py:76-94)
+        self.load = load
+        self.mean_service_holding_time = mean_service_holding_time
+        self.mean_service_inter_arrival_time = 1 / float(load / float(mean_service_holding_time))
+        lambda_a = 1 / self.mean_service_inter_arrival_time  # rmsa_env.py:548-550
+        lambda_h = 1 / self.mean_service_holding_time        # rmsa_env.py:553
+        # node pair tables (optical_network_env.py:68-74, 156-173)
+        N = t.n_nodes
+        if node_request_probabilities is None:
+            probs = np.full(N, fill_value=1.0 / N)
+        else:
+            probs = np.asarray(node_request_probabilities, dtype=np.float64)
+            assert len(probs) == N
+        self.node_request_probabilities = probs
+        cum_src = np.array(list(itertools.accumulate(probs)), np.float64)
+        cum_dst = np.zeros((N, N), np.float64)
+        for s in range(N):
+            w = np.copy(probs)
+            w[s] = 0.0
+            w = w / np.sum(w)
+            cum_dst[s] = list(itertools.accumulate(w))
+        # bit rates (rmsa_env.py:78-99)
+        self.bit_rate_selection = bit_rate_selection
+        mods = list(t.modulations if modulations is None else modulations)
+        self.modulation_formats = mods
+        M = len(mods)
+        if self.ENV_TYPE == 2:
+            table_rates, cum_br, mode = [0], None, 0
+            lo = hi = 0
+        elif bit_rate_selection == "continuous":
+            lo, hi = int(bit_rate_lower_bound), int(bit_rate_higher_bound)
+            assert lo == bit_rate_lower_bound and hi == bit_rate_higher_bound
+            table_rates, cum_br, mode = list(range(lo, hi + 1)), None, 0
+        else:
+            assert bit_rate_selection == "discrete"
+            if bit_rate_probabilities is None:
+                bit_rate_probabilities = [1.0 / len(bit_rates) for _ in range(len(bit_rates))]
+            assert len(bit_rates) == len(bit_rate_probabilities)
+            self.bit_rates = list(bit_rates)
+            self.bit_rate_probabilities = list(bit_rate_probabilities)
+            table_rates = [int(b) for b in bit_rates]
+            cum_br = np.array(list(itertools.accumulate(bit_rate_probabilities)), np.float64)
+            mode, lo, hi = 1, 0, 0
+        # get_number_slots (rmsa_env.py:610-621): ceil(bit_rate / (se * channel_width)) + 1
+        n_slots = np.zeros((len(table_rates), M), np.uint8)
+        if self.ENV_TYPE != 2:
+            for i, br in enumerate(table_rates):
+                for m, mod in enumerate(mods):
+                    n_slots[i, m] = math.ceil(br / (mod.spectral_efficiency * channel_width)) + 1
+        # RMCSA reach tables (_crosstalk_is_acceptable, rmcsa_env.py:341-384), evaluated with the reference's
+        # own float expressions for every (modulation, bit rate)
+        lmax_snr = lmax_xt = None
+        if self.ENV_TYPE == 3:
+            self.worst_xt = worst_xt
+            lmax_snr = np.zeros((M, len(table_rates)), np.float64)
+            lmax_xt = np.zeros(M, np.float64)
+            average_power = 1
+            nf_db = 5.5
+            nf = 10.0 ** (nf_db / 10.0)
+            amp_spam = 100
+            amp_gain_db = 20
+            amp_gain = 10.0 ** (amp_gain_db / 10.0)
+            lambda_ = 1550
+            h = 6.626068e-34
+            f_hz = 2.99e8 / (lambda_ * 1e-9)
+            for m, mod in enumerate(mods):
+                SNR_min_calc = 10 ** ((mod.minimum_osnr + 2) / 10)
+                for i, br in enumerate(table_rates):
+                    v = (average_power * amp_spam) / (
+                        SNR_min_calc * h * f_hz * amp_gain * nf * (br / mod.spectral_efficiency) * 1e9)
+                    lmax_snr[m, i] = v / 1000
+                lmax_xt[m] = 10 ** ((mod.inband_xt - worst_xt - 4) / 10)
+        path_mod = t.path_best_mod if modulations is None else t.path_modulation_for(mods)
+        # ---- hand everything to the C ABI ----
+        keep = dict(
+            n_paths=np.ascontiguousarray(t.n_paths, np.int32), path_hops=np.ascontiguousarray(t.path_hops, np.int32),
+            path_links=np.ascontiguousarray(t.path_links, np.int32),
+            path_length=np.ascontiguousarray(t.path_length, np.float64),
+            path_mod=np.ascontiguousarray(path_mod, np.int32),
+            edge_iter_order=np.ascontiguousarray(t.edge_iter_order, np.int32),
+            cum_src=cum_src, cum_dst=np.ascontiguousarray(cum_dst), bit_rates=np.array(table_rates, np.int32),
+            cum_br=cum_br, n_slots=np.ascontiguousarray(n_slots), lmax_snr=lmax_snr, lmax_xt=lmax_xt)
+        self._keep = keep
+        desc = _lib.TopologyDesc(t.n_nodes, t.n_links, t.k_paths, t.max_hops, M, _ptr(keep["n_paths"]),
+                                 _ptr(keep["path_hops"]), _ptr(keep["path_links"]), _ptr(keep["path_length"]),
+                                 _ptr(keep["path_mod"]), _ptr(keep["edge_iter_order"]))
+        self._topo_h = C.c_void_p()
+        _lib.check(self.lib.orl_topology_create(C.byref(desc), device_id, C.byref(self._topo_h)))
+        cfg = _lib.EnvConfig(self.ENV_TYPE, num_spectrum_resources, num_spatial_resources, episode_length,
+                             int(self.allow_rejection), j, mode, lo, hi, len(table_rates), event_capacity, 0,
+                             lambda_a, lambda_h, _ptr(cum_src), _ptr(keep["cum_dst"]), _ptr(keep["bit_rates"]),
+                             _ptr(cum_br), _ptr(keep["n_slots"]), _ptr(lmax_snr), _ptr(lmax_xt))
+        st = mt_states(self.seeds)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.orl_batch_create(C.byref(cfg), self._topo_h, self.num_envs, st.ctypes.data, C.byref(self._h)))
+        self.n_info = self.lib.orl_batch_info_dim(self._h)
+        self.obs_dim = self.lib.orl_batch_obs_dim(self._h)
+        n = self.num_envs
+        self._act = np.zeros((n, 4), np.int32)
+        self._reward = np.zeros(n, np.float64)
+        self._done = np.zeros(n, np.uint8)
+        self._info = np.zeros((n, self.n_info), np.float64)
+        self._obs = np.zeros((n, self.obs_dim), np.float64) if self.obs_dim else None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.orl_batch_destroy(self._h)
+            self._h = None
+        if getattr(self, "_topo_h", None):
+            self.lib.orl_topology_destroy(self._topo_h)
+            self._topo_h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the gym surface, batched ---------------------------------------------------------------
+    def reset(self, full=False, mask=None):
+        """reset(only_episode_counters = not full) for the envs selected by `mask` (default: all)."""
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        _lib.check(self.lib.orl_batch_reset(self._h, int(full), _ptr(m)))
+        return self.observation() if self.obs_dim else None
+
+    def policy(self, policy, fetch=True):
+        """On-device heuristic; returns [num_envs, 4] int32 actions (or None with fetch=False: they stay on
+        the GPU for the next step(None))."""
+        pid = POLICIES[policy] if isinstance(policy, str) else int(policy)
+        _lib.check(self.lib.orl_batch_policy(self._h, pid, self._act.ctypes.data if fetch else None))
+        return self._act if fetch else None
+
+    def step(self, actions, auto_reset=False, fetch=True):
+        """actions: [num_envs, n_action] ints, or None to use the device-resident result of policy(fetch=False).
+        Returns (obs, reward, done, info) arrays; info is [num_envs, n_info] in `info_keys` order."""
+        a = None
+        if actions is not None:
+            actions = np.asarray(actions)
+            if actions.ndim == 1:
+                actions = actions[:, None]
+            a = np.zeros((self.num_envs, 4), np.int32)
+            a[:, : actions.shape[1]] = actions
+        if fetch:
+            _lib.check(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), _ptr(self._obs), self._reward.ctypes.data,
+                                               self._done.ctypes.data, self._info.ctypes.data))
+            return self._obs, self._reward, self._done, self._info
+        _lib.check(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), None, None, None, None))
+        return None
+
+    def run(self, policy, n_steps, time_kernels=False):
+        """n_steps x (policy; step with auto reset) without leaving the device; returns RunStats."""
+        pid = POLICIES[policy] if isinstance(policy, str) else int(policy)
+        st = _lib.RunStats()
+        _lib.check(self.lib.orl_batch_run(self._h, pid, int(n_steps), int(time_kernels), C.byref(st)))
+        return st
+
+    def sync(self):
+        _lib.check(self.lib.orl_batch_sync(self._h))
+
+    def observation(self):
+        if not self.obs_dim:
+            return None
+        _lib.check(self.lib.orl_batch_observation(self._h, self._obs.ctypes.data))
+        return self._obs
+
+    # ---- state read-back -------------------------------------------------------------------------
+    def services(self):
+        out = np.zeros((self.num_envs, 6))
+        _lib.check(self.lib.orl_batch_get_services(self._h, out.ctypes.data))
+        return out
+
+    def counters(self):
+        out = np.zeros((self.num_envs, 8), np.int64)
+        _lib.check(self.lib.orl_batch_get_counters(self._h, out.ctypes.data))
+        return out
+
+    def slots(self, env=0):
+        out = np.zeros((self.num_spatial_resources, self.topology.n_links, self.num_spectrum_resources), np.uint8)
+        _lib.check(self.lib.orl_batch_get_slots(self._h, env, out.ctypes.data))
+        return out
+
+    def link_stats(self, env=0):
+        out = np.zeros((4, self.topology.n_links))
+        _lib.check(self.lib.orl_batch_get_link_stats(self._h, env, out.ctypes.data))
+        return out
+
+    def net_stats(self, env=0):
+        out = np.zeros(4)
+        _lib.check(self.lib.orl_batch_get_net_stats(self._h, env, out.ctypes.data))
+        return out
+
+    def active(self):
+        out = np.zeros(self.num_envs, np.int32)
+        _lib.check(self.lib.orl_batch_get_active(self._h, out.ctypes.data))
+        return out
+
+    def n_active(self, env=0):
+        return int(self.active()[env])
+
+    def flags(self):
+        out = np.zeros(self.num_envs, np.int32)
+        _lib.check(self.lib.orl_batch_get_flags(self._h, out.ctypes.data))
+        return out
+
+    def totals(self):
+        p, a = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.orl_batch_totals(self._h, C.byref(p), C.byref(a)))
+        return p.value, a.value
+
+
+class BatchedRMSAEnv(BatchedOpticalEnv):
+    """reference: RMSAEnv (rmsa_env.py:18-744); gym id "RMSA-v0"."""
+
+    ENV_TYPE = 0
+
+    def __init__(self, topology=None, num_envs=1, seeds=None, device_id=0, episode_length=1000, load=10,
+                 mean_service_holding_time=10800.0, num_spectrum_resources=100, bit_rate_selection="continuous",
+                 bit_rates=(10, 40, 100), bit_rate_probabilities=None, node_request_probabilities=None,
+                 bit_rate_lower_bound=25.0, bit_rate_higher_bound=100.0, seed=None, allow_rejection=False,
+                 reset=True, channel_width=12.5, event_capacity=0):
+        if seeds is None and seed is not None:
+            seeds = seed
+        self._setup(topology, num_envs, seeds, device_id, episode_length=episode_length, load=load,
+                    mean_service_holding_time=mean_service_holding_time,
+                    num_spectrum_resources=num_spectrum_resources, allow_rejection=allow_rejection,
+                    node_request_probabilities=node_request_probabilities, channel_width=channel_width,
+                    bit_rate_selection=bit_rate_selection, bit_rates=bit_rates,
+                    bit_rate_probabilities=bit_rate_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
+                    bit_rate_higher_bound=bit_rate_higher_bound, event_capacity=event_capacity)
+        self.info_keys = list(RMSA_INFO_KEYS)
+        if bit_rate_selection == "discrete":
+            self.info_keys += ["bit_rate_blocking_%s" % b for b in bit_rates] + ["fairness"]
+
+
+class BatchedDeepRMSAEnv(BatchedOpticalEnv):
+    """reference: DeepRMSAEnv (deeprmsa_env.py:9-132); gym id "DeepRMSA-v0"."""
+
+    ENV_TYPE = 1
+    N_ACTION = 1
+
+    def __init__(self, topology=None, num_envs=1, seeds=None, device_id=0, j=1, episode_length=1000,
+                 mean_service_holding_time=25.0, mean_service_inter_arrival_time=0.1, num_spectrum_resources=100,
+                 node_request_probabilities=None, seed=None, allow_rejection=False, event_capacity=0):
+        if seeds is None and seed is not None:
+            seeds = seed
+        self._setup(topology, num_envs, seeds, device_id, episode_length=episode_length,
+                    load=mean_service_holding_time / mean_service_inter_arrival_time,  # deeprmsa_env.py:25
+                    mean_service_holding_time=mean_service_holding_time,
+                    num_spectrum_resources=num_spectrum_resources, allow_rejection=allow_rejection,
+                    node_request_probabilities=node_request_probabilities, channel_width=12.5, j=j,
+                    event_capacity=event_capacity)
+        self.info_keys = list(RMSA_INFO_KEYS)
+
+
+class BatchedRWAEnv(BatchedOpticalEnv):
+    """reference: RWAEnv (rwa_env.py:15-400); gym id "RWA-v0"."""
+
+    ENV_TYPE = 2
+
+    def __init__(self, topology=None, num_envs=1, seeds=None, device_id=0, episode_length=1000, load=10,
+                 mean_service_holding_time=10800.0, num_spectrum_resources=80, node_request_probabilities=None,
+                 allow_rejection=True, seed=None, reset=True, channel_width=50.0, event_capacity=0):
+        if seeds is None and seed is not None:
+            seeds = seed
+        self._setup(topology, num_envs, seeds, device_id, episode_length=episode_length, load=load,
+                    mean_service_holding_time=mean_service_holding_time,
+                    num_spectrum_resources=num_spectrum_resources, allow_rejection=allow_rejection,
+                    node_request_probabilities=node_request_probabilities, channel_width=channel_width,
+                    event_capacity=event_capacity)
+        rej = self.reject_action
+        self.info_keys = (["service_blocking_rate", "episode_service_blocking_rate"]
+                          + ["path_action_probability[%d]" % i for i in range(self.k_paths + rej)]
+                          + ["wavelength_action_probability[%d]" % i for i in range(num_spectrum_resources + rej)])
+
+
+class BatchedRMCSAEnv(BatchedOpticalEnv):
+    """reference: RMCSAEnv (rmcsa_env.py:18-879); gym id "RMCSA-v0"."""
+
+    ENV_TYPE = 3
+    N_ACTION = 4
+
+    def __init__(self, topology=None, num_envs=1, seeds=None, device_id=0, episode_length=1000, load=10,
+                 mean_service_holding_time=10800.0, num_spectrum_resources=100, num_spatial_resources=7,
+                 modulation_formats=None, worst_xt=None, node_request_probabilities=None,
+                 bit_rate_selection="continuous", bit_rates=(10, 40, 100), bit_rate_probabilities=None,
+                 bit_rate_lower_bound=25, bit_rate_higher_bound=100, seed=None, allow_rejection=False, reset=True,
+                 channel_width=12.5, event_capacity=0):
+        import copy
+
+        if seeds is None and seed is not None:
+            seeds = seed
+        topo = Topology.load(topology) if isinstance(topology, str) else topology
+        mods = copy.deepcopy(list(topo.modulations if modulation_formats is None else modulation_formats))
+        if worst_xt is None:  # rmcsa_env.py:63-67, 119-122
+            worst_xt = {7: -84.7, 12: -61.9, 19: -54.8}.get(num_spatial_resources)
+        for m in mods:  # rmcsa_env.py:127-129: +4 dB margin on both limits
+            m.inband_xt += 4
+        worst_xt += 4
+        self._setup(topo, num_envs, seeds, device_id, episode_length=episode_length, load=load,
+                    mean_service_holding_time=mean_service_holding_time,
+                    num_spectrum_resources=num_spectrum_resources, allow_rejection=allow_rejection,
+                    node_request_probabilities=node_request_probabilities, channel_width=channel_width,
+                    bit_rate_selection=bit_rate_selection, bit_rates=bit_rates,
+                    bit_rate_probabilities=bit_rate_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
+                    bit_rate_higher_bound=bit_rate_higher_bound, num_spatial_resources=num_spatial_resources,
+                    modulations=mods, worst_xt=worst_xt, event_capacity=event_capacity)
+        self.info_keys = RMSA_INFO_KEYS[:4]
+
+
+ENV_CLASSES = {"RMSA": BatchedRMSAEnv, "DeepRMSA": BatchedDeepRMSAEnv, "RWA": BatchedRWAEnv, "RMCSA": BatchedRMCSAEnv,
+               "RMSA-v0": BatchedRMSAEnv, "DeepRMSA-v0": BatchedDeepRMSAEnv, "RWA-v0": BatchedRWAEnv,
+               "RMCSA-v0": BatchedRMCSAEnv}
+
+
+def make(env_id, **kwargs):
+    """gym.make analogue for the registry ids of optical_rl_gym/__init__.py:3-26."""
+    return ENV_CLASSES[env_id](**kwargs)
