@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of RMSA-v0 on NSFNET (320 slots, k=5, load 300 Erlang), batch 65 536
+envs per MI355X, on-device KSP-FF policy (BASELINE.json `metric`; SURVEY.md §8d cfg2 at B = 65 536).
+
+One "step" = one batched env.step() over the whole batch: the slot-scan (policy) kernel followed by the
+step kernel, launched back to back on the batch's stream; inputs are resident in HBM before the timed
+region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
+collective on the data path; torch.distributed is used only for the barrier and the max-over-ranks time).
+
+    python bench.py --gpus 1 --steps 300 --warmup 1500
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+WORKLOADS = {
+    # name: (env family, topology, kwargs, policy)
+    "cfg2": ("RMSA", "nsfnet_chen", dict(load=300, mean_service_holding_time=25, episode_length=1000,
+                                         num_spectrum_resources=320, allow_rejection=False), "SAP_FF"),
+    "cfg5": ("RMSA", "germany50", dict(load=800, mean_service_holding_time=25, episode_length=1000,
+                                       num_spectrum_resources=320, allow_rejection=False), "SAP_FF"),
+    "cfg3": ("DeepRMSA", "nsfnet_chen", dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=1.0 / 12.0,
+                                             j=1, episode_length=50), "SAP"),
+    "cfg4": ("RMCSA", "nsfnet_chen", dict(load=1500, mean_service_holding_time=25, episode_length=1000,
+                                          num_spectrum_resources=320, num_spatial_resources=7,
+                                          allow_rejection=True), "SAP_BM_FC_FF"),
+    "cfg1": ("RWA", "nsfnet_chen", dict(load=450, mean_service_holding_time=25, episode_length=1000,
+                                        allow_rejection=True), "SAP_FF"),
+}
+
+
+def algorithmic_bytes(env, mean_hops, active):
+    """bytes an env-step has to move, per env.
+    scan = C*E*W*8 + 24 (one read of the packed link x slot map + 16 B service descriptor + 8 B action)
+    step = scan + 32*H + 128*H + 64*ceil(log2 A) + 116 + 128 + 81"""
+    C, E, S = env.num_spatial_resources, env.topology.n_links, env.num_spectrum_resources
+    W = (S + 63) // 64
+    scan = C * E * W * 8 + 24
+    rest = 32 * mean_hops + 128 * mean_hops + 64 * math.ceil(math.log2(max(active, 2))) + 116 + 128 + 81
+    if env.obs_dim:
+        rest += 8 * env.obs_dim
+    return scan, rest
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=1500)
+    ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    import optical_rl_gym_amd as orl
+
+    fam, topo, kw, policy = WORKLOADS[args.workload]
+    B = args.batch
+    seeds = [10 + rank * B + i for i in range(B)]  # seed_i = 10 + global env index
+    env = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, device_id=local_rank, **kw)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        env.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    env.run(policy, args.warmup)  # untimed: brings every env to its steady-state occupancy
+    barrier()
+    t0 = time.perf_counter()
+    env.run(policy, args.steps)   # EXACTLY K steps: K x (slot-scan kernel ; step kernel) on the stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations of the same loop, each launch bracketed by HIP events on the batch's stream
+    st = env.run(policy, min(args.steps, 200), time_kernels=True)
+    active = float(env.active().mean())
+    processed, accepted = env.totals()
+    t = env.topology
+    h0 = t.path_hops[:, :, 0]
+    mean_hops = float(h0[h0 > 0].mean())
+    scan_b, rest_b = algorithmic_bytes(env, mean_hops, active)
+    kernels = {
+        "slot_scan(k_policy)": dict(ms=st.ms_policy, bytes=scan_b * B),
+        "step(k_step)": dict(ms=st.ms_step, bytes=rest_b * B),
+    }
+    roof = {}
+    for name, k in kernels.items():
+        ach = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+        roof[name] = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                          frac=round(ach / HBM_PEAK_GBS, 5), traffic=None, us_per_launch=round(k["ms"] * 1e3, 2),
+                          algorithmic_bytes_per_launch=int(k["bytes"]))
+    dominant = max(kernels, key=lambda n: kernels[n]["ms"])
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import OracleBatch
+
+        n_cpu, warm, timed = 64, 1500, 2500
+        ora = OracleBatch(fam, topo, seeds[:n_cpu], **kw)
+        ora.run(policy, warm)
+        c0 = time.perf_counter()
+        ora.run(policy, timed)
+        cdt = time.perf_counter() - c0
+        cpu = dict(value=round(n_cpu * timed / cdt, 1), unit="env-steps/s", cores=1, kind="port",
+                   sample="%d envs x %d steps after %d warm-up steps, same workload and seeds, oracle/orl_oracle.c, 1 thread"
+                          % (n_cpu, timed, warm))
+
+    if rank == 0:
+        total_steps = B * world * args.steps
+        out = {
+            "metric": "env-steps/sec RMSA-v0 NSFNET batch 65536" if args.workload == "cfg2" and B == 65536
+                      else "env-steps/sec %s" % args.workload,
+            "value": round(total_steps / elapsed, 1),
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 bitmaps + f64 statistics",
+            "data": "synthetic",
+            "config": {"workload": "%s: %s-v0 %s, %d slots, k=%d, batch %d envs/GPU, on-device %s policy, seeds 10+i"
+                                   % (args.workload, fam, topo, env.num_spectrum_resources, env.k_paths, B, policy),
+                       "envs_per_gpu": B, "kernels_per_step": 2},
+            "roofline": dict(roof[dominant], kernel=dominant),
+            "roofline_by_kernel": roof,
+            "cpu_baseline": cpu,
+            "state": {"mean_active_services": round(active, 1),
+                      "blocking": round(1.0 - accepted / max(processed, 1), 5)},
+        }
+        print(json.dumps(out))
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
