@@ -70,6 +70,8 @@ struct DevParams {
   const unsigned char* nslots;      // [n_br*M] ceil(bit_rate/(se*channel_width))+1
   const double* lmax_snr;           // [M*n_br] RMCSA reach limits
   const double* lmax_xt;            // [M]
+  const unsigned char* path_rec;    // [N*N*K][32]  {hops, modulation, link[30]}: one 32-B record per path
+  const unsigned char* nslots_path; // [N*N*K][n_br] slots needed on that path (its best modulation) per bit rate
   // per-env state (struct-of-arrays over envs)
   u64* bitmap;      // [B][bm_words]      bm_words = C*E*W rounded up to a multiple of 2
   double* ev_time;  // [B][ev_cap]        +inf = empty slot
@@ -77,6 +79,7 @@ struct DevParams {
   u32* mt;          // [B][624]           update-behind MT19937 state
   double* lstat;    // [B][4][E]          utilization, external_fragmentation, compactness, last_update
   u64* scal;        // [B][32]
+  u64* svc_desc;    // [B]  pending service for the slot-scan kernel: pair_base:32 | br_idx:16 | n_paths:8
   int* core_sums;   // [B][2*C]           per core: sum(lambda_max-lambda_min), sum(free blocks inside)
   i64* br_hist;     // [B][2*n_br]        discrete mode: requested / provisioned histograms
   i64* act_hist;    // [B][(K+1)+(S+1)]   RWA: marginals of actions_output
@@ -342,6 +345,10 @@ __device__ __forceinline__ void env_store(const DevParams& P, const Env& e, int 
 #undef PUTF
 #undef PUTI
   if (lane < SC_COUNT) P.scal[e.env * ORL_SCAL_WORDS + lane] = v;
+  if (lane == 0) {
+    u64 np_ = (u64)(u32)P.n_paths[e.src * P.N + e.dst];
+    P.svc_desc[e.env] = (u64)(u32)((e.src * P.N + e.dst) * P.K) | ((u64)(u32)e.br_idx << 32) | (np_ << 48);
+  }
 }
 
 // stage the env's slot map, link statistics and per-core sums into this wave's LDS window
@@ -746,59 +753,103 @@ __device__ __forceinline__ double link_mean(const DevParams& P, const double* va
 }
 
 // ---------------------------------------------------------------------------------------------
-// heuristics (the policy side): returns the action in a[0..3]
+// heuristics (the policy side) — the slot-scan.
+//
+// GS lanes cooperate on one env (GS = 8: eight envs per wavefront, lanes = paths; GS = 64: one env per
+// wavefront, lanes = (path, core) pairs for RMCSA).  Each lane ANDs the link rows of its path out of the
+// LDS-staged slot map, detects runs of >= n free slots by log-step shift-AND and reports its first fit;
+// a group ballot picks the path.  `bm` is this env's map in LDS.
 // ---------------------------------------------------------------------------------------------
-template <int ENV, int W>
-__device__ __forceinline__ void policy(const DevParams& P, const Env& e, int lane, int pol, int* a) {
+template <int GS> __device__ __forceinline__ u64 group_ballot(bool p, int lane) {
+  u64 b = __ballot(p);
+  if (GS == 64) return b;
+  return (b >> ((lane / GS) * GS)) & ((1ull << (GS & 63)) - 1ull);
+}
+template <int GS> __device__ __forceinline__ int group_max(int v) {
+#pragma unroll
+  for (int o = GS / 2; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+template <int GS> __device__ __forceinline__ int group_get(int v, int src, int lane) { return __shfl(v, (lane & ~(GS - 1)) + src, 64); }
+
+// 32-byte path record: byte 0 hops, byte 1 modulation, bytes 2.. link per hop
+struct PathRec { u64 q[4]; };
+__device__ __forceinline__ PathRec path_rec_load(const DevParams& P, int pidx) {
+  const ulonglong2* r = (const ulonglong2*)(P.path_rec + (size_t)pidx * 32);
+  ulonglong2 a = r[0], b = r[1];
+  PathRec o;
+  o.q[0] = a.x; o.q[1] = a.y; o.q[2] = b.x; o.q[3] = b.y;
+  return o;
+}
+__device__ __forceinline__ int path_rec_byte(const PathRec& r, int i) {
+  int w = i >> 3;
+  u64 v = w == 0 ? r.q[0] : (w == 1 ? r.q[1] : (w == 2 ? r.q[2] : r.q[3]));
+  return (int)((v >> ((i & 7) * 8)) & 0xffull);
+}
+template <int W>
+__device__ __forceinline__ Row<W> path_and_rec(const PathRec& r, const u64* bm, int E, int S, int core) {
+  Row<W> m = row_mask_lo<W>(S);
+  const int hops = path_rec_byte(r, 0);
+  for (int h = 0; h < hops; h++) {
+    int link = path_rec_byte(r, 2 + h);
+    m = row_and<W>(m, row_load<W>(bm + (core * E + link) * W));
+  }
+  return m;
+}
+
+template <int ENV, int W, int GS>
+__device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool valid, int pb, int br_idx, int np_,
+                                         int lane, int pol, int* a) {
   const int K = P.K, S = P.S;
-  const int np_ = P.n_paths[e.src * P.N + e.dst];
-  const int pb = pair_base(P, e.src, e.dst);
+  const int p = lane & (GS - 1);
   a[0] = a[1] = a[2] = a[3] = 0;
   if (ENV == ENV_RMSA) {
-    // lanes = paths.  KSP first-fit incl. the reference's off-by-one: start slots 0 .. S-n-1 only
+    // KSP first-fit incl. the reference's off-by-one: start slots 0 .. S-n-1 only (rmsa_env.py:774-776)
     a[0] = K; a[1] = S;
     int slot = -1, freec = 0;
     int limit = (pol == POL_SP_FF) ? 1 : np_;
-    if (lane < limit) {
-      int pidx = pb + lane;
-      Row<W> m = path_and<W>(P, e, pidx, 0);
-      int n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+    if (valid && p < limit) {
+      int pidx = pb + p;
+      PathRec rec = path_rec_load(P, pidx);
+      int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
+      Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
       Row<W> cand = row_and<W>(row_runs_ge<W>(m, n), row_mask_lo<W>(S - n));
       if (row_any<W>(cand)) { slot = row_ctz<W>(cand); freec = row_popc<W>(m); }
     }
-    u64 fit = __ballot(slot >= 0);
-    if (fit) {
-      int best = (int)__builtin_ctzll(fit);
-      if (pol == POL_LLP_FF) {  // most free slots on the AND-row, first path wins ties (strict >)
-        int mx = wave_max(slot >= 0 ? freec : -1);
-        best = (int)__builtin_ctzll(__ballot(slot >= 0 && freec == mx));
-        if (mx <= 0) best = -1;  // free_slots > max_free_slots with max_free_slots = 0 initially
-      }
-      if (best >= 0) { a[0] = best; a[1] = __shfl(slot, best, 64); }
+    u64 fit = group_ballot<GS>(slot >= 0, lane);
+    int best = fit ? (int)__builtin_ctzll(fit) : -1;
+    if (pol == POL_LLP_FF) {  // most free slots on the AND-row, first path wins ties (strict >)
+      int mx = group_max<GS>(slot >= 0 ? freec : -1);
+      u64 bb = group_ballot<GS>(slot >= 0 && freec == mx, lane);
+      best = (bb && mx > 0) ? (int)__builtin_ctzll(bb) : -1;
     }
+    int bslot = group_get<GS>(slot, best < 0 ? 0 : best, lane);
+    if (best >= 0) { a[0] = best; a[1] = bslot; }
   } else if (ENV == ENV_DEEPRMSA) {
     a[0] = K * P.J;
     bool has = false;
     int limit = (pol == POL_SP_FF) ? 1 : np_;
-    if (lane < limit) {
-      int pidx = pb + lane;
-      Row<W> m = path_and<W>(P, e, pidx, 0);
-      int n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+    if (valid && p < limit) {
+      int pidx = pb + p;
+      PathRec rec = path_rec_load(P, pidx);
+      int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
+      Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
       has = row_any<W>(row_runs_ge<W>(m, n));
     }
-    u64 fit = __ballot(has);
+    u64 fit = group_ballot<GS>(has, lane);
     if (pol == POL_SP_FF) a[0] = (!P.allow_rejection || fit) ? 0 : K * P.J;
     else if (fit) a[0] = (int)__builtin_ctzll(fit) * P.J;
   } else if (ENV == ENV_RWA) {
     a[0] = K; a[1] = S;
     int slot = -1, cap = 0, hops = 0;
     int limit = (pol == POL_SP_FF) ? 1 : np_;
-    if (lane < limit) {
-      int pidx = pb + lane;
-      Row<W> m = path_and<W>(P, e, pidx, 0);
-      hops = P.path_hops[pidx];
+    if (valid && p < limit) {
+      int pidx = pb + p;
+      PathRec rec = path_rec_load(P, pidx);
+      Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
+      hops = path_rec_byte(rec, 0);
       cap = row_popc<W>(m);
-      if (pol == POL_SAP_LF) {  // range(S-1, 0, -1): wavelength 0 is never tried
+      if (pol == POL_SAP_LF) {  // range(S-1, 0, -1): wavelength 0 is never tried (rwa_env.py:473)
         Row<W> c = row_andn<W>(m, row_mask_lo<W>(1));
         if (row_any<W>(c)) slot = row_bitlen<W>(c) - 1;
       } else if (row_any<W>(m)) {
@@ -807,39 +858,43 @@ __device__ __forceinline__ void policy(const DevParams& P, const Env& e, int lan
     }
     int best = -1;
     if (pol == POL_SP_FF) {
-      best = (__ballot(slot >= 0) & 1ull) ? 0 : -1;
+      best = (group_ballot<GS>(slot >= 0, lane) & 1ull) ? 0 : -1;
     } else if (pol == POL_LLP_FF) {
-      // for idp: cap = capacity(path); if cap > best_load: (first-fit exists iff cap > 0) -> take it.
-      // best_load starts at -DBL_MAX, so a path with cap == 0 passes the test but finds no wavelength.
-      int mx = wave_max(slot >= 0 ? cap : -1);
-      if (mx > 0) best = (int)__builtin_ctzll(__ballot(slot >= 0 && cap == mx));
+      // cap > best_load with best_load = -DBL_MAX initially: the first path with the largest positive capacity
+      int mx = group_max<GS>(slot >= 0 ? cap : -1);
+      u64 bb = group_ballot<GS>(slot >= 0 && cap == mx, lane);
+      if (mx > 0 && bb) best = (int)__builtin_ctzll(bb);
     } else {
       // fewest hops among the paths that have a free wavelength; earlier path wins ties (strict <)
-      int mh = -wave_max(slot >= 0 ? -hops : -(1 << 20));
-      u64 bb = __ballot(slot >= 0 && hops == mh);
+      int mh = -group_max<GS>(slot >= 0 ? -hops : -(1 << 20));
+      u64 bb = group_ballot<GS>(slot >= 0 && hops == mh, lane);
       if (bb) best = (int)__builtin_ctzll(bb);
     }
-    if (best >= 0) { a[0] = best; a[1] = __shfl(slot, best, 64); }
+    int bslot = group_get<GS>(slot, best < 0 ? 0 : best, lane);
+    if (best >= 0) { a[0] = best; a[1] = bslot; }
   } else if (ENV == ENV_RMCSA) {
-    // lanes = (path, core) pairs in the reference's loop order: path-major, then core
+    // lanes = (path, core) pairs in the reference's loop order: path-major, then core (rmcsa_env.py:889-906)
     a[0] = K; a[1] = P.M; a[2] = P.C; a[3] = S;
     int best = -1, bslot = 0;
-    for (int base = 0; base < np_ * P.C && best < 0; base += 64) {
-      int q = base + lane, slot = -1;
-      if (q < np_ * P.C) {
+    for (int base = 0; base < np_ * P.C && best < 0; base += GS) {
+      int q = base + p, slot = -1;
+      if (valid && q < np_ * P.C) {
         int pth = q / P.C, core = q - pth * P.C;
         int pidx = pb + pth;
-        Row<W> m = path_and<W>(P, e, pidx, core);
-        int n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+        PathRec rec = path_rec_load(P, pidx);
+        int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
+        Row<W> m = path_and_rec<W>(rec, bm, P.E, S, core);
         Row<W> cand = row_and<W>(row_runs_ge<W>(m, n), row_mask_lo<W>(S - n));
         if (row_any<W>(cand)) slot = row_ctz<W>(cand);
       }
-      u64 fit = __ballot(slot >= 0);
-      if (fit) { int l = (int)__builtin_ctzll(fit); best = base + l; bslot = __shfl(slot, l, 64); }
+      u64 fit = group_ballot<GS>(slot >= 0, lane);
+      int l = fit ? (int)__builtin_ctzll(fit) : 0;
+      int sl = group_get<GS>(slot, l, lane);
+      if (fit) { best = base + l; bslot = sl; }
     }
     if (best >= 0) {
       int pth = best / P.C;
-      a[0] = pth; a[1] = P.path_mod[pb + pth]; a[2] = best - pth * P.C; a[3] = bslot;
+      a[0] = pth; a[1] = P.path_rec[(size_t)(pb + pth) * 32 + 1]; a[2] = best - pth * P.C; a[3] = bslot;
     }
   }
 }

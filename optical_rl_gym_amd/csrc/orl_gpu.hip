@@ -96,23 +96,32 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
   env_store(P, e, lane);
 }
 
-template <int ENV, int W>
-__global__ void __launch_bounds__(64) k_policy(DevParams P, int pol) {
-  const i64 env = blockIdx.x;
-  const int lane = lane_id();
-  Env e;
-  env_load(P, e, env, lane);
-  u64* lds = (u64*)orl_lds_raw;
-  e.bm = lds;
+// Slot-scan kernel.  GS lanes per env: a wavefront serves 64/GS envs whose slot maps are contiguous in HBM,
+// so staging them into LDS is one fully coalesced stream of 16-B-per-lane loads (1 KiB per instruction).
+// Workgroup = 4 wavefronts, each with its own LDS window; no workgroup-level synchronisation is needed.
+template <int ENV, int W, int GS>
+__global__ void __launch_bounds__(256) k_policy(DevParams P, int pol) {
+  constexpr int EPW = 64 / GS;  // envs per wavefront
+  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+  const i64 env0 = ((i64)blockIdx.x * 4 + wave) * EPW;
+  if (env0 >= P.B) return;
+  u64* lds = (u64*)orl_lds_raw + (size_t)wave * EPW * P.bm_words;
   {
-    const ulonglong2* g = (const ulonglong2*)(P.bitmap + env * P.bm_words);
+    i64 nenv = P.B - env0 < EPW ? P.B - env0 : EPW;
+    const int n16 = (int)(nenv * (P.bm_words / 2));
+    const ulonglong2* g = (const ulonglong2*)(P.bitmap + env0 * P.bm_words);
     ulonglong2* l = (ulonglong2*)lds;
-    for (int i = lane; i < P.bm_words / 2; i += 64) l[i] = g[i];
+    for (int i = lane; i < n16; i += 64) l[i] = g[i];
   }
+  const int grp = lane / GS;
+  const i64 env = env0 + grp;
+  const bool valid = env < P.B;
+  u64 d = valid ? P.svc_desc[env] : 0ull;
   wave_fence();
   int a[4];
-  policy<ENV, W>(P, e, lane, pol, a);
-  if (lane == 0) *(int4*)(P.actions + env * 4) = make_int4(a[0], a[1], a[2], a[3]);
+  policy_g<ENV, W, GS>(P, lds + (size_t)grp * P.bm_words, valid, (int)(u32)d, (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu),
+                       lane, pol, a);
+  if (valid && (lane & (GS - 1)) == 0) *(int4*)(P.actions + env * 4) = make_int4(a[0], a[1], a[2], a[3]);
 }
 
 template <int ENV, int W>
@@ -173,6 +182,7 @@ static int fail(int code, const char* fmt, ...) {
 struct orl_topology {
   int device;
   int N, E, K, H, M;
+  std::vector<int32_t> h_hops, h_links, h_mod;  // host copies (per-batch derived tables are built from them)
   int* n_paths;
   unsigned char* path_hops;
   short* path_links;
@@ -215,7 +225,8 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
     return fail(ORL_E_INVALID, "topology out of supported range (N<=512, E<=128, k<=64, hops<=64)");
   HIPCHK(hipSetDevice(device_id));
   orl_topology* t = new orl_topology();
-  memset(t, 0, sizeof *t);
+  t->n_paths = nullptr; t->path_hops = nullptr; t->path_links = nullptr; t->path_mod = nullptr;
+  t->path_length = nullptr; t->edge_iter_order = nullptr;
   t->device = device_id;
   t->N = d->n_nodes; t->E = d->n_links; t->K = d->k_paths; t->H = d->max_hops; t->M = d->n_modulations;
   size_t nn = (size_t)t->N * t->N, npk = nn * t->K;
@@ -223,9 +234,13 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
     if (d->path_hops[i] > t->H || (d->path_modulation[i] >= t->M)) { delete t; return fail(ORL_E_INVALID, "bad path table entry %zu", i); }
   for (size_t i = 0; i < npk * t->H; i++)
     if (d->path_links[i] >= t->E) { delete t; return fail(ORL_E_INVALID, "bad link index in path table"); }
+  if (t->H > 30) { delete t; return fail(ORL_E_INVALID, "max_hops must be <= 30"); }
   int rc = 0;
   std::vector<int32_t> mod(npk);
   for (size_t i = 0; i < npk; i++) mod[i] = d->path_modulation[i] < 0 ? 0 : d->path_modulation[i];
+  t->h_hops.assign(d->path_hops, d->path_hops + npk);
+  t->h_links.assign(d->path_links, d->path_links + npk * t->H);
+  t->h_mod = mod;
   rc |= upload_conv(&t->n_paths, d->n_paths, nn, nullptr);
   rc |= upload_conv(&t->path_hops, d->path_hops, npk, nullptr);
   rc |= upload_conv(&t->path_links, d->path_links, npk * t->H, nullptr);
@@ -271,9 +286,15 @@ static void launch_reset(orl_batch* b, int full, const unsigned char* dmask) {
 #undef CALLW
 }
 static void launch_policy(orl_batch* b, int pol) {
-  dim3 g((unsigned)b->P.B), blk(64);
-  size_t lds = (size_t)b->P.bm_words * 8;
-#define CALLW(WW) hipLaunchKernelGGL((k_policy<EE, WW>), g, blk, lds, b->stream, b->P, pol)
+  // RMCSA scans (path, core) pairs: one env per wavefront.  The other families put 8 envs on a wavefront when k <= 8.
+  const bool wide = (b->P.env_type == ENV_RMCSA) || b->P.K > 8;
+  const int epw = wide ? 1 : 8;
+  const i64 per_wg = 4 * epw;
+  dim3 g((unsigned)((b->P.B + per_wg - 1) / per_wg)), blk(256);
+  size_t lds = (size_t)per_wg * b->P.bm_words * 8;
+#define CALLW(WW) \
+  do { if (wide) hipLaunchKernelGGL((k_policy<EE, WW, 64>), g, blk, lds, b->stream, b->P, pol); \
+       else hipLaunchKernelGGL((k_policy<EE, WW, 8>), g, blk, lds, b->stream, b->P, pol); } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
   ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
@@ -377,7 +398,23 @@ extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, 
     if (c->lmax_snr) { rc |= upload_conv(&p, c->lmax_snr, (size_t)P.n_br * P.M, &b->allocs); P.lmax_snr = p; }
     if (c->lmax_xt) { rc |= upload_conv(&p, c->lmax_xt, (size_t)P.M, &b->allocs); P.lmax_xt = p; }
   }
+  {
+    // derived shared tables: 32-B path records and slots-per-path-per-bit-rate
+    size_t npk = (size_t)P.N * P.N * P.K;
+    std::vector<unsigned char> rec(npk * 32, 0), nsp(npk * (size_t)P.n_br, 1);
+    for (size_t i = 0; i < npk; i++) {
+      rec[i * 32 + 0] = (unsigned char)t->h_hops[i];
+      rec[i * 32 + 1] = (unsigned char)t->h_mod[i];
+      for (int h = 0; h < t->h_hops[i]; h++) rec[i * 32 + 2 + h] = (unsigned char)t->h_links[i * P.H + h];
+      if (c->n_slots)
+        for (int r = 0; r < P.n_br; r++) nsp[i * P.n_br + r] = c->n_slots[(size_t)r * P.M + t->h_mod[i]];
+    }
+    unsigned char* u;
+    rc |= upload_conv(&u, rec.data(), rec.size(), &b->allocs); P.path_rec = u;
+    rc |= upload_conv(&u, nsp.data(), nsp.size(), &b->allocs); P.nslots_path = u;
+  }
   size_t B = (size_t)n_envs;
+  rc |= dalloc(b, &P.svc_desc, B);
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
   rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
   rc |= dalloc(b, &P.ev_info, B * P.ev_cap);
