@@ -448,6 +448,31 @@ __device__ __forceinline__ int rng_choice(Env& e, Rng& r, int lane, const double
   return cnt;
 }
 
+// 32-byte path record: byte 0 hops, byte 1 modulation, bytes 2.. link per hop
+struct PathRec { u64 q[4]; };
+__device__ __forceinline__ PathRec path_rec_load(const DevParams& P, int pidx) {
+  const ulonglong2* r = (const ulonglong2*)(P.path_rec + (size_t)pidx * 32);
+  ulonglong2 a = r[0], b = r[1];
+  PathRec o;
+  o.q[0] = a.x; o.q[1] = a.y; o.q[2] = b.x; o.q[3] = b.y;
+  return o;
+}
+__device__ __forceinline__ int path_rec_byte(const PathRec& r, int i) {
+  int w = i >> 3;
+  u64 v = w == 0 ? r.q[0] : (w == 1 ? r.q[1] : (w == 2 ? r.q[2] : r.q[3]));
+  return (int)((v >> ((i & 7) * 8)) & 0xffull);
+}
+template <int W>
+__device__ __forceinline__ Row<W> path_and_rec(const PathRec& r, const u64* bm, int E, int S, int core) {
+  Row<W> m = row_mask_lo<W>(S);
+  const int hops = path_rec_byte(r, 0);
+  for (int h = 0; h < hops; h++) {
+    int link = path_rec_byte(r, 2 + h);
+    m = row_and<W>(m, row_load<W>(bm + (core * E + link) * W));
+  }
+  return m;
+}
+
 // ---------------------------------------------------------------------------------------------
 // shared helpers on the env state
 // ---------------------------------------------------------------------------------------------
@@ -460,84 +485,164 @@ __device__ __forceinline__ double net_compactness(const DevParams& P, const Env&
   return 1.0;
 }
 
-// _update_link_stats on the row `a` (already modified) of `link`; lane-private work
-template <int ENV, int W>
-__device__ __forceinline__ void link_stats_update(const DevParams& P, Env& e, int link, const Row<W>& a) {
-  const int E = P.E, S = P.S;
-  double last_update = e.ls[3 * E + link];
-  double time_diff = e.now - last_update;
-  if (e.now > 0) {
-    int free_ = row_popc<W>(a);
-    double cur_util = (double)(S - free_) / (double)S;
-    e.ls[link] = ((e.ls[link] * last_update) + (cur_util * time_diff)) / e.now;
-    if (ENV != ENV_RWA) {
-      double cur_frag = 0.0, cur_comp = 0.0;
-      if (free_ > 0) {
-        Row<W> used = row_andn<W>(row_mask_lo<W>(S), a);
-        int nf = row_popc<W>(row_starts<W>(a));
-        int nu = row_popc<W>(row_starts<W>(used));
-        bool edge_free = (a.w[0] & 1ull) && ((a.w[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull);
-        int max_empty = 0;
-        if (nf > 1 && !(nf == 2 && edge_free)) max_empty = row_longest_run<W>(a);
-        cur_frag = 1.0 - ((double)max_empty / (double)free_);
-        if (nu > 1) {
-          int lo = row_ctz<W>(used), hi = row_bitlen<W>(used);
-          cur_comp = ((double)(hi - lo) / (double)(S - free_)) * (1.0 / (double)nu);
-        } else {
-          cur_comp = 1.0;
-        }
-      }
-      e.ls[E + link] = ((e.ls[E + link] * last_update) + (cur_frag * time_diff)) / e.now;
-      e.ls[2 * E + link] = ((e.ls[2 * E + link] * last_update) + (cur_comp * time_diff)) / e.now;
-    }
-  }
-  e.ls[3 * E + link] = e.now;
+// ---- (row, word) lane layout -------------------------------------------------------------------
+// Provision / release touch up to 8 link rows at once: lane = 8*r + w holds 64-bit word w of the r-th
+// link row of the path, so every per-row quantity (popcounts, run starts, lambda_min/max, longest free
+// run) is a handful of single-word instructions plus a 3-step reduction over the 8 lanes of the row.
+__device__ __forceinline__ int g8_sum(int v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; }
+__device__ __forceinline__ int g8_min(int v) {
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ int g8_max(int v) {
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+// value held by the previous lane of the 8-lane row group (lane w-1); `dflt` for w == 0
+__device__ __forceinline__ int g8_prev(int v, int w, int dflt) { int t = __shfl_up(v, 1, 8); return w == 0 ? dflt : t; }
+__device__ __forceinline__ u64 word_mask_lo(int c) { return c >= 64 ? ~0ull : (c <= 0 ? 0ull : ((1ull << c) - 1ull)); }
+// bits [lo, hi) of a 64-bit word, lo/hi relative to the word and unclamped
+__device__ __forceinline__ u64 word_range(int lo, int hi) {
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > 64 ? 64 : hi;
+  return hi <= lo ? 0ull : (word_mask_lo(hi - lo) << lo);
 }
 
-// set (release) or clear (provision) slots [s0, s0+n) on every link of the path; lanes = hops.
-// Maintains the per-core integer sums and runs the per-link statistics, like the reference's
-// per-link loop in _provision_path / _release_path.
+struct RowStat { int free_, nf, nu, lo, hi, occ, fb; };
+
+// a = word w of the row (0 for w >= W).  All 8 lanes of the row group return the same RowStat.
+template <int W, bool FULL>
+__device__ __forceinline__ void row_stat(u64 a, int w, int S, RowStat& st) {
+  const u64 maskw = (w < W) ? word_mask_lo(S - 64 * w) : 0ull;
+  const u64 used = ~a & maskw;
+  const int prev_top = g8_prev((int)(a >> 63), w, 1);  // bit 63 of word w-1 of `a`; w == 0: "used" to the left of slot 0
+  const u64 carry_a = (w == 0) ? 0ull : (u64)prev_top;
+  const u64 carry_u = (w == 0) ? 0ull : (u64)(prev_top ^ 1);  // slot 64w-1 < S for every w < W
+  const u64 st_u = used & ~((used << 1) | carry_u);
+  st.nu = g8_sum(__popcll(st_u));
+  int lo_l = used ? 64 * w + (int)__builtin_ctzll(used) : (1 << 20);
+  int hi_l = used ? 64 * w + 64 - (int)__builtin_clzll(used) : 0;
+  st.lo = g8_min(lo_l);
+  st.hi = g8_max(hi_l);
+  const bool two = st.nu > 1;
+  st.occ = two ? st.hi - st.lo : 0;
+  // free blocks strictly inside [lambda_min, lambda_max)
+  const u64 in = two ? (a & word_range(st.lo - 64 * w, st.hi - 64 * w)) : 0ull;
+  const u64 carry_i = (w > 0 && prev_top && (64 * w - 1 >= st.lo) && (64 * w - 1 < st.hi)) ? 1ull : 0ull;
+  st.fb = g8_sum(__popcll(in & ~((in << 1) | carry_i)));
+  if (FULL) {
+    st.free_ = g8_sum(__popcll(a));
+    st.nf = g8_sum(__popcll(a & ~((a << 1) | carry_a)));
+  }
+}
+
+// longest run of ones across the row (runs continue across word boundaries)
+template <int W>
+__device__ __forceinline__ int row_longest_run8(u64 a, int w) {
+  const bool full = (a == ~0ull);
+  const int lead = full ? 64 : (int)__builtin_ctzll(~a);
+  const int trail = full ? 64 : (int)__builtin_clzll(~a);
+  const int inner = word_longest_run(a);
+  const int pf = g8_prev(full ? 1 : 0, w, 0), pt = g8_prev(trail, w, 0);
+  int c = 0;  // length of the run of ones that ends exactly at the boundary below word w
+#pragma unroll
+  for (int it = 1; it < W; it++) {
+    int pc = g8_prev(c, w, 0);
+    c = (w == 0) ? 0 : (pf ? pc + 64 : pt);
+  }
+  int cand = full ? c + 64 : ((c + lead) > inner ? (c + lead) : inner);
+  if (w >= W) cand = 0;
+  return g8_max(cand);
+}
+
+// set (release) or clear (provision) slots [s0, s0+n) on every link of the path, then do what the
+// reference's per-link loop does (_provision_path rmsa_env.py:381-396, _release_path :417-436):
+// _update_link_stats (rmsa_env.py:464-543) per touched link, plus the integer sums behind
+// _get_network_compactness.  Returns the path's hop count.
 template <int ENV, int W>
-__device__ __forceinline__ void path_apply(const DevParams& P, Env& e, int lane, int pidx, int core, int s0, int n, bool release) {
-  const int hops = P.path_hops[pidx];
+__device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, int pidx, int core, int s0, int n, bool release) {
+  const PathRec rec = path_rec_load(P, pidx);
+  const int hops = path_rec_byte(rec, 0);
+  const int r = lane >> 3, w = lane & 7;
+  const int E = P.E, S = P.S;
   int d_occ = 0, d_fb = 0;
-  if (lane < hops) {
-    int link = P.path_links[pidx * P.H + lane];
-    u64* rp = e.bm + (core * P.E + link) * W;
-    Row<W> a = row_load<W>(rp);
-    int occ0 = 0, fb0 = 0, occ1 = 0, fb1 = 0;
-    if (ENV != ENV_RWA) link_summary<W>(a, P.S, occ0, fb0);
-    Row<W> m = row_range<W>(s0, n);
-    a = release ? row_or<W>(a, m) : row_andn<W>(a, m);
-    row_store<W>(rp, a);
-    if (ENV != ENV_RWA) link_summary<W>(a, P.S, occ1, fb1);
-    d_occ = occ1 - occ0;
-    d_fb = fb1 - fb0;
-    link_stats_update<ENV, W>(P, e, link, a);
+  for (int h0 = 0; h0 < hops; h0 += 8) {
+    const int h = h0 + r;
+    const bool rowv = h < hops;
+    const bool v = rowv && (w < W);
+    const int link = rowv ? path_rec_byte(rec, 2 + h) : 0;
+    u64* wp = e.bm + (core * E + link) * W + (w < W ? w : 0);
+    u64 a = v ? *wp : 0ull;
+    RowStat before, after;
+    if (ENV != ENV_RWA) row_stat<W, false>(a, w, S, before);
+    const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
+    a = release ? (a | m) : (a & ~m);
+    if (v) *wp = a;
+    if (ENV != ENV_RWA) {
+      row_stat<W, true>(a, w, S, after);
+      if (rowv && w == 0) { d_occ += after.occ - before.occ; d_fb += after.fb - before.fb; }
+    } else {
+      after.free_ = g8_sum(__popcll(a));
+    }
+    // _update_link_stats: time-weighted running averages, evaluated in the reference's operation order
+    double last_update = e.ls[3 * E + link];
+    double time_diff = e.now - last_update;
+    if (e.now > 0) {
+      const int free_ = after.free_;
+      double cur_util = (double)(S - free_) / (double)S;
+      double util = ((e.ls[link] * last_update) + (cur_util * time_diff)) / e.now;
+      double frag = 0.0, comp = 0.0;
+      if (ENV != ENV_RWA) {
+        double cur_frag = 0.0, cur_comp = 0.0;
+        const int top = (S - 1) - 64 * w;  // bit of slot S-1 inside this lane's word, if it is here
+        const int edge = g8_sum(((w == 0 && (a & 1ull)) ? 1 : 0) + ((top >= 0 && top < 64 && ((a >> top) & 1ull)) ? 1 : 0));
+        const int max_empty = row_longest_run8<W>(a, w);
+        if (free_ > 0) {
+          int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
+          cur_frag = 1.0 - ((double)me / (double)free_);
+          if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
+          else cur_comp = 1.0;
+        }
+        frag = ((e.ls[E + link] * last_update) + (cur_frag * time_diff)) / e.now;
+        comp = ((e.ls[2 * E + link] * last_update) + (cur_comp * time_diff)) / e.now;
+      }
+      if (rowv && w == 0) {
+        e.ls[link] = util;
+        if (ENV != ENV_RWA) { e.ls[E + link] = frag; e.ls[2 * E + link] = comp; }
+      }
+    }
+    if (rowv && w == 0) e.ls[3 * E + link] = e.now;
+    wave_fence();
   }
   if (ENV != ENV_RWA) {
     d_occ = wave_sum(d_occ);
     d_fb = wave_sum(d_fb);
-    wave_fence();
     if (lane == 0) {
       e.cs[2 * core] += d_occ;
       e.cs[2 * core + 1] += d_fb;
     }
   }
   wave_fence();
+  return hops;
 }
 
 // is_path_free: all links of the path free on [s0, s0+n)
 template <int W>
 __device__ __forceinline__ bool path_is_free(const DevParams& P, const Env& e, int lane, int pidx, int core, int s0, int n) {
   if (s0 + n > P.S) return false;
-  const int hops = P.path_hops[pidx];
+  const PathRec rec = path_rec_load(P, pidx);
+  const int hops = path_rec_byte(rec, 0);
+  const int r = lane >> 3, w = lane & 7;
   bool busy = false;
-  if (lane < hops) {
-    int link = P.path_links[pidx * P.H + lane];
-    Row<W> a = row_load<W>(e.bm + (core * P.E + link) * W);
-    Row<W> m = row_range<W>(s0, n);
-    busy = row_any<W>(row_andn<W>(m, a));
+  for (int h0 = 0; h0 < hops; h0 += 8) {
+    const int h = h0 + r;
+    if (h < hops && w < W) {
+      int link = path_rec_byte(rec, 2 + h);
+      u64 a = e.bm[(core * P.E + link) * W + w];
+      busy = busy || ((word_range(s0 - 64 * w, s0 + n - 64 * w) & ~a) != 0ull);
+    }
   }
   return __ballot(busy) == 0ull;
 }
@@ -545,13 +650,7 @@ __device__ __forceinline__ bool path_is_free(const DevParams& P, const Env& e, i
 // AND of the link rows of a path (lane-private: every lane may call it with its own pidx/core)
 template <int W>
 __device__ __forceinline__ Row<W> path_and(const DevParams& P, const Env& e, int pidx, int core) {
-  Row<W> m = row_mask_lo<W>(P.S);
-  const int hops = P.path_hops[pidx];
-  for (int h = 0; h < hops; h++) {
-    int link = P.path_links[pidx * P.H + h];
-    m = row_and<W>(m, row_load<W>(e.bm + (core * P.E + link) * W));
-  }
-  return m;
+  return path_and_rec<W>(path_rec_load(P, pidx), e.bm, P.E, P.S, core);
 }
 
 // pending-release storage: unordered slots, +inf = empty.  Push = lowest empty slot.
@@ -609,9 +708,9 @@ __device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane
     if (lane == 0) e.ev_time[bi] = __builtin_inf();
     if (bi == e.push_idx) e.push_t = __builtin_inf();
     e.ev_cnt--;
-    path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
+    int hops_r = path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
     e.s_br -= br;
-    e.s_nh -= (i64)n * (int)P.path_hops[pidx];
+    e.s_nh -= (i64)n * hops_r;
     prev_t = bt;
     prev_i = bi;
   }
@@ -702,7 +801,7 @@ __device__ __forceinline__ void deep_observation(const DevParams& P, const Env& 
   if (lane < np_) {
     int pidx = pair_base(P, e.src, e.dst) + lane;
     Row<W> m = path_and<W>(P, e, pidx, 0);
-    int n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+    int n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
     double* sp = obs + 1 + 2 * N + lane * WD;
     Row<W> r = row_runs_ge<W>(m, n);
     Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
@@ -771,31 +870,6 @@ template <int GS> __device__ __forceinline__ int group_max(int v) {
   return v;
 }
 template <int GS> __device__ __forceinline__ int group_get(int v, int src, int lane) { return __shfl(v, (lane & ~(GS - 1)) + src, 64); }
-
-// 32-byte path record: byte 0 hops, byte 1 modulation, bytes 2.. link per hop
-struct PathRec { u64 q[4]; };
-__device__ __forceinline__ PathRec path_rec_load(const DevParams& P, int pidx) {
-  const ulonglong2* r = (const ulonglong2*)(P.path_rec + (size_t)pidx * 32);
-  ulonglong2 a = r[0], b = r[1];
-  PathRec o;
-  o.q[0] = a.x; o.q[1] = a.y; o.q[2] = b.x; o.q[3] = b.y;
-  return o;
-}
-__device__ __forceinline__ int path_rec_byte(const PathRec& r, int i) {
-  int w = i >> 3;
-  u64 v = w == 0 ? r.q[0] : (w == 1 ? r.q[1] : (w == 2 ? r.q[2] : r.q[3]));
-  return (int)((v >> ((i & 7) * 8)) & 0xffull);
-}
-template <int W>
-__device__ __forceinline__ Row<W> path_and_rec(const PathRec& r, const u64* bm, int E, int S, int core) {
-  Row<W> m = row_mask_lo<W>(S);
-  const int hops = path_rec_byte(r, 0);
-  for (int h = 0; h < hops; h++) {
-    int link = path_rec_byte(r, 2 + h);
-    m = row_and<W>(m, row_load<W>(bm + (core * E + link) * W));
-  }
-  return m;
-}
 
 template <int ENV, int W, int GS>
 __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool valid, int pb, int br_idx, int np_,
@@ -919,7 +993,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
       int nb = 0;
       if (route < P.n_paths[e.src * P.N + e.dst]) {
         Row<W> m = path_and<W>(P, e, pidx, 0);
-        nb = first_blocks<W>(m, S, P.nslots[e.br_idx * P.M + P.path_mod[pidx]], block + 1, starts, lens);
+        nb = first_blocks<W>(m, S, P.nslots_path[(size_t)pidx * P.n_br + e.br_idx], block + 1, starts, lens);
       }
       if (block < nb) { path = route; slot = starts[block]; }
     }
@@ -946,16 +1020,16 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
     int pidx = pair_base(P, e.src, e.dst) + path;
     int n = 1;
     if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
-    else if (ENV != ENV_RWA) n = P.nslots[e.br_idx * P.M + P.path_mod[pidx]];
+    else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
     bool ok = path_is_free<W>(P, e, lane, pidx, core, slot, n);
     if (ok && ENV == ENV_RMCSA) {  // _crosstalk_is_acceptable: two reach limits
       double len = P.path_length[pidx];
       ok = (len < P.lmax_xt[mod]) && (len < P.lmax_snr[mod * P.n_br + e.br_idx]);
     }
     if (ok) {
-      path_apply<ENV, W>(P, e, lane, pidx, core, slot, n, false);
+      int hops_p = path_apply<ENV, W>(P, e, lane, pidx, core, slot, n, false);
       e.s_br += e.bit_rate;
-      e.s_nh += (i64)n * (int)P.path_hops[pidx];
+      e.s_nh += (i64)n * hops_p;
       if (ENV != ENV_RWA) {  // _update_network_stats
         double last_update = e.g_last, time_diff = e.now - last_update;
         if (e.now > 0) {
