@@ -30,7 +30,8 @@ def stale():
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [os.path.join(CSRC, "orl_gpu.hip"), "-o", LIB]
+    extra = os.environ.get("ORL_HIPCC_EXTRA", "").split()  # tuning experiments only (e.g. -DORL_STEP_WAVES=6)
+    cmd = [hipcc_path()] + HIPCC_FLAGS + extra + [os.path.join(CSRC, "orl_gpu.hip"), "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
   }
   const int path0 = path, slot0 = slot;
   double prev_comp = 0.0, cur_comp = 0.0;
-  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) prev_comp = net_compactness(P, e, 0);
+  if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && info_out) prev_comp = net_compactness(P, e, 0);
   bool accepted = false;
   bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
   if (in_range && path < P.n_paths[e.src * P.N + e.dst]) {
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
   }
   if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
   if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
-  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) cur_comp = net_compactness(P, e, 0);
+  if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && info_out) cur_comp = net_compactness(P, e, 0);
 
   if (ENV == ENV_RWA) {
     // actions_output marginals (rwa_env.py:103, 148-151).  Each lane owns histogram entries, applies this

@@ -124,8 +124,11 @@ __global__ void __launch_bounds__(256) k_policy(DevParams P, int pol) {
   if (valid && (lane & (GS - 1)) == 0) *(int4*)(P.actions + env * 4) = make_int4(a[0], a[1], a[2], a[3]);
 }
 
+#ifndef ORL_STEP_WAVES
+#define ORL_STEP_WAVES 5  // waves per SIMD the register allocator must leave room for (measured: 4 -> 428 us, 5 -> 389 us, 6 -> 436 us)
+#endif
 template <int ENV, int W>
-__global__ void __launch_bounds__(64) k_step(DevParams P, int auto_reset, int want_info) {
+__global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int auto_reset, int want_info) {
   const i64 env = blockIdx.x;
   const int lane = lane_id();
   Env e;

@@ -1,0 +1,90 @@
+"""Host-side mirrors of the reference interface (gym-shaped envs, heuristics, evaluate_heuristic, VecEnv glue),
+driven through the CPU oracle so they run without a GPU.  Expected numbers are the reference's own outputs for its
+tests/ scripts (reproduced in tests/golden by oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+
+import optical_rl_gym_amd as orl
+from optical_rl_gym_amd.vec_env import OpticalVecEnv
+from tests.helpers import load_golden
+from tests.oracle_backend import OracleBackend
+
+RMSA_KW = dict(allow_rejection=True, load=50, mean_service_holding_time=25, episode_length=100,
+               num_spectrum_resources=64, bit_rate_selection="discrete")
+
+
+def _env(cls, fam, seed=10, **kw):
+    return cls(topology="nsfnet_chen", seed=seed, _backend=OracleBackend(fam, "nsfnet_chen", [seed], **kw), **kw)
+
+
+@pytest.mark.parametrize("heuristic,mean,std", [
+    (orl.shortest_path_first_fit, 88.7, 7.1281), (orl.shortest_available_path_first_fit, 95.0, 3.2558),
+    (orl.least_loaded_path_first_fit, 95.1, 3.3897)])
+def test_rmsa_script_numbers(heuristic, mean, std):
+    env = _env(orl.RMSAEnv, "RMSA", **RMSA_KW)
+    m, s = orl.evaluate_heuristic(env, heuristic, n_eval_episodes=10)
+    assert round(float(m), 4) == mean and round(float(s), 4) == std
+    assert env.episode_services_processed == 100 and env.services_processed == 991
+    assert 0.0 <= env.topology.graph["throughput"]
+
+
+def test_deeprmsa_script_numbers():
+    g = load_golden("g4_deeprmsa_j1_sap")
+    kw = dict(g["meta"]["kwargs"])
+    kw.pop("seed")
+    env = _env(orl.DeepRMSAEnv, "DeepRMSA", **kw)
+    assert env.observation_space.shape == (54,) and env.action_space.n == 5
+    m, s = orl.evaluate_heuristic(env, orl.shortest_available_path_first_fit, n_eval_episodes=10)
+    assert (round(float(m), 4), round(float(s), 4)) == (43.2, 4.6)
+    assert np.array_equal(env.observation(), g["obs"][-1])
+
+
+def test_rwa_script_numbers_and_info():
+    kw = dict(allow_rejection=True, load=450, mean_service_holding_time=25, episode_length=1000)
+    env = _env(orl.RWAEnv, "RWA", **kw)
+    rewards, lengths = orl.evaluate_heuristic(env, orl.shortest_available_path_first_fit, n_eval_episodes=2,
+                                              return_episode_rewards=True)
+    g = load_golden("g5_rwa_testcfg_sapff")
+    assert rewards == g["meta"]["episode_rewards"][:2] and lengths == [1000, 1000]
+    _, _, _, info = env.step(orl.shortest_available_path_first_fit(env))
+    assert info["path_action_probability"].shape == (6,) and abs(info["path_action_probability"].sum() - 1) < 1e-12
+
+
+def test_wrappers_and_service_view():
+    env = _env(orl.RMSAEnv, "RMSA", **RMSA_KW)
+    svc = env.current_service
+    g = load_golden("g9_rmsa_testcfg_sapff")
+    assert (svc.arrival_time, svc.holding_time, svc.source_id, svc.destination_id, svc.bit_rate) == tuple(
+        [g["svc"][0][0], g["svc"][0][1], int(g["svc"][0][2]), int(g["svc"][0][3]), int(g["svc"][0][4])])
+    assert len(env.k_shortest_paths[svc.source, svc.destination]) == 5
+    mat = orl.SimpleMatrixObservation(env)
+    obs = mat.reset()
+    assert obs.shape == (14 * 2 + 22 * 64,) and obs[28:].sum() == 22 * 64
+    po = orl.PathOnlyFirstFitAction(env)
+    # path-only + first-fit on path 0 equals the SP-FF heuristic's decision
+    assert po.action(0) == orl.shortest_path_first_fit(env)
+    _, r, _, _ = po.step(0)
+    assert r == 1 and env.services_accepted == 1
+
+
+def test_vecenv_auto_reset_and_monitor_rows():
+    g = load_golden("g4_deeprmsa_j1_sap")
+    kw = dict(g["meta"]["kwargs"])
+    kw.pop("seed")
+    seeds = [10, 11, 12]
+    batch = OracleBackend("DeepRMSA", "nsfnet_chen", seeds, **kw)
+    venv = OpticalVecEnv(batch)
+    obs = venv.reset()
+    assert obs.shape == (3, 54)
+    n_done = 0
+    for _ in range(120):
+        actions = batch.policy("SAP")[:, 0]
+        obs, rew, done, infos = venv.step(actions)
+        for i in np.flatnonzero(done):
+            n_done += 1
+            assert infos[i]["episode"]["l"] == 49  # Q1: episodes last episode_length - 1 steps
+            assert "episode_service_blocking_rate" in infos[i]["episode"]
+            assert np.array_equal(infos[i]["terminal_observation"], obs[i])
+    assert n_done == 6
+    # env 0 saw the same episodes as the single-env golden (seed 10)
+    assert [r["r"] for r in venv.episode_log if True][0::3][:2] == g["meta"]["episode_rewards"][:2]
