@@ -107,3 +107,60 @@ def test_device_resident_run_matches_stepwise():
         chk(0, "link_stats", a.link_stats(e), b.link_stats(e))
     a.close()
     b.close()
+
+
+def test_gym_front_end_reproduces_reference_script_numbers():
+    """tests/test_rmsa.py / test_deeprmsa.py of the reference, run through the product's gym-shaped classes."""
+    import optical_rl_gym_amd as orl
+
+    kw = dict(allow_rejection=True, load=50, mean_service_holding_time=25, episode_length=100,
+              num_spectrum_resources=64, bit_rate_selection="discrete")
+    for heur, mean, std in ((orl.shortest_path_first_fit, 88.7, 7.1281),
+                            (orl.shortest_available_path_first_fit, 95.0, 3.2558),
+                            (orl.least_loaded_path_first_fit, 95.1, 3.3897)):
+        env = orl.RMSAEnv(topology="nsfnet_chen", seed=10, **kw)
+        m, s = orl.evaluate_heuristic(env, heur, n_eval_episodes=10)
+        assert (round(float(m), 4), round(float(s), 4)) == (mean, std)
+        env.close()
+    g = load_golden("g4_deeprmsa_j1_sap")
+    dkw = dict(g["meta"]["kwargs"])
+    dkw.pop("seed")
+    env = orl.DeepRMSAEnv(topology="nsfnet_chen", seed=10, **dkw)
+    m, s = orl.evaluate_heuristic(env, orl.shortest_available_path_first_fit, n_eval_episodes=10)
+    assert (round(float(m), 4), round(float(s), 4)) == (43.2, 4.6)
+    env.close()
+
+
+@pytest.mark.parametrize("workload,batch", [("cfg2", 65536), ("cfg5", 32768)])
+def test_full_size_batch_sampled_envs_match_oracle(workload, batch):
+    """BASELINE.json sizes.  Envs are independent, so env i of the big batch must equal a 1-env oracle run with
+    seed_i; 24 sampled envs are compared in full (slot map, link statistics, counters, pending service), and
+    cheap invariants are checked on every env."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+    from oracle.oracle import OracleBatch
+
+    fam, topo, kw, policy = WORKLOADS[workload]
+    kw = dict(kw, episode_length=100)
+    steps = 260
+    seeds = [10 + i for i in range(batch)]
+    dev = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+    dev.run(policy, steps)
+    sample = sorted(set([0, 1, 63, 64, 4095, batch // 2, batch - 1] + list(np.random.RandomState(5).randint(0, batch, 17))))
+    ora = OracleBatch(fam, topo, [seeds[i] for i in sample], **kw)
+    ora.run(policy, steps)
+    chk = _exact(workload)
+    cd, sd, ad = dev.counters(), dev.services(), dev.active()
+    chk(0, "counters", cd[sample], ora.counters())
+    chk(0, "services", sd[sample], ora.services())
+    for j, i in enumerate(sample):
+        chk(i, "slots", dev.slots(i), ora.slots(j))
+        chk(i, "link_stats", dev.link_stats(i), ora.link_stats(j))
+        chk(i, "net_stats", dev.net_stats(i), ora.net_stats(j))
+        chk(i, "n_active", int(ad[i]), ora.n_active(j))
+    assert not dev.flags().any()
+    assert (cd[:, 0] == steps + 1).all() and (cd[:, 1] <= cd[:, 0]).all() and (cd[:, 5] <= cd[:, 4]).all()
+    assert (ad >= 0).all() and (ad <= cd[:, 1]).all()
+    p, a = dev.totals()
+    assert p == int(cd[:, 0].sum()) and a == int(cd[:, 1].sum())
+    dev.close()
