@@ -113,11 +113,19 @@ def main():
         "slot_scan(k_policy)": dict(ms=st.ms_policy, bytes=scan_b * B),
         "step(k_step)": dict(ms=st.ms_step, bytes=rest_b * B),
     }
+    # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x calibration + WRITE_SIZE), collected offline with
+    # tools/pmc_traffic.py for exactly this workload/batch and committed under profiles/; null otherwise.
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "r1b_traffic_cfg2.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("workload") == args.workload and tj.get("batch") == B:
+            traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
     roof = {}
     for name, k in kernels.items():
         ach = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
         roof[name] = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                          frac=round(ach / HBM_PEAK_GBS, 5), traffic=None, us_per_launch=round(k["ms"] * 1e3, 2),
+                          frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic.get(name), us_per_launch=round(k["ms"] * 1e3, 2),
                           algorithmic_bytes_per_launch=int(k["bytes"]))
     dominant = max(kernels, key=lambda n: kernels[n]["ms"])
 

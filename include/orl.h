@@ -154,6 +154,10 @@ int orl_batch_get_flags(orl_batch* b, int32_t* out /*[n_envs] bit0 event overflo
 /* summed over envs: services_processed, services_accepted (for throughput/blocking reports) */
 int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted);
 
+/* Profiling aid: reads the whole slot-map array once with 8-B (width16 = 0) or 16-B (1) loads per lane and returns the
+ * number of bytes read, so that rocprofv3's FETCH_SIZE can be calibrated on a known byte count. */
+int64_t orl_batch_debug_stream_read(orl_batch* b, int width16);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,12 +99,24 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
 // Slot-scan kernel.  GS lanes per env: a wavefront serves 64/GS envs whose slot maps are contiguous in HBM,
 // so staging them into LDS is one fully coalesced stream of 16-B-per-lane loads (1 KiB per instruction).
 // Workgroup = 4 wavefronts, each with its own LDS window; no workgroup-level synchronisation is needed.
+#ifndef ORL_POLICY_LDS
+#define ORL_POLICY_LDS 0  // 1 = stage the slot maps through LDS in k_policy (kept for A/B measurements)
+#endif
+#ifndef ORL_POLICY_WAVES
+#define ORL_POLICY_WAVES 4  // wavefronts per workgroup in the slot-scan kernel
+#endif
 template <int ENV, int W, int GS>
-__global__ void __launch_bounds__(256) k_policy(DevParams P, int pol) {
+__global__ void __launch_bounds__(64 * ORL_POLICY_WAVES) k_policy(DevParams P, int pol) {
   constexpr int EPW = 64 / GS;  // envs per wavefront
   const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-  const i64 env0 = ((i64)blockIdx.x * 4 + wave) * EPW;
+  const i64 env0 = ((i64)blockIdx.x * ORL_POLICY_WAVES + wave) * EPW;
   if (env0 >= P.B) return;
+#if ORL_POLICY_LDS == 0
+  // Link rows are read straight from global memory (each lane 40-B rows of its own path).  A/B on MI355X, cfg2,
+  // B = 65 536: 17.2 us per launch vs 19.4 us with LDS staging — the 28 KB/workgroup LDS window caps residency at
+  // 5 workgroups/CU and costs a second dispatch round, while the 7-KB-per-wave footprint stays L2/TCP resident.
+  const u64* lds = P.bitmap + env0 * P.bm_words;
+#else
   u64* lds = (u64*)orl_lds_raw + (size_t)wave * EPW * P.bm_words;
   {
     i64 nenv = P.B - env0 < EPW ? P.B - env0 : EPW;
@@ -113,6 +125,7 @@ __global__ void __launch_bounds__(256) k_policy(DevParams P, int pol) {
     ulonglong2* l = (ulonglong2*)lds;
     for (int i = lane; i < n16; i += 64) l[i] = g[i];
   }
+#endif
   const int grp = lane / GS;
   const i64 env = env0 + grp;
   const bool valid = env < P.B;
@@ -152,6 +165,20 @@ __global__ void __launch_bounds__(64) k_obs(DevParams P) {
   env_load(P, e, env, lane);
   stage_in(P, e, (u64*)orl_lds_raw, lane);
   if (ENV == ENV_DEEPRMSA) deep_observation<W>(P, e, lane, P.obs + env * P.obs_dim, nullptr);
+}
+
+// Counter calibration: streams the whole slot-map array once with a known byte count (FETCH_SIZE on gfx950 is
+// documented to under-report wide coalesced reads; this gives the factor for our own access widths).
+__global__ void k_calib_read(const u64* __restrict__ src, i64 n_words, int width16, u64* sink) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 acc = 0;
+  if (width16) {
+    const ulonglong2* s2 = (const ulonglong2*)src;
+    for (i64 j = i; j < n_words / 2; j += (i64)gridDim.x * blockDim.x) { ulonglong2 v = s2[j]; acc ^= v.x ^ v.y; }
+  } else {
+    for (i64 j = i; j < n_words; j += (i64)gridDim.x * blockDim.x) acc ^= src[j];
+  }
+  if (acc == 0x123456789abcdefull) *sink = acc;  // keep the loads alive
 }
 
 // sums of services_processed / services_accepted over the batch (two atomics per wave)
@@ -292,9 +319,13 @@ static void launch_policy(orl_batch* b, int pol) {
   // RMCSA scans (path, core) pairs: one env per wavefront.  The other families put 8 envs on a wavefront when k <= 8.
   const bool wide = (b->P.env_type == ENV_RMCSA) || b->P.K > 8;
   const int epw = wide ? 1 : 8;
-  const i64 per_wg = 4 * epw;
-  dim3 g((unsigned)((b->P.B + per_wg - 1) / per_wg)), blk(256);
+  const i64 per_wg = ORL_POLICY_WAVES * epw;
+  dim3 g((unsigned)((b->P.B + per_wg - 1) / per_wg)), blk(64 * ORL_POLICY_WAVES);
+#if ORL_POLICY_LDS == 0
+  size_t lds = 0;
+#else
   size_t lds = (size_t)per_wg * b->P.bm_words * 8;
+#endif
 #define CALLW(WW) \
   do { if (wide) hipLaunchKernelGGL((k_policy<EE, WW, 64>), g, blk, lds, b->stream, b->P, pol); \
        else hipLaunchKernelGGL((k_policy<EE, WW, 8>), g, blk, lds, b->stream, b->P, pol); } while (0)
@@ -662,4 +693,14 @@ extern "C" int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accep
   if (processed) *processed = (int64_t)h[0];
   if (accepted) *accepted = (int64_t)h[1];
   return ORL_OK;
+}
+
+/* debug: stream the slot-map array (n_envs * bm_words * 8 bytes) once; returns that byte count */
+extern "C" int64_t orl_batch_debug_stream_read(orl_batch* b, int width16) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  if (hipSetDevice(b->device) != hipSuccess) return ORL_E_HIP;
+  i64 n_words = b->P.B * b->P.bm_words;
+  hipLaunchKernelGGL(k_calib_read, dim3(2048), dim3(256), 0, b->stream, b->P.bitmap, n_words, width16, b->d_totals);
+  if (hipStreamSynchronize(b->stream) != hipSuccess) return ORL_E_HIP;
+  return n_words * 8;
 }
