@@ -31,6 +31,10 @@
 #include <stdint.h>
 #include "orl_log.h"
 
+#ifndef ORL_ABLATE
+#define ORL_ABLATE 0  // timing experiments only: 1 no link-stat floats, 2 no longest-run, 4 no before-summary, 8 no stage_out
+#endif
+
 namespace orl {
 
 typedef unsigned long long u64;
@@ -301,6 +305,7 @@ struct Env {
   int* cs;        // LDS: [2*C]
   double* ev_time;
   u64* ev_info;
+  double* evl;    // LDS copy of ev_time[0, ev_hwm) when the kernel staged it (else nullptr)
   u32* mt;
   i64 env;
 };
@@ -324,6 +329,7 @@ __device__ __forceinline__ void env_load(const DevParams& P, Env& e, i64 env, in
 #undef I64
   e.push_idx = -1;
   e.push_t = 0.0;
+  e.evl = nullptr;
   e.env = env;
   e.ev_time = P.ev_time + env * P.ev_cap;
   e.ev_info = P.ev_info + env * P.ev_cap;
@@ -368,6 +374,7 @@ __device__ __forceinline__ void stage_in(const DevParams& P, Env& e, u64* lds, i
 }
 __device__ __forceinline__ void stage_out(const DevParams& P, Env& e, int lane) {
   wave_fence();
+  if (ORL_ABLATE & 8) return;
   ulonglong2* g = (ulonglong2*)(P.bitmap + e.env * P.bm_words);
   const ulonglong2* l = (const ulonglong2*)e.bm;
   for (int i = lane; i < P.bm_words / 2; i += 64) g[i] = l[i];
@@ -576,7 +583,7 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
     u64* wp = e.bm + (core * E + link) * W + (w < W ? w : 0);
     u64 a = v ? *wp : 0ull;
     RowStat before, after;
-    if (ENV != ENV_RWA) row_stat<W, false>(a, w, S, before);
+    if (ENV != ENV_RWA && !(ORL_ABLATE & 4)) row_stat<W, false>(a, w, S, before); else { before.occ = 0; before.fb = 0; }
     const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
     a = release ? (a | m) : (a & ~m);
     if (v) *wp = a;
@@ -589,7 +596,7 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
     // _update_link_stats: time-weighted running averages, evaluated in the reference's operation order
     double last_update = e.ls[3 * E + link];
     double time_diff = e.now - last_update;
-    if (e.now > 0) {
+    if (e.now > 0 && !(ORL_ABLATE & 1)) {
       const int free_ = after.free_;
       double cur_util = (double)(S - free_) / (double)S;
       double util = ((e.ls[link] * last_update) + (cur_util * time_diff)) / e.now;
@@ -598,7 +605,7 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
         double cur_frag = 0.0, cur_comp = 0.0;
         const int top = (S - 1) - 64 * w;  // bit of slot S-1 inside this lane's word, if it is here
         const int edge = g8_sum(((w == 0 && (a & 1ull)) ? 1 : 0) + ((top >= 0 && top < 64 && ((a >> top) & 1ull)) ? 1 : 0));
-        const int max_empty = row_longest_run8<W>(a, w);
+        const int max_empty = (ORL_ABLATE & 2) ? 1 : row_longest_run8<W>(a, w);
         if (free_ > 0) {
           int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
           cur_frag = 1.0 - ((double)me / (double)free_);
@@ -654,11 +661,16 @@ __device__ __forceinline__ Row<W> path_and(const DevParams& P, const Env& e, int
 }
 
 // pending-release storage: unordered slots, +inf = empty.  Push = lowest empty slot.
+// EVL: the kernel staged ev_time[0, hwm) into LDS (e.evl); scans run there, updates go to both copies.
+template <bool EVL>
+__device__ __forceinline__ double ev_read(const Env& e, int i) { return EVL ? e.evl[i] : e.ev_time[i]; }
+
+template <bool EVL>
 __device__ __forceinline__ void ev_push(const DevParams& P, Env& e, int lane, double t, u64 info) {
   int idx = -1;
   for (int base = 0; base < e.ev_hwm; base += 64) {
     int i = base + lane;
-    bool empty = (i < e.ev_hwm) && (e.ev_time[i] == __builtin_inf());
+    bool empty = (i < e.ev_hwm) && (ev_read<EVL>(e, i) == __builtin_inf());
     u64 b = __ballot(empty);
     if (b) { idx = base + (int)__builtin_ctzll(b); break; }
   }
@@ -666,7 +678,12 @@ __device__ __forceinline__ void ev_push(const DevParams& P, Env& e, int lane, do
     if (e.ev_hwm >= P.ev_cap) { e.flags |= ORL_FLAG_EV_OVERFLOW; return; }
     idx = e.ev_hwm++;
   }
-  if (lane == 0) { e.ev_time[idx] = t; e.ev_info[idx] = info; }
+  if (lane == 0) {
+    e.ev_time[idx] = t;
+    e.ev_info[idx] = info;
+    if (EVL) e.evl[idx] = t;
+  }
+  wave_fence();
   e.ev_cnt++;
   e.push_idx = idx;
   e.push_t = t;
@@ -680,7 +697,7 @@ __device__ __forceinline__ u64 ev_pack(int pidx, int s0, int n, int core, int bi
 // (the reference pops its heap until the top is in the future: rmsa_env.py:590-597).
 // Each round finds the smallest (time, slot) strictly after the previous one, so the result
 // does not depend on whether this kernel's own ev_time stores are visible to the loads yet.
-template <int ENV, int W>
+template <int ENV, int W, bool EVL>
 __device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane) {
   double prev_t = -__builtin_inf();
   int prev_i = -1;
@@ -690,7 +707,7 @@ __device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane
     for (int base = 0; base < e.ev_hwm; base += 64) {
       int i = base + lane;
       if (i < e.ev_hwm) {
-        double t = (i == e.push_idx) ? e.push_t : e.ev_time[i];
+        double t = (i == e.push_idx) ? e.push_t : ev_read<EVL>(e, i);
         bool after = (t > prev_t) || (t == prev_t && i > prev_i);
         if (after && (t < bt || (t == bt && i < bi))) { bt = t; bi = i; }
       }
@@ -705,7 +722,7 @@ __device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane
     u64 info = e.ev_info[bi];
     int pidx = (int)(info & 0xffffffu), s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
     int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
-    if (lane == 0) e.ev_time[bi] = __builtin_inf();
+    if (lane == 0) { e.ev_time[bi] = __builtin_inf(); if (EVL) e.evl[bi] = __builtin_inf(); }
     if (bi == e.push_idx) e.push_t = __builtin_inf();
     e.ev_cnt--;
     int hops_r = path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
@@ -717,18 +734,19 @@ __device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane
   // shrink the scan window when its tail is empty
   while (e.ev_hwm > 0) {
     int i = e.ev_hwm - 1;
-    double t = (i == e.push_idx) ? e.push_t : e.ev_time[i];
+    double t = (i == e.push_idx) ? e.push_t : ev_read<EVL>(e, i);
     // entries released above read +inf or a stale finite time <= now; both mean "empty"
     if (t == __builtin_inf() || t <= e.now) e.ev_hwm--; else break;
   }
 }
 
 // _next_service
-template <int ENV, int W>
-__device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lane) {
+template <int ENV, int W, bool EVL>
+__device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lane, const Rng* prefilled) {
   if (e.new_service) return;
   Rng r;
-  rng_fill(e, r, lane);
+  if (prefilled) r = *prefilled;  // window loaded at kernel entry so its latency hides behind the step logic
+  else rng_fill(e, r, lane);
   double at = e.now + rng_expovariate(e, r, lane, P.lambda_a);
   e.now = at;
   double ht = rng_expovariate(e, r, lane, P.lambda_h);
@@ -747,7 +765,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lan
     }
   }
   rng_commit(e, r, lane);
-  if (ENV == ENV_RWA || ENV == ENV_RMCSA) release_due<ENV, W>(P, e, lane);
+  if (ENV == ENV_RWA || ENV == ENV_RMCSA) release_due<ENV, W, EVL>(P, e, lane);
   e.id = (int)e.esp;
   e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
   e.new_service = 1;
@@ -757,7 +775,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lan
     e.ebrq += bit_rate;
     if (P.bit_rate_mode == 1 && lane == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;
   }
-  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) release_due<ENV, W>(P, e, lane);
+  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) release_due<ENV, W, EVL>(P, e, lane);
 }
 
 // soft reset (reset(only_episode_counters=True)): the pending service is counted again
@@ -976,10 +994,10 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
 // ---------------------------------------------------------------------------------------------
 // step(): everything between receiving the action and handing back (reward, done, info)
 // ---------------------------------------------------------------------------------------------
-template <int ENV, int W>
+template <int ENV, int W, bool EVL>
 __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const int* act, int auto_reset,
                                      double* reward_out, unsigned char* done_out, double* info_out, double* obs_out,
-                                     double* term_obs_out) {
+                                     double* term_obs_out, const Rng* prefilled) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0;
   int path, slot, mod = 0, core = 0;
   bool bad = false;
@@ -1045,7 +1063,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
       e.sa += 1;
       e.esa += 1;
       accepted = true;
-      ev_push(P, e, lane, e.at + e.ht, ev_pack(pidx, slot, n, core, e.bit_rate));
+      ev_push<EVL>(P, e, lane, e.at + e.ht, ev_pack(pidx, slot, n, core, e.bit_rate));
     }
   }
   if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
@@ -1099,7 +1117,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
     }
   }
   e.new_service = 0;
-  next_service<ENV, W>(P, e, lane);
+  next_service<ENV, W, EVL>(P, e, lane, prefilled);
   bool done = (e.esp == (i64)P.episode_length);
   if (ENV == ENV_DEEPRMSA && obs_out) {
     deep_observation<W>(P, e, lane, obs_out, (done && term_obs_out) ? term_obs_out : nullptr);

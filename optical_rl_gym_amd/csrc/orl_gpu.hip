@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
   e.sp = e.sa = e.esp = e.esa = e.brq = e.brp = e.ebrq = e.ebrp = e.s_br = e.s_nh = 0;
   e.src = e.dst = e.bit_rate = e.br_idx = e.id = 0;
   e.ev_hwm = 0; e.ev_cnt = 0; e.new_service = 0; e.flags = 0;
-  next_service<ENV, W>(P, e, lane);
+  next_service<ENV, W, false>(P, e, lane, nullptr);
   stage_out(P, e, lane);
   env_store(P, e, lane);
 }
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(64 * ORL_POLICY_WAVES) k_policy(DevParams P, i
 #ifndef ORL_STEP_WAVES
 #define ORL_STEP_WAVES 5  // waves per SIMD the register allocator must leave room for (measured: 4 -> 428 us, 5 -> 389 us, 6 -> 436 us)
 #endif
-template <int ENV, int W>
+template <int ENV, int W, bool EVL>
 __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int auto_reset, int want_info) {
   const i64 env = blockIdx.x;
   const int lane = lane_id();
@@ -148,11 +148,20 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
   env_load(P, e, env, lane);
   stage_in(P, e, (u64*)orl_lds_raw, lane);
   int4 av = *(const int4*)(P.actions + env * 4);
+  // everything that only depends on the scalar record is requested now, in one batch, and consumed much later:
+  // the MT window for the next service and (EVL) the pending release times, which then live in LDS for all scans
+  Rng pre;
+  rng_fill(e, pre, lane);
+  if (EVL) {
+    e.evl = (double*)((unsigned char*)orl_lds_raw + P.lds_bytes);
+    for (int i = lane; i < e.ev_hwm; i += 64) e.evl[i] = e.ev_time[i];
+    wave_fence();
+  }
   int act[4] = {av.x, av.y, av.z, av.w};
-  step<ENV, W>(P, e, lane, act, auto_reset, P.reward + env, P.done + env,
-               want_info ? P.info + env * P.n_info : nullptr,
-               P.obs_dim ? P.obs + env * P.obs_dim : nullptr,
-               P.obs_dim ? P.term_obs + env * P.obs_dim : nullptr);
+  step<ENV, W, EVL>(P, e, lane, act, auto_reset, P.reward + env, P.done + env,
+                    want_info ? P.info + env * P.n_info : nullptr,
+                    P.obs_dim ? P.obs + env * P.obs_dim : nullptr,
+                    P.obs_dim ? P.term_obs + env * P.obs_dim : nullptr, &pre);
   stage_out(P, e, lane);
   env_store(P, e, lane);
 }
@@ -336,8 +345,13 @@ static void launch_policy(orl_batch* b, int pol) {
 }
 static void launch_step(orl_batch* b, int auto_reset, int want_info) {
   dim3 g((unsigned)b->P.B), blk(64);
-  size_t lds = b->P.lds_bytes;
-#define CALLW(WW) hipLaunchKernelGGL((k_step<EE, WW>), g, blk, lds, b->stream, b->P, auto_reset, want_info)
+  // stage the pending release times through LDS when the per-env window stays small enough for 5 waves/SIMD
+  const size_t ev_bytes = (size_t)b->P.ev_cap * 8;
+  const bool evl = (b->P.lds_bytes + ev_bytes) <= 8 * 1024;
+  size_t lds = b->P.lds_bytes + (evl ? ev_bytes : 0);
+#define CALLW(WW) \
+  do { if (evl) hipLaunchKernelGGL((k_step<EE, WW, true>), g, blk, lds, b->stream, b->P, auto_reset, want_info); \
+       else hipLaunchKernelGGL((k_step<EE, WW, false>), g, blk, lds, b->stream, b->P, auto_reset, want_info); } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
   ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
