@@ -48,7 +48,10 @@ enum { POL_SP_FF = 0, POL_SAP_FF = 1, POL_LLP_FF = 2, POL_SAP_LF = 3 };
 enum {
   SC_NOW = 0, SC_AT, SC_HT, SC_GTHR, SC_GCOMP, SC_GLAST,
   SC_SP, SC_SA, SC_ESP, SC_ESA, SC_BRQ, SC_BRP, SC_EBRQ, SC_EBRP, SC_SBR, SC_SNH,
-  SC_SRC_DST, SC_BR_IDX, SC_ID_MTPOS, SC_EV, SC_FLAGS, SC_COUNT
+  SC_SRC_DST, SC_BR_IDX, SC_ID_MTPOS, SC_EV, SC_FLAGS,
+  SC_NEXTREL,  // f64 lower bound of every pending release time (-inf = unknown, +inf = none pending)
+  SC_HINT,     // low 32 bits: index of a known-empty pending-release slot, or -1
+  SC_COUNT
 };
 #define ORL_SCAL_WORDS 32
 #define ORL_FLAG_EV_OVERFLOW 1
@@ -67,6 +70,7 @@ struct DevParams {
   const unsigned char* path_mod;    // [N*N*K]  best modulation (index)
   const double* path_length;        // [N*N*K]
   const int* edge_iter_order;       // [E]
+  const int* link_pos;              // [E]      inverse permutation: position of link l in topology.edges()
   const double* cum_src;            // [N]      accumulate(node_request_probabilities)
   const double* cum_dst;            // [N*N]    accumulate(renormalised probs with src zeroed)
   const int* bit_rates;             // [n_br]   discrete mode values
@@ -108,18 +112,38 @@ __device__ __forceinline__ u64 rdlane64(u64 v, int l) {
 }
 __device__ __forceinline__ double rdlane_f64(double v, int l) { return __longlong_as_double((i64)rdlane64((u64)__double_as_longlong(v), l)); }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-  return v;
-}
+
 // compiler-level ordering of LDS/global accesses between phases of one wave (no instructions emitted)
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// ---- cross-lane moves as DPP modifiers (VALU, a few cycles) instead of ds_bpermute (LDS pipe, ~100+ cycles of
+// dependent latency per step).  PMC on the first version showed ~800 LDS-pipe shuffles per wavefront-step, almost
+// all of them the 3-step reductions over an 8-lane row group.  All lanes of the reading group are always active.
+#define ORL_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
+#define ORL_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define ORL_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each group of 8
+#define ORL_DPP_MIRROR 0x140      // lane i <-> 15-i inside each row of 16
+#define ORL_DPP_SHR1 0x111        // row_shr:1: lane i reads lane i-1 of its 16-lane row
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+  i64 b = __double_as_longlong(v);
+  u32 lo = (u32)dpp_i<CTRL>((int)(u32)b), hi = (u32)dpp_i<CTRL>((int)(u32)((u64)b >> 32));
+  return __longlong_as_double((i64)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+  v += dpp_i<ORL_DPP_XOR1>(v); v += dpp_i<ORL_DPP_XOR2>(v); v += dpp_i<ORL_DPP_HALF_MIRROR>(v); v += dpp_i<ORL_DPP_MIRROR>(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ int wave_max(int v) {
+  int t;
+  t = dpp_i<ORL_DPP_XOR1>(v); v = t > v ? t : v;
+  t = dpp_i<ORL_DPP_XOR2>(v); v = t > v ? t : v;
+  t = dpp_i<ORL_DPP_HALF_MIRROR>(v); v = t > v ? t : v;
+  t = dpp_i<ORL_DPP_MIRROR>(v); v = t > v ? t : v;
+  int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  a = a > b ? a : b; c = c > d ? c : d;
+  return a > c ? a : c;
+}
 
 // ---------------------------------------------------------------------------------------------
 // bit-packed slot rows: W 64-bit words, bit s of the row = slot s is free; bits >= S are always 0
@@ -348,6 +372,7 @@ __device__ __forceinline__ void env_store(const DevParams& P, const Env& e, int 
   PUTI(SC_SBR, e.s_br) PUTI(SC_SNH, e.s_nh)
   PUTI(SC_SRC_DST, pack2(e.src, e.dst)) PUTI(SC_BR_IDX, pack2(e.bit_rate, e.br_idx))
   PUTI(SC_ID_MTPOS, pack2(e.id, e.mt_pos)) PUTI(SC_EV, pack2(e.ev_hwm, e.ev_cnt)) PUTI(SC_FLAGS, pack2(e.new_service, e.flags))
+  PUTF(SC_NEXTREL, -__builtin_inf()) PUTI(SC_HINT, pack2(-1, 0))  // caches of the 8-lanes-per-env step: unknown
 #undef PUTF
 #undef PUTI
   if (lane < SC_COUNT) P.scal[e.env * ORL_SCAL_WORDS + lane] = v;
@@ -496,19 +521,23 @@ __device__ __forceinline__ double net_compactness(const DevParams& P, const Env&
 // Provision / release touch up to 8 link rows at once: lane = 8*r + w holds 64-bit word w of the r-th
 // link row of the path, so every per-row quantity (popcounts, run starts, lambda_min/max, longest free
 // run) is a handful of single-word instructions plus a 3-step reduction over the 8 lanes of the row.
-__device__ __forceinline__ int g8_sum(int v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; }
+__device__ __forceinline__ int g8_sum(int v) { v += dpp_i<ORL_DPP_XOR1>(v); v += dpp_i<ORL_DPP_XOR2>(v); v += dpp_i<ORL_DPP_HALF_MIRROR>(v); return v; }
 __device__ __forceinline__ int g8_min(int v) {
-#pragma unroll
-  for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+  int t;
+  t = dpp_i<ORL_DPP_XOR1>(v); v = t < v ? t : v;
+  t = dpp_i<ORL_DPP_XOR2>(v); v = t < v ? t : v;
+  t = dpp_i<ORL_DPP_HALF_MIRROR>(v); v = t < v ? t : v;
   return v;
 }
 __device__ __forceinline__ int g8_max(int v) {
-#pragma unroll
-  for (int o = 1; o < 8; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  int t;
+  t = dpp_i<ORL_DPP_XOR1>(v); v = t > v ? t : v;
+  t = dpp_i<ORL_DPP_XOR2>(v); v = t > v ? t : v;
+  t = dpp_i<ORL_DPP_HALF_MIRROR>(v); v = t > v ? t : v;
   return v;
 }
 // value held by the previous lane of the 8-lane row group (lane w-1); `dflt` for w == 0
-__device__ __forceinline__ int g8_prev(int v, int w, int dflt) { int t = __shfl_up(v, 1, 8); return w == 0 ? dflt : t; }
+__device__ __forceinline__ int g8_prev(int v, int w, int dflt) { int t = dpp_i<ORL_DPP_SHR1>(v); return w == 0 ? dflt : t; }
 __device__ __forceinline__ u64 word_mask_lo(int c) { return c >= 64 ? ~0ull : (c <= 0 ? 0ull : ((1ull << c) - 1ull)); }
 // bits [lo, hi) of a 64-bit word, lo/hi relative to the word and unclamped
 __device__ __forceinline__ u64 word_range(int lo, int hi) {
@@ -712,11 +741,16 @@ __device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane
         if (after && (t < bt || (t == bt && i < bi))) { bt = t; bi = i; }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      double ot = __shfl_xor(bt, o, 64);
-      int oi = __shfl_xor(bi, o, 64);
-      if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; }
+#define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; } }
+    ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR) ORL_MIN_STEP(ORL_DPP_MIRROR)
+#undef ORL_MIN_STEP
+    {  // every lane of a 16-lane row now holds the row minimum: combine the four rows through readlane
+      double t0 = rdlane_f64(bt, 0), t1 = rdlane_f64(bt, 16), t2 = rdlane_f64(bt, 32), t3 = rdlane_f64(bt, 48);
+      int i0 = __builtin_amdgcn_readlane(bi, 0), i1 = __builtin_amdgcn_readlane(bi, 16), i2 = __builtin_amdgcn_readlane(bi, 32), i3 = __builtin_amdgcn_readlane(bi, 48);
+      if (t1 < t0 || (t1 == t0 && i1 < i0)) { t0 = t1; i0 = i1; }
+      if (t3 < t2 || (t3 == t2 && i3 < i2)) { t2 = t3; i2 = i3; }
+      if (t2 < t0 || (t2 == t0 && i2 < i0)) { t0 = t2; i0 = i2; }
+      bt = t0; bi = i0;
     }
     if (!(bt <= e.now)) break;
     u64 info = e.ev_info[bi];
@@ -882,11 +916,7 @@ template <int GS> __device__ __forceinline__ u64 group_ballot(bool p, int lane) 
   if (GS == 64) return b;
   return (b >> ((lane / GS) * GS)) & ((1ull << (GS & 63)) - 1ull);
 }
-template <int GS> __device__ __forceinline__ int group_max(int v) {
-#pragma unroll
-  for (int o = GS / 2; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-  return v;
-}
+template <int GS> __device__ __forceinline__ int group_max(int v) { return GS == 8 ? g8_max(v) : wave_max(v); }
 template <int GS> __device__ __forceinline__ int group_get(int v, int src, int lane) { return __shfl(v, (lane & ~(GS - 1)) + src, 64); }
 
 template <int ENV, int W, int GS>

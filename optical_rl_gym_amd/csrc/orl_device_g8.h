@@ -1,0 +1,521 @@
+// orl_device_g8.h — step() with EIGHT lanes per env (eight envs per wavefront).
+//
+// Why: with one wavefront per env (orl_device.h, k_step) almost every instruction is wave-uniform control flow
+// that keeps 1-8 of 64 lanes busy; PMC showed ~2 100 VALU + ~1 000 SALU instructions per env-step and the kernel
+// bound by instruction issue, not by HBM.  Here a group of 8 lanes owns an env and lane w of the group owns
+//   * 64-bit word w of every link row of that env      (W <= 8 words = 512 slots)
+//   * pending-release slots i with i % 8 == w
+//   * the per-link statistics of the links whose position in topology.edges() is == w (mod 8)
+// so every read-modify-write of env state is done by the SAME lane that wrote it last: no LDS staging, no
+// cross-lane visibility hazards, and the state is touched in place in HBM (only the rows/slots a step needs).
+// The instruction stream is about as long as before but serves 8 envs.  Control flow is group-uniform; groups of
+// one wavefront diverge (different release counts, hop counts), which SIMT handles with exec masks.
+//
+// Semantics are identical to orl_device.h (same reference line ranges); shared primitives are reused from there.
+#pragma once
+#include "orl_device.h"
+
+namespace orl {
+namespace g8 {
+
+__device__ __forceinline__ u32 gballot(bool p, int lane) { return (u32)((__ballot(p) >> (lane & 56)) & 0xffull); }
+__device__ __forceinline__ int gget(int v, int src, int lane) { return __shfl(v, (lane & 56) | src, 64); }
+__device__ __forceinline__ u32 gget(u32 v, int src, int lane) { return (u32)__shfl((int)v, (lane & 56) | src, 64); }
+__device__ __forceinline__ double gget(double v, int src, int lane) { return __shfl(v, (lane & 56) | src, 64); }
+__device__ __forceinline__ u64 gget(u64 v, int src, int lane) {
+  u32 lo = gget((u32)v, src, lane), hi = gget((u32)(v >> 32), src, lane);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ double g8_min(double v) {
+  double t;
+  t = dpp_d<ORL_DPP_XOR1>(v); v = t < v ? t : v;
+  t = dpp_d<ORL_DPP_XOR2>(v); v = t < v ? t : v;
+  t = dpp_d<ORL_DPP_HALF_MIRROR>(v); v = t < v ? t : v;
+  return v;
+}
+
+struct EnvG {
+  double now, at, ht, g_thr, g_comp, g_last, next_rel;
+  i64 sp, sa, esp, esa, brq, brp, ebrq, ebrp, s_br, s_nh;
+  int src, dst, bit_rate, br_idx, id, mt_pos, ev_hwm, ev_cnt, new_service, flags, hint;
+  i64 env;
+  u64* bm;
+  double* ls;
+  int* cs;
+  double* ev_time;
+  u64* ev_info;
+  u32* mt;
+  u64* scal;
+};
+
+__device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
+  const u64* s = P.scal + env * ORL_SCAL_WORDS;
+  e.scal = P.scal + env * ORL_SCAL_WORDS;
+#define F64(slot) __longlong_as_double((i64)s[slot])
+  e.now = F64(SC_NOW); e.at = F64(SC_AT); e.ht = F64(SC_HT);
+  e.g_thr = F64(SC_GTHR); e.g_comp = F64(SC_GCOMP); e.g_last = F64(SC_GLAST); e.next_rel = F64(SC_NEXTREL);
+#undef F64
+  e.sp = (i64)s[SC_SP]; e.sa = (i64)s[SC_SA]; e.esp = (i64)s[SC_ESP]; e.esa = (i64)s[SC_ESA];
+  e.brq = (i64)s[SC_BRQ]; e.brp = (i64)s[SC_BRP]; e.ebrq = (i64)s[SC_EBRQ]; e.ebrp = (i64)s[SC_EBRP];
+  e.s_br = (i64)s[SC_SBR]; e.s_nh = (i64)s[SC_SNH];
+  u64 t;
+  t = s[SC_SRC_DST]; e.src = (int)(u32)t; e.dst = (int)(t >> 32);
+  t = s[SC_BR_IDX]; e.bit_rate = (int)(u32)t; e.br_idx = (int)(t >> 32);
+  t = s[SC_ID_MTPOS]; e.id = (int)(u32)t; e.mt_pos = (int)(t >> 32);
+  t = s[SC_EV]; e.ev_hwm = (int)(u32)t; e.ev_cnt = (int)(t >> 32);
+  t = s[SC_FLAGS]; e.new_service = (int)(u32)t; e.flags = (int)(t >> 32);
+  t = s[SC_HINT]; e.hint = (int)(u32)t;
+  e.env = env;
+  e.bm = P.bitmap + env * P.bm_words;
+  e.ls = P.lstat + env * 4 * P.E;
+  e.cs = P.core_sums + env * 2 * P.C;
+  e.ev_time = P.ev_time + env * P.ev_cap;
+  e.ev_info = P.ev_info + env * P.ev_cap;
+  e.mt = P.mt + env * 624;
+}
+
+__device__ __forceinline__ void env_store(const DevParams& P, const EnvG& e, int gl) {
+  if (gl != 0) return;
+  u64* s = e.scal;
+#define PF(slot, x) s[slot] = (u64)__double_as_longlong(x);
+  PF(SC_NOW, e.now) PF(SC_AT, e.at) PF(SC_HT, e.ht) PF(SC_GTHR, e.g_thr) PF(SC_GCOMP, e.g_comp) PF(SC_GLAST, e.g_last)
+  PF(SC_NEXTREL, e.next_rel)
+#undef PF
+  s[SC_SP] = (u64)e.sp; s[SC_SA] = (u64)e.sa; s[SC_ESP] = (u64)e.esp; s[SC_ESA] = (u64)e.esa;
+  s[SC_BRQ] = (u64)e.brq; s[SC_BRP] = (u64)e.brp; s[SC_EBRQ] = (u64)e.ebrq; s[SC_EBRP] = (u64)e.ebrp;
+  s[SC_SBR] = (u64)e.s_br; s[SC_SNH] = (u64)e.s_nh;
+  s[SC_SRC_DST] = pack2(e.src, e.dst); s[SC_BR_IDX] = pack2(e.bit_rate, e.br_idx);
+  s[SC_ID_MTPOS] = pack2(e.id, e.mt_pos); s[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
+  s[SC_FLAGS] = pack2(e.new_service, e.flags); s[SC_HINT] = pack2(e.hint, 0);
+  u64 np_ = (u64)(u32)P.n_paths[e.src * P.N + e.dst];
+  P.svc_desc[e.env] = (u64)(u32)((e.src * P.N + e.dst) * P.K) | ((u64)(u32)e.br_idx << 32) | (np_ << 48);
+}
+
+// ---- MT19937, 16-word window per refill (lane w holds window words w and w+8) ----------------------
+struct RngG { u32 out0, out1, nx0, nx1; int used; };
+
+__device__ __forceinline__ void mt_one(const u32* mt, int i, u32& out, u32& nx) {
+  int i0 = i >= 624 ? i - 624 : i;
+  int i1 = i0 + 1 >= 624 ? i0 + 1 - 624 : i0 + 1;
+  int im = i0 + 397 >= 624 ? i0 + 397 - 624 : i0 + 397;
+  u32 cur = mt[i0], nxt = mt[i1], far = mt[im];
+  u32 y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+  nx = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  u32 t = cur;
+  t ^= (t >> 11);
+  t ^= (t << 7) & 0x9d2c5680u;
+  t ^= (t << 15) & 0xefc60000u;
+  t ^= (t >> 18);
+  out = t;
+}
+__device__ __forceinline__ void rng_fill(const EnvG& e, RngG& r, int gl) {
+  mt_one(e.mt, e.mt_pos + gl, r.out0, r.nx0);
+  mt_one(e.mt, e.mt_pos + 8 + gl, r.out1, r.nx1);
+  r.used = 0;
+}
+__device__ __forceinline__ void rng_commit(EnvG& e, RngG& r, int gl) {
+  if (gl < r.used) { int i = e.mt_pos + gl; e.mt[i >= 624 ? i - 624 : i] = r.nx0; }
+  if (gl + 8 < r.used) { int i = e.mt_pos + 8 + gl; e.mt[i >= 624 ? i - 624 : i] = r.nx1; }
+  int p = e.mt_pos + r.used;
+  e.mt_pos = p >= 624 ? p - 624 : p;
+  r.used = 0;
+}
+__device__ __forceinline__ u32 rng_u32(EnvG& e, RngG& r, int lane) {
+  if (r.used == 16) {
+    rng_commit(e, r, lane & 7);
+    rng_fill(e, r, lane & 7);
+  }
+  u32 a = gget(r.out0, r.used & 7, lane), b = gget(r.out1, r.used & 7, lane);
+  u32 v = r.used < 8 ? a : b;
+  r.used++;
+  return v;
+}
+__device__ __forceinline__ double rng_random(EnvG& e, RngG& r, int lane) {
+  u32 a = rng_u32(e, r, lane) >> 5, b = rng_u32(e, r, lane) >> 6;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double rng_expovariate(EnvG& e, RngG& r, int lane, double lambd) {
+  return -orl_log(1.0 - rng_random(e, r, lane)) / lambd;
+}
+__device__ __forceinline__ int rng_choice(EnvG& e, RngG& r, int lane, const double* cum, int n) {
+  double x = rng_random(e, r, lane) * (cum[n - 1] + 0.0);
+  int cnt = 0;
+  for (int base = 0; base < n - 1; base += 8) {
+    int i = base + (lane & 7);
+    bool le = (i < n - 1) && (cum[i] <= x);
+    cnt += (int)__popc(gballot(le, lane));
+  }
+  return cnt;
+}
+
+// ---- slot rows: lane w owns word w -------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ bool path_is_free(const DevParams& P, const EnvG& e, int lane, int pidx, int core, int s0, int n) {
+  if (s0 + n > P.S) return false;
+  const PathRec rec = path_rec_load(P, pidx);
+  const int hops = path_rec_byte(rec, 0), w = lane & 7;
+  bool busy = false;
+  if (w < W) {
+    const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
+    for (int h = 0; h < hops; h++) {
+      int link = path_rec_byte(rec, 2 + h);
+      busy = busy || ((m & ~e.bm[(core * P.E + link) * W + w]) != 0ull);
+    }
+  }
+  return gballot(busy, lane) == 0u;
+}
+
+__device__ __forceinline__ double net_compactness(const DevParams& P, const EnvG& e, int core, int lane) {
+  // lane 0 of the group is the only writer of cs[]: take its copy
+  int occ = gget(e.cs[2 * core], 0, lane), fb = gget(e.cs[2 * core + 1], 0, lane);
+  if (fb > 0) return ((double)occ / (double)e.s_nh) * ((double)P.E / (double)fb);
+  return 1.0;
+}
+
+template <int ENV, int W>
+__device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane, int pidx, int core, int s0, int n, bool release) {
+  const PathRec rec = path_rec_load(P, pidx);
+  const int hops = path_rec_byte(rec, 0), w = lane & 7;
+  const int E = P.E, S = P.S;
+  int d_occ = 0, d_fb = 0;
+  const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
+  for (int h = 0; h < hops; h++) {
+    const int link = path_rec_byte(rec, 2 + h);
+    u64* wp = e.bm + (core * E + link) * W + (w < W ? w : 0);
+    u64 a = (w < W) ? *wp : 0ull;
+    RowStat before, after;
+    if (ENV != ENV_RWA) row_stat<W, false>(a, w, S, before);
+    a = release ? (a | m) : (a & ~m);
+    if (w < W) *wp = a;
+    if (ENV != ENV_RWA) {
+      row_stat<W, true>(a, w, S, after);
+      d_occ += after.occ - before.occ;
+      d_fb += after.fb - before.fb;
+    } else {
+      after.free_ = g8_sum(__popcll(a));
+    }
+    // _update_link_stats (rmsa_env.py:464-543).  The statistics of a link belong to lane link_pos[link] % 8.
+    const bool own = (w == (P.link_pos[link] & 7));
+    double last_update = e.ls[3 * E + link];
+    double time_diff = e.now - last_update;
+    if (e.now > 0) {
+      const int free_ = after.free_;
+      double cur_util = (double)(S - free_) / (double)S;
+      double util = ((e.ls[link] * last_update) + (cur_util * time_diff)) / e.now;
+      double frag = 0.0, comp = 0.0;
+      if (ENV != ENV_RWA) {
+        double cur_frag = 0.0, cur_comp = 0.0;
+        const int top = (S - 1) - 64 * w;
+        const int edge = g8_sum(((w == 0 && (a & 1ull)) ? 1 : 0) + ((top >= 0 && top < 64 && ((a >> top) & 1ull)) ? 1 : 0));
+        const int max_empty = row_longest_run8<W>(a, w);
+        if (free_ > 0) {
+          int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
+          cur_frag = 1.0 - ((double)me / (double)free_);
+          if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
+          else cur_comp = 1.0;
+        }
+        frag = ((e.ls[E + link] * last_update) + (cur_frag * time_diff)) / e.now;
+        comp = ((e.ls[2 * E + link] * last_update) + (cur_comp * time_diff)) / e.now;
+      }
+      if (own) {
+        e.ls[link] = util;
+        if (ENV != ENV_RWA) { e.ls[E + link] = frag; e.ls[2 * E + link] = comp; }
+      }
+    }
+    if (own) e.ls[3 * E + link] = e.now;
+  }
+  if (ENV != ENV_RWA) {
+    int c0 = gget(e.cs[2 * core], 0, lane) + d_occ, c1 = gget(e.cs[2 * core + 1], 0, lane) + d_fb;
+    if (w == 0) { e.cs[2 * core] = c0; e.cs[2 * core + 1] = c1; }
+  }
+  return hops;
+}
+
+// ---- pending releases: slot i belongs to lane i % 8 -------------------------------------------------
+__device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
+  const int gl = lane & 7;
+  int idx = e.hint;
+  e.hint = -1;
+  if (idx < 0) {
+    for (int base = 0; base < e.ev_hwm; base += 8) {
+      int i = base + gl;
+      bool empty = (i < e.ev_hwm) && (e.ev_time[i] == __builtin_inf());
+      u32 b = gballot(empty, lane);
+      if (b) { idx = base + (int)__builtin_ctz(b); break; }
+    }
+  }
+  if (idx < 0) {
+    if (e.ev_hwm >= P.ev_cap) { e.flags |= ORL_FLAG_EV_OVERFLOW; return; }
+    idx = e.ev_hwm++;
+  }
+  if (gl == (idx & 7)) { e.ev_time[idx] = t; e.ev_info[idx] = info; }
+  e.ev_cnt++;
+  e.next_rel = t < e.next_rel ? t : e.next_rel;  // -inf (unknown) stays -inf
+}
+
+template <int ENV, int W>
+__device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lane, int bi) {
+  const int gl = lane & 7, owner = bi & 7;
+  u64 info = (gl == owner) ? e.ev_info[bi] : 0ull;
+  info = gget(info, owner, lane);
+  if (gl == owner) e.ev_time[bi] = __builtin_inf();
+  const int pidx = (int)(info & 0xffffffu), s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
+  const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
+  e.ev_cnt--;
+  e.hint = (e.hint < 0 || bi < e.hint) ? bi : e.hint;
+  int hops_r = path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
+  e.s_br -= br;
+  e.s_nh -= (i64)n * hops_r;
+}
+
+// release every pending service with release_time <= now in increasing time order (rmsa_env.py:590-597)
+template <int ENV, int W>
+__device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lane) {
+  if (e.next_rel > e.now) return;  // nothing can be due (next_rel is a lower bound of every pending time)
+  const int gl = lane & 7;
+  for (;;) {
+    // one pass over the lane's own slots: its two earliest due entries, whether it has more, and its earliest future one
+    double d0t = __builtin_inf(), d1t = __builtin_inf(), rest = __builtin_inf();
+    int d0i = 0x7fffffff, d1i = 0x7fffffff, ndue = 0;
+    for (int base = gl; base < e.ev_hwm; base += 64) {
+      double tt[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {  // eight independent loads in flight per lane
+        int i = base + 8 * k;
+        tt[k] = (i < e.ev_hwm) ? e.ev_time[i] : __builtin_inf();
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int i = base + 8 * k;
+        const double t = tt[k];
+        if (t <= e.now) {
+          ndue++;
+          if (t < d0t || (t == d0t && i < d0i)) { d1t = d0t; d1i = d0i; d0t = t; d0i = i; }
+          else if (t < d1t || (t == d1t && i < d1i)) { d1t = t; d1i = i; }
+        } else {
+          rest = t < rest ? t : rest;
+        }
+      }
+    }
+    const bool overflow = gballot(ndue > 2, lane) != 0u;
+    if (overflow) {
+      // a lane holds 3+ due entries (rare): release only the globally earliest one, then rescan
+      double bt = d0t; int bi = d0i;
+#define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; } }
+      ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
+#undef ORL_MIN_STEP
+      release_one<ENV, W>(P, e, lane, bi);
+      continue;
+    }
+    for (;;) {
+      double bt = d0t; int bi = d0i;
+#define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; } }
+      ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
+#undef ORL_MIN_STEP
+      if (!(bt <= e.now)) break;
+      if (gl == (bi & 7)) { d0t = d1t; d0i = d1i; d1t = __builtin_inf(); d1i = 0x7fffffff; }
+      release_one<ENV, W>(P, e, lane, bi);
+    }
+    e.next_rel = g8_min(rest);
+    break;
+  }
+  // shrink the scan window when its tail is empty (bounded work per step; a stale larger hwm is harmless)
+  for (int it = 0; it < 4 && e.ev_hwm > 0; it++) {
+    int i = e.ev_hwm - 1;
+    double t = gget((gl == (i & 7)) ? e.ev_time[i] : 0.0, i & 7, lane);
+    if (t == __builtin_inf()) { e.ev_hwm--; if (e.hint == i) e.hint = -1; } else break;
+  }
+}
+
+template <int ENV, int W>
+__device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int lane, RngG& r) {
+  if (e.new_service) return;
+  const int gl = lane & 7;
+  double at = e.now + rng_expovariate(e, r, lane, P.lambda_a);
+  e.now = at;
+  double ht = rng_expovariate(e, r, lane, P.lambda_h);
+  int src = rng_choice(e, r, lane, P.cum_src, P.N);
+  int dst = rng_choice(e, r, lane, P.cum_dst + src * P.N, P.N);
+  int bit_rate = 0, br_idx = 0;
+  if (ENV != ENV_RWA) {
+    if (P.bit_rate_mode == 0) {
+      u32 v = rng_u32(e, r, lane) >> (32 - P.rand_bits);
+      while ((int)v >= P.rand_n) v = rng_u32(e, r, lane) >> (32 - P.rand_bits);
+      br_idx = (int)v;
+      bit_rate = P.br_lo + br_idx;
+    } else {
+      br_idx = rng_choice(e, r, lane, P.cum_br, P.n_br);
+      bit_rate = P.bit_rates[br_idx];
+    }
+  }
+  rng_commit(e, r, gl);
+  if (ENV == ENV_RWA || ENV == ENV_RMCSA) release_due<ENV, W>(P, e, lane);
+  e.id = (int)e.esp;
+  e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
+  e.new_service = 1;
+  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) { e.sp += 1; e.esp += 1; }
+  if (ENV != ENV_RWA) {
+    e.brq += bit_rate;
+    e.ebrq += bit_rate;
+    if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;
+  }
+  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) release_due<ENV, W>(P, e, lane);
+}
+
+// np.mean over the links in topology.edges() order (numpy pairwise sum); lane j reads the statistics it owns
+__device__ __forceinline__ double link_mean(const DevParams& P, const double* vals, int lane) {
+  const int E = P.E, gl = lane & 7;
+  double res;
+  if (E < 8) {
+    res = 0.;
+    for (int i = 0; i < E; i++) res += gget((gl == i) ? vals[P.edge_iter_order[i]] : 0.0, i, lane);
+  } else {
+    double r = vals[P.edge_iter_order[gl]];
+    int i;
+    for (i = 8; i < E - (E % 8); i += 8) r += vals[P.edge_iter_order[i + gl]];
+    double r0 = gget(r, 0, lane), r1 = gget(r, 1, lane), r2 = gget(r, 2, lane), r3 = gget(r, 3, lane);
+    double r4 = gget(r, 4, lane), r5 = gget(r, 5, lane), r6 = gget(r, 6, lane), r7 = gget(r, 7, lane);
+    res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < E; i++) res += gget((gl == (i & 7)) ? vals[P.edge_iter_order[i]] : 0.0, i & 7, lane);
+  }
+  return res / (double)E;
+}
+
+// lane-private AND of a path's rows, only valid BEFORE this kernel modified the slot map (DeepRMSA action decode)
+template <int W>
+__device__ __forceinline__ Row<W> path_and_global(const DevParams& P, const EnvG& e, int pidx) {
+  return path_and_rec<W>(path_rec_load(P, pidx), e.bm, P.E, P.S, 0);
+}
+
+template <int ENV, int W>
+__device__ __forceinline__ void step(const DevParams& P, EnvG& e, int lane, const int* act, int auto_reset, bool want_info) {
+  const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
+  RngG rng;
+  rng_fill(e, rng, gl);  // requested first: consumed only in next_service
+  int path, slot, mod = 0, core = 0;
+  bool bad = false;
+  if (ENV == ENV_DEEPRMSA) {
+    int aa = act[0];
+    path = K; slot = S;
+    if (aa >= 0 && aa < K * P.J) {
+      int route = aa / P.J, block = aa - route * P.J;
+      int starts[8], lens[8];
+      int pidx = pair_base(P, e.src, e.dst) + route;
+      int nb = 0;
+      if (route < P.n_paths[e.src * P.N + e.dst]) {
+        Row<W> m = path_and_global<W>(P, e, pidx);
+        nb = first_blocks<W>(m, S, P.nslots_path[(size_t)pidx * P.n_br + e.br_idx], block + 1, starts, lens);
+      }
+      if (block < nb) { path = route; slot = starts[block]; }
+    }
+  } else if (ENV == ENV_RMCSA) {
+    path = act[0]; mod = act[1]; core = act[2]; slot = act[3];
+    bad = path < 0 || path > K || mod < 0 || mod > P.M || core < 0 || core > P.C || slot < 0 || slot > S;
+  } else if (ENV == ENV_RWA) {
+    path = act[0]; slot = act[1];
+    bad = path < 0 || path >= K + rej || slot < 0 || slot >= S + rej;
+  } else {
+    path = act[0]; slot = act[1];
+    bad = path < 0 || path > K || slot < 0 || slot > S;
+  }
+  if (bad) {
+    e.flags |= ORL_FLAG_BAD_ACTION;
+    path = K; slot = S; mod = P.M; core = P.C;
+  }
+  const int path0 = path, slot0 = slot;
+  double prev_comp = 0.0, cur_comp = 0.0;
+  if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && want_info) prev_comp = net_compactness(P, e, 0, lane);
+  bool accepted = false;
+  bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
+  if (in_range && path < P.n_paths[e.src * P.N + e.dst]) {
+    int pidx = pair_base(P, e.src, e.dst) + path;
+    int n = 1;
+    if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
+    else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
+    bool ok = path_is_free<W>(P, e, lane, pidx, core, slot, n);
+    if (ok && ENV == ENV_RMCSA) {
+      double len = P.path_length[pidx];
+      ok = (len < P.lmax_xt[mod]) && (len < P.lmax_snr[mod * P.n_br + e.br_idx]);
+    }
+    if (ok) {
+      int hops_p = path_apply<ENV, W>(P, e, lane, pidx, core, slot, n, false);
+      e.s_br += e.bit_rate;
+      e.s_nh += (i64)n * hops_p;
+      if (ENV != ENV_RWA) {
+        double last_update = e.g_last, time_diff = e.now - last_update;
+        if (e.now > 0) {
+          double cur_thr = (double)e.s_br;
+          e.g_thr = ((e.g_thr * last_update) + (cur_thr * time_diff)) / e.now;
+          e.g_comp = ((e.g_comp * last_update) + (net_compactness(P, e, core, lane) * time_diff)) / e.now;
+        }
+        e.g_last = e.now;
+        e.brp += e.bit_rate;
+        e.ebrp += e.bit_rate;
+        if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[e.env * 2 * P.n_br + P.n_br + e.br_idx] += 1;
+      }
+      e.sa += 1;
+      e.esa += 1;
+      accepted = true;
+      ev_push(P, e, lane, e.at + e.ht, ev_pack(pidx, slot, n, core, e.bit_rate));
+    }
+  }
+  if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
+  if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
+  if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && want_info) cur_comp = net_compactness(P, e, 0, lane);
+
+  double* info_out = want_info ? P.info + e.env * P.n_info : nullptr;
+  if (ENV == ENV_RWA) {
+    i64* h = P.act_hist + e.env * ((K + 1) + (S + 1));
+    const int npa = K + rej, nsa = S + rej;
+    for (int i = gl; i < npa + nsa; i += 8) {
+      int hi = (i < npa) ? i : (K + 1) + (i - npa);
+      bool hit = !bad && ((i < npa) ? (i == path0) : (i - npa == slot0));
+      i64 v = h[hi] + (hit ? 1 : 0);
+      if (hit) h[hi] = v;
+      if (info_out) info_out[2 + i] = (double)v / (double)e.sp;
+    }
+  }
+  double reward = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
+  if (info_out) {
+    double i0 = (double)(e.sp - e.sa) / (double)e.sp;
+    double i1 = (double)(e.esp - e.esa) / (double)e.esp;
+    if (gl == 0) { info_out[0] = i0; info_out[1] = i1; }
+    if (ENV != ENV_RWA) {
+      double i2 = (double)(e.brq - e.brp) / (double)e.brq;
+      double i3 = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
+      if (gl == 0) { info_out[2] = i2; info_out[3] = i3; }
+    }
+    if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
+      double mc = link_mean(P, e.ls + 2 * P.E, lane);
+      double mu = link_mean(P, e.ls, lane);
+      if (gl == 0) { info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu; }
+      if (P.bit_rate_mode == 1 && gl == 0) {
+        const i64* rq = P.br_hist + e.env * 2 * P.n_br;
+        const i64* pv = rq + P.n_br;
+        double mxv = -__builtin_inf(), mnv = __builtin_inf();
+        for (int i = 0; i < P.n_br; i++) {
+          double bl = 0.0;
+          if (rq[i] > 0) bl = (double)(rq[i] - pv[i]) / (double)rq[i];
+          info_out[8 + i] = bl;
+          mxv = bl > mxv ? bl : mxv;
+          mnv = bl < mnv ? bl : mnv;
+        }
+        info_out[8 + P.n_br] = mxv - mnv;
+      }
+    }
+  }
+  e.new_service = 0;
+  next_service<ENV, W>(P, e, lane, rng);
+  bool done = (e.esp == (i64)P.episode_length);
+  if (done && auto_reset) {
+    e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
+    if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
+  }
+  if (gl == 0) {
+    P.reward[e.env] = reward;
+    P.done[e.env] = done ? 1 : 0;
+  }
+}
+
+}  // namespace g8
+}  // namespace orl

@@ -12,12 +12,14 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
 
 #include "../../include/orl.h"
 #include "orl_device.h"
+#include "orl_device_g8.h"
 
 using namespace orl;
 
@@ -166,6 +168,51 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
   env_store(P, e, lane);
 }
 
+// step(), 8 lanes per env / 8 envs per wavefront (orl_device_g8.h): state is updated in place in HBM, no LDS
+#ifndef ORL_STEP8_WAVES
+#define ORL_STEP8_WAVES 1
+#endif
+template <int ENV, int W>
+__global__ void __launch_bounds__(256, ORL_STEP8_WAVES) k_step8(DevParams P, int auto_reset, int want_info) {
+  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+  const i64 env0 = ((i64)blockIdx.x * 4 + wave) * 8;
+  if (env0 >= P.B) return;
+  // The 8 envs of a wavefront have contiguous slot maps and link statistics in HBM: stage both into this wave's
+  // LDS window with 16-B-per-lane loads, work there, write back at the end.
+  const int per_env = P.bm_words + 4 * P.E;  // u64 words
+  u64* win = (u64*)orl_lds_raw + (size_t)wave * 8 * per_env;
+  const i64 nenv = P.B - env0 < 8 ? P.B - env0 : 8;
+  {
+    const ulonglong2* g = (const ulonglong2*)(P.bitmap + env0 * P.bm_words);
+    ulonglong2* l = (ulonglong2*)win;
+    for (int i = lane; i < (int)(nenv * (P.bm_words / 2)); i += 64) l[i] = g[i];
+    const double* gs = P.lstat + env0 * 4 * P.E;
+    double* ls = (double*)(win + 8 * P.bm_words);
+    for (int i = lane; i < (int)(nenv * 4 * P.E); i += 64) ls[i] = gs[i];
+  }
+  const i64 env = env0 + (lane >> 3);
+  wave_fence();
+  if (env < P.B) {
+    g8::EnvG e;
+    g8::env_load(P, e, env);
+    e.bm = win + (size_t)(lane >> 3) * P.bm_words;
+    e.ls = (double*)(win + 8 * P.bm_words) + (size_t)(lane >> 3) * 4 * P.E;
+    int4 av = *(const int4*)(P.actions + env * 4);
+    int act[4] = {av.x, av.y, av.z, av.w};
+    g8::step<ENV, W>(P, e, lane, act, auto_reset, want_info != 0);
+    g8::env_store(P, e, lane & 7);
+  }
+  wave_fence();
+  {
+    ulonglong2* g = (ulonglong2*)(P.bitmap + env0 * P.bm_words);
+    const ulonglong2* l = (const ulonglong2*)win;
+    for (int i = lane; i < (int)(nenv * (P.bm_words / 2)); i += 64) g[i] = l[i];
+    double* gs = P.lstat + env0 * 4 * P.E;
+    const double* ls = (const double*)(win + 8 * P.bm_words);
+    for (int i = lane; i < (int)(nenv * 4 * P.E); i += 64) gs[i] = ls[i];
+  }
+}
+
 template <int ENV, int W>
 __global__ void __launch_bounds__(64) k_obs(DevParams P) {
   const i64 env = blockIdx.x;
@@ -228,11 +275,13 @@ struct orl_topology {
   unsigned char* path_mod;
   double* path_length;
   int* edge_iter_order;
+  int* link_pos;
 };
 
 struct orl_batch {
   DevParams P;
   int device, wt;
+  int step_impl;  // 64 = one wavefront per env (default: 314 us/launch on cfg2), 8 = eight lanes per env (ORL_STEP_IMPL=8: 327 us)
   hipStream_t stream;
   std::vector<void*> allocs;
   hipEvent_t ev0, ev1;
@@ -265,7 +314,7 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
   HIPCHK(hipSetDevice(device_id));
   orl_topology* t = new orl_topology();
   t->n_paths = nullptr; t->path_hops = nullptr; t->path_links = nullptr; t->path_mod = nullptr;
-  t->path_length = nullptr; t->edge_iter_order = nullptr;
+  t->path_length = nullptr; t->edge_iter_order = nullptr; t->link_pos = nullptr;
   t->device = device_id;
   t->N = d->n_nodes; t->E = d->n_links; t->K = d->k_paths; t->H = d->max_hops; t->M = d->n_modulations;
   size_t nn = (size_t)t->N * t->N, npk = nn * t->K;
@@ -286,6 +335,11 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
   rc |= upload_conv(&t->path_mod, mod.data(), npk, nullptr);
   rc |= upload_conv(&t->path_length, d->path_length, npk, nullptr);
   rc |= upload_conv(&t->edge_iter_order, d->edge_iter_order, (size_t)t->E, nullptr);
+  {
+    std::vector<int32_t> pos((size_t)t->E, 0);
+    for (int i = 0; i < t->E; i++) pos[(size_t)d->edge_iter_order[i]] = i;
+    rc |= upload_conv(&t->link_pos, pos.data(), (size_t)t->E, nullptr);
+  }
   if (rc) { delete t; return ORL_E_HIP; }
   *out = t;
   return ORL_OK;
@@ -295,7 +349,7 @@ extern "C" void orl_topology_destroy(orl_topology* t) {
   if (!t) return;
   hipSetDevice(t->device);
   hipFree(t->n_paths); hipFree(t->path_hops); hipFree(t->path_links); hipFree(t->path_mod);
-  hipFree(t->path_length); hipFree(t->edge_iter_order);
+  hipFree(t->path_length); hipFree(t->edge_iter_order); hipFree(t->link_pos);
   delete t;
 }
 
@@ -343,7 +397,19 @@ static void launch_policy(orl_batch* b, int pol) {
 #undef PER_ENV
 #undef CALLW
 }
+static void launch_obs(orl_batch* b);
 static void launch_step(orl_batch* b, int auto_reset, int want_info) {
+  const size_t lds8 = (size_t)32 * (b->P.bm_words + 4 * b->P.E) * 8;  // 4 wavefronts x 8 envs per workgroup
+  if (b->step_impl == 8 && lds8 <= 64 * 1024) {
+    dim3 g((unsigned)((b->P.B + 31) / 32)), blk(256);
+#define CALLW(WW) hipLaunchKernelGGL((k_step8<EE, WW>), g, blk, lds8, b->stream, b->P, auto_reset, want_info)
+#define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
+    ORL_FOR_ENV(PER_ENV)
+#undef PER_ENV
+#undef CALLW
+    if (b->P.obs_dim) launch_obs(b);  // DeepRMSA observation of the new pending service
+    return;
+  }
   dim3 g((unsigned)b->P.B), blk(64);
   // stage the pending release times through LDS when the per-env window stays small enough for 5 waves/SIMD
   const size_t ev_bytes = (size_t)b->P.ev_cap * 8;
@@ -395,6 +461,10 @@ extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, 
   memset(&b->P, 0, sizeof b->P);
   b->device = t->device;
   b->d_totals = nullptr;
+  {
+    const char* impl = getenv("ORL_STEP_IMPL");
+    b->step_impl = (impl && atoi(impl) == 8) ? 8 : 64;
+  }
   DevParams& P = b->P;
   P.env_type = c->env_type;
   P.N = t->N; P.E = t->E; P.K = t->K; P.H = t->H; P.M = t->M;
@@ -434,7 +504,7 @@ extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, 
   if (P.lds_bytes > 64 * 1024) { delete b; return fail(ORL_E_INVALID, "per-env LDS window too large (%d B)", P.lds_bytes); }
 
   P.n_paths = t->n_paths; P.path_hops = t->path_hops; P.path_links = t->path_links; P.path_mod = t->path_mod;
-  P.path_length = t->path_length; P.edge_iter_order = t->edge_iter_order;
+  P.path_length = t->path_length; P.edge_iter_order = t->edge_iter_order; P.link_pos = t->link_pos;
   int rc = 0;
   {
     double* p; int* q; unsigned char* u;
