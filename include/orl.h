@@ -111,6 +111,9 @@ void orl_topology_destroy(orl_topology* t);
  * the reference's reset(only_episode_counters=False) (rmsa_env.py:160-161): every env holds its first service. */
 int orl_batch_create(const orl_env_config* cfg, const orl_topology* topo, int64_t n_envs, const uint32_t* mt_state,
                      orl_batch** out);
+/* Same, but the device runs random.Random(seed_i) itself (CPython random_seed -> init_by_array on abs(seed)). */
+int orl_batch_create_seeded(const orl_env_config* cfg, const orl_topology* topo, int64_t n_envs, const int64_t* seeds,
+                            orl_batch** out);
 void orl_batch_destroy(orl_batch* b);
 
 int orl_batch_info_dim(const orl_batch* b); /* floats per env in the info row */
@@ -153,6 +156,17 @@ int orl_batch_get_active(orl_batch* b, int32_t* out /*[n_envs] pending releases*
 int orl_batch_get_flags(orl_batch* b, int32_t* out /*[n_envs] bit0 event overflow, bit1 bad action*/);
 /* summed over envs: services_processed, services_accepted (for throughput/blocking reports) */
 int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted);
+
+/* SimpleMatrixObservation (rmsa_env.py:806-837, rmcsa_env.py:914-947) for every env:
+ * uint8 [n_envs][2*n_nodes + cores*links*slots] = one-hot(min(src,dst)), one-hot(max(src,dst)), slot map. */
+int orl_batch_matrix_obs_dim(const orl_batch* b);
+int orl_batch_matrix_observation(orl_batch* b, uint8_t* out);
+
+/* Snapshot / restore of the complete simulation state of the batch (slot maps, pending releases, RNG, statistics,
+ * counters).  The reference has no equivalent (no checkpointing); used for long PPO runs. */
+int64_t orl_batch_state_bytes(orl_batch* b);
+int orl_batch_get_state(orl_batch* b, void* out);
+int orl_batch_set_state(orl_batch* b, const void* in);
 
 /* Profiling aid: reads the whole slot-map array once with 8-B (width16 = 0) or 16-B (1) loads per lane and returns the
  * number of bytes read, so that rocprofv3's FETCH_SIZE can be calibrated on a known byte count. */

@@ -32,7 +32,13 @@ EXPORTS = {
     "orl_topology_create": (C.c_int, [C.POINTER(TopologyDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "orl_topology_destroy": (None, [C.c_void_p]),
     "orl_batch_create": (C.c_int, [C.POINTER(EnvConfig), C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "orl_batch_create_seeded": (C.c_int, [C.POINTER(EnvConfig), C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "orl_batch_destroy": (None, [C.c_void_p]),
+    "orl_batch_matrix_obs_dim": (C.c_int, [C.c_void_p]),
+    "orl_batch_matrix_observation": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_state_bytes": (C.c_int64, [C.c_void_p]),
+    "orl_batch_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_set_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_info_dim": (C.c_int, [C.c_void_p]),
     "orl_batch_obs_dim": (C.c_int, [C.c_void_p]),
     "orl_batch_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -58,6 +58,53 @@ __global__ void __launch_bounds__(64) k_init_mt(DevParams P, const u32* raw) {
   if (lane < ORL_SCAL_WORDS) P.scal[env * ORL_SCAL_WORDS + lane] = v;
 }
 
+// random.Random(seed) on the device: CPython's random_seed() takes abs(seed), splits it into 32-bit words
+// (little-endian, at least one) and calls init_by_array (Modules/_randommodule.c).  One thread per env; the
+// resulting 624 words + index 624 go to the same raw buffer k_init_mt converts.
+__global__ void k_seed_mt(const long long* seeds, i64 n, u32* raw) {
+  i64 env = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  u32* mt = raw + env * 625;
+  long long sv = seeds[env];
+  u64 a = sv < 0 ? (u64)(-(sv + 1)) + 1ull : (u64)sv;
+  u32 key[2] = {(u32)a, (u32)(a >> 32)};
+  const int klen = key[1] ? 2 : 1;
+  mt[0] = 19650218u;
+  for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (u32)i;
+  int i = 1, j = 0;
+  for (int k = 624; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (u32)j;
+    i++; j++;
+    if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    if (j >= klen) j = 0;
+  }
+  for (int k = 623; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (u32)i;
+    i++;
+    if (i >= 624) { mt[0] = mt[623]; i = 1; }
+  }
+  mt[0] = 0x80000000u;
+  mt[624] = 624u;
+}
+
+// SimpleMatrixObservation (rmsa_env.py:806-837, rmcsa_env.py:914-947): [one-hot(min(src,dst)) | one-hot(max(src,dst)) |
+// available_slots.flatten()] as uint8, one workgroup per env, bits unpacked 8 per thread-iteration.
+__global__ void k_matrix_obs(DevParams P, unsigned char* out) {
+  const i64 env = blockIdx.x;
+  const int N = P.N, S = P.S, rows = P.C * P.E;
+  const int dim = 2 * N + rows * S;
+  unsigned char* o = out + env * dim;
+  const u64 sd = P.scal[env * ORL_SCAL_WORDS + SC_SRC_DST];
+  const int src = (int)(u32)sd, dst = (int)(sd >> 32);
+  const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
+  for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) o[i] = (i == mn || i == N + mx) ? 1 : 0;
+  const u64* bm = P.bitmap + env * P.bm_words;
+  for (int i = threadIdx.x; i < rows * S; i += blockDim.x) {
+    int r = i / S, sl = i - r * S;
+    o[2 * N + i] = (unsigned char)((bm[r * P.W + (sl >> 6)] >> (sl & 63)) & 1ull);
+  }
+}
+
 template <int ENV, int W>
 __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsigned char* mask) {
   const i64 env = blockIdx.x;
@@ -437,9 +484,9 @@ template <typename T> static int dalloc(orl_batch* b, T** p, size_t n) {
   return 0;
 }
 
-extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
-                                orl_batch** out) {
-  if (!c || !t || !out || !mt_state || n_envs < 1) return fail(ORL_E_INVALID, "null/invalid argument");
+static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
+                             const int64_t* seeds, orl_batch** out) {
+  if (!c || !t || !out || (!mt_state && !seeds) || n_envs < 1) return fail(ORL_E_INVALID, "null/invalid argument");
   if (c->env_type < 0 || c->env_type > 3) return fail(ORL_E_INVALID, "unknown env_type %d", c->env_type);
   const int S = c->num_spectrum_resources, C = c->num_spatial_resources;
   if (S < 2 || S > 512) return fail(ORL_E_INVALID, "num_spectrum_resources must be in [2, 512]");
@@ -555,7 +602,14 @@ extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, 
   // MT state upload + conversion, then the constructor's full reset
   u32* raw = nullptr;
   HIPCHK(hipMalloc((void**)&raw, B * 625 * sizeof(u32)));
-  HIPCHK(hipMemcpyAsync(raw, mt_state, B * 625 * sizeof(u32), hipMemcpyHostToDevice, b->stream));
+  long long* dseeds = nullptr;
+  if (mt_state) {
+    HIPCHK(hipMemcpyAsync(raw, mt_state, B * 625 * sizeof(u32), hipMemcpyHostToDevice, b->stream));
+  } else {
+    HIPCHK(hipMalloc((void**)&dseeds, B * sizeof(long long)));
+    HIPCHK(hipMemcpyAsync(dseeds, seeds, B * sizeof(long long), hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_seed_mt, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, b->stream, dseeds, (i64)B, raw);
+  }
   HIPCHK(hipMemsetAsync(P.actions, 0, B * 4 * sizeof(int), b->stream));
   hipLaunchKernelGGL(k_init_mt, dim3((unsigned)B), dim3(64), 624 * 4, b->stream, P, raw);
   launch_reset(b, 1, nullptr);
@@ -563,8 +617,20 @@ extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, 
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   hipFree(raw);
+  if (dseeds) hipFree(dseeds);
   *out = b;
   return ORL_OK;
+}
+
+extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
+                                orl_batch** out) {
+  if (!mt_state) return fail(ORL_E_INVALID, "mt_state is null");
+  return batch_create_impl(c, t, n_envs, mt_state, nullptr, out);
+}
+extern "C" int orl_batch_create_seeded(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const int64_t* seeds,
+                                       orl_batch** out) {
+  if (!seeds) return fail(ORL_E_INVALID, "seeds is null");
+  return batch_create_impl(c, t, n_envs, nullptr, seeds, out);
 }
 
 extern "C" void orl_batch_destroy(orl_batch* b) {
@@ -787,4 +853,63 @@ extern "C" int64_t orl_batch_debug_stream_read(orl_batch* b, int width16) {
   hipLaunchKernelGGL(k_calib_read, dim3(2048), dim3(256), 0, b->stream, b->P.bitmap, n_words, width16, b->d_totals);
   if (hipStreamSynchronize(b->stream) != hipSuccess) return ORL_E_HIP;
   return n_words * 8;
+}
+
+extern "C" int orl_batch_matrix_obs_dim(const orl_batch* b) { return b ? 2 * b->P.N + b->P.C * b->P.E * b->P.S : 0; }
+
+extern "C" int orl_batch_matrix_observation(orl_batch* b, uint8_t* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t dim = (size_t)orl_batch_matrix_obs_dim(b), B = (size_t)b->P.B;
+  unsigned char* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, B * dim));
+  hipLaunchKernelGGL(k_matrix_obs, dim3((unsigned)B), dim3(256), 0, b->stream, b->P, d);
+  HIPCHK(hipMemcpyAsync(out, d, B * dim, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  hipFree(d);
+  return ORL_OK;
+}
+
+// ---- snapshot / restore: the per-env arrays, concatenated in a fixed order -------------------------
+struct Section { void* ptr; size_t bytes; };
+static std::vector<Section> state_sections(orl_batch* b) {
+  const DevParams& P = b->P;
+  const size_t B = (size_t)P.B;
+  std::vector<Section> v;
+  v.push_back({P.scal, B * ORL_SCAL_WORDS * 8});
+  v.push_back({P.svc_desc, B * 8});
+  v.push_back({P.bitmap, B * P.bm_words * 8});
+  v.push_back({P.ev_time, B * P.ev_cap * 8});
+  v.push_back({P.ev_info, B * P.ev_cap * 8});
+  v.push_back({P.mt, B * 624 * 4});
+  v.push_back({P.lstat, B * 4 * P.E * 8});
+  v.push_back({P.core_sums, B * 2 * P.C * 4});
+  if (P.br_hist) v.push_back({P.br_hist, B * 2 * P.n_br * 8});
+  if (P.act_hist) v.push_back({P.act_hist, B * ((P.K + 1) + (P.S + 1)) * 8});
+  return v;
+}
+extern "C" int64_t orl_batch_state_bytes(orl_batch* b) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  int64_t n = 0;
+  for (auto& s : state_sections(b)) n += (int64_t)s.bytes;
+  return n;
+}
+extern "C" int orl_batch_get_state(orl_batch* b, void* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  unsigned char* o = (unsigned char*)out;
+  for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(o, s.ptr, s.bytes, hipMemcpyDeviceToHost)); o += s.bytes; }
+  return ORL_OK;
+}
+extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
+  if (!b || !in) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const unsigned char* o = (const unsigned char*)in;
+  for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(s.ptr, o, s.bytes, hipMemcpyHostToDevice)); o += s.bytes; }
+  if (b->P.obs_dim) launch_obs(b);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ORL_OK;
 }

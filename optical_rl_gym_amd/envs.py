@@ -162,9 +162,17 @@ class BatchedOpticalEnv:
                              int(self.allow_rejection), j, mode, lo, hi, len(table_rates), event_capacity, 0,
                              lambda_a, lambda_h, _ptr(cum_src), _ptr(keep["cum_dst"]), _ptr(keep["bit_rates"]),
                              _ptr(cum_br), _ptr(keep["n_slots"]), _ptr(lmax_snr), _ptr(lmax_xt))
-        st = mt_states(self.seeds)
         self._h = C.c_void_p()
-        _lib.check(self.lib.orl_batch_create(C.byref(cfg), self._topo_h, self.num_envs, st.ctypes.data, C.byref(self._h)))
+        int_seeds = [41 if s_ is None else int(s_) for s_ in self.seeds]
+        if all(-2**63 < s_ < 2**63 for s_ in int_seeds):
+            # device-side random.Random(seed): no 2.5 KB/env upload, no Python loop over envs
+            sd = np.array(int_seeds, np.int64)
+            _lib.check(self.lib.orl_batch_create_seeded(C.byref(cfg), self._topo_h, self.num_envs, sd.ctypes.data,
+                                                        C.byref(self._h)))
+        else:  # seeds beyond 64 bits: let CPython expand them
+            st = mt_states(self.seeds)
+            _lib.check(self.lib.orl_batch_create(C.byref(cfg), self._topo_h, self.num_envs, st.ctypes.data,
+                                                 C.byref(self._h)))
         self.n_info = self.lib.orl_batch_info_dim(self._h)
         self.obs_dim = self.lib.orl_batch_obs_dim(self._h)
         n = self.num_envs
@@ -273,6 +281,24 @@ class BatchedOpticalEnv:
         out = np.zeros(self.num_envs, np.int32)
         _lib.check(self.lib.orl_batch_get_flags(self._h, out.ctypes.data))
         return out
+
+    def matrix_observation(self):
+        """SimpleMatrixObservation of every env, built on the device: uint8 [num_envs, 2N + C*E*S]."""
+        dim = self.lib.orl_batch_matrix_obs_dim(self._h)
+        out = np.zeros((self.num_envs, dim), np.uint8)
+        _lib.check(self.lib.orl_batch_matrix_observation(self._h, out.ctypes.data))
+        return out
+
+    def get_state(self):
+        """Opaque snapshot of the whole batch (bytes); restore with set_state()."""
+        buf = np.zeros(self.lib.orl_batch_state_bytes(self._h), np.uint8)
+        _lib.check(self.lib.orl_batch_get_state(self._h, buf.ctypes.data))
+        return buf
+
+    def set_state(self, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        assert buf.size == self.lib.orl_batch_state_bytes(self._h)
+        _lib.check(self.lib.orl_batch_set_state(self._h, buf.ctypes.data))
 
     def totals(self):
         p, a = C.c_int64(), C.c_int64()

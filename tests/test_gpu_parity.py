@@ -164,3 +164,50 @@ def test_full_size_batch_sampled_envs_match_oracle(workload, batch):
     p, a = dev.totals()
     assert p == int(cd[:, 0].sum()) and a == int(cd[:, 1].sum())
     dev.close()
+
+
+def test_device_seeding_equals_cpython():
+    """random.Random(seed) expanded on the device (init_by_array) vs CPython's getstate(), incl. negative and >32-bit seeds."""
+    import optical_rl_gym_amd as orl
+    from oracle.oracle import OracleBatch
+
+    seeds = [0, 1, 10, 41, 2**31 - 1, 2**32, 2**32 + 5, 2**40 + 7, -3, 123456789, 2**62 + 11, 7]
+    kw = dict(load=300, mean_service_holding_time=25, episode_length=50, num_spectrum_resources=320)
+    dev = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=len(seeds), seeds=seeds, **kw)
+    ora = OracleBatch("RMSA", "nsfnet_chen", seeds, **kw)  # CPython expands the seeds here
+    chk = _exact("seeding")
+    chk(0, "first service", dev.services(), ora.services())
+    for t in range(30):
+        a = ora.policy("SAP_FF")
+        _, r_o, _, _ = ora.step(a, auto_reset=True)
+        _, r_d, _, _ = dev.step(a, auto_reset=True)
+        chk(t, "reward", r_d, r_o)
+    chk(30, "services", dev.services(), ora.services())
+    dev.close()
+
+
+def test_matrix_observation_and_snapshot_restore():
+    import optical_rl_gym_amd as orl
+
+    kw = dict(load=200, mean_service_holding_time=25, episode_length=40, num_spectrum_resources=100)
+    dev = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=40, seeds=list(range(40)), **kw)
+    dev.run("SAP_FF", 150)
+    mat = dev.matrix_observation()
+    svc = dev.services()
+    for e in (0, 17, 39):
+        src, dst = int(svc[e, 2]), int(svc[e, 3])
+        tau = np.zeros(28, np.uint8)
+        tau[min(src, dst)] = 1
+        tau[14 + max(src, dst)] = 1
+        assert np.array_equal(mat[e, :28], tau)
+        assert np.array_equal(mat[e, 28:], dev.slots(e).reshape(-1))
+    snap = dev.get_state()
+    dev.run("SAP_FF", 60)
+    after_a = (dev.counters().copy(), dev.services().copy(), dev.slots(3).copy(), dev.link_stats(3).copy())
+    dev.set_state(snap)
+    assert np.array_equal(dev.services(), svc)
+    dev.run("SAP_FF", 60)
+    after_b = (dev.counters(), dev.services(), dev.slots(3), dev.link_stats(3))
+    for x, y in zip(after_a, after_b):
+        assert np.array_equal(x, y)
+    dev.close()
