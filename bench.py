@@ -31,9 +31,12 @@ WORKLOADS = {
                                        num_spectrum_resources=320, allow_rejection=False), "SAP_FF"),
     "cfg3": ("DeepRMSA", "nsfnet_chen", dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=1.0 / 12.0,
                                              j=1, episode_length=50), "SAP"),
-    "cfg4": ("RMCSA", "nsfnet_chen", dict(load=1500, mean_service_holding_time=25, episode_length=1000,
+    "cfg4": ("RMCSA", "cost239", dict(load=1500, mean_service_holding_time=25, episode_length=1000,
                                           num_spectrum_resources=320, num_spatial_resources=7,
                                           allow_rejection=True), "SAP_BM_FC_FF"),
+    "cfg4n": ("RMCSA", "nsfnet_chen", dict(load=1500, mean_service_holding_time=25, episode_length=1000,
+                                           num_spectrum_resources=320, num_spatial_resources=7,
+                                           allow_rejection=True), "SAP_BM_FC_FF"),
     "cfg1": ("RWA", "nsfnet_chen", dict(load=450, mean_service_holding_time=25, episode_length=1000,
                                         allow_rejection=True), "SAP_FF"),
 }
