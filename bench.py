@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=None, help="override the GPU index (default LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,21 +72,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
 
+    dev_index = local_rank if args.device is None else args.device
     dist = None
+    backend = args.dist_backend
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            else:
+                dist.init_process_group(backend)
+        except Exception as exc:  # the data path needs no collective: fall back to gloo for the barrier only
+            print("rank %d: %s backend unavailable (%s); using gloo for the barrier" % (rank, backend, exc), file=sys.stderr)
+            backend = "gloo"
+            dist.init_process_group("gloo")
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
 
     import optical_rl_gym_amd as orl
 
     fam, topo, kw, policy = WORKLOADS[args.workload]
     B = args.batch
     seeds = [10 + rank * B + i for i in range(B)]  # seed_i = 10 + global env index
-    env = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, device_id=local_rank, **kw)
+    env = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, device_id=dev_index, **kw)
 
     def barrier():
         if dist is not None:
@@ -100,7 +112,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

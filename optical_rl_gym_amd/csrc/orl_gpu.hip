@@ -333,6 +333,12 @@ struct orl_batch {
   std::vector<void*> allocs;
   hipEvent_t ev0, ev1;
   unsigned long long* d_totals;
+  // sub-batches for the device-resident run loop: contiguous env ranges, each driven on its own stream so that the
+  // short bandwidth-bound slot-scan of one range overlaps the long issue-bound step kernel of another
+  std::vector<DevParams> subs;
+  std::vector<hipStream_t> sub_streams;
+  const DevParams* view;
+  hipStream_t view_stream;
 };
 
 template <typename T, typename S>
@@ -417,28 +423,32 @@ extern "C" void orl_topology_destroy(orl_topology* t) {
   }
 
 static void launch_reset(orl_batch* b, int full, const unsigned char* dmask) {
-  dim3 g((unsigned)b->P.B), blk(64);
-  size_t lds = b->P.lds_bytes;
-#define CALLW(WW) hipLaunchKernelGGL((k_reset<EE, WW>), g, blk, lds, b->stream, b->P, full, dmask)
+  const DevParams& VP = b->view ? *b->view : b->P;
+  hipStream_t VS = b->view ? b->view_stream : b->stream;
+  dim3 g((unsigned)VP.B), blk(64);
+  size_t lds = VP.lds_bytes;
+#define CALLW(WW) hipLaunchKernelGGL((k_reset<EE, WW>), g, blk, lds, VS, VP, full, dmask)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
   ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
 #undef CALLW
 }
 static void launch_policy(orl_batch* b, int pol) {
+  const DevParams& VP = b->view ? *b->view : b->P;
+  hipStream_t VS = b->view ? b->view_stream : b->stream;
   // RMCSA scans (path, core) pairs: one env per wavefront.  The other families put 8 envs on a wavefront when k <= 8.
-  const bool wide = (b->P.env_type == ENV_RMCSA) || b->P.K > 8;
+  const bool wide = (VP.env_type == ENV_RMCSA) || VP.K > 8;
   const int epw = wide ? 1 : 8;
   const i64 per_wg = ORL_POLICY_WAVES * epw;
-  dim3 g((unsigned)((b->P.B + per_wg - 1) / per_wg)), blk(64 * ORL_POLICY_WAVES);
+  dim3 g((unsigned)((VP.B + per_wg - 1) / per_wg)), blk(64 * ORL_POLICY_WAVES);
 #if ORL_POLICY_LDS == 0
   size_t lds = 0;
 #else
-  size_t lds = (size_t)per_wg * b->P.bm_words * 8;
+  size_t lds = (size_t)per_wg * VP.bm_words * 8;
 #endif
 #define CALLW(WW) \
-  do { if (wide) hipLaunchKernelGGL((k_policy<EE, WW, 64>), g, blk, lds, b->stream, b->P, pol); \
-       else hipLaunchKernelGGL((k_policy<EE, WW, 8>), g, blk, lds, b->stream, b->P, pol); } while (0)
+  do { if (wide) hipLaunchKernelGGL((k_policy<EE, WW, 64>), g, blk, lds, VS, VP, pol); \
+       else hipLaunchKernelGGL((k_policy<EE, WW, 8>), g, blk, lds, VS, VP, pol); } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
   ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
@@ -446,34 +456,38 @@ static void launch_policy(orl_batch* b, int pol) {
 }
 static void launch_obs(orl_batch* b);
 static void launch_step(orl_batch* b, int auto_reset, int want_info) {
-  const size_t lds8 = (size_t)32 * (b->P.bm_words + 4 * b->P.E) * 8;  // 4 wavefronts x 8 envs per workgroup
+  const DevParams& VP = b->view ? *b->view : b->P;
+  hipStream_t VS = b->view ? b->view_stream : b->stream;
+  const size_t lds8 = (size_t)32 * (VP.bm_words + 4 * VP.E) * 8;  // 4 wavefronts x 8 envs per workgroup
   if (b->step_impl == 8 && lds8 <= 64 * 1024) {
-    dim3 g((unsigned)((b->P.B + 31) / 32)), blk(256);
-#define CALLW(WW) hipLaunchKernelGGL((k_step8<EE, WW>), g, blk, lds8, b->stream, b->P, auto_reset, want_info)
+    dim3 g((unsigned)((VP.B + 31) / 32)), blk(256);
+#define CALLW(WW) hipLaunchKernelGGL((k_step8<EE, WW>), g, blk, lds8, VS, VP, auto_reset, want_info)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
     ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
 #undef CALLW
-    if (b->P.obs_dim) launch_obs(b);  // DeepRMSA observation of the new pending service
+    if (VP.obs_dim) launch_obs(b);  // DeepRMSA observation of the new pending service
     return;
   }
-  dim3 g((unsigned)b->P.B), blk(64);
+  dim3 g((unsigned)VP.B), blk(64);
   // stage the pending release times through LDS when the per-env window stays small enough for 5 waves/SIMD
-  const size_t ev_bytes = (size_t)b->P.ev_cap * 8;
-  const bool evl = (b->P.lds_bytes + ev_bytes) <= 8 * 1024;
-  size_t lds = b->P.lds_bytes + (evl ? ev_bytes : 0);
+  const size_t ev_bytes = (size_t)VP.ev_cap * 8;
+  const bool evl = (VP.lds_bytes + ev_bytes) <= 8 * 1024;
+  size_t lds = VP.lds_bytes + (evl ? ev_bytes : 0);
 #define CALLW(WW) \
-  do { if (evl) hipLaunchKernelGGL((k_step<EE, WW, true>), g, blk, lds, b->stream, b->P, auto_reset, want_info); \
-       else hipLaunchKernelGGL((k_step<EE, WW, false>), g, blk, lds, b->stream, b->P, auto_reset, want_info); } while (0)
+  do { if (evl) hipLaunchKernelGGL((k_step<EE, WW, true>), g, blk, lds, VS, VP, auto_reset, want_info); \
+       else hipLaunchKernelGGL((k_step<EE, WW, false>), g, blk, lds, VS, VP, auto_reset, want_info); } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
   ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
 #undef CALLW
 }
 static void launch_obs(orl_batch* b) {
-  dim3 g((unsigned)b->P.B), blk(64);
-  size_t lds = b->P.lds_bytes;
-#define CALLW(WW) hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, b->stream, b->P)
+  const DevParams& VP = b->view ? *b->view : b->P;
+  hipStream_t VS = b->view ? b->view_stream : b->stream;
+  dim3 g((unsigned)VP.B), blk(64);
+  size_t lds = VP.lds_bytes;
+#define CALLW(WW) hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, VS, b->P)
   ORL_FOR_W(CALLW)
 #undef CALLW
 }
@@ -508,6 +522,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   memset(&b->P, 0, sizeof b->P);
   b->device = t->device;
   b->d_totals = nullptr;
+  b->view = nullptr;
+  b->view_stream = nullptr;
   {
     const char* impl = getenv("ORL_STEP_IMPL");
     b->step_impl = (impl && atoi(impl) == 8) ? 8 : 64;
@@ -599,6 +615,27 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&b->ev0));
   HIPCHK(hipEventCreate(&b->ev1));
+  {
+    // measured on MI355X, cfg2, B = 65 536: 1 stream 2.02e8 env-steps/s, 2 streams 2.38e8, 4 streams 2.27e8, 8 streams 2.09e8
+    int n_sub = (n_envs >= 2 * 8192) ? 2 : 1;
+    if (const char* sv = getenv("ORL_STREAMS")) { int v = atoi(sv); if (v >= 1 && v <= 16) n_sub = v; }
+    i64 per = ((n_envs + n_sub - 1) / n_sub + 31) / 32 * 32;  // slot-scan workgroups cover 32 consecutive envs
+    for (i64 lo = 0; lo < n_envs; lo += per) {
+      DevParams q = P;
+      i64 cnt = n_envs - lo < per ? n_envs - lo : per;
+      q.B = cnt;
+      q.bitmap += lo * P.bm_words; q.ev_time += lo * P.ev_cap; q.ev_info += lo * P.ev_cap; q.mt += lo * 624;
+      q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * 2 * C;
+      if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
+      if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
+      q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
+      if (q.obs) { q.obs += lo * P.obs_dim; q.term_obs += lo * P.obs_dim; }
+      b->subs.push_back(q);
+      hipStream_t st;
+      HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      b->sub_streams.push_back(st);
+    }
+  }
   // MT state upload + conversion, then the constructor's full reset
   u32* raw = nullptr;
   HIPCHK(hipMalloc((void**)&raw, B * 625 * sizeof(u32)));
@@ -637,6 +674,7 @@ extern "C" void orl_batch_destroy(orl_batch* b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
+  for (hipStream_t st : b->sub_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   for (void* p : b->allocs) hipFree(p);
@@ -722,13 +760,37 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     evs.resize((size_t)n_steps * 3);
     for (auto& e : evs) HIPCHK(hipEventCreate(&e));
   }
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const bool multi = !time_kernels && b->subs.size() > 1;
   HIPCHK(hipEventRecord(b->ev0, b->stream));
-  for (int64_t s = 0; s < n_steps; s++) {
-    if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s], b->stream));
-    launch_policy(b, policy_id);
-    if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s + 1], b->stream));
-    launch_step(b, 1, 0);
-    if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s + 2], b->stream));
+  if (multi) {
+    // every sub-batch runs its own policy -> step -> policy -> ... chain on its own stream
+    for (size_t k = 0; k < b->subs.size(); k++) HIPCHK(hipStreamWaitEvent(b->sub_streams[k], b->ev0, 0));
+    for (int64_t s = 0; s < n_steps; s++) {
+      for (size_t k = 0; k < b->subs.size(); k++) {
+        b->view = &b->subs[k];
+        b->view_stream = b->sub_streams[k];
+        launch_policy(b, policy_id);
+        launch_step(b, 1, 0);
+      }
+    }
+    b->view = nullptr;
+    b->view_stream = nullptr;
+    for (size_t k = 0; k < b->subs.size(); k++) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(e, b->sub_streams[k]));
+      HIPCHK(hipStreamWaitEvent(b->stream, e, 0));
+      HIPCHK(hipEventDestroy(e));
+    }
+  } else {
+    for (int64_t s = 0; s < n_steps; s++) {
+      if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s], b->stream));
+      launch_policy(b, policy_id);
+      if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s + 1], b->stream));
+      launch_step(b, 1, 0);
+      if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s + 2], b->stream));
+    }
   }
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
