@@ -60,7 +60,7 @@ enum {
 struct DevParams {
   int env_type, N, E, K, H, M, S, W, C, episode_length, allow_rejection, J;
   int bit_rate_mode, br_lo, n_br, rand_n, rand_bits;
-  int ev_cap, bm_words, n_info, obs_dim, lds_bytes;
+  int ev_cap, bm_words, n_info, obs_dim, lds_bytes, cs_words;
   double lambda_a, lambda_h;
   i64 B;
   // shared, read-only (L2-resident) topology / traffic tables
@@ -88,7 +88,8 @@ struct DevParams {
   double* lstat;    // [B][4][E]          utilization, external_fragmentation, compactness, last_update
   u64* scal;        // [B][32]
   u64* svc_desc;    // [B]  pending service for the slot-scan kernel: pair_base:32 | br_idx:16 | n_paths:8
-  int* core_sums;   // [B][2*C]           per core: sum(lambda_max-lambda_min), sum(free blocks inside)
+  int* core_sums;   // [B][cs_words]      [2*C] per core: sum(lambda_max-lambda_min), sum(free blocks inside);
+                    //                    then [C*E] per (core, link): that row's own contribution, (occ << 16) | fb
   i64* br_hist;     // [B][2*n_br]        discrete mode: requested / provisioned histograms
   i64* act_hist;    // [B][(K+1)+(S+1)]   RWA: marginals of actions_output
   // I/O (device resident; the C-ABI copies to/from host buffers)
@@ -394,7 +395,7 @@ __device__ __forceinline__ void stage_in(const DevParams& P, Env& e, u64* lds, i
   for (int i = lane; i < P.bm_words / 2; i += 64) l[i] = g[i];
   const double* gs = P.lstat + e.env * 4 * P.E;
   for (int i = lane; i < 4 * P.E; i += 64) e.ls[i] = gs[i];
-  if (lane < 2 * P.C) e.cs[lane] = P.core_sums[e.env * 2 * P.C + lane];
+  for (int i = lane; i < P.cs_words; i += 64) e.cs[i] = P.core_sums[e.env * P.cs_words + i];
   wave_fence();
 }
 __device__ __forceinline__ void stage_out(const DevParams& P, Env& e, int lane) {
@@ -405,7 +406,7 @@ __device__ __forceinline__ void stage_out(const DevParams& P, Env& e, int lane) 
   for (int i = lane; i < P.bm_words / 2; i += 64) g[i] = l[i];
   double* gs = P.lstat + e.env * 4 * P.E;
   for (int i = lane; i < 4 * P.E; i += 64) gs[i] = e.ls[i];
-  if (lane < 2 * P.C) P.core_sums[e.env * 2 * P.C + lane] = e.cs[lane];
+  for (int i = lane; i < P.cs_words; i += 64) P.core_sums[e.env * P.cs_words + i] = e.cs[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -612,13 +613,14 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
     u64* wp = e.bm + (core * E + link) * W + (w < W ? w : 0);
     u64 a = v ? *wp : 0ull;
     RowStat before, after;
-    if (ENV != ENV_RWA && !(ORL_ABLATE & 4)) row_stat<W, false>(a, w, S, before); else { before.occ = 0; before.fb = 0; }
+    int* sump = e.cs + 2 * P.C + core * E + link;  // this row's contribution as of its last modification
+    if (ENV != ENV_RWA) { int pk = *sump; before.occ = pk >> 16; before.fb = pk & 0xffff; }
     const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
     a = release ? (a | m) : (a & ~m);
     if (v) *wp = a;
     if (ENV != ENV_RWA) {
       row_stat<W, true>(a, w, S, after);
-      if (rowv && w == 0) { d_occ += after.occ - before.occ; d_fb += after.fb - before.fb; }
+      if (rowv && w == 0) { d_occ += after.occ - before.occ; d_fb += after.fb - before.fb; *sump = (after.occ << 16) | after.fb; }
     } else {
       after.free_ = g8_sum(__popcll(a));
     }

@@ -68,7 +68,7 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
   e.env = env;
   e.bm = P.bitmap + env * P.bm_words;
   e.ls = P.lstat + env * 4 * P.E;
-  e.cs = P.core_sums + env * 2 * P.C;
+  e.cs = P.core_sums + env * P.cs_words;
   e.ev_time = P.ev_time + env * P.ev_cap;
   e.ev_info = P.ev_info + env * P.ev_cap;
   e.mt = P.mt + env * 624;
@@ -191,6 +191,7 @@ __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane,
       row_stat<W, true>(a, w, S, after);
       d_occ += after.occ - before.occ;
       d_fb += after.fb - before.fb;
+      if (w == 0) e.cs[2 * P.C + core * E + link] = (after.occ << 16) | after.fb;  // keep the per-row cache of k_step valid
     } else {
       after.free_ = g8_sum(__popcll(a));
     }

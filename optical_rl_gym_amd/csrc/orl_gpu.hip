@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
     lds[i] = (i < P.C * P.E * W) ? v : 0ull;
   }
   for (int i = lane; i < 4 * P.E; i += 64) e.ls[i] = 0.0;
-  if (lane < 2 * P.C) e.cs[lane] = 0;
+  for (int i = lane; i < P.cs_words; i += 64) e.cs[i] = 0;
   for (int i = lane; i < P.ev_cap; i += 64) e.ev_time[i] = __builtin_inf();
   if (P.br_hist) for (int i = lane; i < 2 * P.n_br; i += 64) P.br_hist[env * 2 * P.n_br + i] = 0;
   if (P.act_hist) for (int i = lane; i < (P.K + 1) + (P.S + 1); i += 64) P.act_hist[env * ((P.K + 1) + (P.S + 1)) + i] = 0;
@@ -562,7 +562,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   else if (c->env_type == ORL_ENV_RMCSA) P.n_info = 4;
   else P.n_info = 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
   P.obs_dim = c->env_type == ORL_ENV_DEEPRMSA ? 1 + 2 * P.N + (2 * P.J + 3) * P.K : 0;
-  P.lds_bytes = ((P.bm_words + 4 * P.E + P.E + P.obs_dim) * 8 + 2 * C * 4 + 15) & ~15;
+  P.cs_words = 2 * C + C * P.E;
+  P.lds_bytes = ((P.bm_words + 4 * P.E + P.E + P.obs_dim) * 8 + P.cs_words * 4 + 15) & ~15;
   if (P.lds_bytes < 624 * 4) P.lds_bytes = 624 * 4;  // k_init_mt stages the MT state in the same window
   if (P.lds_bytes > 64 * 1024) { delete b; return fail(ORL_E_INVALID, "per-env LDS window too large (%d B)", P.lds_bytes); }
 
@@ -602,7 +603,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   rc |= dalloc(b, &P.mt, B * 624);
   rc |= dalloc(b, &P.lstat, B * 4 * P.E);
   rc |= dalloc(b, &P.scal, B * ORL_SCAL_WORDS);
-  rc |= dalloc(b, &P.core_sums, B * 2 * C);
+  rc |= dalloc(b, &P.core_sums, B * P.cs_words);
   if (c->bit_rate_mode == 1 && c->env_type != ORL_ENV_RWA) rc |= dalloc(b, &P.br_hist, B * 2 * P.n_br);
   if (c->env_type == ORL_ENV_RWA) rc |= dalloc(b, &P.act_hist, B * ((P.K + 1) + (S + 1)));
   rc |= dalloc(b, &P.actions, B * 4);
@@ -625,7 +626,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       i64 cnt = n_envs - lo < per ? n_envs - lo : per;
       q.B = cnt;
       q.bitmap += lo * P.bm_words; q.ev_time += lo * P.ev_cap; q.ev_info += lo * P.ev_cap; q.mt += lo * 624;
-      q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * 2 * C;
+      q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
       if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
@@ -946,7 +947,7 @@ static std::vector<Section> state_sections(orl_batch* b) {
   v.push_back({P.ev_info, B * P.ev_cap * 8});
   v.push_back({P.mt, B * 624 * 4});
   v.push_back({P.lstat, B * 4 * P.E * 8});
-  v.push_back({P.core_sums, B * 2 * P.C * 4});
+  v.push_back({P.core_sums, B * P.cs_words * 4});
   if (P.br_hist) v.push_back({P.br_hist, B * 2 * P.n_br * 8});
   if (P.act_hist) v.push_back({P.act_hist, B * ((P.K + 1) + (P.S + 1)) * 8});
   return v;
