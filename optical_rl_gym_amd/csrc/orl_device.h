@@ -31,10 +31,6 @@
 #include <stdint.h>
 #include "orl_log.h"
 
-#ifndef ORL_ABLATE
-#define ORL_ABLATE 0  // timing experiments only: 1 no link-stat floats, 2 no longest-run, 4 no before-summary, 8 no stage_out
-#endif
-
 namespace orl {
 
 typedef unsigned long long u64;
@@ -65,9 +61,6 @@ struct DevParams {
   i64 B;
   // shared, read-only (L2-resident) topology / traffic tables
   const int* n_paths;               // [N*N]
-  const unsigned char* path_hops;   // [N*N*K]
-  const short* path_links;          // [N*N*K*H]
-  const unsigned char* path_mod;    // [N*N*K]  best modulation (index)
   const double* path_length;        // [N*N*K]
   const int* edge_iter_order;       // [E]
   const int* link_pos;              // [E]      inverse permutation: position of link l in topology.edges()
@@ -400,7 +393,6 @@ __device__ __forceinline__ void stage_in(const DevParams& P, Env& e, u64* lds, i
 }
 __device__ __forceinline__ void stage_out(const DevParams& P, Env& e, int lane) {
   wave_fence();
-  if (ORL_ABLATE & 8) return;
   ulonglong2* g = (ulonglong2*)(P.bitmap + e.env * P.bm_words);
   const ulonglong2* l = (const ulonglong2*)e.bm;
   for (int i = lane; i < P.bm_words / 2; i += 64) g[i] = l[i];
@@ -627,7 +619,7 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
     // _update_link_stats: time-weighted running averages, evaluated in the reference's operation order
     double last_update = e.ls[3 * E + link];
     double time_diff = e.now - last_update;
-    if (e.now > 0 && !(ORL_ABLATE & 1)) {
+    if (e.now > 0) {
       const int free_ = after.free_;
       double cur_util = (double)(S - free_) / (double)S;
       double util = ((e.ls[link] * last_update) + (cur_util * time_diff)) / e.now;
@@ -636,7 +628,7 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
         double cur_frag = 0.0, cur_comp = 0.0;
         const int top = (S - 1) - 64 * w;  // bit of slot S-1 inside this lane's word, if it is here
         const int edge = g8_sum(((w == 0 && (a & 1ull)) ? 1 : 0) + ((top >= 0 && top < 64 && ((a >> top) & 1ull)) ? 1 : 0));
-        const int max_empty = (ORL_ABLATE & 2) ? 1 : row_longest_run8<W>(a, w);
+        const int max_empty = row_longest_run8<W>(a, w);
         if (free_ > 0) {
           int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
           cur_frag = 1.0 - ((double)me / (double)free_);

@@ -317,9 +317,6 @@ struct orl_topology {
   int N, E, K, H, M;
   std::vector<int32_t> h_hops, h_links, h_mod;  // host copies (per-batch derived tables are built from them)
   int* n_paths;
-  unsigned char* path_hops;
-  short* path_links;
-  unsigned char* path_mod;
   double* path_length;
   int* edge_iter_order;
   int* link_pos;
@@ -366,7 +363,7 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
     return fail(ORL_E_INVALID, "topology out of supported range (N<=512, E<=128, k<=64, hops<=64)");
   HIPCHK(hipSetDevice(device_id));
   orl_topology* t = new orl_topology();
-  t->n_paths = nullptr; t->path_hops = nullptr; t->path_links = nullptr; t->path_mod = nullptr;
+  t->n_paths = nullptr;
   t->path_length = nullptr; t->edge_iter_order = nullptr; t->link_pos = nullptr;
   t->device = device_id;
   t->N = d->n_nodes; t->E = d->n_links; t->K = d->k_paths; t->H = d->max_hops; t->M = d->n_modulations;
@@ -383,9 +380,6 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
   t->h_links.assign(d->path_links, d->path_links + npk * t->H);
   t->h_mod = mod;
   rc |= upload_conv(&t->n_paths, d->n_paths, nn, nullptr);
-  rc |= upload_conv(&t->path_hops, d->path_hops, npk, nullptr);
-  rc |= upload_conv(&t->path_links, d->path_links, npk * t->H, nullptr);
-  rc |= upload_conv(&t->path_mod, mod.data(), npk, nullptr);
   rc |= upload_conv(&t->path_length, d->path_length, npk, nullptr);
   rc |= upload_conv(&t->edge_iter_order, d->edge_iter_order, (size_t)t->E, nullptr);
   {
@@ -401,7 +395,7 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
 extern "C" void orl_topology_destroy(orl_topology* t) {
   if (!t) return;
   hipSetDevice(t->device);
-  hipFree(t->n_paths); hipFree(t->path_hops); hipFree(t->path_links); hipFree(t->path_mod);
+  hipFree(t->n_paths);
   hipFree(t->path_length); hipFree(t->edge_iter_order); hipFree(t->link_pos);
   delete t;
 }
@@ -567,7 +561,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   if (P.lds_bytes < 624 * 4) P.lds_bytes = 624 * 4;  // k_init_mt stages the MT state in the same window
   if (P.lds_bytes > 64 * 1024) { delete b; return fail(ORL_E_INVALID, "per-env LDS window too large (%d B)", P.lds_bytes); }
 
-  P.n_paths = t->n_paths; P.path_hops = t->path_hops; P.path_links = t->path_links; P.path_mod = t->path_mod;
+  P.n_paths = t->n_paths;
   P.path_length = t->path_length; P.edge_iter_order = t->edge_iter_order; P.link_pos = t->link_pos;
   int rc = 0;
   {
