@@ -131,7 +131,7 @@ def main():
     # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x calibration + WRITE_SIZE), collected offline with
     # tools/pmc_traffic.py for exactly this workload/batch and committed under profiles/; null otherwise.
     traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r1c_traffic_cfg2.json")
+    tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("workload") == args.workload and tj.get("batch") == B:

@@ -5,6 +5,8 @@ tools/pmc_summary.py + the calibration factors turn the counters into HBM bytes 
 import os
 import sys
 
+os.environ["ORL_STREAMS"] = "1"  # whole-batch launches on one stream: the configuration the roofline pass of bench.py times
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import optical_rl_gym_amd as orl  # noqa: E402
 from bench import WORKLOADS  # noqa: E402

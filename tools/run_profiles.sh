@@ -6,7 +6,11 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --gpus 1 --steps 300 --warmup 1500 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 tail -c 2500 $O/bench_cfg2.json
+rm -rf $O/stats $O/stats1 $O/tr_f $O/tr_w $O/sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --gpus 1 --steps 300 --warmup 1500 --no-cpu-baseline > $O/stats.log 2>&1
+export ORL_STREAMS=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --gpus 1 --steps 300 --warmup 1500 --no-cpu-baseline > $O/stats1.log 2>&1
+unset ORL_STREAMS
 for cfg in "cfg1 4096" "cfg3 4096" "cfg4 16384" "cfg4n 16384" "cfg5 32768" "cfg2 4096"; do
   set -- $cfg
   python3 $R/bench.py --workload $1 --batch $2 --steps 200 --warmup 1500 --no-cpu-baseline > $O/bench_$1_$2.json 2> $O/bench_$1_$2.err
@@ -14,5 +18,6 @@ for cfg in "cfg1 4096" "cfg3 4096" "cfg4 16384" "cfg4n 16384" "cfg5 32768" "cfg2
 done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/tr_f -- python3 $R/tools/pmc_traffic.py > $O/tr_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/tr_w -- python3 $R/tools/pmc_traffic.py > $O/tr_w.log 2>&1
+export ORL_STREAMS=1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $O/sq -- python3 $R/bench.py --steps 20 --warmup 1200 --no-cpu-baseline > $O/sq.log 2>&1
 ls $O
