@@ -328,8 +328,11 @@ struct Env {
   i64 env;
 };
 
-__device__ __forceinline__ void env_load(const DevParams& P, Env& e, i64 env, int lane) {
-  u64 v = (lane < ORL_SCAL_WORDS) ? P.scal[env * ORL_SCAL_WORDS + lane] : 0ull;
+// the load and the unpacking are separate so that a kernel can put other independent loads between them
+__device__ __forceinline__ u64 env_fetch(const DevParams& P, i64 env, int lane) {
+  return (lane < ORL_SCAL_WORDS) ? P.scal[env * ORL_SCAL_WORDS + lane] : 0ull;
+}
+__device__ __forceinline__ void env_unpack(const DevParams& P, Env& e, i64 env, int lane, u64 v) {
 #define F64(slot) __longlong_as_double((i64)rdlane64(v, slot))
 #define I64(slot) ((i64)rdlane64(v, slot))
   e.now = F64(SC_NOW); e.at = F64(SC_AT); e.ht = F64(SC_HT);
@@ -352,6 +355,9 @@ __device__ __forceinline__ void env_load(const DevParams& P, Env& e, i64 env, in
   e.ev_time = P.ev_time + env * P.ev_cap;
   e.ev_info = P.ev_info + env * P.ev_cap;
   e.mt = P.mt + env * 624;
+}
+__device__ __forceinline__ void env_load(const DevParams& P, Env& e, i64 env, int lane) {
+  env_unpack(P, e, env, lane, env_fetch(P, env, lane));
 }
 
 __device__ __forceinline__ u64 pack2(int lo, int hi) { return ((u64)(u32)hi << 32) | (u64)(u32)lo; }
@@ -411,6 +417,16 @@ __device__ __forceinline__ void stage_out(const DevParams& P, Env& e, int lane) 
 // place — the same recurrence, evaluated lazily, so the output sequence is identical but a
 // refill is 32 lanes x (3 loads + 1 store) with no 2.5-KB regeneration burst.
 // ---------------------------------------------------------------------------------------------
+// values a kernel may request at entry so that their latency overlaps the staging of the env state
+struct Prefetch {
+  bool have_rec;   // rec / nslots belong to the action's path
+  int pidx;
+  u64 rq0, rq1, rq2, rq3;
+  int nslots;
+  bool have_cum;   // cum_my = cum_src[min(lane, N-1)] (only when N <= 64)
+  double cum_my;
+};
+
 struct Rng {
   u32 out;   // lane j < 32: tempered output number (consumed + j) of the stream
   u32 nxt;   // lane j < 32: next-generation value for that array position
@@ -496,6 +512,12 @@ __device__ __forceinline__ Row<W> path_and_rec(const PathRec& r, const u64* bm, 
     m = row_and<W>(m, row_load<W>(bm + (core * E + link) * W));
   }
   return m;
+}
+
+// same draw when lane i already holds cum[min(i, n-1)] in a register (n <= 64)
+__device__ __forceinline__ int rng_choice_pre(Env& e, Rng& r, int lane, double cum_my, int n) {
+  double x = rng_random(e, r, lane) * (rdlane_f64(cum_my, n - 1) + 0.0);
+  return (int)__popcll(__ballot(lane < n - 1 && cum_my <= x));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -591,8 +613,7 @@ __device__ __forceinline__ int row_longest_run8(u64 a, int w) {
 // _update_link_stats (rmsa_env.py:464-543) per touched link, plus the integer sums behind
 // _get_network_compactness.  Returns the path's hop count.
 template <int ENV, int W>
-__device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, int pidx, int core, int s0, int n, bool release) {
-  const PathRec rec = path_rec_load(P, pidx);
+__device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, const PathRec rec, int core, int s0, int n, bool release) {
   const int hops = path_rec_byte(rec, 0);
   const int r = lane >> 3, w = lane & 7;
   const int E = P.E, S = P.S;
@@ -660,9 +681,8 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
 
 // is_path_free: all links of the path free on [s0, s0+n)
 template <int W>
-__device__ __forceinline__ bool path_is_free(const DevParams& P, const Env& e, int lane, int pidx, int core, int s0, int n) {
+__device__ __forceinline__ bool path_is_free(const DevParams& P, const Env& e, int lane, const PathRec rec, int core, int s0, int n) {
   if (s0 + n > P.S) return false;
-  const PathRec rec = path_rec_load(P, pidx);
   const int hops = path_rec_byte(rec, 0);
   const int r = lane >> 3, w = lane & 7;
   bool busy = false;
@@ -753,7 +773,7 @@ __device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane
     if (lane == 0) { e.ev_time[bi] = __builtin_inf(); if (EVL) e.evl[bi] = __builtin_inf(); }
     if (bi == e.push_idx) e.push_t = __builtin_inf();
     e.ev_cnt--;
-    int hops_r = path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
+    int hops_r = path_apply<ENV, W>(P, e, lane, path_rec_load(P, pidx), core, s0, n, true);
     e.s_br -= br;
     e.s_nh -= (i64)n * hops_r;
     prev_t = bt;
@@ -770,7 +790,7 @@ __device__ __forceinline__ void release_due(const DevParams& P, Env& e, int lane
 
 // _next_service
 template <int ENV, int W, bool EVL>
-__device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lane, const Rng* prefilled) {
+__device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lane, const Rng* prefilled, const Prefetch* pf = nullptr) {
   if (e.new_service) return;
   Rng r;
   if (prefilled) r = *prefilled;  // window loaded at kernel entry so its latency hides behind the step logic
@@ -778,7 +798,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lan
   double at = e.now + rng_expovariate(e, r, lane, P.lambda_a);
   e.now = at;
   double ht = rng_expovariate(e, r, lane, P.lambda_h);
-  int src = rng_choice(e, r, lane, P.cum_src, P.N);
+  int src = (pf && pf->have_cum) ? rng_choice_pre(e, r, lane, pf->cum_my, P.N) : rng_choice(e, r, lane, P.cum_src, P.N);
   int dst = rng_choice(e, r, lane, P.cum_dst + src * P.N, P.N);
   int bit_rate = 0, br_idx = 0;
   if (ENV != ENV_RWA) {
@@ -1021,7 +1041,7 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
 template <int ENV, int W, bool EVL>
 __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const int* act, int auto_reset,
                                      double* reward_out, unsigned char* done_out, double* info_out, double* obs_out,
-                                     double* term_obs_out, const Rng* prefilled) {
+                                     double* term_obs_out, const Rng* prefilled, const Prefetch* pf = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0;
   int path, slot, mod = 0, core = 0;
   bool bad = false;
@@ -1061,15 +1081,19 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
   if (in_range && path < P.n_paths[e.src * P.N + e.dst]) {
     int pidx = pair_base(P, e.src, e.dst) + path;
     int n = 1;
+    const bool hit = pf && pf->have_rec && pf->pidx == pidx;  // the record requested at kernel entry is this path's
+    PathRec prec;
+    if (hit) { prec.q[0] = pf->rq0; prec.q[1] = pf->rq1; prec.q[2] = pf->rq2; prec.q[3] = pf->rq3; }
+    else prec = path_rec_load(P, pidx);
     if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
-    else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
-    bool ok = path_is_free<W>(P, e, lane, pidx, core, slot, n);
+    else if (ENV != ENV_RWA) n = hit ? pf->nslots : (int)P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
+    bool ok = path_is_free<W>(P, e, lane, prec, core, slot, n);
     if (ok && ENV == ENV_RMCSA) {  // _crosstalk_is_acceptable: two reach limits
       double len = P.path_length[pidx];
       ok = (len < P.lmax_xt[mod]) && (len < P.lmax_snr[mod * P.n_br + e.br_idx]);
     }
     if (ok) {
-      int hops_p = path_apply<ENV, W>(P, e, lane, pidx, core, slot, n, false);
+      int hops_p = path_apply<ENV, W>(P, e, lane, prec, core, slot, n, false);
       e.s_br += e.bit_rate;
       e.s_nh += (i64)n * hops_p;
       if (ENV != ENV_RWA) {  // _update_network_stats
@@ -1141,7 +1165,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
     }
   }
   e.new_service = 0;
-  next_service<ENV, W, EVL>(P, e, lane, prefilled);
+  next_service<ENV, W, EVL>(P, e, lane, prefilled, pf);
   bool done = (e.esp == (i64)P.episode_length);
   if (ENV == ENV_DEEPRMSA && obs_out) {
     deep_observation<W>(P, e, lane, obs_out, (done && term_obs_out) ? term_obs_out : nullptr);

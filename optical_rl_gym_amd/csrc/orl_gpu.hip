@@ -194,13 +194,28 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
   const i64 env = blockIdx.x;
   const int lane = lane_id();
   Env e;
-  env_load(P, e, env, lane);
+  // Round trip 1: everything addressed by the env index alone is requested before anything is waited for — the
+  // scalar record, the action, the slot map / link statistics / per-core sums (into LDS), the source-node table.
+  const u64 sv = env_fetch(P, env, lane);
+  const int4 av = *(const int4*)(P.actions + env * 4);
+  Prefetch pf;
+  pf.have_cum = P.N <= 64;
+  pf.cum_my = pf.have_cum ? P.cum_src[lane < P.N - 1 ? lane : P.N - 1] : 0.0;
+  e.env = env;
   stage_in(P, e, (u64*)orl_lds_raw, lane);
-  int4 av = *(const int4*)(P.actions + env * 4);
-  // everything that only depends on the scalar record is requested now, in one batch, and consumed much later:
-  // the MT window for the next service and (EVL) the pending release times, which then live in LDS for all scans
+  env_unpack(P, e, env, lane, sv);
+  // Round trip 2: what the scalar record addresses — the MT window of the next service, the pending release times
+  // (EVL: into LDS for all scans) and the path record + slot count of the action's path.
   Rng pre;
   rng_fill(e, pre, lane);
+  {
+    const int route = (ENV == ENV_DEEPRMSA) ? (av.x >= 0 ? av.x / P.J : P.K) : av.x;
+    pf.have_rec = route >= 0 && route < P.K;
+    pf.pidx = pair_base(P, e.src, e.dst) + (pf.have_rec ? route : 0);
+    const PathRec r0 = path_rec_load(P, pf.pidx);
+    pf.rq0 = r0.q[0]; pf.rq1 = r0.q[1]; pf.rq2 = r0.q[2]; pf.rq3 = r0.q[3];
+    pf.nslots = P.nslots_path[(size_t)pf.pidx * P.n_br + e.br_idx];
+  }
   if (EVL) {
     e.evl = (double*)((unsigned char*)orl_lds_raw + P.lds_bytes);
     for (int i = lane; i < e.ev_hwm; i += 64) e.evl[i] = e.ev_time[i];
@@ -210,7 +225,7 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
   step<ENV, W, EVL>(P, e, lane, act, auto_reset, P.reward + env, P.done + env,
                     want_info ? P.info + env * P.n_info : nullptr,
                     P.obs_dim ? P.obs + env * P.obs_dim : nullptr,
-                    P.obs_dim ? P.term_obs + env * P.obs_dim : nullptr, &pre);
+                    P.obs_dim ? P.term_obs + env * P.obs_dim : nullptr, &pre, &pf);
   stage_out(P, e, lane);
   env_store(P, e, lane);
 }
