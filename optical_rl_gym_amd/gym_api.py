@@ -310,6 +310,22 @@ def shortest_available_path_best_modulation_first_core_first_fit(env):
     return env.unwrapped.policy_action("SAP_BM_FC_FF")
 
 
+def random_policy(env):
+    """utils.py:99-100 (the stream is this package's numpy generator, not gym 0.21's)"""
+    return env.action_space.sample()
+
+
+def start_environment(env, steps):
+    """utils.py:62-70"""
+    done = True
+    for _ in range(steps):
+        if done:
+            env.reset()
+        while not done:
+            _, _, done, _ = env.step(env.action_space.sample())
+    return env
+
+
 def evaluate_heuristic(env, heuristic, n_eval_episodes=10, render=False, callback=None, reward_threshold=None,
                        return_episode_rewards=False):
     """utils.py:103-141, same episode accounting: reset() (soft), loop until done, sum rewards."""
