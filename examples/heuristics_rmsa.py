@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """The reference's tests/test_rmsa.py flow on the MI355X build: same kwargs, same heuristics, same printed numbers
 (SP-FF 88.7000 +- 7.1281, SAP-FF 95.0000 +- 3.2558, LLP-FF 95.1000 +- 3.3897), then the same policy on a 4 096-env batch."""
+import os
+import sys
 import time
 
-import optical_rl_gym_amd as orl
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a source checkout
+
+import optical_rl_gym_amd as orl  # noqa: E402
 
 env_args = dict(topology="nsfnet_chen", seed=10, allow_rejection=True, load=50, mean_service_holding_time=25,
                 episode_length=100, num_spectrum_resources=64, bit_rate_selection="discrete")

@@ -234,3 +234,23 @@ def test_gym_front_end_rwa_and_rmcsa_script_numbers():
                                               n_eval_episodes=3, return_episode_rewards=True)
     assert rewards == g["meta"]["episode_rewards"] and lengths == [999] * 3
     env.close()
+
+
+def test_vecenv_adapter_on_hip_batch():
+    """SB3-VecEnv-shaped adapter over a HIP batch: auto (soft) reset, terminal_observation, Monitor-style episode rows."""
+    import optical_rl_gym_amd as orl
+    from optical_rl_gym_amd.vec_env import OpticalVecEnv
+
+    g = load_golden("g4_deeprmsa_j1_sap")
+    kw = dict(g["meta"]["kwargs"])
+    kw.pop("seed")
+    batch = orl.BatchedDeepRMSAEnv("nsfnet_chen", num_envs=3, seeds=[10, 11, 12], **kw)
+    venv = OpticalVecEnv(batch)
+    obs = venv.reset()
+    assert obs.shape == (3, 54) and np.array_equal(obs[0], g["obs"][0])
+    for _ in range(120):
+        obs, rew, done, infos = venv.step(batch.policy("SAP")[:, 0].copy())
+        for i in np.flatnonzero(done):
+            assert infos[i]["episode"]["l"] == 49 and np.array_equal(infos[i]["terminal_observation"], obs[i])
+    assert [r["r"] for r in venv.episode_log][0::3][:2] == g["meta"]["episode_rewards"][:2]
+    venv.close()
