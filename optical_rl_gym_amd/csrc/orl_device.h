@@ -47,6 +47,7 @@ enum {
   SC_SRC_DST, SC_BR_IDX, SC_ID_MTPOS, SC_EV, SC_FLAGS,
   SC_NEXTREL,  // f64 lower bound of every pending release time (-inf = unknown, +inf = none pending)
   SC_HINT,     // low 32 bits: index of a known-empty pending-release slot, or -1
+  SC_ACC,      // split pipeline: low 32 = this step's action was provisioned, high 32 = its core
   SC_COUNT
 };
 #define ORL_SCAL_WORDS 32
@@ -81,6 +82,11 @@ struct DevParams {
   double* lstat;    // [B][4][E]          utilization, external_fragmentation, compactness, last_update
   u64* scal;        // [B][32]
   u64* svc_desc;    // [B]  pending service for the slot-scan kernel: pair_base:32 | br_idx:16 | n_paths:8
+  // split pipeline (orl_device_split.h): row-update work items produced by the control kernels
+  ulonglong2* q_a;  // [q_cap] provision items of this step
+  ulonglong2* q_b;  // [q_cap] release items of this step
+  u32* q_cnt;       // [0] = items in q_a, [1] = items in q_b (zeroed before every step)
+  i64 q_cap;
   int* core_sums;   // [B][cs_words]      [2*C] per core: sum(lambda_max-lambda_min), sum(free blocks inside);
                     //                    then [C*E] per (core, link): that row's own contribution, (occ << 16) | fb
   i64* br_hist;     // [B][2*n_br]        discrete mode: requested / provisioned histograms

@@ -232,6 +232,50 @@ __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane,
   return hops;
 }
 
+// ---- release sink -----------------------------------------------------------------------------------
+// The monolithic kernel applies a release right away (path_apply).  The split pipeline instead collects the
+// touched link rows as work items for the flat row kernel: one item per (core, link) with up to four
+// [s0, s0+n) masks in release order (several services released in one step may share a link; only the first
+// touch of a link sees a non-zero time_diff).  Item k of an env lives in lane k % 8, slot k / 8.
+#define ORL_ISLOTS 4
+struct Sink {
+  bool allowed, active;
+  int cnt;
+  u32 key[ORL_ISLOTS];  // link, or 0xffffffff (per-link statistics are shared by all cores of the link)
+  u64 mk[ORL_ISLOTS];   // up to 4 x (s0 | n << 9), 16 bits each, in release order
+  u32 cr[ORL_ISLOTS];   // the core of each mask, 5 bits each
+  int nm[ORL_ISLOTS];
+};
+__device__ __forceinline__ void sink_init(Sink& s, bool allowed) {
+  s.allowed = allowed; s.active = false; s.cnt = 0;
+#pragma unroll
+  for (int k = 0; k < ORL_ISLOTS; k++) { s.key[k] = 0xffffffffu; s.mk[k] = 0; s.cr[k] = 0; s.nm[k] = 0; }
+}
+__device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, int s0, int n, int lane) {
+  const int hops = path_rec_byte(rec, 0), gl = lane & 7;
+  const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
+  for (int h = 0; h < hops; h++) {
+    const u32 key = (u32)path_rec_byte(rec, 2 + h);
+    int mine = -1;
+#pragma unroll
+    for (int k = 0; k < ORL_ISLOTS; k++) if (s.key[k] == key) mine = k;
+    const u32 fb = gballot(mine >= 0, lane);
+    if (fb) {  // the link already has an item: append the mask (release order)
+#pragma unroll
+      for (int k = 0; k < ORL_ISLOTS; k++)
+        if (mine == k) { s.mk[k] |= m << (16 * s.nm[k]); s.cr[k] |= (u32)core << (5 * s.nm[k]); s.nm[k]++; }
+    } else {
+      const int idx = s.cnt, slot = idx >> 3;
+      if (gl == (idx & 7)) {
+#pragma unroll
+        for (int k = 0; k < ORL_ISLOTS; k++)
+          if (slot == k) { s.key[k] = key; s.mk[k] = m; s.cr[k] = (u32)core; s.nm[k] = 1; }
+      }
+      s.cnt++;
+    }
+  }
+}
+
 // ---- pending releases: slot i belongs to lane i % 8 -------------------------------------------------
 __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
   const int gl = lane & 7;
@@ -255,7 +299,7 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
 }
 
 template <int ENV, int W>
-__device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lane, int bi) {
+__device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lane, int bi, Sink& sink) {
   const int gl = lane & 7, owner = bi & 7;
   u64 info = (gl == owner) ? e.ev_info[bi] : 0ull;
   info = gget(info, owner, lane);
@@ -264,14 +308,21 @@ __device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lan
   const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
   e.ev_cnt--;
   e.hint = (e.hint < 0 || bi < e.hint) ? bi : e.hint;
-  int hops_r = path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
+  int hops_r;
+  if (sink.active) {
+    const PathRec rec = path_rec_load(P, pidx);
+    hops_r = path_rec_byte(rec, 0);
+    sink_add(sink, rec, core, s0, n, lane);
+  } else {
+    hops_r = path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
+  }
   e.s_br -= br;
   e.s_nh -= (i64)n * hops_r;
 }
 
 // release every pending service with release_time <= now in increasing time order (rmsa_env.py:590-597)
 template <int ENV, int W>
-__device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lane) {
+__device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lane, Sink& sink) {
   if (e.next_rel > e.now) return;  // nothing can be due (next_rel is a lower bound of every pending time)
   const int gl = lane & 7;
   for (;;) {
@@ -299,13 +350,19 @@ __device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lan
       }
     }
     const bool overflow = gballot(ndue > 2, lane) != 0u;
+    {
+      // item mode only when every touched link is guaranteed an item slot and at most 4 masks can meet on a link
+      const int tot = g8_sum(ndue);
+      sink.active = sink.allowed && !overflow && sink.cnt == 0 && tot <= 4 &&
+                    (P.E <= 8 * ORL_ISLOTS || tot * P.H <= 8 * ORL_ISLOTS);
+    }
     if (overflow) {
       // a lane holds 3+ due entries (rare): release only the globally earliest one, then rescan
       double bt = d0t; int bi = d0i;
 #define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; } }
       ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
 #undef ORL_MIN_STEP
-      release_one<ENV, W>(P, e, lane, bi);
+      release_one<ENV, W>(P, e, lane, bi, sink);
       continue;
     }
     for (;;) {
@@ -315,7 +372,7 @@ __device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lan
 #undef ORL_MIN_STEP
       if (!(bt <= e.now)) break;
       if (gl == (bi & 7)) { d0t = d1t; d0i = d1i; d1t = __builtin_inf(); d1i = 0x7fffffff; }
-      release_one<ENV, W>(P, e, lane, bi);
+      release_one<ENV, W>(P, e, lane, bi, sink);
     }
     e.next_rel = g8_min(rest);
     break;
@@ -329,7 +386,7 @@ __device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lan
 }
 
 template <int ENV, int W>
-__device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int lane, RngG& r) {
+__device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int lane, RngG& r, Sink& sink) {
   if (e.new_service) return;
   const int gl = lane & 7;
   double at = e.now + rng_expovariate(e, r, lane, P.lambda_a);
@@ -350,7 +407,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
     }
   }
   rng_commit(e, r, gl);
-  if (ENV == ENV_RWA || ENV == ENV_RMCSA) release_due<ENV, W>(P, e, lane);
+  if (ENV == ENV_RWA || ENV == ENV_RMCSA) release_due<ENV, W>(P, e, lane, sink);
   e.id = (int)e.esp;
   e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
   e.new_service = 1;
@@ -360,7 +417,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
     e.ebrq += bit_rate;
     if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;
   }
-  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) release_due<ENV, W>(P, e, lane);
+  if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) release_due<ENV, W>(P, e, lane, sink);
 }
 
 // np.mean over the links in topology.edges() order (numpy pairwise sum); lane j reads the statistics it owns
@@ -506,7 +563,9 @@ __device__ __forceinline__ void step(const DevParams& P, EnvG& e, int lane, cons
     }
   }
   e.new_service = 0;
-  next_service<ENV, W>(P, e, lane, rng);
+  Sink nosink;
+  sink_init(nosink, false);
+  next_service<ENV, W>(P, e, lane, rng, nosink);
   bool done = (e.esp == (i64)P.episode_length);
   if (done && auto_reset) {
     e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;

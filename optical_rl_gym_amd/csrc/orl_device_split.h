@@ -1,0 +1,316 @@
+// orl_device_split.h — step() as a pipeline of lane-efficient kernels ("split" implementation).
+//
+// One step of the batch =
+//   k_ctrl_a   8 lanes per env: decode + validate the action, counters, push the release event; every link row the
+//              provision touches becomes a 16-byte work item in queue A
+//   k_rows     8 lanes per ITEM (lane = 64-bit word of the link row), grid-stride over queue A: clear the slots,
+//              per-link statistics, compactness sums (integer atomics per env)
+//   k_ctrl_b   8 lanes per env: network statistics, info, next service (RNG, node pair, bit rate), due releases ->
+//              work items in queue B (one per touched link, up to four masks in release order)
+//   k_rows     over queue B: set the slots, statistics, sums
+// Why: in the monolithic kernels the row work (bit tricks + float64 running averages) ran under per-env control
+// flow — one or two link rows per pass, multiplied by the worst hop count and release count among the envs sharing a
+// wavefront.  Flattened into a queue, every 8-lane group of the row kernel always has a row to work on, and the
+// control kernels shrink to the genuinely serial part.  Semantics, operation order of every float64 expression and
+// the reference line ranges are those of orl_device.h / orl_device_g8.h; the parity suite runs against this path.
+#pragma once
+#include "orl_device_g8.h"
+
+namespace orl {
+namespace sp {
+
+using g8::EnvG;
+using g8::gballot;
+using g8::gget;
+
+// work item: x = env:32 | link:8 | nmask:3 | op:1 (1 = release/set) | core of mask k: 5 bits each ; y = 4 x (s0:9 | n:7)
+__device__ __forceinline__ ulonglong2 make_item(i64 env, u32 link, int nmask, u64 masks, u32 cores, int op) {
+  ulonglong2 it;
+  it.x = (u64)(u32)env | ((u64)(link & 0xffu) << 32) | ((u64)(u32)nmask << 40) | ((u64)(u32)op << 43) | ((u64)(cores & 0xfffffu) << 44);
+  it.y = masks;
+  return it;
+}
+
+// reserve `cnt` consecutive queue slots for every 8-lane group of the workgroup: one atomic per workgroup
+__device__ __forceinline__ int wg_reserve(int cnt, u32* counter, int* s_cnt, int* s_base) {
+  const int grp = (int)(threadIdx.x >> 3);
+  if ((threadIdx.x & 7) == 0) s_cnt[grp] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int i = 0; i < 32; i++) { s_base[i] = tot; tot += s_cnt[i]; }
+    int b = tot ? (int)atomicAdd(counter, (u32)tot) : 0;
+    for (int i = 0; i < 32; i++) s_base[i] += b;
+  }
+  __syncthreads();
+  return s_base[grp];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// control kernel A: everything of step() up to (and excluding) the effects of the provision on the link rows
+// ---------------------------------------------------------------------------------------------------------------
+template <int ENV, int W>
+__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, int* s_cnt, int* s_base) {
+  const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
+  int cnt = 0, core = 0, slot = 0, n = 1;
+  PathRec rec;
+  rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
+  if (valid) {
+    EnvG e;
+    g8::env_load(P, e, env);
+    const int4 av = *(const int4*)(P.actions + env * 4);
+    int path, mod = 0;
+    bool bad = false;
+    if (ENV == ENV_DEEPRMSA) {  // deeprmsa_env.py:48-58
+      int aa = av.x;
+      path = K; slot = S;
+      if (aa >= 0 && aa < K * P.J) {
+        int route = aa / P.J, block = aa - route * P.J;
+        int starts[8], lens[8];
+        int pidx = pair_base(P, e.src, e.dst) + route;
+        int nb = 0;
+        if (route < P.n_paths[e.src * P.N + e.dst]) {
+          Row<W> m = g8::path_and_global<W>(P, e, pidx);
+          nb = first_blocks<W>(m, S, P.nslots_path[(size_t)pidx * P.n_br + e.br_idx], block + 1, starts, lens);
+        }
+        if (block < nb) { path = route; slot = starts[block]; }
+      }
+    } else if (ENV == ENV_RMCSA) {
+      path = av.x; mod = av.y; core = av.z; slot = av.w;
+      bad = path < 0 || path > K || mod < 0 || mod > P.M || core < 0 || core > P.C || slot < 0 || slot > S;
+    } else if (ENV == ENV_RWA) {
+      path = av.x; slot = av.y;
+      bad = path < 0 || path >= K + rej || slot < 0 || slot >= S + rej;
+    } else {
+      path = av.x; slot = av.y;
+      bad = path < 0 || path > K || slot < 0 || slot > S;
+    }
+    if (bad) {
+      e.flags |= ORL_FLAG_BAD_ACTION;
+      path = K; slot = S; mod = P.M; core = P.C;
+    }
+    const int path0 = path, slot0 = slot;
+    double* info_out = want_info ? P.info + env * P.n_info : nullptr;
+    if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && info_out) {
+      // compactness before the provision; k_ctrl_b turns it into the difference (rmsa_env.py:168-170, 250-251)
+      double pc = g8::net_compactness(P, e, 0, lane);
+      if (gl == 0) info_out[5] = pc;
+    }
+    bool accepted = false;
+    bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
+    if (in_range && path < P.n_paths[e.src * P.N + e.dst]) {
+      int pidx = pair_base(P, e.src, e.dst) + path;
+      if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
+      else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
+      rec = path_rec_load(P, pidx);
+      bool ok = false;
+      if (slot + n <= S) {  // is_path_free: lane w checks word w of every link row of the path
+        const int hops = path_rec_byte(rec, 0);
+        bool busy = false;
+        if (gl < W) {
+          const u64 m = word_range(slot - 64 * gl, slot + n - 64 * gl);
+          for (int h = 0; h < hops; h++)
+            busy = busy || ((m & ~e.bm[(core * P.E + path_rec_byte(rec, 2 + h)) * W + gl]) != 0ull);
+        }
+        ok = gballot(busy, lane) == 0u;
+      }
+      if (ok && ENV == ENV_RMCSA) {
+        double len = P.path_length[pidx];
+        ok = (len < P.lmax_xt[mod]) && (len < P.lmax_snr[mod * P.n_br + e.br_idx]);
+      }
+      if (ok) {
+        const int hops = path_rec_byte(rec, 0);
+        cnt = hops;
+        e.s_br += e.bit_rate;
+        e.s_nh += (i64)n * hops;
+        if (ENV != ENV_RWA) {
+          e.brp += e.bit_rate;
+          e.ebrp += e.bit_rate;
+          if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[env * 2 * P.n_br + P.n_br + e.br_idx] += 1;
+        }
+        e.sa += 1;
+        e.esa += 1;
+        accepted = true;
+        g8::ev_push(P, e, lane, e.at + e.ht, ev_pack(pidx, slot, n, core, e.bit_rate));
+      }
+    }
+    if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
+    if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
+    if (ENV == ENV_RWA) {  // actions_output marginals (rwa_env.py:103, 148-151)
+      i64* h = P.act_hist + env * ((K + 1) + (S + 1));
+      const int npa = K + rej, nsa = S + rej;
+      for (int i = gl; i < npa + nsa; i += 8) {
+        int hi = (i < npa) ? i : (K + 1) + (i - npa);
+        bool hit = !bad && ((i < npa) ? (i == path0) : (i - npa == slot0));
+        i64 v = h[hi] + (hit ? 1 : 0);
+        if (hit) h[hi] = v;
+        if (info_out) info_out[2 + i] = (double)v / (double)e.sp;
+      }
+    }
+    if (gl == 0) {
+      P.reward[env] = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
+      e.scal[SC_ACC] = pack2(accepted ? 1 : 0, core);
+    }
+    g8::env_store(P, e, gl);
+  }
+  const int base = wg_reserve(cnt, P.q_cnt + 0, s_cnt, s_base);
+  for (int h = gl; h < cnt; h += 8)
+    P.q_a[base + h] = make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), (u32)core, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// control kernel B: what step() does after the provision: network statistics, info, next service, due releases
+// ---------------------------------------------------------------------------------------------------------------
+template <int ENV, int W>
+__device__ __forceinline__ void ctrl_b(const DevParams& P, i64 env, bool valid, int lane, int auto_reset, bool want_info,
+                                       int* s_cnt, int* s_base) {
+  const int gl = lane & 7;
+  g8::Sink sink;
+  g8::sink_init(sink, true);
+  if (valid) {
+    EnvG e;
+    g8::env_load(P, e, env);
+    g8::RngG rng;
+    g8::rng_fill(e, rng, gl);
+    const u64 acc = e.scal[SC_ACC];
+    const bool accepted = (u32)acc != 0;
+    const int core = (int)(acc >> 32);
+    if (accepted && ENV != ENV_RWA) {  // _update_network_stats (rmsa_env.py:439-462), with the sums k_rows just updated
+      double last_update = e.g_last, time_diff = e.now - last_update;
+      if (e.now > 0) {
+        double cur_thr = (double)e.s_br;
+        e.g_thr = ((e.g_thr * last_update) + (cur_thr * time_diff)) / e.now;
+        e.g_comp = ((e.g_comp * last_update) + (g8::net_compactness(P, e, core, lane) * time_diff)) / e.now;
+      }
+      e.g_last = e.now;
+    }
+    double* info_out = want_info ? P.info + env * P.n_info : nullptr;
+    if (info_out) {
+      double i0 = (double)(e.sp - e.sa) / (double)e.sp;
+      double i1 = (double)(e.esp - e.esa) / (double)e.esp;
+      if (gl == 0) { info_out[0] = i0; info_out[1] = i1; }
+      if (ENV != ENV_RWA) {
+        double i2 = (double)(e.brq - e.brp) / (double)e.brq;
+        double i3 = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
+        if (gl == 0) { info_out[2] = i2; info_out[3] = i3; }
+      }
+      if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
+        double cur_comp = g8::net_compactness(P, e, 0, lane);
+        double mc = g8::link_mean(P, e.ls + 2 * P.E, lane);
+        double mu = g8::link_mean(P, e.ls, lane);
+        if (gl == 0) {
+          double prev_comp = info_out[5];
+          info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu;
+        }
+        if (P.bit_rate_mode == 1 && gl == 0) {
+          const i64* rq = P.br_hist + env * 2 * P.n_br;
+          const i64* pv = rq + P.n_br;
+          double mxv = -__builtin_inf(), mnv = __builtin_inf();
+          for (int i = 0; i < P.n_br; i++) {
+            double bl = 0.0;
+            if (rq[i] > 0) bl = (double)(rq[i] - pv[i]) / (double)rq[i];
+            info_out[8 + i] = bl;
+            mxv = bl > mxv ? bl : mxv;
+            mnv = bl < mnv ? bl : mnv;
+          }
+          info_out[8 + P.n_br] = mxv - mnv;
+        }
+      }
+    }
+    e.new_service = 0;
+    g8::next_service<ENV, W>(P, e, lane, rng, sink);
+    bool done = (e.esp == (i64)P.episode_length);
+    if (done && auto_reset) {
+      e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
+      if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
+    }
+    if (gl == 0) P.done[env] = done ? 1 : 0;
+    g8::env_store(P, e, gl);
+  }
+  const int cnt = sink.active ? sink.cnt : 0;
+  const int base = wg_reserve(cnt, P.q_cnt + 1, s_cnt, s_base);
+#pragma unroll
+  for (int k = 0; k < ORL_ISLOTS; k++) {
+    int idx = 8 * k + gl;
+    if (idx < cnt) P.q_b[base + idx] = make_item(env, sink.key[k], sink.nm[k], sink.mk[k], sink.cr[k], 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// row kernel: one 8-lane group per work item, lane w = word w of the link row
+// ---------------------------------------------------------------------------------------------------------------
+template <int ENV, int W>
+__device__ __forceinline__ void row_item(const DevParams& P, ulonglong2 it, int lane) {
+  const int w = lane & 7, E = P.E, S = P.S;
+  const i64 env = (i64)(u32)it.x;
+  const int link = (int)((it.x >> 32) & 0xff), nmask = (int)((it.x >> 40) & 7);
+  const bool release = ((it.x >> 43) & 1) != 0;
+  const u32 cores = (u32)(it.x >> 44);
+  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
+  u64* bm = P.bitmap + env * P.bm_words;
+  int* cs = P.core_sums + env * P.cs_words;
+  double* ls = P.lstat + env * 4 * E;
+  double last_update = ls[3 * E + link];
+  double util = ls[link], frag = 0.0, comp = 0.0;
+  if (ENV != ENV_RWA) { frag = ls[E + link]; comp = ls[2 * E + link]; }
+  for (int k = 0; k < nmask; k++) {
+    const int core = (int)((cores >> (5 * k)) & 0x1f);
+    const int s0 = (int)((it.y >> (16 * k)) & 0x1ff), n = (int)((it.y >> (16 * k + 9)) & 0x7f);
+    u64* wp = bm + (size_t)(core * E + link) * W + (w < W ? w : 0);
+    u64 a = (w < W) ? *wp : 0ull;
+    const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
+    a = release ? (a | m) : (a & ~m);
+    if (w < W) *wp = a;
+    RowStat after;
+    if (ENV != ENV_RWA) {
+      row_stat<W, true>(a, w, S, after);
+      if (w == 0) {  // this row's contribution to the compactness sums of its core
+        int* sump = cs + 2 * P.C + core * E + link;
+        const int pk = *sump;
+        const int d_occ = after.occ - (pk >> 16), d_fb = after.fb - (pk & 0xffff);
+        *sump = (after.occ << 16) | after.fb;
+        if (d_occ) atomicAdd(cs + 2 * core, d_occ);
+        if (d_fb) atomicAdd(cs + 2 * core + 1, d_fb);
+      }
+    } else {
+      after.free_ = g8_sum(__popcll(a));
+    }
+    if (now > 0) {
+      if (k == 0) {  // _update_link_stats on the row of the first touch (rmsa_env.py:464-543)
+        const double time_diff = now - last_update;
+        const int free_ = after.free_;
+        double cur_util = (double)(S - free_) / (double)S;
+        util = ((util * last_update) + (cur_util * time_diff)) / now;
+        if (ENV != ENV_RWA) {
+          double cur_frag = 0.0, cur_comp = 0.0;
+          const int top = (S - 1) - 64 * w;
+          const int edge = g8_sum(((w == 0 && (a & 1ull)) ? 1 : 0) + ((top >= 0 && top < 64 && ((a >> top) & 1ull)) ? 1 : 0));
+          const int max_empty = row_longest_run8<W>(a, w);
+          if (free_ > 0) {
+            int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
+            cur_frag = 1.0 - ((double)me / (double)free_);
+            if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
+            else cur_comp = 1.0;
+          }
+          frag = ((frag * last_update) + (cur_frag * time_diff)) / now;
+          comp = ((comp * last_update) + (cur_comp * time_diff)) / now;
+        }
+      } else {
+        // the same link touched again in the same step: the reference's update has last_update == now and
+        // time_diff == 0, i.e. new = ((old * now) + (cur * 0.0)) / now with a finite cur
+        util = ((util * now) + 0.0) / now;
+        if (ENV != ENV_RWA) { frag = ((frag * now) + 0.0) / now; comp = ((comp * now) + 0.0) / now; }
+      }
+    }
+  }
+  if (w == 0) {
+    if (now > 0) {
+      ls[link] = util;
+      if (ENV != ENV_RWA) { ls[E + link] = frag; ls[2 * E + link] = comp; }
+    }
+    ls[3 * E + link] = now;
+  }
+}
+
+}  // namespace sp
+}  // namespace orl

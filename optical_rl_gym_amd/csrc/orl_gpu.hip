@@ -20,6 +20,7 @@
 #include "../../include/orl.h"
 #include "orl_device.h"
 #include "orl_device_g8.h"
+#include "orl_device_split.h"
 
 using namespace orl;
 
@@ -275,6 +276,28 @@ __global__ void __launch_bounds__(256, ORL_STEP8_WAVES) k_step8(DevParams P, int
   }
 }
 
+// ---- split pipeline (orl_device_split.h): 32 envs per workgroup in the control kernels, 32 items per workgroup-pass
+// in the row kernel ---------------------------------------------------------------------------------------------
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_ctrl_a(DevParams P, int want_info) {
+  __shared__ int s_cnt[32], s_base[32];
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  sp::ctrl_a<ENV, W>(P, env, env < P.B, lane_id(), want_info != 0, s_cnt, s_base);
+}
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_ctrl_b(DevParams P, int auto_reset, int want_info) {
+  __shared__ int s_cnt[32], s_base[32];
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  sp::ctrl_b<ENV, W>(P, env, env < P.B, lane_id(), auto_reset, want_info != 0, s_cnt, s_base);
+}
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_rows(DevParams P, int phase) {
+  const ulonglong2* q = phase ? P.q_b : P.q_a;
+  const u32 qlen = P.q_cnt[phase];
+  const u32 stride = gridDim.x * 32u;
+  for (u32 idx = (blockIdx.x * 256u + threadIdx.x) >> 3; idx < qlen; idx += stride) sp::row_item<ENV, W>(P, q[idx], lane_id());
+}
+
 template <int ENV, int W>
 __global__ void __launch_bounds__(64) k_obs(DevParams P) {
   const i64 env = blockIdx.x;
@@ -340,7 +363,7 @@ struct orl_topology {
 struct orl_batch {
   DevParams P;
   int device, wt;
-  int step_impl;  // 64 = one wavefront per env (default: 314 us/launch on cfg2), 8 = eight lanes per env (ORL_STEP_IMPL=8: 327 us)
+  int step_impl;  // ORL_STEP_IMPL: 64 = one wavefront per env, 8 = eight lanes per env (monolithic), 1 = split pipeline
   hipStream_t stream;
   std::vector<void*> allocs;
   hipEvent_t ev0, ev1;
@@ -467,6 +490,25 @@ static void launch_obs(orl_batch* b);
 static void launch_step(orl_batch* b, int auto_reset, int want_info) {
   const DevParams& VP = b->view ? *b->view : b->P;
   hipStream_t VS = b->view ? b->view_stream : b->stream;
+  if (b->step_impl == 1) {
+    dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
+    i64 items = VP.B * 3;  // expected work items per phase; the row kernel strides over whatever the queue holds
+    dim3 gr((unsigned)((items / 32 < 256 ? 256 : (items / 32 > 4096 ? 4096 : items / 32))));
+    hipMemsetAsync(VP.q_cnt, 0, 4 * sizeof(u32), VS);
+#define CALLW(WW)                                                                                      \
+  do {                                                                                                 \
+    hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info);                             \
+    hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 0);                                       \
+    hipLaunchKernelGGL((k_ctrl_b<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info);                 \
+    hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
+  } while (0)
+#define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
+    ORL_FOR_ENV(PER_ENV)
+#undef PER_ENV
+#undef CALLW
+    if (VP.obs_dim) launch_obs(b);
+    return;
+  }
   const size_t lds8 = (size_t)32 * (VP.bm_words + 4 * VP.E) * 8;  // 4 wavefronts x 8 envs per workgroup
   if (b->step_impl == 8 && lds8 <= 64 * 1024) {
     dim3 g((unsigned)((VP.B + 31) / 32)), blk(256);
@@ -535,7 +577,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   b->view_stream = nullptr;
   {
     const char* impl = getenv("ORL_STEP_IMPL");
-    b->step_impl = (impl && atoi(impl) == 8) ? 8 : 64;
+    b->step_impl = impl ? atoi(impl) : 64;
+    if (b->step_impl != 8 && b->step_impl != 1) b->step_impl = 64;
   }
   DevParams& P = b->P;
   P.env_type = c->env_type;
@@ -606,6 +649,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   }
   size_t B = (size_t)n_envs;
   rc |= dalloc(b, &P.svc_desc, B);
+  P.q_cap = (i64)B * 32;
+  rc |= dalloc(b, &P.q_a, (size_t)P.q_cap);
+  rc |= dalloc(b, &P.q_b, (size_t)P.q_cap);
+  rc |= dalloc(b, &P.q_cnt, 64);
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
   rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
   rc |= dalloc(b, &P.ev_info, B * P.ev_cap);
@@ -636,6 +683,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       q.B = cnt;
       q.bitmap += lo * P.bm_words; q.ev_time += lo * P.ev_cap; q.ev_info += lo * P.ev_cap; q.mt += lo * 624;
       q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
+      q.q_a += lo * 32; q.q_b += lo * 32; q.q_cnt += 4 * (1 + (int)b->subs.size()); q.q_cap = cnt * 32;
       if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
