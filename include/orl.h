@@ -171,6 +171,8 @@ int orl_batch_set_state(orl_batch* b, const void* in);
 /* Profiling aid: reads the whole slot-map array once with 8-B (width16 = 0) or 16-B (1) loads per lane and returns the
  * number of bytes read, so that rocprofv3's FETCH_SIZE can be calibrated on a known byte count. */
 int64_t orl_batch_debug_stream_read(orl_batch* b, int width16);
+/* Statistics: env-steps of the split pipeline whose releases took the serial path (more than 8 in one step). */
+int64_t orl_batch_debug_serial_count(orl_batch* b);
 
 #ifdef __cplusplus
 }

@@ -23,13 +23,19 @@ using g8::EnvG;
 using g8::gballot;
 using g8::gget;
 
-// work item: x = env:32 | link:8 | nmask:3 | op:1 (1 = release/set) | core of mask k: 5 bits each ; y = 4 x (s0:9 | n:7)
-__device__ __forceinline__ ulonglong2 make_item(i64 env, u32 link, int nmask, u64 masks, u32 cores, int op) {
-  ulonglong2 it;
-  it.x = (u64)(u32)env | ((u64)(link & 0xffu) << 32) | ((u64)(u32)nmask << 40) | ((u64)(u32)op << 43) | ((u64)(cores & 0xfffffu) << 44);
-  it.y = masks;
+// work item (32 bytes, two 16-byte halves):
+//   a.x = env:32 | link:8 | nmask:4 | op:1 (1 = release/set)      a.y = masks 0..3, 16 bits each (s0:9 | n:7)
+//   b.x = masks 4..7                                                b.y = core of mask k, 5 bits each
+struct Item { ulonglong2 a, b; };
+__device__ __forceinline__ Item make_item(i64 env, u32 link, int nmask, u64 m0, u64 m1, u64 cores, int op) {
+  Item it;
+  it.a.x = (u64)(u32)env | ((u64)(link & 0xffu) << 32) | ((u64)(u32)nmask << 40) | ((u64)(u32)op << 44);
+  it.a.y = m0;
+  it.b.x = m1;
+  it.b.y = cores;
   return it;
 }
+__device__ __forceinline__ void item_store(ulonglong2* q, int idx, const Item& it) { q[2 * idx] = it.a; q[2 * idx + 1] = it.b; }
 
 // reserve `cnt` consecutive queue slots for every 8-lane group of the workgroup: one atomic per workgroup
 __device__ __forceinline__ int wg_reserve(int cnt, u32* counter, int* s_cnt, int* s_base) {
@@ -155,18 +161,17 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
   }
   const int base = wg_reserve(cnt, P.q_cnt + 0, s_cnt, s_base);
   for (int h = gl; h < cnt; h += 8)
-    P.q_a[base + h] = make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), (u32)core, 0);
+    item_store(P.q_a, base + h, make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), 0ull, (u64)(u32)core, 0));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // control kernel B: what step() does after the provision: network statistics, info, next service, due releases
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
-__device__ __forceinline__ void ctrl_b(const DevParams& P, i64 env, bool valid, int lane, int auto_reset, bool want_info,
-                                       int* s_cnt, int* s_base) {
+__device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid, int lane, int auto_reset, bool want_info) {
   const int gl = lane & 7;
   g8::Sink sink;
-  g8::sink_init(sink, true);
+  g8::sink_init(sink, false);
   if (valid) {
     EnvG e;
     g8::env_load(P, e, env);
@@ -218,7 +223,7 @@ __device__ __forceinline__ void ctrl_b(const DevParams& P, i64 env, bool valid, 
       }
     }
     e.new_service = 0;
-    g8::next_service<ENV, W>(P, e, lane, rng, sink);
+    g8::next_service<ENV, W, false>(P, e, lane, rng, sink);  // the due releases are k_ctrl_b2's job
     bool done = (e.esp == (i64)P.episode_length);
     if (done && auto_reset) {
       e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
@@ -227,25 +232,84 @@ __device__ __forceinline__ void ctrl_b(const DevParams& P, i64 env, bool valid, 
     if (gl == 0) P.done[env] = done ? 1 : 0;
     g8::env_store(P, e, gl);
   }
+}
+
+// control kernel B2: the due releases of the step (rmsa_env.py:590-597) -> work items.  Only the clock, the
+// pending-release bookkeeping and the two running sums of the env record are touched.
+template <int ENV, int W>
+__device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid, int lane, int* s_cnt, int* s_base, u32* s_tally) {
+  const int gl = lane & 7;
+  g8::Sink sink;
+  g8::sink_init(sink, true);
+  for (int i = (int)threadIdx.x; i < 32 * 32; i += 256) s_tally[i] = 0u;
+  __syncthreads();
+  sink.tally = s_tally + 32 * (int)(threadIdx.x >> 3);
+  if (valid) {
+    EnvG e;
+    u64* s = P.scal + env * ORL_SCAL_WORDS;
+    e.scal = s;
+    e.env = env;
+    e.now = __longlong_as_double((i64)s[SC_NOW]);
+    e.next_rel = __longlong_as_double((i64)s[SC_NEXTREL]);
+    e.s_br = (i64)s[SC_SBR];
+    e.s_nh = (i64)s[SC_SNH];
+    u64 t = s[SC_EV];
+    e.ev_hwm = (int)(u32)t; e.ev_cnt = (int)(t >> 32);
+    e.hint = (int)(u32)s[SC_HINT];
+    e.flags = 0;
+    e.bm = P.bitmap + env * P.bm_words;
+    e.ls = P.lstat + env * 4 * P.E;
+    e.cs = P.core_sums + env * P.cs_words;
+    e.ev_time = P.ev_time + env * P.ev_cap;
+    e.ev_info = P.ev_info + env * P.ev_cap;
+    g8::release_due<ENV, W, true>(P, e, lane, sink);
+    if (sink.deferred) {
+      // more simultaneous releases than the item form holds (> 4, or 3+ in one lane's slots): leave everything
+      // untouched and let k_rel_serial release them one by one
+      if (gl == 0) s[SC_ACC] = s[SC_ACC] | (1ull << 16);
+    } else if (gl == 0) {
+      s[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
+      s[SC_SBR] = (u64)e.s_br;
+      s[SC_SNH] = (u64)e.s_nh;
+      s[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
+      s[SC_HINT] = pack2(e.hint, 0);
+    }
+  }
   const int cnt = sink.active ? sink.cnt : 0;
   const int base = wg_reserve(cnt, P.q_cnt + 1, s_cnt, s_base);
 #pragma unroll
   for (int k = 0; k < ORL_ISLOTS; k++) {
     int idx = 8 * k + gl;
-    if (idx < cnt) P.q_b[base + idx] = make_item(env, sink.key[k], sink.nm[k], sink.mk[k], sink.cr[k], 1);
+    if (idx < cnt) item_store(P.q_b, base + idx, make_item(env, sink.key[k], sink.nm[k], sink.mk0[k], sink.mk1[k], sink.cr[k], 1));
   }
+}
+
+// rare path: envs whose due releases did not fit the item form (flag bit 16 of SC_ACC) release them in place
+template <int ENV, int W>
+__device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane) {
+  u64* s = P.scal + env * ORL_SCAL_WORDS;
+  if (!((s[SC_ACC] >> 16) & 1ull)) return;
+  const int gl = lane & 7;
+  if (gl == 0) atomicAdd(P.q_cnt + 2, 1u);  // statistics: env-steps that took the serial path
+  EnvG e;
+  g8::env_load(P, e, env);
+  g8::Sink nosink;
+  g8::sink_init(nosink, false);
+  g8::release_due<ENV, W, false>(P, e, lane, nosink);
+  if (gl == 0) s[SC_ACC] = s[SC_ACC] & ~(1ull << 16);
+  g8::env_store(P, e, gl);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // row kernel: one 8-lane group per work item, lane w = word w of the link row
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
-__device__ __forceinline__ void row_item(const DevParams& P, ulonglong2 it, int lane) {
+__device__ __forceinline__ void row_item(const DevParams& P, const Item it, int lane) {
   const int w = lane & 7, E = P.E, S = P.S;
-  const i64 env = (i64)(u32)it.x;
-  const int link = (int)((it.x >> 32) & 0xff), nmask = (int)((it.x >> 40) & 7);
-  const bool release = ((it.x >> 43) & 1) != 0;
-  const u32 cores = (u32)(it.x >> 44);
+  const i64 env = (i64)(u32)it.a.x;
+  const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
+  const bool release = ((it.a.x >> 44) & 1) != 0;
+  const u64 cores = it.b.y;
   const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
   u64* bm = P.bitmap + env * P.bm_words;
   int* cs = P.core_sums + env * P.cs_words;
@@ -255,7 +319,8 @@ __device__ __forceinline__ void row_item(const DevParams& P, ulonglong2 it, int 
   if (ENV != ENV_RWA) { frag = ls[E + link]; comp = ls[2 * E + link]; }
   for (int k = 0; k < nmask; k++) {
     const int core = (int)((cores >> (5 * k)) & 0x1f);
-    const int s0 = (int)((it.y >> (16 * k)) & 0x1ff), n = (int)((it.y >> (16 * k + 9)) & 0x7f);
+    const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
+    const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
     u64* wp = bm + (size_t)(core * E + link) * W + (w < W ? w : 0);
     u64 a = (w < W) ? *wp : 0ull;
     const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);

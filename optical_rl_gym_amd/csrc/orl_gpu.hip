@@ -285,17 +285,33 @@ __global__ void __launch_bounds__(256) k_ctrl_a(DevParams P, int want_info) {
   sp::ctrl_a<ENV, W>(P, env, env < P.B, lane_id(), want_info != 0, s_cnt, s_base);
 }
 template <int ENV, int W>
-__global__ void __launch_bounds__(256) k_ctrl_b(DevParams P, int auto_reset, int want_info) {
-  __shared__ int s_cnt[32], s_base[32];
+__global__ void __launch_bounds__(256) k_ctrl_b1(DevParams P, int auto_reset, int want_info) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
-  sp::ctrl_b<ENV, W>(P, env, env < P.B, lane_id(), auto_reset, want_info != 0, s_cnt, s_base);
+  sp::ctrl_b1<ENV, W>(P, env, env < P.B, lane_id(), auto_reset, want_info != 0);
+}
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_ctrl_b2(DevParams P) {
+  __shared__ int s_cnt[32], s_base[32];
+  __shared__ u32 s_tally[32 * 32];
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  sp::ctrl_b2<ENV, W>(P, env, env < P.B, lane_id(), s_cnt, s_base, s_tally);
+}
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_rel_serial(DevParams P) {
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (env < P.B) sp::rel_serial<ENV, W>(P, env, lane_id());
 }
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_rows(DevParams P, int phase) {
   const ulonglong2* q = phase ? P.q_b : P.q_a;
   const u32 qlen = P.q_cnt[phase];
   const u32 stride = gridDim.x * 32u;
-  for (u32 idx = (blockIdx.x * 256u + threadIdx.x) >> 3; idx < qlen; idx += stride) sp::row_item<ENV, W>(P, q[idx], lane_id());
+  for (u32 idx = (blockIdx.x * 256u + threadIdx.x) >> 3; idx < qlen; idx += stride) {
+    sp::Item it;
+    it.a = q[2 * idx];
+    it.b = q[2 * idx + 1];
+    sp::row_item<ENV, W>(P, it, lane_id());
+  }
 }
 
 template <int ENV, int W>
@@ -494,13 +510,15 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info) {
     dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
     i64 items = VP.B * 3;  // expected work items per phase; the row kernel strides over whatever the queue holds
     dim3 gr((unsigned)((items / 32 < 256 ? 256 : (items / 32 > 4096 ? 4096 : items / 32))));
-    hipMemsetAsync(VP.q_cnt, 0, 4 * sizeof(u32), VS);
+    hipMemsetAsync(VP.q_cnt, 0, 2 * sizeof(u32), VS);  // [2] accumulates the number of serial-path env-steps
 #define CALLW(WW)                                                                                      \
   do {                                                                                                 \
     hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info);                             \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 0);                                       \
-    hipLaunchKernelGGL((k_ctrl_b<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info);                 \
+    hipLaunchKernelGGL((k_ctrl_b1<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info);                \
+    hipLaunchKernelGGL((k_ctrl_b2<EE, WW>), gc, blk, 0, VS, VP);                                       \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
+    hipLaunchKernelGGL((k_rel_serial<EE, WW>), gc, blk, 0, VS, VP);                                    \
   } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
     ORL_FOR_ENV(PER_ENV)
@@ -650,9 +668,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   size_t B = (size_t)n_envs;
   rc |= dalloc(b, &P.svc_desc, B);
   P.q_cap = (i64)B * 32;
-  rc |= dalloc(b, &P.q_a, (size_t)P.q_cap);
-  rc |= dalloc(b, &P.q_b, (size_t)P.q_cap);
+  rc |= dalloc(b, &P.q_a, (size_t)P.q_cap * 2);  // 32-byte items
+  rc |= dalloc(b, &P.q_b, (size_t)P.q_cap * 2);
   rc |= dalloc(b, &P.q_cnt, 64);
+  if (!rc) hipMemset(P.q_cnt, 0, 64 * sizeof(u32));
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
   rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
   rc |= dalloc(b, &P.ev_info, B * P.ev_cap);
@@ -683,7 +702,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       q.B = cnt;
       q.bitmap += lo * P.bm_words; q.ev_time += lo * P.ev_cap; q.ev_info += lo * P.ev_cap; q.mt += lo * 624;
       q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
-      q.q_a += lo * 32; q.q_b += lo * 32; q.q_cnt += 4 * (1 + (int)b->subs.size()); q.q_cap = cnt * 32;
+      q.q_a += lo * 64; q.q_b += lo * 64; q.q_cnt += 4 * (1 + (int)b->subs.size()); q.q_cap = cnt * 32;
       if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
@@ -1032,4 +1051,17 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
   if (b->P.obs_dim) launch_obs(b);
   HIPCHK(hipStreamSynchronize(b->stream));
   return ORL_OK;
+}
+
+/* debug: number of env-steps that fell back to the serial release path of the split pipeline since creation */
+extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
+  if (!b) return -1;
+  if (hipSetDevice(b->device) != hipSuccess) return -1;
+  hipStreamSynchronize(b->stream);
+  for (hipStream_t st : b->sub_streams) hipStreamSynchronize(st);
+  int64_t tot = 0;
+  u32 v = 0;
+  if (hipMemcpy(&v, b->P.q_cnt + 2, 4, hipMemcpyDeviceToHost) == hipSuccess) tot += v;
+  for (auto& q : b->subs) if (hipMemcpy(&v, q.q_cnt + 2, 4, hipMemcpyDeviceToHost) == hipSuccess) tot += v;
+  return tot;
 }
