@@ -310,10 +310,12 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
   e.next_rel = t < e.next_rel ? t : e.next_rel;  // -inf (unknown) stays -inf
 }
 
+// `pre`: the owner lane already holds this entry's info word and path record (requested in one batch after the scan)
 template <int ENV, int W, bool SINK_ONLY>
-__device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lane, int bi, Sink& sink) {
+__device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lane, int bi, Sink& sink, bool pre = false,
+                                            u64 pre_info = 0, PathRec pre_rec = PathRec()) {
   const int gl = lane & 7, owner = bi & 7;
-  u64 info = (gl == owner) ? e.ev_info[bi] : 0ull;
+  u64 info = pre ? pre_info : ((gl == owner) ? e.ev_info[bi] : 0ull);
   info = gget(info, owner, lane);
   if (gl == owner) e.ev_time[bi] = __builtin_inf();
   const int pidx = (int)(info & 0xffffffu), s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
@@ -322,7 +324,13 @@ __device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lan
   e.hint = (e.hint < 0 || bi < e.hint) ? bi : e.hint;
   int hops_r;
   if (sink.active) {
-    const PathRec rec = path_rec_load(P, pidx);
+    PathRec rec;
+    if (pre) {
+      rec.q[0] = gget(pre_rec.q[0], owner, lane); rec.q[1] = gget(pre_rec.q[1], owner, lane);
+      rec.q[2] = gget(pre_rec.q[2], owner, lane); rec.q[3] = gget(pre_rec.q[3], owner, lane);
+    } else {
+      rec = path_rec_load(P, pidx);
+    }
     hops_r = path_rec_byte(rec, 0);
     sink_add(sink, rec, core, s0, n, lane);
   } else {
@@ -404,14 +412,25 @@ __device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lan
       release_one<ENV, W, SINK_ONLY>(P, e, lane, bi, sink);
       continue;
     }
+    // sink mode: every lane requests the info word and the path record of its (at most two) due entries now, in
+    // two batched round trips, instead of two dependent round trips per release inside the ordered loop
+    const bool pre = SINK_ONLY && sink.active;
+    u64 inf0 = 0, inf1 = 0;
+    PathRec rc0 = PathRec(), rc1 = PathRec();
+    if (pre) {
+      if (d0i != 0x7fffffff) inf0 = e.ev_info[d0i];
+      if (d1i != 0x7fffffff) inf1 = e.ev_info[d1i];
+      if (d0i != 0x7fffffff) rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu));
+      if (d1i != 0x7fffffff) rc1 = path_rec_load(P, (int)(inf1 & 0xffffffu));
+    }
     for (;;) {
       double bt = d0t; int bi = d0i;
 #define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; } }
       ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
 #undef ORL_MIN_STEP
       if (!(bt <= e.now)) break;
-      if (gl == (bi & 7)) { d0t = d1t; d0i = d1i; d1t = __builtin_inf(); d1i = 0x7fffffff; }
-      release_one<ENV, W, SINK_ONLY>(P, e, lane, bi, sink);
+      release_one<ENV, W, SINK_ONLY>(P, e, lane, bi, sink, pre, inf0, rc0);
+      if (gl == (bi & 7)) { d0t = d1t; d0i = d1i; d1t = __builtin_inf(); d1i = 0x7fffffff; inf0 = inf1; rc0 = rc1; }
     }
     e.next_rel = g8_min(rest);
     break;

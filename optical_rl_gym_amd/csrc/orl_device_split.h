@@ -56,7 +56,8 @@ __device__ __forceinline__ int wg_reserve(int cnt, u32* counter, int* s_cnt, int
 // control kernel A: everything of step() up to (and excluding) the effects of the provision on the link rows
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
-__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, int* s_cnt, int* s_base) {
+__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, int* s_cnt, int* s_base,
+                                       const int4* given = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   int cnt = 0, core = 0, slot = 0, n = 1;
   PathRec rec;
@@ -64,7 +65,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
   if (valid) {
     EnvG e;
     g8::env_load(P, e, env);
-    const int4 av = *(const int4*)(P.actions + env * 4);
+    const int4 av = given ? *given : *(const int4*)(P.actions + env * 4);
     int path, mod = 0;
     bool bad = false;
     if (ENV == ENV_DEEPRMSA) {  // deeprmsa_env.py:48-58

@@ -284,6 +284,23 @@ __global__ void __launch_bounds__(256) k_ctrl_a(DevParams P, int want_info) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   sp::ctrl_a<ENV, W>(P, env, env < P.B, lane_id(), want_info != 0, s_cnt, s_base);
 }
+// device-policy loop: slot-scan and control kernel A in one launch (same 8-lanes-per-env layout; the action never
+// leaves the registers, the link rows the scan just read are still in cache for the validation)
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_policy_ctrl_a(DevParams P, int pol) {
+  __shared__ int s_cnt[32], s_base[32];
+  const int lane = lane_id();
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool valid = env < P.B;
+  const i64 env0 = env - ((lane >> 3));  // first env of this wavefront
+  u64 d = valid ? P.svc_desc[env] : 0ull;
+  int a[4];
+  policy_g<ENV, W, 8>(P, P.bitmap + env0 * P.bm_words + (size_t)(lane >> 3) * P.bm_words, valid, (int)(u32)d,
+                      (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane, pol, a);
+  const int4 av = make_int4(a[0], a[1], a[2], a[3]);
+  if (valid && (lane & 7) == 0) *(int4*)(P.actions + env * 4) = av;
+  sp::ctrl_a<ENV, W>(P, env, valid, lane, false, s_cnt, s_base, &av);
+}
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_b1(DevParams P, int auto_reset, int want_info) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -503,7 +520,16 @@ static void launch_policy(orl_batch* b, int pol) {
 #undef CALLW
 }
 static void launch_obs(orl_batch* b);
-static void launch_step(orl_batch* b, int auto_reset, int want_info) {
+static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_policy = -1);
+// policy + step of the device-resident loop; the split pipeline fuses the slot-scan with its first control kernel
+static void launch_policy_step(orl_batch* b, int pol) {
+  const DevParams& VP = b->view ? *b->view : b->P;
+  const bool wide = (VP.env_type == ENV_RMCSA) || VP.K > 8;
+  if (b->step_impl == 1 && !wide) { launch_step(b, 1, 0, pol); return; }
+  launch_policy(b, pol);
+  launch_step(b, 1, 0);
+}
+static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_policy) {
   const DevParams& VP = b->view ? *b->view : b->P;
   hipStream_t VS = b->view ? b->view_stream : b->stream;
   if (b->step_impl == 1) {
@@ -513,7 +539,8 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info) {
     hipMemsetAsync(VP.q_cnt, 0, 2 * sizeof(u32), VS);  // [2] accumulates the number of serial-path env-steps
 #define CALLW(WW)                                                                                      \
   do {                                                                                                 \
-    hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info);                             \
+    if (fused_policy >= 0) hipLaunchKernelGGL((k_policy_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, fused_policy); \
+    else hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info);                         \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 0);                                       \
     hipLaunchKernelGGL((k_ctrl_b1<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info);                \
     hipLaunchKernelGGL((k_ctrl_b2<EE, WW>), gc, blk, 0, VS, VP);                                       \
@@ -847,8 +874,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
       for (size_t k = 0; k < b->subs.size(); k++) {
         b->view = &b->subs[k];
         b->view_stream = b->sub_streams[k];
-        launch_policy(b, policy_id);
-        launch_step(b, 1, 0);
+        launch_policy_step(b, policy_id);
       }
     }
     b->view = nullptr;
@@ -862,11 +888,12 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     }
   } else {
     for (int64_t s = 0; s < n_steps; s++) {
-      if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s], b->stream));
+      if (!time_kernels) { launch_policy_step(b, policy_id); continue; }
+      HIPCHK(hipEventRecord(evs[3 * s], b->stream));
       launch_policy(b, policy_id);
-      if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s + 1], b->stream));
+      HIPCHK(hipEventRecord(evs[3 * s + 1], b->stream));
       launch_step(b, 1, 0);
-      if (time_kernels) HIPCHK(hipEventRecord(evs[3 * s + 2], b->stream));
+      HIPCHK(hipEventRecord(evs[3 * s + 2], b->stream));
     }
   }
   HIPCHK(hipEventRecord(b->ev1, b->stream));
