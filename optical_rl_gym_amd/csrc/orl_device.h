@@ -85,7 +85,9 @@ struct DevParams {
   // split pipeline (orl_device_split.h): row-update work items produced by the control kernels
   ulonglong2* q_a;  // [q_cap] provision items of this step
   ulonglong2* q_b;  // [q_cap] release items of this step
-  u32* q_cnt;       // [0] = items in q_a, [1] = items in q_b (zeroed before every step)
+  u32* q_cnt_a;     // [ceil(B/32)] items each control workgroup put into its region of q_a
+  u32* q_cnt_b;     // [ceil(B/32)] same for q_b
+  u32* q_stat;      // [1] env-steps that took the serial release path (statistics)
   i64 q_cap;
   int* core_sums;   // [B][cs_words]      [2*C] per core: sum(lambda_max-lambda_min), sum(free blocks inside);
                     //                    then [C*E] per (core, link): that row's own contribution, (occ << 16) | fb
@@ -513,9 +515,11 @@ template <int W>
 __device__ __forceinline__ Row<W> path_and_rec(const PathRec& r, const u64* bm, int E, int S, int core) {
   Row<W> m = row_mask_lo<W>(S);
   const int hops = path_rec_byte(r, 0);
-  for (int h = 0; h < hops; h++) {
-    int link = path_rec_byte(r, 2 + h);
-    m = row_and<W>(m, row_load<W>(bm + (core * E + link) * W));
+  const u64* base = bm + (size_t)core * E * W;
+  for (int h = 0; h < hops; h += 2) {  // two link rows in flight per round
+    const Row<W> r0 = row_load<W>(base + path_rec_byte(r, 2 + h) * W);
+    const Row<W> r1 = row_load<W>(base + path_rec_byte(r, (h + 1 < hops) ? 3 + h : 2 + h) * W);
+    m = row_and<W>(m, row_and<W>(r0, r1));
   }
   return m;
 }

@@ -294,11 +294,18 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
   int idx = e.hint;
   e.hint = -1;
   if (idx < 0) {
-    for (int base = 0; base < e.ev_hwm; base += 8) {
-      int i = base + gl;
-      bool empty = (i < e.ev_hwm) && (e.ev_time[i] == __builtin_inf());
-      u32 b = gballot(empty, lane);
-      if (b) { idx = base + (int)__builtin_ctz(b); break; }
+    for (int base = 0; base < e.ev_hwm && idx < 0; base += 32) {  // four 8-slot chunks requested together
+      double t[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        int i = base + 8 * c + gl;
+        t[c] = (i < e.ev_hwm) ? e.ev_time[i] : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        u32 b = gballot(t[c] == __builtin_inf(), lane);
+        if (b && idx < 0) idx = base + 8 * c + (int)__builtin_ctz(b);
+      }
     }
   }
   if (idx < 0) {

@@ -37,19 +37,21 @@ __device__ __forceinline__ Item make_item(i64 env, u32 link, int nmask, u64 m0, 
 }
 __device__ __forceinline__ void item_store(ulonglong2* q, int idx, const Item& it) { q[2 * idx] = it.a; q[2 * idx + 1] = it.b; }
 
-// reserve `cnt` consecutive queue slots for every 8-lane group of the workgroup: one atomic per workgroup
-__device__ __forceinline__ int wg_reserve(int cnt, u32* counter, int* s_cnt, int* s_base) {
+// Every control workgroup (32 envs) owns a fixed region of ORL_QREGION item slots in the queue and publishes how many it
+// filled; the row kernel runs one workgroup per region.  No global atomic: a single queue-tail counter serialised the
+// 2 048 workgroups of a 65 536-env launch (~12 ns per atomic on one address).
+#define ORL_QREGION 1024
+__device__ __forceinline__ int wg_reserve(int cnt, u32* region_counts, int* s_cnt, int* s_base) {
   const int grp = (int)(threadIdx.x >> 3);
   if ((threadIdx.x & 7) == 0) s_cnt[grp] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) {
     int tot = 0;
     for (int i = 0; i < 32; i++) { s_base[i] = tot; tot += s_cnt[i]; }
-    int b = tot ? (int)atomicAdd(counter, (u32)tot) : 0;
-    for (int i = 0; i < 32; i++) s_base[i] += b;
+    region_counts[blockIdx.x] = (u32)tot;
   }
   __syncthreads();
-  return s_base[grp];
+  return (int)blockIdx.x * ORL_QREGION + s_base[grp];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -116,8 +118,16 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         bool busy = false;
         if (gl < W) {
           const u64 m = word_range(slot - 64 * gl, slot + n - 64 * gl);
-          for (int h = 0; h < hops; h++)
-            busy = busy || ((m & ~e.bm[(core * P.E + path_rec_byte(rec, 2 + h)) * W + gl]) != 0ull);
+          const u64* rowbase = e.bm + (size_t)core * P.E * W + gl;
+          u64 miss = 0;
+          for (int h = 0; h < hops; h += 4) {  // four independent row-word loads in flight
+            const u64 r0 = rowbase[path_rec_byte(rec, 2 + h) * W];
+            const u64 r1 = (h + 1 < hops) ? rowbase[path_rec_byte(rec, 3 + h) * W] : ~0ull;
+            const u64 r2 = (h + 2 < hops) ? rowbase[path_rec_byte(rec, 4 + h) * W] : ~0ull;
+            const u64 r3 = (h + 3 < hops) ? rowbase[path_rec_byte(rec, 5 + h) * W] : ~0ull;
+            miss |= m & ~(r0 & r1 & r2 & r3);
+          }
+          busy = miss != 0ull;
         }
         ok = gballot(busy, lane) == 0u;
       }
@@ -160,7 +170,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     }
     g8::env_store(P, e, gl);
   }
-  const int base = wg_reserve(cnt, P.q_cnt + 0, s_cnt, s_base);
+  const int base = wg_reserve(cnt, P.q_cnt_a, s_cnt, s_base);
   for (int h = gl; h < cnt; h += 8)
     item_store(P.q_a, base + h, make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), 0ull, (u64)(u32)core, 0));
 }
@@ -277,7 +287,7 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
     }
   }
   const int cnt = sink.active ? sink.cnt : 0;
-  const int base = wg_reserve(cnt, P.q_cnt + 1, s_cnt, s_base);
+  const int base = wg_reserve(cnt, P.q_cnt_b, s_cnt, s_base);
 #pragma unroll
   for (int k = 0; k < ORL_ISLOTS; k++) {
     int idx = 8 * k + gl;
@@ -291,7 +301,7 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
   u64* s = P.scal + env * ORL_SCAL_WORDS;
   if (!((s[SC_ACC] >> 16) & 1ull)) return;
   const int gl = lane & 7;
-  if (gl == 0) atomicAdd(P.q_cnt + 2, 1u);  // statistics: env-steps that took the serial path
+  if (gl == 0) atomicAdd(P.q_stat, 1u);  // statistics: env-steps that took the serial path
   EnvG e;
   g8::env_load(P, e, env);
   g8::Sink nosink;
@@ -311,19 +321,24 @@ __device__ __forceinline__ void row_item(const DevParams& P, const Item it, int 
   const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
   const bool release = ((it.a.x >> 44) & 1) != 0;
   const u64 cores = it.b.y;
-  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
   u64* bm = P.bitmap + env * P.bm_words;
   int* cs = P.core_sums + env * P.cs_words;
   double* ls = P.lstat + env * 4 * E;
+  // everything the item needs is requested before anything is used: clock, the four link statistics, the first
+  // mask's row word and that row's cached contribution to the compactness sums
+  const int core0 = (int)(cores & 0x1f);
+  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
   double last_update = ls[3 * E + link];
   double util = ls[link], frag = 0.0, comp = 0.0;
   if (ENV != ENV_RWA) { frag = ls[E + link]; comp = ls[2 * E + link]; }
+  u64 a_first = (w < W) ? bm[(size_t)(core0 * E + link) * W + w] : 0ull;
+  int pk_first = (ENV != ENV_RWA) ? cs[2 * P.C + core0 * E + link] : 0;
   for (int k = 0; k < nmask; k++) {
     const int core = (int)((cores >> (5 * k)) & 0x1f);
     const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
     const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
     u64* wp = bm + (size_t)(core * E + link) * W + (w < W ? w : 0);
-    u64 a = (w < W) ? *wp : 0ull;
+    u64 a = (k == 0) ? a_first : ((w < W) ? *wp : 0ull);
     const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
     a = release ? (a | m) : (a & ~m);
     if (w < W) *wp = a;
@@ -332,7 +347,7 @@ __device__ __forceinline__ void row_item(const DevParams& P, const Item it, int 
       row_stat<W, true>(a, w, S, after);
       if (w == 0) {  // this row's contribution to the compactness sums of its core
         int* sump = cs + 2 * P.C + core * E + link;
-        const int pk = *sump;
+        const int pk = (k == 0) ? pk_first : *sump;
         const int d_occ = after.occ - (pk >> 16), d_fb = after.fb - (pk & 0xffff);
         *sump = (after.occ << 16) | after.fb;
         if (d_occ) atomicAdd(cs + 2 * core, d_occ);

@@ -318,12 +318,17 @@ __global__ void __launch_bounds__(256) k_rel_serial(DevParams P) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   if (env < P.B) sp::rel_serial<ENV, W>(P, env, lane_id());
 }
+#ifndef ORL_ROWS_SPLIT
+#define ORL_ROWS_SPLIT 3
+#endif
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_rows(DevParams P, int phase) {
-  const ulonglong2* q = phase ? P.q_b : P.q_a;
-  const u32 qlen = P.q_cnt[phase];
-  const u32 stride = gridDim.x * 32u;
-  for (u32 idx = (blockIdx.x * 256u + threadIdx.x) >> 3; idx < qlen; idx += stride) {
+  // ORL_ROWS_SPLIT workgroups per producer region (32 envs' worth of items, dense from the region's start), taking
+  // interleaved chunks of 32 items: a region holds ~75 items, so one workgroup alone would run 3 mostly serial passes
+  const u32 region = blockIdx.x / ORL_ROWS_SPLIT, part = blockIdx.x % ORL_ROWS_SPLIT;
+  const ulonglong2* q = (phase ? P.q_b : P.q_a) + (size_t)region * ORL_QREGION * 2;
+  const u32 n = (phase ? P.q_cnt_b : P.q_cnt_a)[region];
+  for (u32 idx = part * 32u + (threadIdx.x >> 3); idx < n; idx += 32u * ORL_ROWS_SPLIT) {
     sp::Item it;
     it.a = q[2 * idx];
     it.b = q[2 * idx + 1];
@@ -534,9 +539,7 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
   hipStream_t VS = b->view ? b->view_stream : b->stream;
   if (b->step_impl == 1) {
     dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
-    i64 items = VP.B * 3;  // expected work items per phase; the row kernel strides over whatever the queue holds
-    dim3 gr((unsigned)((items / 32 < 256 ? 256 : (items / 32 > 4096 ? 4096 : items / 32))));
-    hipMemsetAsync(VP.q_cnt, 0, 2 * sizeof(u32), VS);  // [2] accumulates the number of serial-path env-steps
+    dim3 gr(gc.x * ORL_ROWS_SPLIT);  // the row kernel runs ORL_ROWS_SPLIT workgroups per control workgroup's item region
 #define CALLW(WW)                                                                                      \
   do {                                                                                                 \
     if (fused_policy >= 0) hipLaunchKernelGGL((k_policy_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, fused_policy); \
@@ -694,11 +697,16 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   }
   size_t B = (size_t)n_envs;
   rc |= dalloc(b, &P.svc_desc, B);
-  P.q_cap = (i64)B * 32;
-  rc |= dalloc(b, &P.q_a, (size_t)P.q_cap * 2);  // 32-byte items
-  rc |= dalloc(b, &P.q_b, (size_t)P.q_cap * 2);
-  rc |= dalloc(b, &P.q_cnt, 64);
-  if (!rc) hipMemset(P.q_cnt, 0, 64 * sizeof(u32));
+  {
+    const size_t regions = (B + 31) / 32 + 16;  // +16: sub-batch views start at multiples of 32 envs
+    P.q_cap = (i64)regions * ORL_QREGION;
+    rc |= dalloc(b, &P.q_a, (size_t)P.q_cap * 2);  // 32-byte items
+    rc |= dalloc(b, &P.q_b, (size_t)P.q_cap * 2);
+    rc |= dalloc(b, &P.q_cnt_a, regions);
+    rc |= dalloc(b, &P.q_cnt_b, regions);
+    rc |= dalloc(b, &P.q_stat, 16);
+    if (!rc) hipMemset(P.q_stat, 0, 16 * sizeof(u32));
+  }
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
   rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
   rc |= dalloc(b, &P.ev_info, B * P.ev_cap);
@@ -729,7 +737,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       q.B = cnt;
       q.bitmap += lo * P.bm_words; q.ev_time += lo * P.ev_cap; q.ev_info += lo * P.ev_cap; q.mt += lo * 624;
       q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
-      q.q_a += lo * 64; q.q_b += lo * 64; q.q_cnt += 4 * (1 + (int)b->subs.size()); q.q_cap = cnt * 32;
+      q.q_a += (lo / 32) * ORL_QREGION * 2; q.q_b += (lo / 32) * ORL_QREGION * 2; q.q_cnt_a += lo / 32; q.q_cnt_b += lo / 32;
       if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
@@ -1086,9 +1094,7 @@ extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
   if (hipSetDevice(b->device) != hipSuccess) return -1;
   hipStreamSynchronize(b->stream);
   for (hipStream_t st : b->sub_streams) hipStreamSynchronize(st);
-  int64_t tot = 0;
   u32 v = 0;
-  if (hipMemcpy(&v, b->P.q_cnt + 2, 4, hipMemcpyDeviceToHost) == hipSuccess) tot += v;
-  for (auto& q : b->subs) if (hipMemcpy(&v, q.q_cnt + 2, 4, hipMemcpyDeviceToHost) == hipSuccess) tot += v;
-  return tot;
+  if (hipMemcpy(&v, b->P.q_stat, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)v;
 }
