@@ -47,7 +47,10 @@ enum {
   SC_SRC_DST, SC_BR_IDX, SC_ID_MTPOS, SC_EV, SC_FLAGS,
   SC_NEXTREL,  // f64 lower bound of every pending release time (-inf = unknown, +inf = none pending)
   SC_HINT,     // low 32 bits: index of a known-empty pending-release slot, or -1
-  SC_ACC,      // split pipeline: low 32 = this step's action was provisioned, high 32 = its core
+  SC_ACC,      // split pipeline: low 32 = bit 0 action provisioned, bit 1 g_comp update pending, bit 16 serial releases; high 32 = core
+  SC_NOWA,     // split pipeline: clock of the provision phase (the row kernel of phase A reads it)
+  SC_GC_A,     // split pipeline: last_compactness * last_update of the pending network-compactness update
+  SC_GC_TD,    // split pipeline: its time_diff
   SC_COUNT
 };
 #define ORL_SCAL_WORDS 32

@@ -57,7 +57,13 @@ __device__ __forceinline__ int wg_reserve(int cnt, u32* region_counts, int* s_cn
 // ---------------------------------------------------------------------------------------------------------------
 // control kernel A: everything of step() up to (and excluding) the effects of the provision on the link rows
 // ---------------------------------------------------------------------------------------------------------------
-template <int ENV, int W>
+template <int ENV, int W, bool DEFER_GCOMP>
+__device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
+                                             double* info_out);
+
+// MERGE: device-resident loop without info — the work of control kernel B1 (next service) is done right here, on the env
+// record that is already in registers; only the network-compactness update has to wait for the row kernel (k_ctrl_b2).
+template <int ENV, int W, bool MERGE = false>
 __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, int* s_cnt, int* s_base,
                                        const int4* given = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
@@ -167,7 +173,9 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     if (gl == 0) {
       P.reward[env] = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
       e.scal[SC_ACC] = pack2(accepted ? 1 : 0, core);
+      e.scal[SC_NOWA] = (u64)__double_as_longlong(e.now);
     }
+    if (MERGE) service_part<ENV, W, true>(P, e, env, lane, 1, accepted, core, nullptr);
     g8::env_store(P, e, gl);
   }
   const int base = wg_reserve(cnt, P.q_cnt_a, s_cnt, s_base);
@@ -178,71 +186,84 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
 // ---------------------------------------------------------------------------------------------------------------
 // control kernel B: what step() does after the provision: network statistics, info, next service, due releases
 // ---------------------------------------------------------------------------------------------------------------
-template <int ENV, int W>
-__device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid, int lane, int auto_reset, bool want_info) {
+template <int ENV, int W, bool DEFER_GCOMP>
+__device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
+                                             double* info_out) {
   const int gl = lane & 7;
-  g8::Sink sink;
-  g8::sink_init(sink, false);
-  if (valid) {
-    EnvG e;
-    g8::env_load(P, e, env);
-    g8::RngG rng;
-    g8::rng_fill(e, rng, gl);
-    const u64 acc = e.scal[SC_ACC];
-    const bool accepted = (u32)acc != 0;
-    const int core = (int)(acc >> 32);
-    if (accepted && ENV != ENV_RWA) {  // _update_network_stats (rmsa_env.py:439-462), with the sums k_rows just updated
-      double last_update = e.g_last, time_diff = e.now - last_update;
-      if (e.now > 0) {
-        double cur_thr = (double)e.s_br;
-        e.g_thr = ((e.g_thr * last_update) + (cur_thr * time_diff)) / e.now;
+  g8::RngG rng;
+  g8::rng_fill(e, rng, gl);
+  if (accepted && ENV != ENV_RWA) {  // _update_network_stats (rmsa_env.py:439-462)
+    double last_update = e.g_last, time_diff = e.now - last_update;
+    if (e.now > 0) {
+      double cur_thr = (double)e.s_br;
+      e.g_thr = ((e.g_thr * last_update) + (cur_thr * time_diff)) / e.now;
+      if (DEFER_GCOMP) {
+        // the compactness term needs the sums after the provision's row updates: k_ctrl_b2 finishes
+        // g_comp = (g_comp * last_update + compactness * time_diff) / now from these two stashed factors
+        if (gl == 0) {
+          e.scal[SC_GC_A] = (u64)__double_as_longlong(e.g_comp * last_update);
+          e.scal[SC_GC_TD] = (u64)__double_as_longlong(time_diff);
+          e.scal[SC_ACC] = pack2(3, core);
+        }
+      } else {
         e.g_comp = ((e.g_comp * last_update) + (g8::net_compactness(P, e, core, lane) * time_diff)) / e.now;
       }
-      e.g_last = e.now;
     }
-    double* info_out = want_info ? P.info + env * P.n_info : nullptr;
-    if (info_out) {
-      double i0 = (double)(e.sp - e.sa) / (double)e.sp;
-      double i1 = (double)(e.esp - e.esa) / (double)e.esp;
-      if (gl == 0) { info_out[0] = i0; info_out[1] = i1; }
-      if (ENV != ENV_RWA) {
-        double i2 = (double)(e.brq - e.brp) / (double)e.brq;
-        double i3 = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
-        if (gl == 0) { info_out[2] = i2; info_out[3] = i3; }
-      }
-      if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
-        double cur_comp = g8::net_compactness(P, e, 0, lane);
-        double mc = g8::link_mean(P, e.ls + 2 * P.E, lane);
-        double mu = g8::link_mean(P, e.ls, lane);
-        if (gl == 0) {
-          double prev_comp = info_out[5];
-          info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu;
-        }
-        if (P.bit_rate_mode == 1 && gl == 0) {
-          const i64* rq = P.br_hist + env * 2 * P.n_br;
-          const i64* pv = rq + P.n_br;
-          double mxv = -__builtin_inf(), mnv = __builtin_inf();
-          for (int i = 0; i < P.n_br; i++) {
-            double bl = 0.0;
-            if (rq[i] > 0) bl = (double)(rq[i] - pv[i]) / (double)rq[i];
-            info_out[8 + i] = bl;
-            mxv = bl > mxv ? bl : mxv;
-            mnv = bl < mnv ? bl : mnv;
-          }
-          info_out[8 + P.n_br] = mxv - mnv;
-        }
-      }
-    }
-    e.new_service = 0;
-    g8::next_service<ENV, W, false>(P, e, lane, rng, sink);  // the due releases are k_ctrl_b2's job
-    bool done = (e.esp == (i64)P.episode_length);
-    if (done && auto_reset) {
-      e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
-      if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
-    }
-    if (gl == 0) P.done[env] = done ? 1 : 0;
-    g8::env_store(P, e, gl);
+    e.g_last = e.now;
   }
+  if (info_out) {
+    double i0 = (double)(e.sp - e.sa) / (double)e.sp;
+    double i1 = (double)(e.esp - e.esa) / (double)e.esp;
+    if (gl == 0) { info_out[0] = i0; info_out[1] = i1; }
+    if (ENV != ENV_RWA) {
+      double i2 = (double)(e.brq - e.brp) / (double)e.brq;
+      double i3 = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
+      if (gl == 0) { info_out[2] = i2; info_out[3] = i3; }
+    }
+    if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
+      double cur_comp = g8::net_compactness(P, e, 0, lane);
+      double mc = g8::link_mean(P, e.ls + 2 * P.E, lane);
+      double mu = g8::link_mean(P, e.ls, lane);
+      if (gl == 0) {
+        double prev_comp = info_out[5];
+        info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu;
+      }
+      if (P.bit_rate_mode == 1 && gl == 0) {
+        const i64* rq = P.br_hist + env * 2 * P.n_br;
+        const i64* pv = rq + P.n_br;
+        double mxv = -__builtin_inf(), mnv = __builtin_inf();
+        for (int i = 0; i < P.n_br; i++) {
+          double bl = 0.0;
+          if (rq[i] > 0) bl = (double)(rq[i] - pv[i]) / (double)rq[i];
+          info_out[8 + i] = bl;
+          mxv = bl > mxv ? bl : mxv;
+          mnv = bl < mnv ? bl : mnv;
+        }
+        info_out[8 + P.n_br] = mxv - mnv;
+      }
+    }
+  }
+  g8::Sink nosink;
+  g8::sink_init(nosink, false);
+  e.new_service = 0;
+  g8::next_service<ENV, W, false>(P, e, lane, rng, nosink);  // the due releases are k_ctrl_b2's job
+  bool done = (e.esp == (i64)P.episode_length);
+  if (done && auto_reset) {
+    e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
+    if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
+  }
+  if (gl == 0) P.done[env] = done ? 1 : 0;
+}
+
+template <int ENV, int W>
+__device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid, int lane, int auto_reset, bool want_info) {
+  if (!valid) return;
+  EnvG e;
+  g8::env_load(P, e, env);
+  const u64 acc = e.scal[SC_ACC];
+  service_part<ENV, W, false>(P, e, env, lane, auto_reset, ((u32)acc & 1u) != 0, (int)(acc >> 32),
+                              want_info ? P.info + env * P.n_info : nullptr);
+  g8::env_store(P, e, lane & 7);
 }
 
 // control kernel B2: the due releases of the step (rmsa_env.py:590-597) -> work items.  Only the clock, the
@@ -273,11 +294,20 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
     e.cs = P.core_sums + env * P.cs_words;
     e.ev_time = P.ev_time + env * P.ev_cap;
     e.ev_info = P.ev_info + env * P.ev_cap;
+    const u64 acc = s[SC_ACC];
+    if ((u32)acc & 2u) {  // network compactness update left pending by the merged control kernel (sums are final now)
+      const int core = (int)(acc >> 32);
+      const double a0 = __longlong_as_double((i64)s[SC_GC_A]), td = __longlong_as_double((i64)s[SC_GC_TD]);
+      const double now_a = __longlong_as_double((i64)s[SC_NOWA]);
+      // s_nh at provision time = the value the merged kernel stored (this kernel has not released anything yet)
+      const double gc = (a0 + (g8::net_compactness(P, e, core, lane) * td)) / now_a;
+      if (gl == 0) { s[SC_GCOMP] = (u64)__double_as_longlong(gc); s[SC_ACC] = acc & ~2ull; }
+    }
     g8::release_due<ENV, W, true>(P, e, lane, sink);
     if (sink.deferred) {
       // more simultaneous releases than the item form holds (> 4, or 3+ in one lane's slots): leave everything
       // untouched and let k_rel_serial release them one by one
-      if (gl == 0) s[SC_ACC] = s[SC_ACC] | (1ull << 16);
+      if (gl == 0) s[SC_ACC] = (s[SC_ACC] & ~2ull) | (1ull << 16);
     } else if (gl == 0) {
       s[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
       s[SC_SBR] = (u64)e.s_br;
@@ -315,7 +345,7 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
 // row kernel: one 8-lane group per work item, lane w = word w of the link row
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
-__device__ __forceinline__ void row_item(const DevParams& P, const Item it, int lane) {
+__device__ __forceinline__ void row_item(const DevParams& P, const Item it, int lane, int now_slot) {
   const int w = lane & 7, E = P.E, S = P.S;
   const i64 env = (i64)(u32)it.a.x;
   const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
@@ -327,7 +357,7 @@ __device__ __forceinline__ void row_item(const DevParams& P, const Item it, int 
   // everything the item needs is requested before anything is used: clock, the four link statistics, the first
   // mask's row word and that row's cached contribution to the compactness sums
   const int core0 = (int)(cores & 0x1f);
-  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
+  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + now_slot]);
   double last_update = ls[3 * E + link];
   double util = ls[link], frag = 0.0, comp = 0.0;
   if (ENV != ENV_RWA) { frag = ls[E + link]; comp = ls[2 * E + link]; }

@@ -282,7 +282,7 @@ template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_a(DevParams P, int want_info) {
   __shared__ int s_cnt[32], s_base[32];
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
-  sp::ctrl_a<ENV, W>(P, env, env < P.B, lane_id(), want_info != 0, s_cnt, s_base);
+  sp::ctrl_a<ENV, W, false>(P, env, env < P.B, lane_id(), want_info != 0, s_cnt, s_base);
 }
 // device-policy loop: slot-scan and control kernel A in one launch (same 8-lanes-per-env layout; the action never
 // leaves the registers, the link rows the scan just read are still in cache for the validation)
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) k_policy_ctrl_a(DevParams P, int pol) {
                       (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane, pol, a);
   const int4 av = make_int4(a[0], a[1], a[2], a[3]);
   if (valid && (lane & 7) == 0) *(int4*)(P.actions + env * 4) = av;
-  sp::ctrl_a<ENV, W>(P, env, valid, lane, false, s_cnt, s_base, &av);
+  sp::ctrl_a<ENV, W, true>(P, env, valid, lane, false, s_cnt, s_base, &av);
 }
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_b1(DevParams P, int auto_reset, int want_info) {
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) k_rows(DevParams P, int phase) {
     sp::Item it;
     it.a = q[2 * idx];
     it.b = q[2 * idx + 1];
-    sp::row_item<ENV, W>(P, it, lane_id());
+    sp::row_item<ENV, W>(P, it, lane_id(), phase ? SC_NOW : SC_NOWA);
   }
 }
 
@@ -545,7 +545,7 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
     if (fused_policy >= 0) hipLaunchKernelGGL((k_policy_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, fused_policy); \
     else hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info);                         \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 0);                                       \
-    hipLaunchKernelGGL((k_ctrl_b1<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info);                \
+    if (fused_policy < 0) hipLaunchKernelGGL((k_ctrl_b1<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info); \
     hipLaunchKernelGGL((k_ctrl_b2<EE, WW>), gc, blk, 0, VS, VP);                                       \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
     hipLaunchKernelGGL((k_rel_serial<EE, WW>), gc, blk, 0, VS, VP);                                    \
