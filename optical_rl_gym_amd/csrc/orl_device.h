@@ -51,6 +51,7 @@ enum {
   SC_NOWA,     // split pipeline: clock of the provision phase (the row kernel of phase A reads it)
   SC_GC_A,     // split pipeline: last_compactness * last_update of the pending network-compactness update
   SC_GC_TD,    // split pipeline: its time_diff
+  SC_TSOON,    // f64: every pending release earlier than this is in the env's soon list (-inf = list invalid)
   SC_COUNT
 };
 #define ORL_SCAL_WORDS 32
@@ -91,6 +92,8 @@ struct DevParams {
   u32* q_cnt_a;     // [ceil(B/32)] items each control workgroup put into its region of q_a
   u32* q_cnt_b;     // [ceil(B/32)] same for q_b
   u32* q_stat;      // [1] env-steps that took the serial release path (statistics)
+  double* soon_t;   // [B][16] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8
+  u32* soon_i;      // [B][16] their slots in ev_time / ev_info
   i64 q_cap;
   int* core_sums;   // [B][cs_words]      [2*C] per core: sum(lambda_max-lambda_min), sum(free blocks inside);
                     //                    then [C*E] per (core, link): that row's own contribution, (occ << 16) | fb
@@ -383,7 +386,7 @@ __device__ __forceinline__ void env_store(const DevParams& P, const Env& e, int 
   PUTI(SC_SBR, e.s_br) PUTI(SC_SNH, e.s_nh)
   PUTI(SC_SRC_DST, pack2(e.src, e.dst)) PUTI(SC_BR_IDX, pack2(e.bit_rate, e.br_idx))
   PUTI(SC_ID_MTPOS, pack2(e.id, e.mt_pos)) PUTI(SC_EV, pack2(e.ev_hwm, e.ev_cnt)) PUTI(SC_FLAGS, pack2(e.new_service, e.flags))
-  PUTF(SC_NEXTREL, -__builtin_inf()) PUTI(SC_HINT, pack2(-1, 0))  // caches of the 8-lanes-per-env step: unknown
+  PUTF(SC_NEXTREL, -__builtin_inf()) PUTI(SC_HINT, pack2(-1, 0)) PUTF(SC_TSOON, -__builtin_inf())  // caches of the 8-lane kernels: unknown
 #undef PUTF
 #undef PUTI
   if (lane < SC_COUNT) P.scal[e.env * ORL_SCAL_WORDS + lane] = v;

@@ -35,7 +35,7 @@ __device__ __forceinline__ double g8_min(double v) {
 }
 
 struct EnvG {
-  double now, at, ht, g_thr, g_comp, g_last, next_rel;
+  double now, at, ht, g_thr, g_comp, g_last, next_rel, t_soon;
   i64 sp, sa, esp, esa, brq, brp, ebrq, ebrp, s_br, s_nh;
   int src, dst, bit_rate, br_idx, id, mt_pos, ev_hwm, ev_cnt, new_service, flags, hint;
   i64 env;
@@ -44,6 +44,8 @@ struct EnvG {
   int* cs;
   double* ev_time;
   u64* ev_info;
+  double* soon_t;
+  u32* soon_i;
   u32* mt;
   u64* scal;
 };
@@ -54,6 +56,7 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
 #define F64(slot) __longlong_as_double((i64)s[slot])
   e.now = F64(SC_NOW); e.at = F64(SC_AT); e.ht = F64(SC_HT);
   e.g_thr = F64(SC_GTHR); e.g_comp = F64(SC_GCOMP); e.g_last = F64(SC_GLAST); e.next_rel = F64(SC_NEXTREL);
+  e.t_soon = F64(SC_TSOON);
 #undef F64
   e.sp = (i64)s[SC_SP]; e.sa = (i64)s[SC_SA]; e.esp = (i64)s[SC_ESP]; e.esa = (i64)s[SC_ESA];
   e.brq = (i64)s[SC_BRQ]; e.brp = (i64)s[SC_BRP]; e.ebrq = (i64)s[SC_EBRQ]; e.ebrp = (i64)s[SC_EBRP];
@@ -71,6 +74,8 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
   e.cs = P.core_sums + env * P.cs_words;
   e.ev_time = P.ev_time + env * P.ev_cap;
   e.ev_info = P.ev_info + env * P.ev_cap;
+  e.soon_t = P.soon_t + env * 16;
+  e.soon_i = P.soon_i + env * 16;
   e.mt = P.mt + env * 624;
 }
 
@@ -79,7 +84,7 @@ __device__ __forceinline__ void env_store(const DevParams& P, const EnvG& e, int
   u64* s = e.scal;
 #define PF(slot, x) s[slot] = (u64)__double_as_longlong(x);
   PF(SC_NOW, e.now) PF(SC_AT, e.at) PF(SC_HT, e.ht) PF(SC_GTHR, e.g_thr) PF(SC_GCOMP, e.g_comp) PF(SC_GLAST, e.g_last)
-  PF(SC_NEXTREL, e.next_rel)
+  PF(SC_NEXTREL, e.next_rel) PF(SC_TSOON, e.t_soon)
 #undef PF
   s[SC_SP] = (u64)e.sp; s[SC_SA] = (u64)e.sa; s[SC_ESP] = (u64)e.esp; s[SC_ESA] = (u64)e.esa;
   s[SC_BRQ] = (u64)e.brq; s[SC_BRP] = (u64)e.brp; s[SC_EBRQ] = (u64)e.ebrq; s[SC_EBRP] = (u64)e.ebrp;
@@ -315,6 +320,28 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
   if (gl == (idx & 7)) { e.ev_time[idx] = t; e.ev_info[idx] = info; }
   e.ev_cnt++;
   e.next_rel = t < e.next_rel ? t : e.next_rel;  // -inf (unknown) stays -inf
+  if (t < e.t_soon) {
+    // invariant of the soon list: it holds EVERY pending release earlier than t_soon
+    const double a0 = e.soon_t[gl], a1 = e.soon_t[gl + 8];
+    const u32 f0 = gballot(a0 == __builtin_inf(), lane), f1 = gballot(a1 == __builtin_inf(), lane);
+    if (f0 | f1) {
+      const int slot = f0 ? (int)__builtin_ctz(f0) : 8 + (int)__builtin_ctz(f1);
+      if (gl == (slot & 7)) { e.soon_t[slot] = t; e.soon_i[slot] = (u32)idx; }
+    } else {
+      // full: keep the 16 earliest; the horizon moves down to the latest of what was there
+      double m = a0 > a1 ? a0 : a1;
+      int ms = a0 > a1 ? gl : gl + 8;
+#define ORL_MAX_STEP(CTRL) { double om = dpp_d<CTRL>(m); int os = dpp_i<CTRL>(ms); if (om > m || (om == m && os < ms)) { m = om; ms = os; } }
+      ORL_MAX_STEP(ORL_DPP_XOR1) ORL_MAX_STEP(ORL_DPP_XOR2) ORL_MAX_STEP(ORL_DPP_HALF_MIRROR)
+#undef ORL_MAX_STEP
+      if (t < m) {
+        if (gl == (ms & 7)) { e.soon_t[ms] = t; e.soon_i[ms] = (u32)idx; }
+        e.t_soon = m;
+      } else {
+        e.t_soon = t;
+      }
+    }
+  }
 }
 
 // `pre`: the owner lane already holds this entry's info word and path record (requested in one batch after the scan)
@@ -631,6 +658,7 @@ __device__ __forceinline__ void step(const DevParams& P, EnvG& e, int lane, cons
   Sink nosink;
   sink_init(nosink, false);
   next_service<ENV, W>(P, e, lane, rng, nosink);
+  e.t_soon = -__builtin_inf();  // the in-kernel releases do not maintain the soon list
   bool done = (e.esp == (i64)P.episode_length);
   if (done && auto_reset) {
     e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;

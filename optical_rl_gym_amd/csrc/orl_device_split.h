@@ -266,6 +266,161 @@ __device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid,
   g8::env_store(P, e, lane & 7);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Due releases through the SOON LIST.  Scanning all ~330 pending release times of an env every step was the largest
+// cost of control kernel B2 (41 dependent-latency loads per lane).  Each env keeps the (up to 16) earliest pending
+// releases in a small list with the invariant "every pending release earlier than t_soon is in the list"; while
+// now < t_soon the due releases are found by looking at 2 list slots per lane, and only when the clock passes t_soon
+// (about every tenth step) the list is rebuilt from a full scan.  Pushes keep the invariant (g8::ev_push).
+// ---------------------------------------------------------------------------------------------------------------
+template <int ENV, int W>
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, g8::Sink& sink) {
+  if (e.next_rel > e.now) return;
+  const int gl = lane & 7;
+  const double INF = __builtin_inf();
+  double s0t = e.soon_t[gl], s1t = e.soon_t[gl + 8];
+  int s0i = (int)e.soon_i[gl], s1i = (int)e.soon_i[gl + 8];
+  bool dirty = false;
+  for (int round = 0; round < 64; round++) {
+    int due_all = -1;  // number of due entries overall, known when this round scanned everything
+#ifdef ORL_EXPERIMENT_NOREBUILD
+    if (false) {
+#else
+    if (!(e.now < e.t_soon)) {
+#endif
+      // rebuild: the three earliest pending releases among this lane's slots (i % 8 == lane)
+      double t0 = INF, t1 = INF, t2 = INF;
+      int i0 = 0, i1 = 0, nd = 0;
+      for (int base = gl; base < e.ev_hwm; base += 64) {
+        double tt[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          int i = base + 8 * k;
+          tt[k] = (i < e.ev_hwm) ? e.ev_time[i] : INF;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const double t = tt[k];
+          const int i = base + 8 * k;
+          nd += (t <= e.now) ? 1 : 0;
+          if (t < t2) {
+            if (t < t1) {
+              t2 = t1;
+              if (t < t0) { t1 = t0; i1 = i0; t0 = t; i0 = i; } else { t1 = t; i1 = i; }
+            } else {
+              t2 = t;
+            }
+          }
+        }
+      }
+      const double T = g8::g8_min(t2);
+      s0t = t0 < T ? t0 : INF; s0i = i0;
+      s1t = t1 < T ? t1 : INF; s1i = i1;
+      e.t_soon = T;
+      dirty = true;
+      due_all = g8_sum(nd);
+    }
+    // the list's due entries: at most two per lane, earliest first
+    const bool u0 = s0t <= e.now, u1 = s1t <= e.now;
+    const bool first0 = u0 && (!u1 || s0t < s1t || (s0t == s1t && s0i < s1i));
+    double d0t = INF, d1t = INF;
+    int d0i = 0x7fffffff, d1i = 0x7fffffff, d0s = 0, d1s = 0;
+    if (first0) { d0t = s0t; d0i = s0i; d0s = 0; if (u1) { d1t = s1t; d1i = s1i; d1s = 1; } }
+    else if (u1) { d0t = s1t; d0i = s1i; d0s = 1; if (u0) { d1t = s0t; d1i = s0i; d1s = 0; } }
+    const int tot = g8_sum((u0 ? 1 : 0) + (u1 ? 1 : 0));
+    if (tot == 0) {
+      if (e.now < e.t_soon) break;
+      if (round > 0 || due_all >= 0) {  // nothing below the horizon is due although the clock passed it: equal times
+        if (!sink.active) { sink.deferred = true; return; }
+        break;
+      }
+      continue;
+    }
+    if (!sink.active) {
+      // Item mode needs <= ORL_IMASKS releases meeting on one link.  The number of due releases is known exactly:
+      // the whole list (now < t_soon: nothing outside is due) or the full scan just done.
+      const int total = due_all >= 0 ? due_all : tot;
+      sink.active = total <= ORL_IMASKS;
+      if (!sink.active && sink.tally && P.E <= 8 * ORL_ISLOTS) {
+        for (int i = gl; i < e.ev_hwm; i += 8) {
+          if (e.ev_time[i] <= e.now) {
+            const u64 info = e.ev_info[i];
+            const PathRec rec = path_rec_load(P, (int)(info & 0xffffffu));
+            const int hops = path_rec_byte(rec, 0);
+            for (int h = 0; h < hops; h++) {
+              const int link = path_rec_byte(rec, 2 + h);
+              atomicAdd(sink.tally + (link >> 2), 1u << (8 * (link & 3)));
+            }
+          }
+        }
+        wave_fence();
+        u32 mx = 0;
+        for (int wd = gl; wd < 32; wd += 8) {
+          const u32 v = sink.tally[wd];
+          const u32 a0 = v & 0xff, a1 = (v >> 8) & 0xff, a2 = (v >> 16) & 0xff, a3 = v >> 24;
+          u32 m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3;
+          m01 = m01 > m23 ? m01 : m23;
+          mx = mx > m01 ? mx : m01;
+        }
+        sink.active = g8_max((int)mx) <= ORL_IMASKS && total < 200;
+      }
+      if (!sink.active || !(P.E <= 8 * ORL_ISLOTS || total * P.H <= 8 * ORL_ISLOTS)) {
+        sink.active = false;
+        sink.deferred = true;  // nothing has been touched: k_rel_serial takes this env
+        return;
+      }
+    }
+    // info word + path record of the (at most two) due entries of this lane, in two batched round trips
+    u64 inf0 = 0, inf1 = 0;
+    PathRec rc0 = PathRec(), rc1 = PathRec();
+    if (d0i != 0x7fffffff) inf0 = e.ev_info[d0i];
+    if (d1i != 0x7fffffff) inf1 = e.ev_info[d1i];
+    if (d0i != 0x7fffffff) rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu));
+    if (d1i != 0x7fffffff) rc1 = path_rec_load(P, (int)(inf1 & 0xffffffu));
+    for (;;) {
+      double bt = d0t;
+      int bi = d0i, bl = gl;
+#define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); int ol = dpp_i<CTRL>(bl); \
+                             if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; bl = ol; } }
+      ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
+#undef ORL_MIN_STEP
+      if (!(bt <= e.now)) break;
+      const u64 info = gget(inf0, bl, lane);
+      PathRec rec;
+      rec.q[0] = gget(rc0.q[0], bl, lane); rec.q[1] = gget(rc0.q[1], bl, lane);
+      rec.q[2] = gget(rc0.q[2], bl, lane); rec.q[3] = gget(rc0.q[3], bl, lane);
+      if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
+      if (gl == bl) {  // the holder drops the entry from its list slot and moves to its second due entry
+        if (d0s == 0) s0t = INF; else s1t = INF;
+        d0t = d1t; d0i = d1i; d0s = d1s; d1t = INF; d1i = 0x7fffffff; inf0 = inf1; rc0 = rc1;
+      }
+      dirty = true;
+      const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
+      const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
+      e.ev_cnt--;
+      e.hint = (e.hint < 0 || bi < e.hint) ? bi : e.hint;
+      g8::sink_add(sink, rec, core, s0, n, lane);
+      e.s_br -= br;
+      e.s_nh -= (i64)n * path_rec_byte(rec, 0);
+    }
+    if (e.now < e.t_soon) break;
+  }
+  {
+    const double m = s0t < s1t ? s0t : s1t;
+    const double lm = g8::g8_min(m);
+    e.next_rel = lm < e.t_soon ? lm : e.t_soon;
+  }
+  if (dirty) {
+    e.soon_t[gl] = s0t; e.soon_t[gl + 8] = s1t;
+    e.soon_i[gl] = (u32)s0i; e.soon_i[gl + 8] = (u32)s1i;
+  }
+  for (int it = 0; it < 4 && e.ev_hwm > 0; it++) {  // shrink the scan window when its tail is empty
+    int i = e.ev_hwm - 1;
+    double t = gget((gl == (i & 7)) ? e.ev_time[i] : 0.0, i & 7, lane);
+    if (t == INF) { e.ev_hwm--; if (e.hint == i) e.hint = -1; } else break;
+  }
+}
+
 // control kernel B2: the due releases of the step (rmsa_env.py:590-597) -> work items.  Only the clock, the
 // pending-release bookkeeping and the two running sums of the env record are touched.
 template <int ENV, int W>
@@ -303,13 +458,17 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
       const double gc = (a0 + (g8::net_compactness(P, e, core, lane) * td)) / now_a;
       if (gl == 0) { s[SC_GCOMP] = (u64)__double_as_longlong(gc); s[SC_ACC] = acc & ~2ull; }
     }
-    g8::release_due<ENV, W, true>(P, e, lane, sink);
+    e.t_soon = __longlong_as_double((i64)s[SC_TSOON]);
+    e.soon_t = P.soon_t + env * 16;
+    e.soon_i = P.soon_i + env * 16;
+    release_soon<ENV, W>(P, e, lane, sink);
     if (sink.deferred) {
       // more simultaneous releases than the item form holds (> 4, or 3+ in one lane's slots): leave everything
       // untouched and let k_rel_serial release them one by one
       if (gl == 0) s[SC_ACC] = (s[SC_ACC] & ~2ull) | (1ull << 16);
     } else if (gl == 0) {
       s[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
+      s[SC_TSOON] = (u64)__double_as_longlong(e.t_soon);
       s[SC_SBR] = (u64)e.s_br;
       s[SC_SNH] = (u64)e.s_nh;
       s[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
@@ -337,6 +496,7 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
   g8::Sink nosink;
   g8::sink_init(nosink, false);
   g8::release_due<ENV, W, false>(P, e, lane, nosink);
+  e.t_soon = -__builtin_inf();  // released in place: the soon list is stale
   if (gl == 0) s[SC_ACC] = s[SC_ACC] & ~(1ull << 16);
   g8::env_store(P, e, gl);
 }

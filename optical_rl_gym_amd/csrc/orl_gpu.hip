@@ -705,6 +705,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     rc |= dalloc(b, &P.q_cnt_a, regions);
     rc |= dalloc(b, &P.q_cnt_b, regions);
     rc |= dalloc(b, &P.q_stat, 16);
+    rc |= dalloc(b, &P.soon_t, B * 16);
+    rc |= dalloc(b, &P.soon_i, B * 16);
     if (!rc) hipMemset(P.q_stat, 0, 16 * sizeof(u32));
   }
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
@@ -737,7 +739,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       q.B = cnt;
       q.bitmap += lo * P.bm_words; q.ev_time += lo * P.ev_cap; q.ev_info += lo * P.ev_cap; q.mt += lo * 624;
       q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
-      q.q_a += (lo / 32) * ORL_QREGION * 2; q.q_b += (lo / 32) * ORL_QREGION * 2; q.q_cnt_a += lo / 32; q.q_cnt_b += lo / 32;
+      q.q_a += (lo / 32) * ORL_QREGION * 2; q.q_b += (lo / 32) * ORL_QREGION * 2; q.q_cnt_a += lo / 32; q.q_cnt_b += lo / 32; q.soon_t += lo * 16; q.soon_i += lo * 16;
       if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
@@ -1059,6 +1061,8 @@ static std::vector<Section> state_sections(orl_batch* b) {
   v.push_back({P.mt, B * 624 * 4});
   v.push_back({P.lstat, B * 4 * P.E * 8});
   v.push_back({P.core_sums, B * P.cs_words * 4});
+  v.push_back({P.soon_t, B * 16 * 8});
+  v.push_back({P.soon_i, B * 16 * 4});
   if (P.br_hist) v.push_back({P.br_hist, B * 2 * P.n_br * 8});
   if (P.act_hist) v.push_back({P.act_hist, B * ((P.K + 1) + (P.S + 1)) * 8});
   return v;
