@@ -237,62 +237,6 @@ __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane,
   return hops;
 }
 
-// ---- release sink -----------------------------------------------------------------------------------
-// The monolithic kernel applies a release right away (path_apply).  The split pipeline instead collects the
-// touched link rows as work items for the flat row kernel: one item per (core, link) with up to four
-// [s0, s0+n) masks in release order (several services released in one step may share a link; only the first
-// touch of a link sees a non-zero time_diff).  Item k of an env lives in lane k % 8, slot k / 8.
-#define ORL_ISLOTS 4  // item slots per lane (the slot loops below are written out for exactly 4)
-#define ORL_IMASKS 8  // masks one item can carry = releases of one step that the item form can represent
-struct Sink {
-  u32* tally;  // LDS, 32 words per env, zeroed: per-link touch counters (4 x 8 bit per word) for the capacity check
-  bool allowed, active;
-  bool deferred;  // split pipeline: this env's releases do not fit the item form; k_rel_serial handles them
-  int cnt;
-  u32 key[ORL_ISLOTS];  // link, or 0xffffffff (per-link statistics are shared by all cores of the link)
-  u64 mk0[ORL_ISLOTS];  // masks 0..3: (s0 | n << 9), 16 bits each, in release order
-  u64 mk1[ORL_ISLOTS];  // masks 4..7
-  u64 cr[ORL_ISLOTS];   // the core of each mask, 5 bits each
-  int nm[ORL_ISLOTS];
-};
-__device__ __forceinline__ void sink_init(Sink& s, bool allowed) {
-  s.tally = nullptr; s.allowed = allowed; s.active = false; s.deferred = false; s.cnt = 0;
-#pragma unroll
-  for (int k = 0; k < ORL_ISLOTS; k++) { s.key[k] = 0xffffffffu; s.mk0[k] = 0; s.mk1[k] = 0; s.cr[k] = 0; s.nm[k] = 0; }
-}
-__device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, int s0, int n, int lane) {
-  const int hops = path_rec_byte(rec, 0), gl = lane & 7;
-  const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
-  for (int h = 0; h < hops; h++) {
-    const u32 key = (u32)path_rec_byte(rec, 2 + h);
-    int mine = -1;
-#pragma unroll
-    for (int k = 0; k < ORL_ISLOTS; k++) if (s.key[k] == key) mine = k;
-    const u32 fb = gballot(mine >= 0, lane);
-    if (fb) {  // the link already has an item: append the mask (release order)
-#define ORL_APPEND(k)                                                                   \
-  if (mine == k) {                                                                      \
-    const int j = s.nm[k];                                                              \
-    const u64 lo = (j < 4) ? (m << (16 * (j & 3))) : 0ull;                              \
-    const u64 hi = (j < 4) ? 0ull : (m << (16 * (j & 3)));                              \
-    s.mk0[k] |= lo; s.mk1[k] |= hi;                                                     \
-    s.cr[k] |= (u64)(u32)core << (5 * j);                                               \
-    s.nm[k] = j + 1;                                                                    \
-  }
-      ORL_APPEND(0) ORL_APPEND(1) ORL_APPEND(2) ORL_APPEND(3)
-#undef ORL_APPEND
-    } else {
-      const int idx = s.cnt, slot = idx >> 3;
-      if (gl == (idx & 7)) {
-#define ORL_NEW(k) if (slot == k) { s.key[k] = key; s.mk0[k] = m; s.mk1[k] = 0; s.cr[k] = (u64)(u32)core; s.nm[k] = 1; }
-        ORL_NEW(0) ORL_NEW(1) ORL_NEW(2) ORL_NEW(3)
-#undef ORL_NEW
-      }
-      s.cnt++;
-    }
-  }
-}
-
 // ---- pending releases: slot i belongs to lane i % 8 -------------------------------------------------
 __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
   const int gl = lane & 7;
@@ -344,39 +288,24 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
   }
 }
 
-// `pre`: the owner lane already holds this entry's info word and path record (requested in one batch after the scan)
-template <int ENV, int W, bool SINK_ONLY>
-__device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lane, int bi, Sink& sink, bool pre = false,
-                                            u64 pre_info = 0, PathRec pre_rec = PathRec()) {
+template <int ENV, int W>
+__device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lane, int bi) {
   const int gl = lane & 7, owner = bi & 7;
-  u64 info = pre ? pre_info : ((gl == owner) ? e.ev_info[bi] : 0ull);
+  u64 info = (gl == owner) ? e.ev_info[bi] : 0ull;
   info = gget(info, owner, lane);
   if (gl == owner) e.ev_time[bi] = __builtin_inf();
   const int pidx = (int)(info & 0xffffffu), s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
   const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
   e.ev_cnt--;
   e.hint = (e.hint < 0 || bi < e.hint) ? bi : e.hint;
-  int hops_r;
-  if (sink.active) {
-    PathRec rec;
-    if (pre) {
-      rec.q[0] = gget(pre_rec.q[0], owner, lane); rec.q[1] = gget(pre_rec.q[1], owner, lane);
-      rec.q[2] = gget(pre_rec.q[2], owner, lane); rec.q[3] = gget(pre_rec.q[3], owner, lane);
-    } else {
-      rec = path_rec_load(P, pidx);
-    }
-    hops_r = path_rec_byte(rec, 0);
-    sink_add(sink, rec, core, s0, n, lane);
-  } else {
-    hops_r = SINK_ONLY ? 0 : path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
-  }
+  const int hops_r = path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
   e.s_br -= br;
   e.s_nh -= (i64)n * hops_r;
 }
 
-// release every pending service with release_time <= now in increasing time order (rmsa_env.py:590-597)
-template <int ENV, int W, bool SINK_ONLY = false>
-__device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lane, Sink& sink) {
+// release every pending service with release_time <= now in increasing time order (rmsa_env.py:590-597), in place
+template <int ENV, int W>
+__device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lane) {
   if (e.next_rel > e.now) return;  // nothing can be due (next_rel is a lower bound of every pending time)
   const int gl = lane & 7;
   for (;;) {
@@ -404,68 +333,22 @@ __device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lan
       }
     }
     const bool overflow = gballot(ndue > 2, lane) != 0u;
-    if (sink.allowed && !sink.active) {
-      // item mode needs a slot for every touched link and at most ORL_IMASKS releases meeting on one link
-      const int tot = g8_sum(ndue);
-      if (tot == 0) { e.next_rel = g8_min(rest); break; }
-      sink.active = sink.cnt == 0 && tot <= ORL_IMASKS && (P.E <= 8 * ORL_ISLOTS || tot * P.H <= 8 * ORL_ISLOTS);
-      if (!sink.active && sink.cnt == 0 && sink.tally && P.E <= 8 * ORL_ISLOTS) {
-        // More releases than one item can hold masks for (the release count per step is geometric: ~0.2 % of
-        // env-steps exceed 8).  What matters is the count PER LINK, so tally the touches of every due release
-        // first — every lane walks its own due slots, no side effects — and take item mode when no link exceeds it.
-        for (int i = gl; i < e.ev_hwm; i += 8) {
-          if (e.ev_time[i] <= e.now) {
-            const u64 info = e.ev_info[i];
-            const PathRec rec = path_rec_load(P, (int)(info & 0xffffffu));
-            const int hops = path_rec_byte(rec, 0);
-            for (int h = 0; h < hops; h++) {
-              const int link = path_rec_byte(rec, 2 + h);
-              atomicAdd(sink.tally + (link >> 2), 1u << (8 * (link & 3)));
-            }
-          }
-        }
-        wave_fence();
-        u32 mx = 0;
-        for (int wd = gl; wd < 32; wd += 8) {
-          const u32 v = sink.tally[wd];
-          const u32 a0 = v & 0xff, a1 = (v >> 8) & 0xff, a2 = (v >> 16) & 0xff, a3 = v >> 24;
-          u32 m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3;
-          m01 = m01 > m23 ? m01 : m23;
-          mx = mx > m01 ? mx : m01;
-        }
-        sink.active = g8_max((int)mx) <= ORL_IMASKS && tot < 200;
-      }
-      if (!sink.active) { sink.deferred = true; return; }  // nothing has been touched yet
-    }
+#define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; } }
     if (overflow) {
       // a lane holds 3+ due entries (rare): release only the globally earliest one, then rescan
       double bt = d0t; int bi = d0i;
-#define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; } }
       ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
-#undef ORL_MIN_STEP
-      release_one<ENV, W, SINK_ONLY>(P, e, lane, bi, sink);
+      release_one<ENV, W>(P, e, lane, bi);
       continue;
-    }
-    // sink mode: every lane requests the info word and the path record of its (at most two) due entries now, in
-    // two batched round trips, instead of two dependent round trips per release inside the ordered loop
-    const bool pre = SINK_ONLY && sink.active;
-    u64 inf0 = 0, inf1 = 0;
-    PathRec rc0 = PathRec(), rc1 = PathRec();
-    if (pre) {
-      if (d0i != 0x7fffffff) inf0 = e.ev_info[d0i];
-      if (d1i != 0x7fffffff) inf1 = e.ev_info[d1i];
-      if (d0i != 0x7fffffff) rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu));
-      if (d1i != 0x7fffffff) rc1 = path_rec_load(P, (int)(inf1 & 0xffffffu));
     }
     for (;;) {
       double bt = d0t; int bi = d0i;
-#define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; } }
       ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
-#undef ORL_MIN_STEP
       if (!(bt <= e.now)) break;
-      release_one<ENV, W, SINK_ONLY>(P, e, lane, bi, sink, pre, inf0, rc0);
-      if (gl == (bi & 7)) { d0t = d1t; d0i = d1i; d1t = __builtin_inf(); d1i = 0x7fffffff; inf0 = inf1; rc0 = rc1; }
+      release_one<ENV, W>(P, e, lane, bi);
+      if (gl == (bi & 7)) { d0t = d1t; d0i = d1i; d1t = __builtin_inf(); d1i = 0x7fffffff; }
     }
+#undef ORL_MIN_STEP
     e.next_rel = g8_min(rest);
     break;
   }
@@ -478,7 +361,7 @@ __device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lan
 }
 
 template <int ENV, int W, bool REL = true>
-__device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int lane, RngG& r, Sink& sink) {
+__device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int lane, RngG& r) {
   if (e.new_service) return;
   const int gl = lane & 7;
   double at = e.now + rng_expovariate(e, r, lane, P.lambda_a);
@@ -499,7 +382,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
     }
   }
   rng_commit(e, r, gl);
-  if (REL && (ENV == ENV_RWA || ENV == ENV_RMCSA)) release_due<ENV, W>(P, e, lane, sink);
+  if (REL && (ENV == ENV_RWA || ENV == ENV_RMCSA)) release_due<ENV, W>(P, e, lane);
   e.id = (int)e.esp;
   e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
   e.new_service = 1;
@@ -509,7 +392,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
     e.ebrq += bit_rate;
     if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;
   }
-  if (REL && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA)) release_due<ENV, W>(P, e, lane, sink);
+  if (REL && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA)) release_due<ENV, W>(P, e, lane);
 }
 
 // np.mean over the links in topology.edges() order (numpy pairwise sum); lane j reads the statistics it owns
@@ -655,9 +538,7 @@ __device__ __forceinline__ void step(const DevParams& P, EnvG& e, int lane, cons
     }
   }
   e.new_service = 0;
-  Sink nosink;
-  sink_init(nosink, false);
-  next_service<ENV, W>(P, e, lane, rng, nosink);
+  next_service<ENV, W>(P, e, lane, rng);
   e.t_soon = -__builtin_inf();  // the in-kernel releases do not maintain the soon list
   bool done = (e.esp == (i64)P.episode_length);
   if (done && auto_reset) {

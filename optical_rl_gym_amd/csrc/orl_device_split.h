@@ -54,6 +54,40 @@ __device__ __forceinline__ int wg_reserve(int cnt, u32* region_counts, int* s_cn
   return (int)blockIdx.x * ORL_QREGION + s_base[grp];
 }
 
+// ---- release sink -----------------------------------------------------------------------------------
+// Control kernel B2 does not touch link rows: the releases of a step are collected as work items for the row kernel,
+// one item per touched LINK (per-link statistics are shared by all cores of the link) carrying up to ORL_IMASKS
+// [s0, s0+n) masks in release order, each with its core.  While collecting, the items live in an LDS table indexed
+// by the link (24 bytes per link and env): appending a mask is one LDS read-modify-write by the lane that owns the
+// hop, with no search and no per-lane registers.
+#define ORL_IMASKS 8  // masks one item can carry = releases of one step that may meet on one link
+struct SinkEntry {
+  u64 mk0;  // masks 0..3: (s0 | n << 9), 16 bits each, in release order
+  u64 mk1;  // masks 4..7
+  u64 crn;  // the core of each mask, 5 bits each (40 bits) | number of masks << 40
+};
+struct Sink {
+  SinkEntry* tab;  // LDS, E entries of this env, crn zeroed
+  u32* tally;      // LDS, 32 words per env, zeroed: per-link touch counters (4 x 8 bit per word) for the capacity check
+  bool active;     // item mode decided: the releases of this step fit the item form
+  bool deferred;   // they do not: nothing has been touched, k_rel_serial releases them in place
+  int cnt;         // links this LANE has opened an item for
+};
+// lane h of the group appends the mask to the item of hop h's link (the links of one path are distinct)
+__device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, int s0, int n, int lane) {
+  const int hops = path_rec_byte(rec, 0);
+  const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
+  for (int h = lane & 7; h < hops; h += 8) {
+    SinkEntry* t = s.tab + path_rec_byte(rec, 2 + h);
+    const u64 crn = t->crn;
+    const int j = (int)(crn >> 40);
+    if (j < 4) t->mk0 = (j == 0 ? 0ull : t->mk0) | (m << (16 * j));
+    else t->mk1 = (j == 4 ? 0ull : t->mk1) | (m << (16 * (j - 4)));
+    t->crn = (crn & 0xffffffffffull) | ((u64)(u32)core << (5 * j)) | ((u64)(u32)(j + 1) << 40);
+    s.cnt += (j == 0) ? 1 : 0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // control kernel A: everything of step() up to (and excluding) the effects of the provision on the link rows
 // ---------------------------------------------------------------------------------------------------------------
@@ -243,10 +277,8 @@ __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 en
       }
     }
   }
-  g8::Sink nosink;
-  g8::sink_init(nosink, false);
   e.new_service = 0;
-  g8::next_service<ENV, W, false>(P, e, lane, rng, nosink);  // the due releases are k_ctrl_b2's job
+  g8::next_service<ENV, W, false>(P, e, lane, rng);  // the due releases are k_ctrl_b2's job
   bool done = (e.esp == (i64)P.episode_length);
   if (done && auto_reset) {
     e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
@@ -274,7 +306,7 @@ __device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid,
 // (about every tenth step) the list is rebuilt from a full scan.  Pushes keep the invariant (g8::ev_push).
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
-__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, g8::Sink& sink) {
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink) {
   if (e.next_rel > e.now) return;
   const int gl = lane & 7;
   const double INF = __builtin_inf();
@@ -283,11 +315,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
   bool dirty = false;
   for (int round = 0; round < 64; round++) {
     int due_all = -1;  // number of due entries overall, known when this round scanned everything
-#ifdef ORL_EXPERIMENT_NOREBUILD
-    if (false) {
-#else
     if (!(e.now < e.t_soon)) {
-#endif
       // rebuild: the three earliest pending releases among this lane's slots (i % 8 == lane)
       double t0 = INF, t1 = INF, t2 = INF;
       int i0 = 0, i1 = 0, nd = 0;
@@ -341,7 +369,10 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       // the whole list (now < t_soon: nothing outside is due) or the full scan just done.
       const int total = due_all >= 0 ? due_all : tot;
       sink.active = total <= ORL_IMASKS;
-      if (!sink.active && sink.tally && P.E <= 8 * ORL_ISLOTS) {
+      if (!sink.active && total < 200) {
+        // More releases than one item holds masks for (the release count per step is geometric: ~0.2 % of env-steps
+        // exceed 8).  What matters is the count PER LINK: tally the touches of every due release first — every lane
+        // walks its own slots, no side effects — and take item mode when no link exceeds the item form.
         for (int i = gl; i < e.ev_hwm; i += 8) {
           if (e.ev_time[i] <= e.now) {
             const u64 info = e.ev_info[i];
@@ -362,21 +393,17 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           m01 = m01 > m23 ? m01 : m23;
           mx = mx > m01 ? mx : m01;
         }
-        sink.active = g8_max((int)mx) <= ORL_IMASKS && total < 200;
+        sink.active = g8_max((int)mx) <= ORL_IMASKS;
       }
-      if (!sink.active || !(P.E <= 8 * ORL_ISLOTS || total * P.H <= 8 * ORL_ISLOTS)) {
-        sink.active = false;
+      if (!sink.active) {
         sink.deferred = true;  // nothing has been touched: k_rel_serial takes this env
         return;
       }
     }
-    // info word + path record of the (at most two) due entries of this lane, in two batched round trips
-    u64 inf0 = 0, inf1 = 0;
-    PathRec rc0 = PathRec(), rc1 = PathRec();
-    if (d0i != 0x7fffffff) inf0 = e.ev_info[d0i];
-    if (d1i != 0x7fffffff) inf1 = e.ev_info[d1i];
-    if (d0i != 0x7fffffff) rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu));
-    if (d1i != 0x7fffffff) rc1 = path_rec_load(P, (int)(inf1 & 0xffffffu));
+    // info word + path record of this lane's first due entry, requested by all lanes together
+    u64 inf0 = 0;
+    PathRec rc0 = PathRec();
+    if (d0i != 0x7fffffff) { inf0 = e.ev_info[d0i]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
     for (;;) {
       double bt = d0t;
       int bi = d0i, bl = gl;
@@ -392,14 +419,15 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
       if (gl == bl) {  // the holder drops the entry from its list slot and moves to its second due entry
         if (d0s == 0) s0t = INF; else s1t = INF;
-        d0t = d1t; d0i = d1i; d0s = d1s; d1t = INF; d1i = 0x7fffffff; inf0 = inf1; rc0 = rc1;
+        d0t = d1t; d0i = d1i; d0s = d1s; d1t = INF; d1i = 0x7fffffff;
+        if (d0i != 0x7fffffff) { inf0 = e.ev_info[d0i]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }  // rare
       }
       dirty = true;
       const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
       const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
       e.ev_cnt--;
       e.hint = (e.hint < 0 || bi < e.hint) ? bi : e.hint;
-      g8::sink_add(sink, rec, core, s0, n, lane);
+      sink_add(sink, rec, core, s0, n, lane);
       e.s_br -= br;
       e.s_nh -= (i64)n * path_rec_byte(rec, 0);
     }
@@ -424,13 +452,16 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 // control kernel B2: the due releases of the step (rmsa_env.py:590-597) -> work items.  Only the clock, the
 // pending-release bookkeeping and the two running sums of the env record are touched.
 template <int ENV, int W>
-__device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid, int lane, int* s_cnt, int* s_base, u32* s_tally) {
-  const int gl = lane & 7;
-  g8::Sink sink;
-  g8::sink_init(sink, true);
+__device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid, int lane, int* s_cnt, int* s_base, u32* s_tally,
+                                        SinkEntry* s_tab) {
+  const int gl = lane & 7, E = P.E;
   for (int i = (int)threadIdx.x; i < 32 * 32; i += 256) s_tally[i] = 0u;
+  for (int i = (int)threadIdx.x; i < 32 * E; i += 256) s_tab[i].crn = 0ull;
   __syncthreads();
+  Sink sink;
+  sink.tab = s_tab + E * (int)(threadIdx.x >> 3);
   sink.tally = s_tally + 32 * (int)(threadIdx.x >> 3);
+  sink.active = false; sink.deferred = false; sink.cnt = 0;
   if (valid) {
     EnvG e;
     u64* s = P.scal + env * ORL_SCAL_WORDS;
@@ -475,12 +506,20 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
       s[SC_HINT] = pack2(e.hint, 0);
     }
   }
-  const int cnt = sink.active ? sink.cnt : 0;
+  const int cnt = g8_sum(sink.active ? sink.cnt : 0);
   const int base = wg_reserve(cnt, P.q_cnt_b, s_cnt, s_base);
-#pragma unroll
-  for (int k = 0; k < ORL_ISLOTS; k++) {
-    int idx = 8 * k + gl;
-    if (idx < cnt) item_store(P.q_b, base + idx, make_item(env, sink.key[k], sink.nm[k], sink.mk0[k], sink.mk1[k], sink.cr[k], 1));
+  if (cnt) {  // the env's items = the table entries that hold masks, in link order
+    int at = base;
+    for (int l0 = 0; l0 < E; l0 += 8) {
+      const int l = l0 + gl;
+      const u64 crn = (l < E) ? sink.tab[l].crn : 0ull;
+      const int nm = (int)(crn >> 40);
+      const u32 fb = gballot(nm > 0, lane);
+      if (nm > 0)
+        item_store(P.q_b, at + __popc(fb & ((1u << gl) - 1u)),
+                   make_item(env, (u32)l, nm, sink.tab[l].mk0, nm > 4 ? sink.tab[l].mk1 : 0ull, crn & 0xffffffffffull, 1));
+      at += __popc(fb);
+    }
   }
 }
 
@@ -493,9 +532,7 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
   if (gl == 0) atomicAdd(P.q_stat, 1u);  // statistics: env-steps that took the serial path
   EnvG e;
   g8::env_load(P, e, env);
-  g8::Sink nosink;
-  g8::sink_init(nosink, false);
-  g8::release_due<ENV, W, false>(P, e, lane, nosink);
+  g8::release_due<ENV, W>(P, e, lane);
   e.t_soon = -__builtin_inf();  // released in place: the soon list is stale
   if (gl == 0) s[SC_ACC] = s[SC_ACC] & ~(1ull << 16);
   g8::env_store(P, e, gl);

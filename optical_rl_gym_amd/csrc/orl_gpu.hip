@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) k_ctrl_b2(DevParams P) {
   __shared__ int s_cnt[32], s_base[32];
   __shared__ u32 s_tally[32 * 32];
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
-  sp::ctrl_b2<ENV, W>(P, env, env < P.B, lane_id(), s_cnt, s_base, s_tally);
+  sp::ctrl_b2<ENV, W>(P, env, env < P.B, lane_id(), s_cnt, s_base, s_tally, (sp::SinkEntry*)orl_lds_raw);  // 32 x E entries
 }
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_rel_serial(DevParams P) {
@@ -540,13 +540,15 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
   if (b->step_impl == 1) {
     dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
     dim3 gr(gc.x * ORL_ROWS_SPLIT);  // the row kernel runs ORL_ROWS_SPLIT workgroups per control workgroup's item region
+    const size_t lds_b2 = (size_t)32 * VP.E * sizeof(sp::SinkEntry);
 #define CALLW(WW)                                                                                      \
   do {                                                                                                 \
     if (fused_policy >= 0) hipLaunchKernelGGL((k_policy_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, fused_policy); \
     else hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info);                         \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 0);                                       \
     if (fused_policy < 0) hipLaunchKernelGGL((k_ctrl_b1<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info); \
-    hipLaunchKernelGGL((k_ctrl_b2<EE, WW>), gc, blk, 0, VS, VP);                                       \
+    if (lds_b2 > 48 * 1024) hipFuncSetAttribute((const void*)k_ctrl_b2<EE, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b2); \
+    hipLaunchKernelGGL((k_ctrl_b2<EE, WW>), gc, blk, lds_b2, VS, VP);                                     \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
     hipLaunchKernelGGL((k_rel_serial<EE, WW>), gc, blk, 0, VS, VP);                                    \
   } while (0)
