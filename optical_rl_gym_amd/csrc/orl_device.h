@@ -83,7 +83,7 @@ struct DevParams {
   double* ev_time;  // [B][ev_cap]        +inf = empty slot
   u64* ev_info;     // [B][ev_cap]        packed {pair_path:24 | slot:12 | n:8 | core:5 | bit_rate:15}
   u32* mt;          // [B][624]           update-behind MT19937 state
-  double* lstat;    // [B][4][E]          utilization, external_fragmentation, compactness, last_update
+  double* lstat;    // [B][E][4]          utilization, external_fragmentation, compactness, last_update
   u64* scal;        // [B][32]
   u64* svc_desc;    // [B]  pending service for the slot-scan kernel: pair_base:32 | br_idx:16 | n_paths:8
   // split pipeline (orl_device_split.h): row-update work items produced by the control kernels
@@ -654,12 +654,12 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
       after.free_ = g8_sum(__popcll(a));
     }
     // _update_link_stats: time-weighted running averages, evaluated in the reference's operation order
-    double last_update = e.ls[3 * E + link];
+    double last_update = e.ls[4 * link + 3];
     double time_diff = e.now - last_update;
     if (e.now > 0) {
       const int free_ = after.free_;
       double cur_util = (double)(S - free_) / (double)S;
-      double util = ((e.ls[link] * last_update) + (cur_util * time_diff)) / e.now;
+      double util = ((e.ls[4 * link] * last_update) + (cur_util * time_diff)) / e.now;
       double frag = 0.0, comp = 0.0;
       if (ENV != ENV_RWA) {
         double cur_frag = 0.0, cur_comp = 0.0;
@@ -672,15 +672,15 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
           if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
           else cur_comp = 1.0;
         }
-        frag = ((e.ls[E + link] * last_update) + (cur_frag * time_diff)) / e.now;
-        comp = ((e.ls[2 * E + link] * last_update) + (cur_comp * time_diff)) / e.now;
+        frag = ((e.ls[4 * link + 1] * last_update) + (cur_frag * time_diff)) / e.now;
+        comp = ((e.ls[4 * link + 2] * last_update) + (cur_comp * time_diff)) / e.now;
       }
       if (rowv && w == 0) {
-        e.ls[link] = util;
-        if (ENV != ENV_RWA) { e.ls[E + link] = frag; e.ls[2 * E + link] = comp; }
+        e.ls[4 * link] = util;
+        if (ENV != ENV_RWA) { e.ls[4 * link + 1] = frag; e.ls[4 * link + 2] = comp; }
       }
     }
-    if (rowv && w == 0) e.ls[3 * E + link] = e.now;
+    if (rowv && w == 0) e.ls[4 * link + 3] = e.now;
     wave_fence();
   }
   if (ENV != ENV_RWA) {
@@ -913,7 +913,7 @@ __device__ __forceinline__ void deep_observation(const DevParams& P, const Env& 
 // np.mean over the per-link values taken in topology.edges() order: numpy pairwise sum then / E
 __device__ __forceinline__ double link_mean(const DevParams& P, const double* vals /*LDS [E]*/, double* scratch /*LDS [E]*/, int lane) {
   const int E = P.E;
-  for (int i = lane; i < E; i += 64) scratch[i] = vals[P.edge_iter_order[i]];
+  for (int i = lane; i < E; i += 64) scratch[i] = vals[4 * P.edge_iter_order[i]];
   wave_fence();
   double res;
   if (E < 8) {
@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
     }
     if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
       double* scratch = e.scratch;
-      double mc = link_mean(P, e.ls + 2 * P.E, scratch, lane);
+      double mc = link_mean(P, e.ls + 2, scratch, lane);
       double mu = link_mean(P, e.ls, scratch, lane);
       if (lane == 0) { info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu; }
       if (P.bit_rate_mode == 1 && lane == 0) {  // rmsa_env.py:217-227, 268-273

@@ -202,12 +202,12 @@ __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane,
     }
     // _update_link_stats (rmsa_env.py:464-543).  The statistics of a link belong to lane link_pos[link] % 8.
     const bool own = (w == (P.link_pos[link] & 7));
-    double last_update = e.ls[3 * E + link];
+    double last_update = e.ls[4 * link + 3];
     double time_diff = e.now - last_update;
     if (e.now > 0) {
       const int free_ = after.free_;
       double cur_util = (double)(S - free_) / (double)S;
-      double util = ((e.ls[link] * last_update) + (cur_util * time_diff)) / e.now;
+      double util = ((e.ls[4 * link] * last_update) + (cur_util * time_diff)) / e.now;
       double frag = 0.0, comp = 0.0;
       if (ENV != ENV_RWA) {
         double cur_frag = 0.0, cur_comp = 0.0;
@@ -220,15 +220,15 @@ __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane,
           if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
           else cur_comp = 1.0;
         }
-        frag = ((e.ls[E + link] * last_update) + (cur_frag * time_diff)) / e.now;
-        comp = ((e.ls[2 * E + link] * last_update) + (cur_comp * time_diff)) / e.now;
+        frag = ((e.ls[4 * link + 1] * last_update) + (cur_frag * time_diff)) / e.now;
+        comp = ((e.ls[4 * link + 2] * last_update) + (cur_comp * time_diff)) / e.now;
       }
       if (own) {
-        e.ls[link] = util;
-        if (ENV != ENV_RWA) { e.ls[E + link] = frag; e.ls[2 * E + link] = comp; }
+        e.ls[4 * link] = util;
+        if (ENV != ENV_RWA) { e.ls[4 * link + 1] = frag; e.ls[4 * link + 2] = comp; }
       }
     }
-    if (own) e.ls[3 * E + link] = e.now;
+    if (own) e.ls[4 * link + 3] = e.now;
   }
   if (ENV != ENV_RWA) {
     int c0 = gget(e.cs[2 * core], 0, lane) + d_occ, c1 = gget(e.cs[2 * core + 1], 0, lane) + d_fb;
@@ -243,7 +243,9 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
   int idx = e.hint;
   e.hint = -1;
   if (idx < 0) {
-    for (int base = 0; base < e.ev_hwm && idx < 0; base += 32) {  // four 8-slot chunks requested together
+    // Top-down: pushes reuse the LOWEST freed slot (hint), so the low indices are dense and the holes sit near the
+    // high-water mark; the first 32-slot window from the top almost always has one.
+    for (int base = (e.ev_hwm - 1) & ~31; base >= 0 && idx < 0; base -= 32) {  // four 8-slot chunks requested together
       double t[4];
 #pragma unroll
       for (int c = 0; c < 4; c++) {
@@ -401,15 +403,15 @@ __device__ __forceinline__ double link_mean(const DevParams& P, const double* va
   double res;
   if (E < 8) {
     res = 0.;
-    for (int i = 0; i < E; i++) res += gget((gl == i) ? vals[P.edge_iter_order[i]] : 0.0, i, lane);
+    for (int i = 0; i < E; i++) res += gget((gl == i) ? vals[4 * P.edge_iter_order[i]] : 0.0, i, lane);
   } else {
-    double r = vals[P.edge_iter_order[gl]];
+    double r = vals[4 * P.edge_iter_order[gl]];
     int i;
-    for (i = 8; i < E - (E % 8); i += 8) r += vals[P.edge_iter_order[i + gl]];
+    for (i = 8; i < E - (E % 8); i += 8) r += vals[4 * P.edge_iter_order[i + gl]];
     double r0 = gget(r, 0, lane), r1 = gget(r, 1, lane), r2 = gget(r, 2, lane), r3 = gget(r, 3, lane);
     double r4 = gget(r, 4, lane), r5 = gget(r, 5, lane), r6 = gget(r, 6, lane), r7 = gget(r, 7, lane);
     res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < E; i++) res += gget((gl == (i & 7)) ? vals[P.edge_iter_order[i]] : 0.0, i & 7, lane);
+    for (; i < E; i++) res += gget((gl == (i & 7)) ? vals[4 * P.edge_iter_order[i]] : 0.0, i & 7, lane);
   }
   return res / (double)E;
 }
@@ -519,7 +521,7 @@ __device__ __forceinline__ void step(const DevParams& P, EnvG& e, int lane, cons
       if (gl == 0) { info_out[2] = i2; info_out[3] = i3; }
     }
     if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
-      double mc = link_mean(P, e.ls + 2 * P.E, lane);
+      double mc = link_mean(P, e.ls + 2, lane);
       double mu = link_mean(P, e.ls, lane);
       if (gl == 0) { info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu; }
       if (P.bit_rate_mode == 1 && gl == 0) {

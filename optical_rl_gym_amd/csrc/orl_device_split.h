@@ -256,7 +256,7 @@ __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 en
     }
     if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
       double cur_comp = g8::net_compactness(P, e, 0, lane);
-      double mc = g8::link_mean(P, e.ls + 2 * P.E, lane);
+      double mc = g8::link_mean(P, e.ls + 2, lane);
       double mu = g8::link_mean(P, e.ls, lane);
       if (gl == 0) {
         double prev_comp = info_out[5];
@@ -555,9 +555,9 @@ __device__ __forceinline__ void row_item(const DevParams& P, const Item it, int 
   // mask's row word and that row's cached contribution to the compactness sums
   const int core0 = (int)(cores & 0x1f);
   const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + now_slot]);
-  double last_update = ls[3 * E + link];
-  double util = ls[link], frag = 0.0, comp = 0.0;
-  if (ENV != ENV_RWA) { frag = ls[E + link]; comp = ls[2 * E + link]; }
+  const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
+  double last_update = ls23.y;
+  double util = ls01.x, frag = ls01.y, comp = ls23.x;
   u64 a_first = (w < W) ? bm[(size_t)(core0 * E + link) * W + w] : 0ull;
   int pk_first = (ENV != ENV_RWA) ? cs[2 * P.C + core0 * E + link] : 0;
   for (int k = 0; k < nmask; k++) {
@@ -612,11 +612,8 @@ __device__ __forceinline__ void row_item(const DevParams& P, const Item it, int 
     }
   }
   if (w == 0) {
-    if (now > 0) {
-      ls[link] = util;
-      if (ENV != ENV_RWA) { ls[E + link] = frag; ls[2 * E + link] = comp; }
-    }
-    ls[3 * E + link] = now;
+    if (now > 0) *(double2*)(ls + 4 * link) = make_double2(util, frag);
+    *(double2*)(ls + 4 * link + 2) = make_double2(comp, now);
   }
 }
 

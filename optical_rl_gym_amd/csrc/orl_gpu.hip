@@ -997,7 +997,11 @@ extern "C" int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out) 
   if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
-  HIPCHK(hipMemcpy(out, b->P.lstat + env * 4 * b->P.E, (size_t)4 * b->P.E * 8, hipMemcpyDeviceToHost));
+  const int E = b->P.E;
+  std::vector<double> h((size_t)4 * E);  // device layout [E][4] (one 32-byte record per link) -> ABI layout [4][E]
+  HIPCHK(hipMemcpy(h.data(), b->P.lstat + env * 4 * E, h.size() * 8, hipMemcpyDeviceToHost));
+  for (int l = 0; l < E; l++)
+    for (int k = 0; k < 4; k++) out[(size_t)k * E + l] = h[(size_t)4 * l + k];
   return ORL_OK;
 }
 extern "C" int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out) {
