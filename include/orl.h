@@ -173,6 +173,8 @@ int orl_batch_set_state(orl_batch* b, const void* in);
 int64_t orl_batch_debug_stream_read(orl_batch* b, int width16);
 /* Statistics: env-steps of the split pipeline whose releases took the serial path (more than 8 in one step). */
 int64_t orl_batch_debug_serial_count(orl_batch* b);
+/* Builds with -DORL_TIMING only (zeros otherwise): shader-clock cycles per phase of the split control kernels. */
+int orl_batch_debug_prof(orl_batch* b, uint64_t* out32, int reset);
 
 #ifdef __cplusplus
 }

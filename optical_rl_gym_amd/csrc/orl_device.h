@@ -58,6 +58,12 @@ enum {
 #define ORL_FLAG_EV_OVERFLOW 1
 #define ORL_FLAG_BAD_ACTION 2
 
+// soon list (split pipeline): the earliest pending releases of an env, ORL_SOON_PER_LANE per lane of its 8-lane group
+#ifndef ORL_SOON_PER_LANE
+#define ORL_SOON_PER_LANE 4
+#endif
+#define ORL_SOON (8 * ORL_SOON_PER_LANE)
+
 struct DevParams {
   int env_type, N, E, K, H, M, S, W, C, episode_length, allow_rejection, J;
   int bit_rate_mode, br_lo, n_br, rand_n, rand_bits;
@@ -89,11 +95,12 @@ struct DevParams {
   // split pipeline (orl_device_split.h): row-update work items produced by the control kernels
   ulonglong2* q_a;  // [q_cap] provision items of this step
   ulonglong2* q_b;  // [q_cap] release items of this step
-  u32* q_cnt_a;     // [ceil(B/32)] items each control workgroup put into its region of q_a
-  u32* q_cnt_b;     // [ceil(B/32)] same for q_b
+  u32* q_cnt_a;     // [4 * ceil(B/32)] items each control wavefront (8 envs) put into its region of q_a
+  u32* q_cnt_b;     // same for q_b
+  int q_wave;       // item slots per wavefront region
   u32* q_stat;      // [1] env-steps that took the serial release path (statistics)
-  double* soon_t;   // [B][16] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8
-  u32* soon_i;      // [B][16] their slots in ev_time / ev_info
+  double* soon_t;   // [B][ORL_SOON] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8, ...
+  u32* soon_i;      // [B][ORL_SOON] their slots in ev_time / ev_info
   i64 q_cap;
   int* core_sums;   // [B][cs_words]      [2*C] per core: sum(lambda_max-lambda_min), sum(free blocks inside);
                     //                    then [C*E] per (core, link): that row's own contribution, (occ << 16) | fb

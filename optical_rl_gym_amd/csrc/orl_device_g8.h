@@ -74,8 +74,8 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
   e.cs = P.core_sums + env * P.cs_words;
   e.ev_time = P.ev_time + env * P.ev_cap;
   e.ev_info = P.ev_info + env * P.ev_cap;
-  e.soon_t = P.soon_t + env * 16;
-  e.soon_i = P.soon_i + env * 16;
+  e.soon_t = P.soon_t + env * ORL_SOON;
+  e.soon_i = P.soon_i + env * ORL_SOON;
   e.mt = P.mt + env * 624;
 }
 
@@ -268,15 +268,24 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
   e.next_rel = t < e.next_rel ? t : e.next_rel;  // -inf (unknown) stays -inf
   if (t < e.t_soon) {
     // invariant of the soon list: it holds EVERY pending release earlier than t_soon
-    const double a0 = e.soon_t[gl], a1 = e.soon_t[gl + 8];
-    const u32 f0 = gballot(a0 == __builtin_inf(), lane), f1 = gballot(a1 == __builtin_inf(), lane);
-    if (f0 | f1) {
-      const int slot = f0 ? (int)__builtin_ctz(f0) : 8 + (int)__builtin_ctz(f1);
+    double a[ORL_SOON_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < ORL_SOON_PER_LANE; k++) a[k] = e.soon_t[gl + 8 * k];
+    int slot = -1;
+#pragma unroll
+    for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+      const u32 f = gballot(a[k] == __builtin_inf(), lane);
+      if (f && slot < 0) slot = 8 * k + (int)__builtin_ctz(f);
+    }
+    if (slot >= 0) {
       if (gl == (slot & 7)) { e.soon_t[slot] = t; e.soon_i[slot] = (u32)idx; }
     } else {
-      // full: keep the 16 earliest; the horizon moves down to the latest of what was there
-      double m = a0 > a1 ? a0 : a1;
-      int ms = a0 > a1 ? gl : gl + 8;
+      // full: keep the earliest ORL_SOON; the horizon moves down to the latest of what was there
+      double m = a[0];
+      int ms = gl;
+#pragma unroll
+      for (int k = 1; k < ORL_SOON_PER_LANE; k++)
+        if (a[k] > m) { m = a[k]; ms = gl + 8 * k; }
 #define ORL_MAX_STEP(CTRL) { double om = dpp_d<CTRL>(m); int os = dpp_i<CTRL>(ms); if (om > m || (om == m && os < ms)) { m = om; ms = os; } }
       ORL_MAX_STEP(ORL_DPP_XOR1) ORL_MAX_STEP(ORL_DPP_XOR2) ORL_MAX_STEP(ORL_DPP_HALF_MIRROR)
 #undef ORL_MAX_STEP

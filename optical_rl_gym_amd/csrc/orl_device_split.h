@@ -19,6 +19,25 @@
 namespace orl {
 namespace sp {
 
+// -DORL_TIMING: shader-clock cycles per phase, summed over the first lane of every wavefront (orl_batch_debug_prof)
+#define ORL_PROF_SLOTS 32
+#define ORL_PROF_WAVES 16384
+struct Prof { long long t; unsigned long long acc[16]; };
+#ifdef ORL_TIMING
+__device__ unsigned long long g_prof[ORL_PROF_WAVES * ORL_PROF_SLOTS];
+#define ORL_PROF_BEGIN() Prof prof; for (int k_ = 0; k_ < 16; k_++) prof.acc[k_] = 0; prof.t = clock64()
+#define ORL_PROF(k) do { long long n_ = clock64(); prof.acc[k] += (unsigned long long)(n_ - prof.t); prof.t = n_; } while (0)
+#define ORL_PROF_END() do { if ((threadIdx.x & 63) == 0) { const size_t w_ = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % ORL_PROF_WAVES; \
+    unsigned long long* g_ = g_prof + w_ * ORL_PROF_SLOTS; \
+    unsigned long long tot_ = 0; for (int k_ = 0; k_ < 14; k_++) { g_[k_] += prof.acc[k_]; tot_ += prof.acc[k_]; } \
+    if (tot_ > g_[15]) g_[15] = tot_;  /* slowest launch of this wavefront */ \
+    if (tot_ > 60000) { g_[14] += 1; for (int k_ = 0; k_ < 14; k_++) g_[16 + k_] += prof.acc[k_]; } } } while (0)
+#else
+#define ORL_PROF_BEGIN() Prof prof
+#define ORL_PROF(k) do { } while (0)
+#define ORL_PROF_END() do { } while (0)
+#endif
+
 using g8::EnvG;
 using g8::gballot;
 using g8::gget;
@@ -35,23 +54,25 @@ __device__ __forceinline__ Item make_item(i64 env, u32 link, int nmask, u64 m0, 
   it.b.y = cores;
   return it;
 }
-__device__ __forceinline__ void item_store(ulonglong2* q, int idx, const Item& it) { q[2 * idx] = it.a; q[2 * idx + 1] = it.b; }
+__device__ __forceinline__ void item_store(ulonglong2* q, size_t idx, const Item& it) { q[2 * idx] = it.a; q[2 * idx + 1] = it.b; }
 
-// Every control workgroup (32 envs) owns a fixed region of ORL_QREGION item slots in the queue and publishes how many it
-// filled; the row kernel runs one workgroup per region.  No global atomic: a single queue-tail counter serialised the
-// 2 048 workgroups of a 65 536-env launch (~12 ns per atomic on one address).
-#define ORL_QREGION 1024
-__device__ __forceinline__ int wg_reserve(int cnt, u32* region_counts, int* s_cnt, int* s_base) {
-  const int grp = (int)(threadIdx.x >> 3);
-  if ((threadIdx.x & 7) == 0) s_cnt[grp] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int i = 0; i < 32; i++) { s_base[i] = tot; tot += s_cnt[i]; }
-    region_counts[blockIdx.x] = (u32)tot;
+// Every control WAVEFRONT (8 envs) owns a fixed region of P.q_wave item slots in the queue (8 x the most items one env
+// can produce: max(hops, links)) and publishes how many it filled; the row kernel maps its dense item index onto the
+// four regions of a control workgroup.  No global atomic (a single queue-tail counter serialised the 2 048 workgroups
+// of a 65 536-env launch, ~12 ns per atomic on one address) and no workgroup barrier (waiting for the slowest of four
+// wavefronts was a third of control kernel B2's time).  `cnt` is uniform within each 8-lane group; all 64 lanes call.
+__device__ __forceinline__ size_t wave_reserve(const DevParams& P, int cnt, u32* wave_counts, int lane) {
+  const int grp = lane >> 3;
+  int pre = 0, tot = 0;
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const int c = __builtin_amdgcn_readlane(cnt, 8 * g);
+    pre += (g < grp) ? c : 0;
+    tot += c;
   }
-  __syncthreads();
-  return (int)blockIdx.x * ORL_QREGION + s_base[grp];
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (lane == 0) wave_counts[wave] = (u32)tot;
+  return wave * (size_t)P.q_wave + (size_t)pre;
 }
 
 // ---- release sink -----------------------------------------------------------------------------------
@@ -98,8 +119,7 @@ __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 en
 // MERGE: device-resident loop without info — the work of control kernel B1 (next service) is done right here, on the env
 // record that is already in registers; only the network-compactness update has to wait for the row kernel (k_ctrl_b2).
 template <int ENV, int W, bool MERGE = false>
-__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, int* s_cnt, int* s_base,
-                                       const int4* given = nullptr) {
+__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, const int4* given = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   int cnt = 0, core = 0, slot = 0, n = 1;
   PathRec rec;
@@ -212,7 +232,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     if (MERGE) service_part<ENV, W, true>(P, e, env, lane, 1, accepted, core, nullptr);
     g8::env_store(P, e, gl);
   }
-  const int base = wg_reserve(cnt, P.q_cnt_a, s_cnt, s_base);
+  const size_t base = wave_reserve(P, cnt, P.q_cnt_a, lane);
   for (int h = gl; h < cnt; h += 8)
     item_store(P.q_a, base + h, make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), 0ull, (u64)(u32)core, 0));
 }
@@ -300,25 +320,39 @@ __device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid,
 
 // ---------------------------------------------------------------------------------------------------------------
 // Due releases through the SOON LIST.  Scanning all ~330 pending release times of an env every step was the largest
-// cost of control kernel B2 (41 dependent-latency loads per lane).  Each env keeps the (up to 16) earliest pending
-// releases in a small list with the invariant "every pending release earlier than t_soon is in the list"; while
-// now < t_soon the due releases are found by looking at 2 list slots per lane, and only when the clock passes t_soon
-// (about every tenth step) the list is rebuilt from a full scan.  Pushes keep the invariant (g8::ev_push).
+// cost of control kernel B2 (41 dependent-latency loads per lane).  Each env keeps its earliest pending releases in
+// a small list (ORL_SOON_PER_LANE per lane of its group) with the invariant "every pending release earlier than
+// t_soon is in the list"; while now < t_soon the due releases are found by looking at the lane's own list slots, and
+// only when the clock passes t_soon the list is rebuilt from a full scan.  Pushes keep the invariant (g8::ev_push).
 // ---------------------------------------------------------------------------------------------------------------
+struct SoonRegs { double t[ORL_SOON_PER_LANE]; int i[ORL_SOON_PER_LANE]; bool dirty; };
+// The list is returned in registers: the caller writes it back (when dirty) after everything that still loads.
 template <int ENV, int W>
-__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink) {
-  if (e.next_rel > e.now) return;
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof) {
+  constexpr int NS = ORL_SOON_PER_LANE;
+  out.dirty = false;
+  // The rebuild scan costs the wavefront the same whether one of its 8 envs runs it or all of them (the other lanes
+  // idle meanwhile), so when any env's horizon has passed, every env of the wavefront rebuilds: their horizons
+  // stay in phase and the wavefront pays for a scan far less often.
+  const bool sync_rebuild = __ballot(!(e.now < e.t_soon) && !(e.next_rel > e.now)) != 0ull;
+  if (e.next_rel > e.now && !sync_rebuild) return;
   const int gl = lane & 7;
   const double INF = __builtin_inf();
-  double s0t = e.soon_t[gl], s1t = e.soon_t[gl + 8];
-  int s0i = (int)e.soon_i[gl], s1i = (int)e.soon_i[gl + 8];
+  double st[NS];
+  int si[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) { st[k] = e.soon_t[gl + 8 * k]; si[k] = (int)e.soon_i[gl + 8 * k]; }
   bool dirty = false;
+  ORL_PROF(4);
   for (int round = 0; round < 64; round++) {
     int due_all = -1;  // number of due entries overall, known when this round scanned everything
-    if (!(e.now < e.t_soon)) {
-      // rebuild: the three earliest pending releases among this lane's slots (i % 8 == lane)
-      double t0 = INF, t1 = INF, t2 = INF;
-      int i0 = 0, i1 = 0, nd = 0;
+    if (!(e.now < e.t_soon) || (round == 0 && sync_rebuild)) {
+      // rebuild: the NS + 1 earliest pending releases among this lane's slots (i % 8 == lane), kept sorted
+      double bt[NS + 1];
+      int bi[NS + 1];
+#pragma unroll
+      for (int k = 0; k <= NS; k++) { bt[k] = INF; bi[k] = 0; }
+      int nd = 0, top = -1;
       for (int base = gl; base < e.ev_hwm; base += 64) {
         double tt[8];
 #pragma unroll
@@ -331,31 +365,42 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           const double t = tt[k];
           const int i = base + 8 * k;
           nd += (t <= e.now) ? 1 : 0;
-          if (t < t2) {
-            if (t < t1) {
-              t2 = t1;
-              if (t < t0) { t1 = t0; i1 = i0; t0 = t; i0 = i; } else { t1 = t; i1 = i; }
-            } else {
-              t2 = t;
+          top = (t != INF) ? i : top;  // i grows along the scan; slots beyond ev_hwm read as INF
+          if (t < bt[NS]) {
+            bt[NS] = t; bi[NS] = i;
+#pragma unroll
+            for (int j = NS - 1; j >= 0; j--) {  // one insertion pass (strict <: equal times keep slot order)
+              const bool sw = bt[j + 1] < bt[j];
+              const double lo = sw ? bt[j + 1] : bt[j], hi = sw ? bt[j] : bt[j + 1];
+              const int li = sw ? bi[j + 1] : bi[j], hi_i = sw ? bi[j] : bi[j + 1];
+              bt[j] = lo; bt[j + 1] = hi; bi[j] = li; bi[j + 1] = hi_i;
             }
           }
         }
       }
-      const double T = g8::g8_min(t2);
-      s0t = t0 < T ? t0 : INF; s0i = i0;
-      s1t = t1 < T ? t1 : INF; s1i = i1;
+      const double T = g8::g8_min(bt[NS]);
+#pragma unroll
+      for (int k = 0; k < NS; k++) { st[k] = bt[k] < T ? bt[k] : INF; si[k] = bi[k]; }
       e.t_soon = T;
       dirty = true;
       due_all = g8_sum(nd);
+      // the scan saw every slot: shrink the window to the highest occupied one (a stale larger window is harmless, so
+      // the steps between two rebuilds do not bother)
+      e.ev_hwm = g8_max(top) + 1;
+      if (e.hint >= e.ev_hwm) e.hint = -1;
+      ORL_PROF(5);
     }
-    // the list's due entries: at most two per lane, earliest first
-    const bool u0 = s0t <= e.now, u1 = s1t <= e.now;
-    const bool first0 = u0 && (!u1 || s0t < s1t || (s0t == s1t && s0i < s1i));
-    double d0t = INF, d1t = INF;
-    int d0i = 0x7fffffff, d1i = 0x7fffffff, d0s = 0, d1s = 0;
-    if (first0) { d0t = s0t; d0i = s0i; d0s = 0; if (u1) { d1t = s1t; d1i = s1i; d1s = 1; } }
-    else if (u1) { d0t = s1t; d0i = s1i; d0s = 1; if (u0) { d1t = s0t; d1i = s0i; d1s = 0; } }
-    const int tot = g8_sum((u0 ? 1 : 0) + (u1 ? 1 : 0));
+    // this lane's candidate: the earliest due entry of its list slots (equal times: lower event slot first)
+    int ndl = 0;
+    double ct = INF;
+    int ci = 0x7fffffff, ck = 0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const bool due = st[k] <= e.now;
+      ndl += due ? 1 : 0;
+      if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; ck = k; }
+    }
+    const int tot = g8_sum(ndl);
     if (tot == 0) {
       if (e.now < e.t_soon) break;
       if (round > 0 || due_all >= 0) {  // nothing below the horizon is due although the clock passed it: equal times
@@ -400,13 +445,14 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         return;
       }
     }
-    // info word + path record of this lane's first due entry, requested by all lanes together
+    // info word + path record of this lane's candidate, requested by all lanes together
     u64 inf0 = 0;
     PathRec rc0 = PathRec();
-    if (d0i != 0x7fffffff) { inf0 = e.ev_info[d0i]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
+    if (ci != 0x7fffffff) { inf0 = e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
+    ORL_PROF(6);
     for (;;) {
-      double bt = d0t;
-      int bi = d0i, bl = gl;
+      double bt = ct;
+      int bi = ci, bl = gl;
 #define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); int ol = dpp_i<CTRL>(bl); \
                              if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; bl = ol; } }
       ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
@@ -417,10 +463,17 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       rec.q[0] = gget(rc0.q[0], bl, lane); rec.q[1] = gget(rc0.q[1], bl, lane);
       rec.q[2] = gget(rc0.q[2], bl, lane); rec.q[3] = gget(rc0.q[3], bl, lane);
       if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
-      if (gl == bl) {  // the holder drops the entry from its list slot and moves to its second due entry
-        if (d0s == 0) s0t = INF; else s1t = INF;
-        d0t = d1t; d0i = d1i; d0s = d1s; d1t = INF; d1i = 0x7fffffff;
-        if (d0i != 0x7fffffff) { inf0 = e.ev_info[d0i]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }  // rare
+      if (gl == bl) {  // the holder drops the entry from its list and moves to its next due entry, if any (rare)
+        ct = INF; ci = 0x7fffffff;
+        int nk = 0;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+          if (k == ck) st[k] = INF;
+          const bool due = st[k] <= e.now;
+          if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
+        }
+        ck = nk;
+        if (ci != 0x7fffffff) { inf0 = e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
       }
       dirty = true;
       const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
@@ -431,37 +484,48 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       e.s_br -= br;
       e.s_nh -= (i64)n * path_rec_byte(rec, 0);
     }
+    ORL_PROF(7);
     if (e.now < e.t_soon) break;
   }
   {
-    const double m = s0t < s1t ? s0t : s1t;
+    double m = st[0];
+#pragma unroll
+    for (int k = 1; k < NS; k++) m = st[k] < m ? st[k] : m;
     const double lm = g8::g8_min(m);
     e.next_rel = lm < e.t_soon ? lm : e.t_soon;
   }
-  if (dirty) {
-    e.soon_t[gl] = s0t; e.soon_t[gl + 8] = s1t;
-    e.soon_i[gl] = (u32)s0i; e.soon_i[gl + 8] = (u32)s1i;
-  }
-  for (int it = 0; it < 4 && e.ev_hwm > 0; it++) {  // shrink the scan window when its tail is empty
-    int i = e.ev_hwm - 1;
-    double t = gget((gl == (i & 7)) ? e.ev_time[i] : 0.0, i & 7, lane);
-    if (t == INF) { e.ev_hwm--; if (e.hint == i) e.hint = -1; } else break;
-  }
+  out.dirty = dirty;
+#pragma unroll
+  for (int k = 0; k < NS; k++) { out.t[k] = st[k]; out.i[k] = si[k]; }
+  ORL_PROF(8);
 }
 
 // control kernel B2: the due releases of the step (rmsa_env.py:590-597) -> work items.  Only the clock, the
 // pending-release bookkeeping and the two running sums of the env record are touched.
 template <int ENV, int W>
-__device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid, int lane, int* s_cnt, int* s_base, u32* s_tally,
-                                        SinkEntry* s_tab) {
+__device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid, int lane, u32* s_tally, SinkEntry* s_tab) {
   const int gl = lane & 7, E = P.E;
-  for (int i = (int)threadIdx.x; i < 32 * 32; i += 256) s_tally[i] = 0u;
-  for (int i = (int)threadIdx.x; i < 32 * E; i += 256) s_tab[i].crn = 0ull;
-  __syncthreads();
+  ORL_PROF_BEGIN();
+  {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
+    u32* ty = s_tally + 32 * 8 * (int)(threadIdx.x >> 6);
+    SinkEntry* tb = s_tab + E * 8 * (int)(threadIdx.x >> 6);
+    for (int i = lane; i < 8 * 32; i += 64) ty[i] = 0u;
+    for (int i = lane; i < 8 * E; i += 64) tb[i].crn = 0ull;
+    wave_fence();
+  }
   Sink sink;
   sink.tab = s_tab + E * (int)(threadIdx.x >> 3);
   sink.tally = s_tally + 32 * (int)(threadIdx.x >> 3);
   sink.active = false; sink.deferred = false; sink.cnt = 0;
+  SoonRegs soon;
+  soon.dirty = false;
+  double next_rel = 0.0, t_soon = 0.0;
+  i64 s_br = 0, s_nh = 0;
+  u64 ev = 0, acc_word = 0;
+  int hint = -1;
+  double gc = 0.0;
+  bool gc_pending = false;
+  ORL_PROF(1);
   if (valid) {
     EnvG e;
     u64* s = P.scal + env * ORL_SCAL_WORDS;
@@ -486,30 +550,24 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
       const double a0 = __longlong_as_double((i64)s[SC_GC_A]), td = __longlong_as_double((i64)s[SC_GC_TD]);
       const double now_a = __longlong_as_double((i64)s[SC_NOWA]);
       // s_nh at provision time = the value the merged kernel stored (this kernel has not released anything yet)
-      const double gc = (a0 + (g8::net_compactness(P, e, core, lane) * td)) / now_a;
-      if (gl == 0) { s[SC_GCOMP] = (u64)__double_as_longlong(gc); s[SC_ACC] = acc & ~2ull; }
+      gc = (a0 + (g8::net_compactness(P, e, core, lane) * td)) / now_a;
+      gc_pending = true;
     }
+    acc_word = acc & ~2ull;
+    ORL_PROF(2);
     e.t_soon = __longlong_as_double((i64)s[SC_TSOON]);
-    e.soon_t = P.soon_t + env * 16;
-    e.soon_i = P.soon_i + env * 16;
-    release_soon<ENV, W>(P, e, lane, sink);
-    if (sink.deferred) {
-      // more simultaneous releases than the item form holds (> 4, or 3+ in one lane's slots): leave everything
-      // untouched and let k_rel_serial release them one by one
-      if (gl == 0) s[SC_ACC] = (s[SC_ACC] & ~2ull) | (1ull << 16);
-    } else if (gl == 0) {
-      s[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
-      s[SC_TSOON] = (u64)__double_as_longlong(e.t_soon);
-      s[SC_SBR] = (u64)e.s_br;
-      s[SC_SNH] = (u64)e.s_nh;
-      s[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
-      s[SC_HINT] = pack2(e.hint, 0);
-    }
+    e.soon_t = P.soon_t + env * ORL_SOON;
+    e.soon_i = P.soon_i + env * ORL_SOON;
+    ORL_PROF(3);
+    release_soon<ENV, W>(P, e, lane, sink, soon, prof);
+    next_rel = e.next_rel; t_soon = e.t_soon; s_br = e.s_br; s_nh = e.s_nh; ev = pack2(e.ev_hwm, e.ev_cnt); hint = e.hint;
   }
+  ORL_PROF(9);
   const int cnt = g8_sum(sink.active ? sink.cnt : 0);
-  const int base = wg_reserve(cnt, P.q_cnt_b, s_cnt, s_base);
+  const size_t base = wave_reserve(P, cnt, P.q_cnt_b, lane);
+  ORL_PROF(10);
   if (cnt) {  // the env's items = the table entries that hold masks, in link order
-    int at = base;
+    size_t at = base;
     for (int l0 = 0; l0 < E; l0 += 8) {
       const int l = l0 + gl;
       const u64 crn = (l < E) ? sink.tab[l].crn : 0ull;
@@ -521,6 +579,35 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
       at += __popc(fb);
     }
   }
+  // the env record goes back last: stores hold the memory counter, and nothing after this point waits on it
+  if (valid) {
+    u64* s = P.scal + env * ORL_SCAL_WORDS;
+    if (gl == 0) {
+      // deferred: more releases meet on one link than an item holds masks for; the pending-release state is left
+      // untouched and k_rel_serial (flag bit 16) releases them in place
+      if (gc_pending) s[SC_GCOMP] = (u64)__double_as_longlong(gc);
+      if (gc_pending || sink.deferred) s[SC_ACC] = acc_word | (sink.deferred ? (1ull << 16) : 0ull);
+    }
+    if (!sink.deferred) {
+      if (soon.dirty) {
+#pragma unroll
+        for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+          P.soon_t[env * ORL_SOON + gl + 8 * k] = soon.t[k];
+          P.soon_i[env * ORL_SOON + gl + 8 * k] = (u32)soon.i[k];
+        }
+      }
+      if (gl == 0) {
+        s[SC_NEXTREL] = (u64)__double_as_longlong(next_rel);
+        s[SC_TSOON] = (u64)__double_as_longlong(t_soon);
+        s[SC_SBR] = (u64)s_br;
+        s[SC_SNH] = (u64)s_nh;
+        s[SC_EV] = ev;
+        s[SC_HINT] = pack2(hint, 0);
+      }
+    }
+  }
+  ORL_PROF(11);
+  ORL_PROF_END();
 }
 
 // rare path: envs whose due releases did not fit the item form (flag bit 16 of SC_ACC) release them in place

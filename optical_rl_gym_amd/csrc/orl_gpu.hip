@@ -280,15 +280,13 @@ __global__ void __launch_bounds__(256, ORL_STEP8_WAVES) k_step8(DevParams P, int
 // in the row kernel ---------------------------------------------------------------------------------------------
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_a(DevParams P, int want_info) {
-  __shared__ int s_cnt[32], s_base[32];
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
-  sp::ctrl_a<ENV, W, false>(P, env, env < P.B, lane_id(), want_info != 0, s_cnt, s_base);
+  sp::ctrl_a<ENV, W, false>(P, env, env < P.B, lane_id(), want_info != 0);
 }
 // device-policy loop: slot-scan and control kernel A in one launch (same 8-lanes-per-env layout; the action never
 // leaves the registers, the link rows the scan just read are still in cache for the validation)
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_policy_ctrl_a(DevParams P, int pol) {
-  __shared__ int s_cnt[32], s_base[32];
   const int lane = lane_id();
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   const bool valid = env < P.B;
@@ -299,7 +297,7 @@ __global__ void __launch_bounds__(256) k_policy_ctrl_a(DevParams P, int pol) {
                       (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane, pol, a);
   const int4 av = make_int4(a[0], a[1], a[2], a[3]);
   if (valid && (lane & 7) == 0) *(int4*)(P.actions + env * 4) = av;
-  sp::ctrl_a<ENV, W, true>(P, env, valid, lane, false, s_cnt, s_base, &av);
+  sp::ctrl_a<ENV, W, true>(P, env, valid, lane, false, &av);
 }
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_b1(DevParams P, int auto_reset, int want_info) {
@@ -308,10 +306,9 @@ __global__ void __launch_bounds__(256) k_ctrl_b1(DevParams P, int auto_reset, in
 }
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_b2(DevParams P) {
-  __shared__ int s_cnt[32], s_base[32];
   __shared__ u32 s_tally[32 * 32];
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
-  sp::ctrl_b2<ENV, W>(P, env, env < P.B, lane_id(), s_cnt, s_base, s_tally, (sp::SinkEntry*)orl_lds_raw);  // 32 x E entries
+  sp::ctrl_b2<ENV, W>(P, env, env < P.B, lane_id(), s_tally, (sp::SinkEntry*)orl_lds_raw);  // 32 x E entries
 }
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_rel_serial(DevParams P) {
@@ -323,15 +320,19 @@ __global__ void __launch_bounds__(256) k_rel_serial(DevParams P) {
 #endif
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_rows(DevParams P, int phase) {
-  // ORL_ROWS_SPLIT workgroups per producer region (32 envs' worth of items, dense from the region's start), taking
-  // interleaved chunks of 32 items: a region holds ~75 items, so one workgroup alone would run 3 mostly serial passes
-  const u32 region = blockIdx.x / ORL_ROWS_SPLIT, part = blockIdx.x % ORL_ROWS_SPLIT;
-  const ulonglong2* q = (phase ? P.q_b : P.q_a) + (size_t)region * ORL_QREGION * 2;
-  const u32 n = (phase ? P.q_cnt_b : P.q_cnt_a)[region];
+  // ORL_ROWS_SPLIT workgroups per control workgroup (32 envs = four wavefront regions, ~75 items), taking interleaved
+  // chunks of 32 items of the dense index over the four regions: one workgroup alone would run 3 mostly serial passes
+  const u32 grp4 = blockIdx.x / ORL_ROWS_SPLIT, part = blockIdx.x % ORL_ROWS_SPLIT;
+  const ulonglong2* q = (phase ? P.q_b : P.q_a) + (size_t)grp4 * 4 * P.q_wave * 2;
+  const uint4 c = *(const uint4*)((phase ? P.q_cnt_b : P.q_cnt_a) + 4 * grp4);
+  const u32 p1 = c.x, p2 = p1 + c.y, p3 = p2 + c.z, n = p3 + c.w;
   for (u32 idx = part * 32u + (threadIdx.x >> 3); idx < n; idx += 32u * ORL_ROWS_SPLIT) {
+    const u32 sub = (idx >= p1 ? 1u : 0u) + (idx >= p2 ? 1u : 0u) + (idx >= p3 ? 1u : 0u);
+    const u32 off = idx - (sub == 0 ? 0u : sub == 1 ? p1 : sub == 2 ? p2 : p3);
+    const size_t at = (size_t)sub * P.q_wave + off;
     sp::Item it;
-    it.a = q[2 * idx];
-    it.b = q[2 * idx + 1];
+    it.a = q[2 * at];
+    it.b = q[2 * at + 1];
     sp::row_item<ENV, W>(P, it, lane_id(), phase ? SC_NOW : SC_NOWA);
   }
 }
@@ -700,15 +701,18 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   size_t B = (size_t)n_envs;
   rc |= dalloc(b, &P.svc_desc, B);
   {
-    const size_t regions = (B + 31) / 32 + 16;  // +16: sub-batch views start at multiples of 32 envs
-    P.q_cap = (i64)regions * ORL_QREGION;
+    // one queue region per control wavefront (8 envs), sized for the most items its envs can produce in a step:
+    // a provision touches <= H links, the releases of a step <= E links (one item per link)
+    const size_t waves = ((B + 31) / 32 + 16) * 4;  // +16 workgroups: sub-batch views start at multiples of 32 envs
+    P.q_wave = 8 * (P.H > P.E ? P.H : P.E);
+    P.q_cap = (i64)waves * P.q_wave;
     rc |= dalloc(b, &P.q_a, (size_t)P.q_cap * 2);  // 32-byte items
     rc |= dalloc(b, &P.q_b, (size_t)P.q_cap * 2);
-    rc |= dalloc(b, &P.q_cnt_a, regions);
-    rc |= dalloc(b, &P.q_cnt_b, regions);
+    rc |= dalloc(b, &P.q_cnt_a, waves);
+    rc |= dalloc(b, &P.q_cnt_b, waves);
     rc |= dalloc(b, &P.q_stat, 16);
-    rc |= dalloc(b, &P.soon_t, B * 16);
-    rc |= dalloc(b, &P.soon_i, B * 16);
+    rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
+    rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
     if (!rc) hipMemset(P.q_stat, 0, 16 * sizeof(u32));
   }
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
@@ -741,7 +745,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       q.B = cnt;
       q.bitmap += lo * P.bm_words; q.ev_time += lo * P.ev_cap; q.ev_info += lo * P.ev_cap; q.mt += lo * 624;
       q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
-      q.q_a += (lo / 32) * ORL_QREGION * 2; q.q_b += (lo / 32) * ORL_QREGION * 2; q.q_cnt_a += lo / 32; q.q_cnt_b += lo / 32; q.soon_t += lo * 16; q.soon_i += lo * 16;
+      q.q_a += (lo / 8) * P.q_wave * 2; q.q_b += (lo / 8) * P.q_wave * 2; q.q_cnt_a += lo / 8; q.q_cnt_b += lo / 8; q.soon_t += lo * ORL_SOON; q.soon_i += lo * ORL_SOON;
       if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
@@ -1067,8 +1071,8 @@ static std::vector<Section> state_sections(orl_batch* b) {
   v.push_back({P.mt, B * 624 * 4});
   v.push_back({P.lstat, B * 4 * P.E * 8});
   v.push_back({P.core_sums, B * P.cs_words * 4});
-  v.push_back({P.soon_t, B * 16 * 8});
-  v.push_back({P.soon_i, B * 16 * 4});
+  v.push_back({P.soon_t, B * ORL_SOON * 8});
+  v.push_back({P.soon_i, B * ORL_SOON * 4});
   if (P.br_hist) v.push_back({P.br_hist, B * 2 * P.n_br * 8});
   if (P.act_hist) v.push_back({P.act_hist, B * ((P.K + 1) + (P.S + 1)) * 8});
   return v;
@@ -1099,6 +1103,28 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
 }
 
 /* debug: number of env-steps that fell back to the serial release path of the split pipeline since creation */
+extern "C" int orl_batch_debug_prof(orl_batch* b, uint64_t* out32, int reset) {
+  if (!b || !out32) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  memset(out32, 0, 32 * 8);
+#ifdef ORL_TIMING
+  {
+    std::vector<unsigned long long> h((size_t)ORL_PROF_WAVES * ORL_PROF_SLOTS);
+    HIPCHK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(sp::g_prof), h.size() * 8));
+    for (size_t w = 0; w < ORL_PROF_WAVES; w++)
+      for (int k = 0; k < ORL_PROF_SLOTS; k++) {
+        if (k == 15) out32[k] = h[w * ORL_PROF_SLOTS + k] > out32[k] ? h[w * ORL_PROF_SLOTS + k] : out32[k];  // max
+        else out32[k] += h[w * ORL_PROF_SLOTS + k];
+      }
+    if (reset) {
+      std::fill(h.begin(), h.end(), 0ull);
+      HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(sp::g_prof), h.data(), h.size() * 8));
+    }
+  }
+#endif
+  return ORL_OK;
+}
 extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
   if (!b) return -1;
   if (hipSetDevice(b->device) != hipSuccess) return -1;
