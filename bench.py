@@ -2,9 +2,9 @@
 """Headline benchmark: env-steps/s of RMSA-v0 on NSFNET (320 slots, k=5, load 300 Erlang), batch 65 536
 envs per MI355X, on-device KSP-FF policy (BASELINE.json `metric`; SURVEY.md §8d cfg2 at B = 65 536).
 
-One "step" = one batched env.step() over the whole batch: the slot-scan (policy) kernel followed by the
-step kernel, launched back to back on the batch's stream; inputs are resident in HBM before the timed
-region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
+One "step" = one batched policy + env.step() over the whole batch, entirely on the device: at this batch size
+the split pipeline (slot-scan fused with control kernel A; row kernel; control kernel B2; row kernel; serial
+fallback), launched back to back on the batch's streams; inputs are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
 collective on the data path; torch.distributed is used only for the barrier and the max-over-ranks time).
 
     python bench.py --gpus 1 --steps 300 --warmup 1500
@@ -45,14 +45,27 @@ WORKLOADS = {
 def algorithmic_bytes(env, mean_hops, active):
     """bytes an env-step has to move, per env.
     scan = C*E*W*8 + 24 (one read of the packed link x slot map + 16 B service descriptor + 8 B action)
-    step = scan + 32*H + 128*H + 64*ceil(log2 A) + 116 + 128 + 81"""
+    step = scan + 32*H + 128*H + 64*ceil(log2 A) + 116 + 128 + 81
+    Returned per kernel name (DESIGN.md §5 says which term each kernel of the split pipeline carries)."""
     C, E, S = env.num_spatial_resources, env.topology.n_links, env.num_spectrum_resources
     W = (S + 63) // 64
     scan = C * E * W * 8 + 24
-    rest = 32 * mean_hops + 128 * mean_hops + 64 * math.ceil(math.log2(max(active, 2))) + 116 + 128 + 81
-    if env.obs_dim:
-        rest += 8 * env.obs_dim
-    return scan, rest
+    lg = 64 * math.ceil(math.log2(max(active, 2)))
+    fixed = 116 + 128 + 81 + (8 * env.obs_dim if env.obs_dim else 0)
+    rest = 32 * mean_hops + 128 * mean_hops + lg + fixed
+    return {
+        "k_policy": scan,                                   # slot scan alone
+        "k_step": rest, "k_step8": rest,                    # monolithic step kernels
+        # split pipeline: validation reads of the chosen path + RNG/env record/outputs + the release push
+        "k_policy_ctrl_a": scan + 32 * mean_hops + fixed + lg / 2,
+        "k_ctrl_a": 32 * mean_hops + fixed / 2 + lg / 2,
+        "k_ctrl_b1": fixed / 2,
+        "k_rows(provision)": 64 * mean_hops,               # link rows + per-link statistics, read and written
+        "k_rows(release)": 64 * mean_hops,
+        "k_ctrl_b2": lg / 2,                                # due-release detection
+        "k_rel_serial": 0.0,
+        "k_obs": 8 * env.obs_dim if env.obs_dim else 0.0,
+    }
 
 
 def main():
@@ -116,18 +129,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations of the same loop, each launch bracketed by HIP events on the batch's stream
-    st = env.run(policy, min(args.steps, 200), time_kernels=True)
+    # per-kernel durations of the same launches, each bracketed by HIP events on the stream it runs on (one stream,
+    # whole batch), and the stand-alone slot-scan kernel (the form orl_batch_policy launches for host-driven agents)
+    n_t = min(args.steps, 200)
+    st = env.run(policy, n_t, time_kernels=1)
+    st2 = env.run(policy, n_t, time_kernels=2)
     active = float(env.active().mean())
     processed, accepted = env.totals()
     t = env.topology
     h0 = t.path_hops[:, :, 0]
     mean_hops = float(h0[h0 > 0].mean())
-    scan_b, rest_b = algorithmic_bytes(env, mean_hops, active)
-    kernels = {
-        "slot_scan(k_policy)": dict(ms=st.ms_policy, bytes=scan_b * B),
-        "step(k_step)": dict(ms=st.ms_step, bytes=rest_b * B),
-    }
+    alg = algorithmic_bytes(env, mean_hops, active)
+    kernels = {}
+    for name, ms in st.kernels():
+        kernels[name] = dict(ms=ms, bytes=alg.get(name, 0.0) * B)
+    kernels.setdefault("k_policy", dict(ms=st2.ms_policy, bytes=alg["k_policy"] * B, standalone=True))
     # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x calibration + WRITE_SIZE), collected offline with
     # tools/pmc_traffic.py for exactly this workload/batch and committed under profiles/; null otherwise.
     traffic = {}
@@ -142,7 +158,9 @@ def main():
         roof[name] = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                           frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic.get(name), us_per_launch=round(k["ms"] * 1e3, 2),
                           algorithmic_bytes_per_launch=int(k["bytes"]))
-    dominant = max(kernels, key=lambda n: kernels[n]["ms"])
+        if k.get("standalone"):
+            roof[name]["note"] = "stand-alone slot-scan kernel (orl_batch_policy); the device loop fuses it into k_policy_ctrl_a"
+    dominant = max((n for n in kernels if not kernels[n].get("standalone")), key=lambda n: kernels[n]["ms"])
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -176,7 +194,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %s-v0 %s, %d slots, k=%d, batch %d envs/GPU, on-device %s policy, seeds 10+i"
                                    % (args.workload, fam, topo, env.num_spectrum_resources, env.k_paths, B, policy),
-                       "envs_per_gpu": B, "kernels_per_step": 2},
+                       "envs_per_gpu": B, "kernels_per_step": st.n_kernels,
+                       "step_kernels": [n for n, _ in st.kernels()]},
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_by_kernel": roof,
             "cpu_baseline": cpu,

@@ -92,11 +92,18 @@ typedef struct orl_batch orl_batch;
 /* current service record: arrival_time, holding_time, source_id, destination_id, bit_rate, service_id */
 #define ORL_N_SERVICE 6
 
+#define ORL_MAX_STEP_KERNELS 12
 typedef struct {
   double ms_total;   /* wall time of the whole call on the device (HIP events) */
-  double ms_policy;  /* average duration of one slot-scan (policy) launch */
-  double ms_step;    /* average duration of one step launch */
+  double ms_policy;  /* time_kernels == 2: average duration of one stand-alone slot-scan (policy) launch */
+  double ms_step;    /* time_kernels == 2: average duration of the launches of one step() */
   int64_t launches;  /* kernel launches issued */
+  /* time_kernels == 1: the kernels one policy+step of the device loop launches, in launch order, each bracketed by HIP
+   * events on the stream it runs on; average duration per launch */
+  int32_t n_kernels;
+  int32_t reserved;
+  double ms_kernel[ORL_MAX_STEP_KERNELS];
+  char kernel_name[ORL_MAX_STEP_KERNELS][32];
 } orl_run_stats;
 
 int orl_abi_version(void);
@@ -141,7 +148,8 @@ int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double*
 int orl_batch_observation(orl_batch* b, double* obs_out);
 
 /* n_steps x { policy ; step(auto_reset) } entirely on the device (the loop of utils.evaluate_heuristic,
- * utils.py:113-128, with VecEnv-style auto reset).  time_kernels != 0 brackets every launch with HIP events. */
+ * utils.py:113-128, with VecEnv-style auto reset).  time_kernels: 0 = production run (sub-batches on their streams), 1 = the same launches on one stream with every kernel
+ * bracketed by HIP events (stats->ms_kernel), 2 = stand-alone slot-scan kernel + step launches (ms_policy, ms_step). */
 int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels, orl_run_stats* stats);
 
 int orl_batch_sync(orl_batch* b);

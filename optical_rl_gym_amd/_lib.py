@@ -22,7 +22,13 @@ class EnvConfig(C.Structure):
 
 
 class RunStats(C.Structure):
-    _fields_ = [("ms_total", C.c_double), ("ms_policy", C.c_double), ("ms_step", C.c_double), ("launches", C.c_int64)]
+    _fields_ = [("ms_total", C.c_double), ("ms_policy", C.c_double), ("ms_step", C.c_double), ("launches", C.c_int64),
+                ("n_kernels", C.c_int32), ("reserved", C.c_int32), ("ms_kernel", C.c_double * 12),
+                ("kernel_name", (C.c_char * 32) * 12)]
+
+    def kernels(self):
+        """[(name, ms per launch)] of one policy+step of the device loop (time_kernels=1)."""
+        return [(bytes(self.kernel_name[i].value).decode(), self.ms_kernel[i]) for i in range(self.n_kernels)]
 
 
 EXPORTS = {

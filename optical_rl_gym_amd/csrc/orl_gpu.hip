@@ -399,8 +399,10 @@ struct orl_topology {
   int* link_pos;
 };
 
+struct TkRec;
 struct orl_batch {
   DevParams P;
+  TkRec* tk = nullptr;  // per-kernel timing of orl_batch_run(time_kernels = 1)
   int device, wt;
   int step_impl;  // ORL_STEP_IMPL: 64 = one wavefront per env, 8 = eight lanes per env (monolithic), 1 = split pipeline
   hipStream_t stream;
@@ -493,6 +495,10 @@ extern "C" void orl_topology_destroy(orl_topology* t) {
     default: { MACRO(ENV_RMCSA) } break;                    \
   }
 
+// per-kernel timing (orl_batch_run, time_kernels == 1): an event after every launch
+struct TkRec { std::vector<hipEvent_t> ev; std::vector<const char*> name; };
+#define ORL_TK(NAME) do { if (b->tk) { hipEvent_t e_; hipEventCreate(&e_); hipEventRecord(e_, VS); b->tk->ev.push_back(e_); b->tk->name.push_back(NAME); } } while (0)
+
 static void launch_reset(orl_batch* b, int full, const unsigned char* dmask) {
   const DevParams& VP = b->view ? *b->view : b->P;
   hipStream_t VS = b->view ? b->view_stream : b->stream;
@@ -524,6 +530,7 @@ static void launch_policy(orl_batch* b, int pol) {
   ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
 #undef CALLW
+  ORL_TK("k_policy");
 }
 static void launch_obs(orl_batch* b);
 static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_policy = -1);
@@ -544,14 +551,18 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
     const size_t lds_b2 = (size_t)32 * VP.E * sizeof(sp::SinkEntry);
 #define CALLW(WW)                                                                                      \
   do {                                                                                                 \
-    if (fused_policy >= 0) hipLaunchKernelGGL((k_policy_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, fused_policy); \
-    else hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info);                         \
+    if (fused_policy >= 0) { hipLaunchKernelGGL((k_policy_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, fused_policy); ORL_TK("k_policy_ctrl_a"); } \
+    else { hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info); ORL_TK("k_ctrl_a"); } \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 0);                                       \
-    if (fused_policy < 0) hipLaunchKernelGGL((k_ctrl_b1<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info); \
+    ORL_TK("k_rows(provision)");                                                                       \
+    if (fused_policy < 0) { hipLaunchKernelGGL((k_ctrl_b1<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info); ORL_TK("k_ctrl_b1"); } \
     if (lds_b2 > 48 * 1024) hipFuncSetAttribute((const void*)k_ctrl_b2<EE, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b2); \
     hipLaunchKernelGGL((k_ctrl_b2<EE, WW>), gc, blk, lds_b2, VS, VP);                                     \
+    ORL_TK("k_ctrl_b2");                                                                               \
     hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
+    ORL_TK("k_rows(release)");                                                                         \
     hipLaunchKernelGGL((k_rel_serial<EE, WW>), gc, blk, 0, VS, VP);                                    \
+    ORL_TK("k_rel_serial");                                                                            \
   } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
     ORL_FOR_ENV(PER_ENV)
@@ -568,6 +579,7 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
     ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
 #undef CALLW
+    ORL_TK("k_step8");
     if (VP.obs_dim) launch_obs(b);  // DeepRMSA observation of the new pending service
     return;
   }
@@ -583,15 +595,17 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
   ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
 #undef CALLW
+  ORL_TK("k_step");
 }
 static void launch_obs(orl_batch* b) {
   const DevParams& VP = b->view ? *b->view : b->P;
   hipStream_t VS = b->view ? b->view_stream : b->stream;
   dim3 g((unsigned)VP.B), blk(64);
   size_t lds = VP.lds_bytes;
-#define CALLW(WW) hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, VS, b->P)
+#define CALLW(WW) hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, VS, VP)
   ORL_FOR_W(CALLW)
 #undef CALLW
+  ORL_TK("k_obs");
 }
 
 template <typename T> static int dalloc(orl_batch* b, T** p, size_t n) {
@@ -627,8 +641,12 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   b->view = nullptr;
   b->view_stream = nullptr;
   {
+    // Measured on MI355X (tools/compare_impls.sh): the split pipeline wins once the batch fills the chip several
+    // times over (cfg2 65 536 envs: 3.5e8 vs 2.5e8 env-steps/s; cfg5 32 768: 1.64e8 vs 1.23e8; RMCSA 16 384: 1.17e8 vs
+    // 1.04e8); below that its six launches per step cost more than they save (cfg2 16 384: 1.83e8 vs 2.04e8).
     const char* impl = getenv("ORL_STEP_IMPL");
-    b->step_impl = impl ? atoi(impl) : 64;
+    const int64_t split_from = (c->env_type == ORL_ENV_RMCSA) ? 16384 : 24576;
+    b->step_impl = impl ? atoi(impl) : (n_envs >= split_from ? 1 : 64);
     if (b->step_impl != 8 && b->step_impl != 1) b->step_impl = 64;
   }
   DevParams& P = b->P;
@@ -876,7 +894,8 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
   if (policy_id < 0 || policy_id > 3) return fail(ORL_E_INVALID, "unknown policy %d", policy_id);
   HIPCHK(hipSetDevice(b->device));
   std::vector<hipEvent_t> evs;
-  if (time_kernels) {
+  TkRec tk;
+  if (time_kernels == 2) {
     evs.resize((size_t)n_steps * 3);
     for (auto& e : evs) HIPCHK(hipEventCreate(&e));
   }
@@ -902,6 +921,15 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
       HIPCHK(hipStreamWaitEvent(b->stream, e, 0));
       HIPCHK(hipEventDestroy(e));
     }
+  } else if (time_kernels == 1) {
+    // the production launches on the batch's stream, an event after every kernel (ORL_TK in the launch functions)
+    for (int64_t s = 0; s < n_steps; s++) {
+      hipStream_t VS = b->stream;
+      b->tk = &tk;
+      ORL_TK("");  // start of the step
+      launch_policy_step(b, policy_id);
+      b->tk = nullptr;
+    }
   } else {
     for (int64_t s = 0; s < n_steps; s++) {
       if (!time_kernels) { launch_policy_step(b, policy_id); continue; }
@@ -918,10 +946,10 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
   if (stats) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    memset(stats, 0, sizeof *stats);
     stats->ms_total = ms;
     stats->launches = 2 * n_steps;
-    stats->ms_policy = stats->ms_step = 0;
-    if (time_kernels && n_steps > 0) {
+    if (time_kernels == 2 && n_steps > 0) {
       double sp = 0, ss = 0;
       for (int64_t s = 0; s < n_steps; s++) {
         float a = 0, c2 = 0;
@@ -932,8 +960,25 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
       stats->ms_policy = sp / (double)n_steps;
       stats->ms_step = ss / (double)n_steps;
     }
+    if (time_kernels == 1 && n_steps > 0) {
+      const size_t per = tk.ev.size() / (size_t)n_steps;  // 1 start mark + one event per kernel
+      const int nk = (int)per - 1 < ORL_MAX_STEP_KERNELS ? (int)per - 1 : ORL_MAX_STEP_KERNELS;
+      stats->n_kernels = nk;
+      stats->launches = (int64_t)(per - 1) * n_steps;
+      for (int k = 0; k < nk; k++) {
+        double sum = 0;
+        for (int64_t s = 0; s < n_steps; s++) {
+          float a = 0;
+          HIPCHK(hipEventElapsedTime(&a, tk.ev[(size_t)s * per + k], tk.ev[(size_t)s * per + k + 1]));
+          sum += a;
+        }
+        stats->ms_kernel[k] = sum / (double)n_steps;
+        snprintf(stats->kernel_name[k], sizeof stats->kernel_name[k], "%s", tk.name[k + 1]);
+      }
+    }
   }
   for (auto& e : evs) hipEventDestroy(e);
+  for (auto& e : tk.ev) hipEventDestroy(e);
   return ORL_OK;
 }
 
