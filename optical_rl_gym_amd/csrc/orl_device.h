@@ -46,15 +46,17 @@ enum {
   SC_SP, SC_SA, SC_ESP, SC_ESA, SC_BRQ, SC_BRP, SC_EBRQ, SC_EBRP, SC_SBR, SC_SNH,
   SC_SRC_DST, SC_BR_IDX, SC_ID_MTPOS, SC_EV, SC_FLAGS,
   SC_NEXTREL,  // f64 lower bound of every pending release time (-inf = unknown, +inf = none pending)
-  SC_HINT,     // low 32 bits: index of a known-empty pending-release slot, or -1
+  SC_HINT,     // low 32 bits: number of entries on the free-slot stack (SC_FREE0..3); 0 = none known
   SC_ACC,      // split pipeline: low 32 = bit 0 action provisioned, bit 1 g_comp update pending, bit 16 serial releases; high 32 = core
   SC_NOWA,     // split pipeline: clock of the provision phase (the row kernel of phase A reads it)
   SC_GC_A,     // split pipeline: last_compactness * last_update of the pending network-compactness update
   SC_GC_TD,    // split pipeline: its time_diff
   SC_TSOON,    // f64: every pending release earlier than this is in the env's soon list (-inf = list invalid)
+  SC_FREE0, SC_FREE1, SC_FREE2, SC_FREE3,  // 16 x u16: known-empty pending-release slots (a stack; 8-lane kernels)
   SC_COUNT
 };
 #define ORL_SCAL_WORDS 32
+#define ORL_FREE_SLOTS 16
 #define ORL_FLAG_EV_OVERFLOW 1
 #define ORL_FLAG_BAD_ACTION 2
 
@@ -393,7 +395,7 @@ __device__ __forceinline__ void env_store(const DevParams& P, const Env& e, int 
   PUTI(SC_SBR, e.s_br) PUTI(SC_SNH, e.s_nh)
   PUTI(SC_SRC_DST, pack2(e.src, e.dst)) PUTI(SC_BR_IDX, pack2(e.bit_rate, e.br_idx))
   PUTI(SC_ID_MTPOS, pack2(e.id, e.mt_pos)) PUTI(SC_EV, pack2(e.ev_hwm, e.ev_cnt)) PUTI(SC_FLAGS, pack2(e.new_service, e.flags))
-  PUTF(SC_NEXTREL, -__builtin_inf()) PUTI(SC_HINT, pack2(-1, 0)) PUTF(SC_TSOON, -__builtin_inf())  // caches of the 8-lane kernels: unknown
+  PUTF(SC_NEXTREL, -__builtin_inf()) PUTI(SC_HINT, 0ull) PUTF(SC_TSOON, -__builtin_inf())  // caches of the 8-lane kernels: unknown
 #undef PUTF
 #undef PUTI
   if (lane < SC_COUNT) P.scal[e.env * ORL_SCAL_WORDS + lane] = v;

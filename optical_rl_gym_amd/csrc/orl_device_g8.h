@@ -37,7 +37,8 @@ __device__ __forceinline__ double g8_min(double v) {
 struct EnvG {
   double now, at, ht, g_thr, g_comp, g_last, next_rel, t_soon;
   i64 sp, sa, esp, esa, brq, brp, ebrq, ebrp, s_br, s_nh;
-  int src, dst, bit_rate, br_idx, id, mt_pos, ev_hwm, ev_cnt, new_service, flags, hint;
+  int src, dst, bit_rate, br_idx, id, mt_pos, ev_hwm, ev_cnt, new_service, flags;
+  int nfree, pop_idx;  // free-slot stack: entries known, and the top entry (the next slot a push takes), -1 if none
   i64 env;
   u64* bm;
   double* ls;
@@ -67,7 +68,14 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
   t = s[SC_ID_MTPOS]; e.id = (int)(u32)t; e.mt_pos = (int)(t >> 32);
   t = s[SC_EV]; e.ev_hwm = (int)(u32)t; e.ev_cnt = (int)(t >> 32);
   t = s[SC_FLAGS]; e.new_service = (int)(u32)t; e.flags = (int)(t >> 32);
-  t = s[SC_HINT]; e.hint = (int)(u32)t;
+  {
+    // the free-slot stack travels in the record; only its top entry is kept (one push per step at most)
+    const u64 f0 = s[SC_FREE0], f1 = s[SC_FREE1], f2 = s[SC_FREE2], f3 = s[SC_FREE3];
+    t = s[SC_HINT]; e.nfree = (int)(u32)t;
+    const int top = e.nfree - 1;
+    const u64 w = (top >> 2) == 0 ? f0 : (top >> 2) == 1 ? f1 : (top >> 2) == 2 ? f2 : f3;
+    e.pop_idx = (top >= 0) ? (int)((w >> (16 * (top & 3))) & 0xffffu) : -1;
+  }
   e.env = env;
   e.bm = P.bitmap + env * P.bm_words;
   e.ls = P.lstat + env * 4 * P.E;
@@ -91,7 +99,7 @@ __device__ __forceinline__ void env_store(const DevParams& P, const EnvG& e, int
   s[SC_SBR] = (u64)e.s_br; s[SC_SNH] = (u64)e.s_nh;
   s[SC_SRC_DST] = pack2(e.src, e.dst); s[SC_BR_IDX] = pack2(e.bit_rate, e.br_idx);
   s[SC_ID_MTPOS] = pack2(e.id, e.mt_pos); s[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
-  s[SC_FLAGS] = pack2(e.new_service, e.flags); s[SC_HINT] = pack2(e.hint, 0);
+  s[SC_FLAGS] = pack2(e.new_service, e.flags); s[SC_HINT] = pack2(e.nfree, 0);
   u64 np_ = (u64)(u32)P.n_paths[e.src * P.N + e.dst];
   P.svc_desc[e.env] = (u64)(u32)((e.src * P.N + e.dst) * P.K) | ((u64)(u32)e.br_idx << 32) | (np_ << 48);
 }
@@ -237,16 +245,35 @@ __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane,
   return hops;
 }
 
+// a released slot goes onto the env's free-slot stack (dropped when the stack is full: the next rebuild finds it)
+__device__ __forceinline__ void free_push(EnvG& e, int gl, int slot) {
+  if (e.nfree < ORL_FREE_SLOTS) {
+    if (gl == 0) ((unsigned short*)(e.scal + SC_FREE0))[e.nfree] = (unsigned short)slot;
+    e.nfree++;
+  }
+}
+
+#if defined(ORL_TIMING) && ORL_TIMING == 3
+__device__ unsigned long long g_dbg[16];  // event counts of ev_push (orl_batch_debug_prof, slots 0..15)
+#define ORL_DBG(k, v) do { if ((lane & 7) == 0) atomicAdd(&g_dbg[k], (unsigned long long)(v)); } while (0)
+#else
+#define ORL_DBG(k, v) do { } while (0)
+#endif
 // ---- pending releases: slot i belongs to lane i % 8 -------------------------------------------------
 __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
   const int gl = lane & 7;
-  int idx = e.hint;
-  e.hint = -1;
-  if (idx < 0) {
-    // Top-down: pushes reuse the LOWEST freed slot (hint), so the low indices are dense and the holes sit near the
-    // high-water mark; the first 32-slot window from the top almost always has one.
+  // a slot for the entry: the top of the free-slot stack (fed by the releases and by the rebuild scan of control
+  // kernel B2); a dense table appends; only a table with holes nobody recorded is searched
+  int idx = -1;
+  ORL_DBG(0, 1); ORL_DBG(1, (e.pop_idx < 0 && e.ev_cnt < e.ev_hwm) ? 1 : 0); ORL_DBG(2, e.ev_hwm); ORL_DBG(3, e.ev_cnt);
+  if (e.pop_idx >= 0) {
+    idx = e.pop_idx;
+    e.pop_idx = -1;  // one push per launch; the remaining entries stay in the record
+    e.nfree--;
+  } else if (e.ev_cnt < e.ev_hwm) {
     for (int base = (e.ev_hwm - 1) & ~31; base >= 0 && idx < 0; base -= 32) {  // four 8-slot chunks requested together
       double t[4];
+      ORL_DBG(4, 1);
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         int i = base + 8 * c + gl;
@@ -266,6 +293,7 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
   if (gl == (idx & 7)) { e.ev_time[idx] = t; e.ev_info[idx] = info; }
   e.ev_cnt++;
   e.next_rel = t < e.next_rel ? t : e.next_rel;  // -inf (unknown) stays -inf
+  ORL_DBG(5, t < e.t_soon ? 1 : 0);
   if (t < e.t_soon) {
     // invariant of the soon list: it holds EVERY pending release earlier than t_soon
     double a[ORL_SOON_PER_LANE];
@@ -308,7 +336,7 @@ __device__ __forceinline__ void release_one(const DevParams& P, EnvG& e, int lan
   const int pidx = (int)(info & 0xffffffu), s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
   const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
   e.ev_cnt--;
-  e.hint = (e.hint < 0 || bi < e.hint) ? bi : e.hint;
+  free_push(e, gl, bi);
   const int hops_r = path_apply<ENV, W>(P, e, lane, pidx, core, s0, n, true);
   e.s_br -= br;
   e.s_nh -= (i64)n * hops_r;
@@ -367,7 +395,7 @@ __device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lan
   for (int it = 0; it < 4 && e.ev_hwm > 0; it++) {
     int i = e.ev_hwm - 1;
     double t = gget((gl == (i & 7)) ? e.ev_time[i] : 0.0, i & 7, lane);
-    if (t == __builtin_inf()) { e.ev_hwm--; if (e.hint == i) e.hint = -1; } else break;
+    if (t == __builtin_inf()) { e.ev_hwm--; e.nfree = 0; } else break;  // the stack may name slots beyond the window: drop it
   }
 }
 

@@ -19,23 +19,38 @@
 namespace orl {
 namespace sp {
 
-// -DORL_TIMING: shader-clock cycles per phase, summed over the first lane of every wavefront (orl_batch_debug_prof)
+// -DORL_TIMING=1 (control kernel B2) / =2 (merged slot-scan + control kernel A): shader-clock cycles per phase, per
+// wavefront, summed on the host (orl_batch_debug_prof, tools/phase_prof.py)
 #define ORL_PROF_SLOTS 32
 #define ORL_PROF_WAVES 16384
 struct Prof { long long t; unsigned long long acc[16]; };
 #ifdef ORL_TIMING
 __device__ unsigned long long g_prof[ORL_PROF_WAVES * ORL_PROF_SLOTS];
-#define ORL_PROF_BEGIN() Prof prof; for (int k_ = 0; k_ < 16; k_++) prof.acc[k_] = 0; prof.t = clock64()
-#define ORL_PROF(k) do { long long n_ = clock64(); prof.acc[k] += (unsigned long long)(n_ - prof.t); prof.t = n_; } while (0)
-#define ORL_PROF_END() do { if ((threadIdx.x & 63) == 0) { const size_t w_ = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % ORL_PROF_WAVES; \
-    unsigned long long* g_ = g_prof + w_ * ORL_PROF_SLOTS; \
+#define ORL_PROF_BEGIN_() for (int k_ = 0; k_ < 16; k_++) prof.acc[k_] = 0; prof.t = clock64()
+#define ORL_PROF_(k) do { long long n_ = clock64(); prof.acc[k] += (unsigned long long)(n_ - prof.t); prof.t = n_; } while (0)
+#define ORL_PROF_END_() do { if ((threadIdx.x & 63) == 0) { const size_t w_ = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % ORL_PROF_WAVES; \
+    unsigned long long* g_ = ::orl::sp::g_prof + w_ * ORL_PROF_SLOTS; \
     unsigned long long tot_ = 0; for (int k_ = 0; k_ < 14; k_++) { g_[k_] += prof.acc[k_]; tot_ += prof.acc[k_]; } \
     if (tot_ > g_[15]) g_[15] = tot_;  /* slowest launch of this wavefront */ \
     if (tot_ > 60000) { g_[14] += 1; for (int k_ = 0; k_ < 14; k_++) g_[16 + k_] += prof.acc[k_]; } } } while (0)
+#endif
+#if defined(ORL_TIMING) && ORL_TIMING == 1
+#define ORL_PROF_BEGIN() ORL_PROF_BEGIN_()
+#define ORL_PROF(k) ORL_PROF_(k)
+#define ORL_PROF_END() ORL_PROF_END_()
 #else
-#define ORL_PROF_BEGIN() Prof prof
+#define ORL_PROF_BEGIN() do { } while (0)
 #define ORL_PROF(k) do { } while (0)
 #define ORL_PROF_END() do { } while (0)
+#endif
+#if defined(ORL_TIMING) && ORL_TIMING == 2
+#define ORL_PROFA_BEGIN() ORL_PROF_BEGIN_()
+#define ORL_PROFA(k) ORL_PROF_(k)
+#define ORL_PROFA_END() ORL_PROF_END_()
+#else
+#define ORL_PROFA_BEGIN() do { } while (0)
+#define ORL_PROFA(k) do { } while (0)
+#define ORL_PROFA_END() do { } while (0)
 #endif
 
 using g8::EnvG;
@@ -114,12 +129,13 @@ __device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, 
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W, bool DEFER_GCOMP>
 __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             double* info_out);
+                                             double* info_out, Prof& prof);
 
 // MERGE: device-resident loop without info — the work of control kernel B1 (next service) is done right here, on the env
 // record that is already in registers; only the network-compactness update has to wait for the row kernel (k_ctrl_b2).
 template <int ENV, int W, bool MERGE = false>
-__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, const int4* given = nullptr) {
+__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, Prof& prof,
+                                       const int4* given = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   int cnt = 0, core = 0, slot = 0, n = 1;
   PathRec rec;
@@ -159,6 +175,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
       path = K; slot = S; mod = P.M; core = P.C;
     }
     const int path0 = path, slot0 = slot;
+    ORL_PROFA(2);
     double* info_out = want_info ? P.info + env * P.n_info : nullptr;
     if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && info_out) {
       // compactness before the provision; k_ctrl_b turns it into the difference (rmsa_env.py:168-170, 250-251)
@@ -195,6 +212,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         double len = P.path_length[pidx];
         ok = (len < P.lmax_xt[mod]) && (len < P.lmax_snr[mod * P.n_br + e.br_idx]);
       }
+      ORL_PROFA(3);
       if (ok) {
         const int hops = path_rec_byte(rec, 0);
         cnt = hops;
@@ -209,6 +227,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         e.esa += 1;
         accepted = true;
         g8::ev_push(P, e, lane, e.at + e.ht, ev_pack(pidx, slot, n, core, e.bit_rate));
+        ORL_PROFA(4);
       }
     }
     if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
@@ -229,12 +248,15 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
       e.scal[SC_ACC] = pack2(accepted ? 1 : 0, core);
       e.scal[SC_NOWA] = (u64)__double_as_longlong(e.now);
     }
-    if (MERGE) service_part<ENV, W, true>(P, e, env, lane, 1, accepted, core, nullptr);
+    ORL_PROFA(5);
+    if (MERGE) service_part<ENV, W, true>(P, e, env, lane, 1, accepted, core, nullptr, prof);
     g8::env_store(P, e, gl);
+    ORL_PROFA(8);
   }
   const size_t base = wave_reserve(P, cnt, P.q_cnt_a, lane);
   for (int h = gl; h < cnt; h += 8)
     item_store(P.q_a, base + h, make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), 0ull, (u64)(u32)core, 0));
+  ORL_PROFA(9);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -242,7 +264,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W, bool DEFER_GCOMP>
 __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             double* info_out) {
+                                             double* info_out, Prof& prof) {
   const int gl = lane & 7;
   g8::RngG rng;
   g8::rng_fill(e, rng, gl);
@@ -298,7 +320,9 @@ __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 en
     }
   }
   e.new_service = 0;
+  ORL_PROFA(6);
   g8::next_service<ENV, W, false>(P, e, lane, rng);  // the due releases are k_ctrl_b2's job
+  ORL_PROFA(7);
   bool done = (e.esp == (i64)P.episode_length);
   if (done && auto_reset) {
     e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
@@ -313,8 +337,9 @@ __device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid,
   EnvG e;
   g8::env_load(P, e, env);
   const u64 acc = e.scal[SC_ACC];
+  Prof prof;
   service_part<ENV, W, false>(P, e, env, lane, auto_reset, ((u32)acc & 1u) != 0, (int)(acc >> 32),
-                              want_info ? P.info + env * P.n_info : nullptr);
+                              want_info ? P.info + env * P.n_info : nullptr, prof);
   g8::env_store(P, e, lane & 7);
 }
 
@@ -352,7 +377,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       int bi[NS + 1];
 #pragma unroll
       for (int k = 0; k <= NS; k++) { bt[k] = INF; bi[k] = 0; }
-      int nd = 0, top = -1;
+      int nd = 0, top = -1, h0 = 0x7fffffff, h1 = 0x7fffffff;  // h0 < h1: the first two empty slots this lane sees
       for (int base = gl; base < e.ev_hwm; base += 64) {
         double tt[8];
 #pragma unroll
@@ -366,6 +391,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           const int i = base + 8 * k;
           nd += (t <= e.now) ? 1 : 0;
           top = (t != INF) ? i : top;  // i grows along the scan; slots beyond ev_hwm read as INF
+          if (t == INF) { h1 = (h0 != 0x7fffffff && h1 == 0x7fffffff) ? i : h1; h0 = (h0 == 0x7fffffff) ? i : h0; }
           if (t < bt[NS]) {
             bt[NS] = t; bi[NS] = i;
 #pragma unroll
@@ -387,7 +413,15 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       // the scan saw every slot: shrink the window to the highest occupied one (a stale larger window is harmless, so
       // the steps between two rebuilds do not bother)
       e.ev_hwm = g8_max(top) + 1;
-      if (e.hint >= e.ev_hwm) e.hint = -1;
+      {
+        // ... and refill the free-slot stack from what the scan saw: up to two empty slots per lane below the new window
+        const bool v0 = h0 < e.ev_hwm, v1 = h1 < e.ev_hwm;
+        const u32 b0 = gballot(v0, lane), b1 = gballot(v1, lane);
+        unsigned short* fs = (unsigned short*)(e.scal + SC_FREE0);
+        if (v0) fs[__popc(b0 & ((1u << gl) - 1u))] = (unsigned short)h0;
+        if (v1) fs[__popc(b0) + __popc(b1 & ((1u << gl) - 1u))] = (unsigned short)h1;
+        e.nfree = __popc(b0) + __popc(b1);
+      }
       ORL_PROF(5);
     }
     // this lane's candidate: the earliest due entry of its list slots (equal times: lower event slot first)
@@ -479,7 +513,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
       const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
       e.ev_cnt--;
-      e.hint = (e.hint < 0 || bi < e.hint) ? bi : e.hint;
+      g8::free_push(e, gl, bi);
       sink_add(sink, rec, core, s0, n, lane);
       e.s_br -= br;
       e.s_nh -= (i64)n * path_rec_byte(rec, 0);
@@ -505,6 +539,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 template <int ENV, int W>
 __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid, int lane, u32* s_tally, SinkEntry* s_tab) {
   const int gl = lane & 7, E = P.E;
+  Prof prof;
   ORL_PROF_BEGIN();
   {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
     u32* ty = s_tally + 32 * 8 * (int)(threadIdx.x >> 6);
@@ -522,7 +557,7 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
   double next_rel = 0.0, t_soon = 0.0;
   i64 s_br = 0, s_nh = 0;
   u64 ev = 0, acc_word = 0;
-  int hint = -1;
+  int nfree = 0;
   double gc = 0.0;
   bool gc_pending = false;
   ORL_PROF(1);
@@ -537,7 +572,8 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
     e.s_nh = (i64)s[SC_SNH];
     u64 t = s[SC_EV];
     e.ev_hwm = (int)(u32)t; e.ev_cnt = (int)(t >> 32);
-    e.hint = (int)(u32)s[SC_HINT];
+    e.nfree = (int)(u32)s[SC_HINT];
+    e.pop_idx = -1;
     e.flags = 0;
     e.bm = P.bitmap + env * P.bm_words;
     e.ls = P.lstat + env * 4 * P.E;
@@ -560,7 +596,7 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
     e.soon_i = P.soon_i + env * ORL_SOON;
     ORL_PROF(3);
     release_soon<ENV, W>(P, e, lane, sink, soon, prof);
-    next_rel = e.next_rel; t_soon = e.t_soon; s_br = e.s_br; s_nh = e.s_nh; ev = pack2(e.ev_hwm, e.ev_cnt); hint = e.hint;
+    next_rel = e.next_rel; t_soon = e.t_soon; s_br = e.s_br; s_nh = e.s_nh; ev = pack2(e.ev_hwm, e.ev_cnt); nfree = e.nfree;
   }
   ORL_PROF(9);
   const int cnt = g8_sum(sink.active ? sink.cnt : 0);
@@ -587,6 +623,7 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
       // untouched and k_rel_serial (flag bit 16) releases them in place
       if (gc_pending) s[SC_GCOMP] = (u64)__double_as_longlong(gc);
       if (gc_pending || sink.deferred) s[SC_ACC] = acc_word | (sink.deferred ? (1ull << 16) : 0ull);
+      s[SC_HINT] = pack2(nfree, 0);  // also when deferred: a rebuild may have rewritten the free-slot stack
     }
     if (!sink.deferred) {
       if (soon.dirty) {
@@ -602,7 +639,6 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
         s[SC_SBR] = (u64)s_br;
         s[SC_SNH] = (u64)s_nh;
         s[SC_EV] = ev;
-        s[SC_HINT] = pack2(hint, 0);
       }
     }
   }

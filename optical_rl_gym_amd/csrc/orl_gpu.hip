@@ -281,7 +281,8 @@ __global__ void __launch_bounds__(256, ORL_STEP8_WAVES) k_step8(DevParams P, int
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_a(DevParams P, int want_info) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
-  sp::ctrl_a<ENV, W, false>(P, env, env < P.B, lane_id(), want_info != 0);
+  sp::Prof prof;
+  sp::ctrl_a<ENV, W, false>(P, env, env < P.B, lane_id(), want_info != 0, prof);
 }
 // device-policy loop: slot-scan and control kernel A in one launch (same 8-lanes-per-env layout; the action never
 // leaves the registers, the link rows the scan just read are still in cache for the validation)
@@ -291,13 +292,17 @@ __global__ void __launch_bounds__(256) k_policy_ctrl_a(DevParams P, int pol) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   const bool valid = env < P.B;
   const i64 env0 = env - ((lane >> 3));  // first env of this wavefront
+  sp::Prof prof;
+  ORL_PROFA_BEGIN();
   u64 d = valid ? P.svc_desc[env] : 0ull;
   int a[4];
   policy_g<ENV, W, 8>(P, P.bitmap + env0 * P.bm_words + (size_t)(lane >> 3) * P.bm_words, valid, (int)(u32)d,
                       (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane, pol, a);
   const int4 av = make_int4(a[0], a[1], a[2], a[3]);
   if (valid && (lane & 7) == 0) *(int4*)(P.actions + env * 4) = av;
-  sp::ctrl_a<ENV, W, true>(P, env, valid, lane, false, &av);
+  ORL_PROFA(1);
+  sp::ctrl_a<ENV, W, true>(P, env, valid, lane, false, prof, &av);
+  ORL_PROFA_END();
 }
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_b1(DevParams P, int auto_reset, int want_info) {
@@ -1153,7 +1158,12 @@ extern "C" int orl_batch_debug_prof(orl_batch* b, uint64_t* out32, int reset) {
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   memset(out32, 0, 32 * 8);
-#ifdef ORL_TIMING
+#if defined(ORL_TIMING) && ORL_TIMING == 3
+  {
+    HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g8::g_dbg), 16 * 8));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g8::g_dbg), z, 16 * 8)); }
+  }
+#elif defined(ORL_TIMING)
   {
     std::vector<unsigned long long> h((size_t)ORL_PROF_WAVES * ORL_PROF_SLOTS);
     HIPCHK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(sp::g_prof), h.size() * 8));
