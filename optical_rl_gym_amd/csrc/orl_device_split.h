@@ -740,5 +740,133 @@ __device__ __forceinline__ void row_item(const DevParams& P, const Item it, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// row kernel, one LANE per work item (the form the device uses): the whole link row (W words) sits in the lane's
+// registers, so the row statistics are plain per-lane bit arithmetic without cross-lane steps, a wavefront retires
+// 64 items instead of 8, and a 65 536-env launch is a single round of ~2 700 wavefronts instead of four rounds of
+// 6 144.  Same arithmetic, expression for expression, as row_item above.
+// ---------------------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat& st, int& max_empty, int& edge) {
+  int nu = 0, lo = 1 << 20, hi = 0, free_ = 0, nf = 0, best = 0, c = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) {
+    const u64 maskw = word_mask_lo(S - 64 * w);
+    const u64 used = ~a[w] & maskw;
+    const u64 prev_top = (w == 0) ? 0ull : (a[w - 1] >> 63);
+    const u64 carry_a = (w == 0) ? 0ull : prev_top;
+    const u64 carry_u = (w == 0) ? 0ull : (prev_top ^ 1ull);  // slot 64w-1 < S for every w < W
+    nu += __popcll(used & ~((used << 1) | carry_u));
+    if (used) {
+      const int l = 64 * w + (int)__builtin_ctzll(used);
+      lo = l < lo ? l : lo;
+      hi = 64 * w + 64 - (int)__builtin_clzll(used);  // w ascending: the last word with a used slot wins
+    }
+    free_ += __popcll(a[w]);
+    nf += __popcll(a[w] & ~((a[w] << 1) | carry_a));
+    // longest run of free slots (runs continue across word boundaries)
+    if (a[w] == ~0ull) {
+      c += 64;
+      best = c > best ? c : best;
+    } else {
+      const int lead = (int)__builtin_ctzll(~a[w]);
+      const int inner = word_longest_run(a[w]);
+      const int cand = (c + lead) > inner ? (c + lead) : inner;
+      best = cand > best ? cand : best;
+      c = (int)__builtin_clzll(~a[w]);
+    }
+  }
+  const bool two = nu > 1;
+  int fb = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) {  // free blocks strictly inside [lambda_min, lambda_max)
+    const u64 in = two ? (a[w] & word_range(lo - 64 * w, hi - 64 * w)) : 0ull;
+    const bool prev_top = (w > 0) && ((a[w > 0 ? w - 1 : 0] >> 63) != 0ull);
+    const u64 carry_i = (prev_top && (64 * w - 1 >= lo) && (64 * w - 1 < hi)) ? 1ull : 0ull;
+    fb += __popcll(in & ~((in << 1) | carry_i));
+  }
+  st.nu = nu; st.lo = lo; st.hi = hi; st.occ = two ? hi - lo : 0; st.fb = fb; st.free_ = free_; st.nf = nf;
+  max_empty = best;
+  const int tw = (S - 1) >> 6, tb = (S - 1) & 63;
+  int top_bit = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) top_bit = (w == tw) ? (int)((a[w] >> tb) & 1ull) : top_bit;
+  edge = (int)(a[0] & 1ull) + top_bit;
+}
+
+template <int ENV, int W>
+__device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it, int now_slot) {
+  const int E = P.E, S = P.S;
+  const i64 env = (i64)(u32)it.a.x;
+  const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
+  const bool release = ((it.a.x >> 44) & 1) != 0;
+  const u64 cores = it.b.y;
+  u64* bm = P.bitmap + env * P.bm_words;
+  int* cs = P.core_sums + env * P.cs_words;
+  double* ls = P.lstat + env * 4 * E;
+  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + now_slot]);
+  const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
+  double last_update = ls23.y;
+  double util = ls01.x, frag = ls01.y, comp = ls23.x;
+  for (int k = 0; k < nmask; k++) {
+    const int core = (int)((cores >> (5 * k)) & 0x1f);
+    const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
+    const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
+    u64* row = bm + (size_t)(core * E + link) * W;
+    int* sump = cs + 2 * P.C + core * E + link;
+    u64 a[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) a[w] = row[w];
+    const int pk = (ENV != ENV_RWA) ? *sump : 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+      const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
+      a[w] = release ? (a[w] | m) : (a[w] & ~m);
+      if (m) row[w] = a[w];
+    }
+    RowStat after;
+    int max_empty = 0, edge = 0;
+    if (ENV != ENV_RWA) {
+      row_stat_lane<W>(a, S, after, max_empty, edge);
+      // this row's contribution to the compactness sums of its core
+      const int d_occ = after.occ - (pk >> 16), d_fb = after.fb - (pk & 0xffff);
+      *sump = (after.occ << 16) | after.fb;
+      if (d_occ) atomicAdd(cs + 2 * core, d_occ);
+      if (d_fb) atomicAdd(cs + 2 * core + 1, d_fb);
+    } else {
+      int f = 0;
+#pragma unroll
+      for (int w = 0; w < W; w++) f += __popcll(a[w]);
+      after.free_ = f;
+    }
+    if (now > 0) {
+      if (k == 0) {  // _update_link_stats on the row of the first touch (rmsa_env.py:464-543)
+        const double time_diff = now - last_update;
+        const int free_ = after.free_;
+        double cur_util = (double)(S - free_) / (double)S;
+        util = ((util * last_update) + (cur_util * time_diff)) / now;
+        if (ENV != ENV_RWA) {
+          double cur_frag = 0.0, cur_comp = 0.0;
+          if (free_ > 0) {
+            int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
+            cur_frag = 1.0 - ((double)me / (double)free_);
+            if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
+            else cur_comp = 1.0;
+          }
+          frag = ((frag * last_update) + (cur_frag * time_diff)) / now;
+          comp = ((comp * last_update) + (cur_comp * time_diff)) / now;
+        }
+      } else {
+        // the same link touched again in the same step: the reference's update has last_update == now and
+        // time_diff == 0, i.e. new = ((old * now) + (cur * 0.0)) / now with a finite cur
+        util = ((util * now) + 0.0) / now;
+        if (ENV != ENV_RWA) { frag = ((frag * now) + 0.0) / now; comp = ((comp * now) + 0.0) / now; }
+      }
+    }
+  }
+  if (now > 0) *(double2*)(ls + 4 * link) = make_double2(util, frag);
+  *(double2*)(ls + 4 * link + 2) = make_double2(comp, now);
+}
+
 }  // namespace sp
 }  // namespace orl

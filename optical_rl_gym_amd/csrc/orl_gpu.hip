@@ -342,6 +342,35 @@ __global__ void __launch_bounds__(256) k_rows(DevParams P, int phase) {
   }
 }
 
+// lane-per-item row kernel: one workgroup covers ORL_ROWS1_GROUPS control workgroups (32 envs each, ~75 items) and maps
+// its threads onto the dense item index over their 4 * ORL_ROWS1_GROUPS wavefront regions
+#ifndef ORL_ROWS1_GROUPS
+#define ORL_ROWS1_GROUPS 3
+#endif
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_rows1(DevParams P, int phase) {
+  constexpr int NR = 4 * ORL_ROWS1_GROUPS;
+  const u32 r0 = blockIdx.x * NR;
+  const u32 n_regions = (u32)((P.B + 31) / 32) * 4u;  // regions the control kernels of this launch wrote
+  const u32* cnt = (phase ? P.q_cnt_b : P.q_cnt_a) + r0;
+  u32 cum[NR + 1];
+  cum[0] = 0;
+#pragma unroll
+  for (int j = 0; j < NR; j++) cum[j + 1] = cum[j] + ((r0 + j < n_regions) ? cnt[j] : 0u);
+  const ulonglong2* q = (phase ? P.q_b : P.q_a) + (size_t)r0 * P.q_wave * 2;
+  for (u32 idx = threadIdx.x; idx < cum[NR]; idx += 256) {
+    u32 j = 0, base = 0;
+#pragma unroll
+    for (int t = 1; t < NR; t++)
+      if (idx >= cum[t]) { j = (u32)t; base = cum[t]; }
+    const size_t at = (size_t)j * P.q_wave + (idx - base);
+    sp::Item it;
+    it.a = q[2 * at];
+    it.b = q[2 * at + 1];
+    sp::row_item_lane<ENV, W>(P, it, phase ? SC_NOW : SC_NOWA);
+  }
+}
+
 template <int ENV, int W>
 __global__ void __launch_bounds__(64) k_obs(DevParams P) {
   const i64 env = blockIdx.x;
@@ -417,7 +446,8 @@ struct orl_batch {
   // sub-batches for the device-resident run loop: contiguous env ranges, each driven on its own stream so that the
   // short bandwidth-bound slot-scan of one range overlaps the long issue-bound step kernel of another
   std::vector<DevParams> subs;
-  std::vector<hipStream_t> sub_streams;
+  std::vector<hipStream_t> sub_streams;    // stream of sub-batch k (several sub-batches may share one)
+  std::vector<hipStream_t> owned_streams;  // the distinct streams behind sub_streams
   const DevParams* view;
   hipStream_t view_stream;
 };
@@ -552,19 +582,19 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
   hipStream_t VS = b->view ? b->view_stream : b->stream;
   if (b->step_impl == 1) {
     dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
-    dim3 gr(gc.x * ORL_ROWS_SPLIT);  // the row kernel runs ORL_ROWS_SPLIT workgroups per control workgroup's item region
+    dim3 gr((gc.x + ORL_ROWS1_GROUPS - 1) / ORL_ROWS1_GROUPS);  // lane-per-item row kernel
     const size_t lds_b2 = (size_t)32 * VP.E * sizeof(sp::SinkEntry);
 #define CALLW(WW)                                                                                      \
   do {                                                                                                 \
     if (fused_policy >= 0) { hipLaunchKernelGGL((k_policy_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, fused_policy); ORL_TK("k_policy_ctrl_a"); } \
     else { hipLaunchKernelGGL((k_ctrl_a<EE, WW>), gc, blk, 0, VS, VP, want_info); ORL_TK("k_ctrl_a"); } \
-    hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 0);                                       \
+    hipLaunchKernelGGL((k_rows1<EE, WW>), gr, blk, 0, VS, VP, 0);                                       \
     ORL_TK("k_rows(provision)");                                                                       \
     if (fused_policy < 0) { hipLaunchKernelGGL((k_ctrl_b1<EE, WW>), gc, blk, 0, VS, VP, auto_reset, want_info); ORL_TK("k_ctrl_b1"); } \
     if (lds_b2 > 48 * 1024) hipFuncSetAttribute((const void*)k_ctrl_b2<EE, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b2); \
     hipLaunchKernelGGL((k_ctrl_b2<EE, WW>), gc, blk, lds_b2, VS, VP);                                     \
     ORL_TK("k_ctrl_b2");                                                                               \
-    hipLaunchKernelGGL((k_rows<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
+    hipLaunchKernelGGL((k_rows1<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
     ORL_TK("k_rows(release)");                                                                         \
     hipLaunchKernelGGL((k_rel_serial<EE, WW>), gc, blk, 0, VS, VP);                                    \
     ORL_TK("k_rel_serial");                                                                            \
@@ -759,8 +789,15 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   HIPCHK(hipEventCreate(&b->ev1));
   {
     // measured on MI355X, cfg2, B = 65 536: 1 stream 2.02e8 env-steps/s, 2 streams 2.38e8, 4 streams 2.27e8, 8 streams 2.09e8
-    int n_sub = (n_envs >= 2 * 8192) ? 2 : 1;
-    if (const char* sv = getenv("ORL_STREAMS")) { int v = atoi(sv); if (v >= 1 && v <= 16) n_sub = v; }
+    int n_streams = (n_envs >= 2 * 8192) ? 2 : 1;
+    if (const char* sv = getenv("ORL_STREAMS")) { int v = atoi(sv); if (v >= 1 && v <= 16) n_streams = v; }
+    int n_sub = n_streams;  // ORL_SUBS > ORL_STREAMS: sub-batch k runs on stream k % n_streams
+    if (const char* sv = getenv("ORL_SUBS")) { int v = atoi(sv); if (v >= n_streams && v <= 64) n_sub = v; }
+    for (int i = 0; i < n_streams; i++) {
+      hipStream_t st;
+      HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      b->owned_streams.push_back(st);
+    }
     i64 per = ((n_envs + n_sub - 1) / n_sub + 31) / 32 * 32;  // slot-scan workgroups cover 32 consecutive envs
     for (i64 lo = 0; lo < n_envs; lo += per) {
       DevParams q = P;
@@ -773,10 +810,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
       if (q.obs) { q.obs += lo * P.obs_dim; q.term_obs += lo * P.obs_dim; }
+      b->sub_streams.push_back(b->owned_streams[b->subs.size() % (size_t)n_streams]);
       b->subs.push_back(q);
-      hipStream_t st;
-      HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-      b->sub_streams.push_back(st);
     }
   }
   // MT state upload + conversion, then the constructor's full reset
@@ -817,7 +852,7 @@ extern "C" void orl_batch_destroy(orl_batch* b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
-  for (hipStream_t st : b->sub_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  for (hipStream_t st : b->owned_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   for (void* p : b->allocs) hipFree(p);
@@ -909,7 +944,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   if (multi) {
     // every sub-batch runs its own policy -> step -> policy -> ... chain on its own stream
-    for (size_t k = 0; k < b->subs.size(); k++) HIPCHK(hipStreamWaitEvent(b->sub_streams[k], b->ev0, 0));
+    for (hipStream_t st : b->owned_streams) HIPCHK(hipStreamWaitEvent(st, b->ev0, 0));
     for (int64_t s = 0; s < n_steps; s++) {
       for (size_t k = 0; k < b->subs.size(); k++) {
         b->view = &b->subs[k];
@@ -919,10 +954,10 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     }
     b->view = nullptr;
     b->view_stream = nullptr;
-    for (size_t k = 0; k < b->subs.size(); k++) {
+    for (hipStream_t st : b->owned_streams) {
       hipEvent_t e;
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      HIPCHK(hipEventRecord(e, b->sub_streams[k]));
+      HIPCHK(hipEventRecord(e, st));
       HIPCHK(hipStreamWaitEvent(b->stream, e, 0));
       HIPCHK(hipEventDestroy(e));
     }
@@ -1184,7 +1219,7 @@ extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
   if (!b) return -1;
   if (hipSetDevice(b->device) != hipSuccess) return -1;
   hipStreamSynchronize(b->stream);
-  for (hipStream_t st : b->sub_streams) hipStreamSynchronize(st);
+  for (hipStream_t st : b->owned_streams) hipStreamSynchronize(st);
   u32 v = 0;
   if (hipMemcpy(&v, b->P.q_stat, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int64_t)v;
