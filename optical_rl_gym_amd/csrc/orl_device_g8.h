@@ -254,8 +254,8 @@ __device__ __forceinline__ void free_push(EnvG& e, int gl, int slot) {
 }
 
 #if defined(ORL_TIMING) && ORL_TIMING == 3
-__device__ unsigned long long g_dbg[16];  // event counts of ev_push (orl_batch_debug_prof, slots 0..15)
-#define ORL_DBG(k, v) do { if ((lane & 7) == 0) atomicAdd(&g_dbg[k], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long g_dbg[64];  // event counts of ev_push (orl_batch_debug_prof, slots 0..15)
+#define ORL_DBG(k, v) do { if ((lane & 7) == 0) atomicAdd(&::orl::g8::g_dbg[k], (unsigned long long)(v)); } while (0)
 #else
 #define ORL_DBG(k, v) do { } while (0)
 #endif

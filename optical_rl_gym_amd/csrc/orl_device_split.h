@@ -372,39 +372,75 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
   for (int round = 0; round < 64; round++) {
     int due_all = -1;  // number of due entries overall, known when this round scanned everything
     if (!(e.now < e.t_soon) || (round == 0 && sync_rebuild)) {
-      // rebuild: the NS + 1 earliest pending releases among this lane's slots (i % 8 == lane), kept sorted
-      double bt[NS + 1];
-      int bi[NS + 1];
+      // rebuild: the NS earliest pending releases among this lane's slots (i % 8 == lane).  The selection runs on
+      // 32-bit keys — quantised time-to-release (1/4096 time unit, saturating) above the slot's ordinal in the lane —
+      // so that keeping the NS + 1 smallest is a branch-free min/max chain per slot; 64-bit compare-and-select
+      // insertion made the rebuilding wavefronts, which set this kernel's duration, compute-bound.  The exact times of
+      // the chosen slots are re-read afterwards, and the horizon is a lower bound taken from the (NS+1)-th key (when
+      // it does not lie beyond the clock, the loop below releases what the list holds and rebuilds again).
+      u32 kb[NS + 1];
 #pragma unroll
-      for (int k = 0; k <= NS; k++) { bt[k] = INF; bi[k] = 0; }
+      for (int k = 0; k <= NS; k++) kb[k] = 0xffffffffu;
       int nd = 0, top = -1, h0 = 0x7fffffff, h1 = 0x7fffffff;  // h0 < h1: the first two empty slots this lane sees
-      for (int base = gl; base < e.ev_hwm; base += 64) {
+      const int hwm = e.ev_hwm;
+      for (int base = gl, ord = 0; base < hwm; base += 64, ord += 8) {
         double tt[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          int i = base + 8 * k;
-          tt[k] = (i < e.ev_hwm) ? e.ev_time[i] : INF;
+          const int i = base + 8 * k;
+          const double v = e.ev_time[i < hwm ? i : hwm - 1];
+          tt[k] = (i < hwm) ? v : INF;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
           const double t = tt[k];
           const int i = base + 8 * k;
           nd += (t <= e.now) ? 1 : 0;
-          top = (t != INF) ? i : top;  // i grows along the scan; slots beyond ev_hwm read as INF
-          if (t == INF) { h1 = (h0 != 0x7fffffff && h1 == 0x7fffffff) ? i : h1; h0 = (h0 == 0x7fffffff) ? i : h0; }
-          if (t < bt[NS]) {
-            bt[NS] = t; bi[NS] = i;
+          const bool empty = (t == INF);
+          top = empty ? top : i;  // i grows along the scan; slots beyond ev_hwm read as INF
+          h1 = (empty && h0 != 0x7fffffff && h1 == 0x7fffffff) ? i : h1;
+          h0 = (empty && h0 == 0x7fffffff) ? i : h0;
+          // time to release in 1/4096 units, offset by 2^19 so that overdue entries keep their order (a long
+          // inter-arrival gap leaves a dozen releases due at once), saturating at 2^23 - 1 (and for empty slots)
+          u32 q = (u32)__builtin_fmax(__builtin_fmin((t - e.now) * 4096.0 + 524288.0, 8388607.0), 0.0);
+          q = empty ? 8388607u : q;
+          u32 x = (q << 8) | (u32)(ord + k);  // 8 ordinal bits: ev_cap <= 2048 (checked on the host)
 #pragma unroll
-            for (int j = NS - 1; j >= 0; j--) {  // one insertion pass (strict <: equal times keep slot order)
-              const bool sw = bt[j + 1] < bt[j];
-              const double lo = sw ? bt[j + 1] : bt[j], hi = sw ? bt[j] : bt[j + 1];
-              const int li = sw ? bi[j + 1] : bi[j], hi_i = sw ? bi[j] : bi[j + 1];
-              bt[j] = lo; bt[j + 1] = hi; bi[j] = li; bi[j + 1] = hi_i;
-            }
+          for (int j = 0; j <= NS; j++) {  // sorted insertion: kb[] ascending
+            const u32 lo = kb[j] < x ? kb[j] : x;
+            x = kb[j] < x ? x : kb[j];
+            kb[j] = lo;
           }
         }
       }
-      const double T = g8::g8_min(bt[NS]);
+      // exact times of the NS chosen slots (just read: cache hits), in key order; equal keys keep slot order
+      double bt[NS];
+      int bi[NS];
+#pragma unroll
+      for (int k = 0; k < NS; k++) {
+        const bool any = (kb[k] >> 8) < 8388607u;
+        bi[k] = gl + 8 * (int)(kb[k] & 255u);
+        bt[k] = any ? e.ev_time[bi[k]] : INF;
+      }
+      // every slot this lane did not choose is no earlier than its (NS+1)-th key; two quanta lower covers the
+      // rounding of (t - now) * 4096 and of the sum below
+      const u32 qn = kb[NS] >> 8;
+      const double T_lane = (qn >= 8388607u) ? INF : (qn < 2u ? -INF : e.now + ((double)qn - 524290.0) * (1.0 / 4096.0));
+      const double T = g8::g8_min(T_lane);
+#if defined(ORL_TIMING) && ORL_TIMING == 3
+      if (!(e.now < T) && g8_sum(nd) > 0) {
+        unsigned long long was = 0;
+        if (gl == 0) was = atomicAdd(&g8::g_dbg[12], 1ull);
+        was = gget(was, 0, lane);
+        if (was == 0) {  // first occurrence: dump
+          if (gl == 0) { g8::g_dbg[16] = (u64)__double_as_longlong(e.now); g8::g_dbg[17] = (u64)__double_as_longlong(T); g8::g_dbg[18] = (u64)hwm; g8::g_dbg[19] = (u64)nd; }
+          g8::g_dbg[20 + gl] = ((u64)kb[NS] << 32) | kb[0];
+          g8::g_dbg[28 + gl] = (u64)__double_as_longlong(T_lane);
+          g8::g_dbg[36 + gl] = ((u64)kb[1] << 32) | kb[2];
+          g8::g_dbg[44 + gl] = (u64)__double_as_longlong(bt[0]);
+        }
+      }
+#endif
 #pragma unroll
       for (int k = 0; k < NS; k++) { st[k] = bt[k] < T ? bt[k] : INF; si[k] = bi[k]; }
       e.t_soon = T;
@@ -438,7 +474,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
     if (tot == 0) {
       if (e.now < e.t_soon) break;
       if (round > 0 || due_all >= 0) {  // nothing below the horizon is due although the clock passed it: equal times
-        if (!sink.active) { sink.deferred = true; return; }
+        if (!sink.active) { ORL_DBG(8, 1); ORL_DBG(9, e.now < e.t_soon ? 0 : 1); ORL_DBG(10, due_all > 0 ? 1 : 0); sink.deferred = true; return; }
         break;
       }
       continue;
@@ -475,6 +511,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         sink.active = g8_max((int)mx) <= ORL_IMASKS;
       }
       if (!sink.active) {
+        ORL_DBG(11, 1);
         sink.deferred = true;  // nothing has been touched: k_rel_serial takes this env
         return;
       }

@@ -711,6 +711,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     cap = (int)(load + 10.0 * sqrt(load) + 64.0);
   }
   P.ev_cap = (cap + 63) / 64 * 64;
+  if (b->step_impl == 1 && P.ev_cap > 2048) b->step_impl = 64;  // the split pipeline indexes release slots with 8 + 3 bits
   int words = C * P.E * b->wt;
   P.bm_words = (words + 1) & ~1;
   int rej = P.allow_rejection;
@@ -1195,8 +1196,8 @@ extern "C" int orl_batch_debug_prof(orl_batch* b, uint64_t* out32, int reset) {
   memset(out32, 0, 32 * 8);
 #if defined(ORL_TIMING) && ORL_TIMING == 3
   {
-    HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g8::g_dbg), 16 * 8));
-    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g8::g_dbg), z, 16 * 8)); }
+    HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g8::g_dbg), 64 * 8));  // debug builds: the caller passes 64 words
+    if (reset) { unsigned long long z[64] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g8::g_dbg), z, 64 * 8)); }
   }
 #elif defined(ORL_TIMING)
   {
