@@ -488,14 +488,26 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         // More releases than one item holds masks for (the release count per step is geometric: ~0.2 % of env-steps
         // exceed 8).  What matters is the count PER LINK: tally the touches of every due release first — every lane
         // walks its own slots, no side effects — and take item mode when no link exceeds the item form.
-        for (int i = gl; i < e.ev_hwm; i += 8) {
-          if (e.ev_time[i] <= e.now) {
-            const u64 info = e.ev_info[i];
-            const PathRec rec = path_rec_load(P, (int)(info & 0xffffffu));
-            const int hops = path_rec_byte(rec, 0);
-            for (int h = 0; h < hops; h++) {
-              const int link = path_rec_byte(rec, 2 + h);
-              atomicAdd(sink.tally + (link >> 2), 1u << (8 * (link & 3)));
+        // (release times requested eight at a time: one dependent load per slot made these rare wavefronts the
+        // stragglers that set the kernel's duration)
+        for (int base = gl; base < e.ev_hwm; base += 64) {
+          double tt[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int i = base + 8 * k;
+            const double v = e.ev_time[i < e.ev_hwm ? i : e.ev_hwm - 1];
+            tt[k] = (i < e.ev_hwm) ? v : INF;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            if (tt[k] <= e.now) {
+              const u64 info = e.ev_info[base + 8 * k];
+              const PathRec rec = path_rec_load(P, (int)(info & 0xffffffu));
+              const int hops = path_rec_byte(rec, 0);
+              for (int h = 0; h < hops; h++) {
+                const int link = path_rec_byte(rec, 2 + h);
+                atomicAdd(sink.tally + (link >> 2), 1u << (8 * (link & 3)));
+              }
             }
           }
         }
