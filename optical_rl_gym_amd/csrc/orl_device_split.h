@@ -137,6 +137,7 @@ template <int ENV, int W, bool MERGE = false>
 __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, Prof& prof,
                                        const int4* given = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.q_def[0] = 0u;  // control kernel B2 of this step appends
   int cnt = 0, core = 0, slot = 0, n = 1;
   PathRec rec;
   rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
@@ -672,6 +673,7 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
       // untouched and k_rel_serial (flag bit 16) releases them in place
       if (gc_pending) s[SC_GCOMP] = (u64)__double_as_longlong(gc);
       if (gc_pending || sink.deferred) s[SC_ACC] = acc_word | (sink.deferred ? (1ull << 16) : 0ull);
+      if (sink.deferred) P.q_def[16 + atomicAdd(P.q_def, 1u)] = (u32)env;  // rare: the row kernel's serial tail takes it
       s[SC_HINT] = pack2(nfree, 0);  // also when deferred: a rebuild may have rewritten the free-slot stack
     }
     if (!sink.deferred) {
@@ -857,16 +859,20 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
   const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
   double last_update = ls23.y;
   double util = ls01.x, frag = ls01.y, comp = ls23.x;
+  u64 a[W];
+  int pk = 0, prev_core = -1;
   for (int k = 0; k < nmask; k++) {
     const int core = (int)((cores >> (5 * k)) & 0x1f);
     const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
     const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
     u64* row = bm + (size_t)(core * E + link) * W;
     int* sump = cs + 2 * P.C + core * E + link;
-    u64 a[W];
+    if (core != prev_core) {  // several releases on the same core row keep working on the registers
 #pragma unroll
-    for (int w = 0; w < W; w++) a[w] = row[w];
-    const int pk = (ENV != ENV_RWA) ? *sump : 0;
+      for (int w = 0; w < W; w++) a[w] = row[w];
+      pk = (ENV != ENV_RWA) ? *sump : 0;
+      prev_core = core;
+    }
 #pragma unroll
     for (int w = 0; w < W; w++) {
       const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
@@ -879,7 +885,8 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
       row_stat_lane<W>(a, S, after, max_empty, edge);
       // this row's contribution to the compactness sums of its core
       const int d_occ = after.occ - (pk >> 16), d_fb = after.fb - (pk & 0xffff);
-      *sump = (after.occ << 16) | after.fb;
+      pk = (after.occ << 16) | after.fb;
+      *sump = pk;
       if (d_occ) atomicAdd(cs + 2 * core, d_occ);
       if (d_fb) atomicAdd(cs + 2 * core + 1, d_fb);
     } else {

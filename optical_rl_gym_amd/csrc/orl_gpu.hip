@@ -315,11 +315,6 @@ __global__ void __launch_bounds__(256) k_ctrl_b2(DevParams P) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   sp::ctrl_b2<ENV, W>(P, env, env < P.B, lane_id(), s_tally, (sp::SinkEntry*)orl_lds_raw);  // 32 x E entries
 }
-template <int ENV, int W>
-__global__ void __launch_bounds__(256) k_rel_serial(DevParams P) {
-  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
-  if (env < P.B) sp::rel_serial<ENV, W>(P, env, lane_id());
-}
 #ifndef ORL_ROWS_SPLIT
 #define ORL_ROWS_SPLIT 3
 #endif
@@ -368,6 +363,13 @@ __global__ void __launch_bounds__(256) k_rows1(DevParams P, int phase) {
     it.a = q[2 * at];
     it.b = q[2 * at + 1];
     sp::row_item_lane<ENV, W>(P, it, phase ? SC_NOW : SC_NOWA);
+  }
+  if (phase) {
+    // serial tail: envs whose releases did not fit the item form (about one env-step in 10^7) release them in place,
+    // 8 lanes per env; they have no items in this launch
+    const u32 nd = P.q_def[0];
+    for (u32 d = blockIdx.x * 32u + (threadIdx.x >> 3); d < nd; d += gridDim.x * 32u)
+      sp::rel_serial<ENV, W>(P, (i64)P.q_def[16 + d], lane_id());
   }
 }
 
@@ -596,8 +598,6 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
     ORL_TK("k_ctrl_b2");                                                                               \
     hipLaunchKernelGGL((k_rows1<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
     ORL_TK("k_rows(release)");                                                                         \
-    hipLaunchKernelGGL((k_rel_serial<EE, WW>), gc, blk, 0, VS, VP);                                    \
-    ORL_TK("k_rel_serial");                                                                            \
   } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
     ORL_FOR_ENV(PER_ENV)
@@ -765,9 +765,11 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     rc |= dalloc(b, &P.q_cnt_a, waves);
     rc |= dalloc(b, &P.q_cnt_b, waves);
     rc |= dalloc(b, &P.q_stat, 16);
+    rc |= dalloc(b, &P.q_def, 2 * B + 16 * 80);  // [B + 16] for the whole batch, then one region per sub-batch
     rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
     rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
     if (!rc) hipMemset(P.q_stat, 0, 16 * sizeof(u32));
+    if (!rc) hipMemset(P.q_def, 0, (2 * B + 16 * 80) * sizeof(u32));
   }
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
   rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
@@ -810,6 +812,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
+      q.q_def = P.q_def + (B + 16) + lo + 16 * b->subs.size();
       if (q.obs) { q.obs += lo * P.obs_dim; q.term_obs += lo * P.obs_dim; }
       b->sub_streams.push_back(b->owned_streams[b->subs.size() % (size_t)n_streams]);
       b->subs.push_back(q);
