@@ -1,18 +1,26 @@
-// orl_device_split.h — step() as a pipeline of lane-efficient kernels ("split" implementation).
+// orl_device_split.h — step() as a pipeline of kernels ("split" implementation; the default from 24 576 envs).
 //
-// One step of the batch =
-//   k_ctrl_a   8 lanes per env: decode + validate the action, counters, push the release event; every link row the
-//              provision touches becomes a 16-byte work item in queue A
-//   k_rows     8 lanes per ITEM (lane = 64-bit word of the link row), grid-stride over queue A: clear the slots,
-//              per-link statistics, compactness sums (integer atomics per env)
-//   k_ctrl_b   8 lanes per env: network statistics, info, next service (RNG, node pair, bit rate), due releases ->
-//              work items in queue B (one per touched link, up to four masks in release order)
-//   k_rows     over queue B: set the slots, statistics, sums
+// One policy + step of the batch (device-resident loop) =
+//   k_policy_ctrl_a  8 lanes per env: the slot scan (policy), then — the action still in registers — decode + validate,
+//                    counters, reward, the release push, network throughput, the next service (RNG, node pair, bit
+//                    rate), done / auto reset; every link row the provision touches becomes a 32-byte work item
+//   k_rows1(A)       one lane per item: clear the slots, per-link statistics, compactness sums (integer atomics)
+//   k_ctrl_b2        8 lanes per env: finish the network-compactness average (needs the sums after the provision),
+//                    find the due releases through the env's soon list -> one work item per touched link
+//   k_rows1(B)       one lane per item: set the slots, statistics, sums; tail: the rare envs whose releases did not
+//                    fit the item form release them in place (8 lanes per env)
+// Host-driven step() (agent in the loop, info wanted) launches k_ctrl_a / k_ctrl_b1 instead of the merged kernel.
+//
 // Why: in the monolithic kernels the row work (bit tricks + float64 running averages) ran under per-env control
 // flow — one or two link rows per pass, multiplied by the worst hop count and release count among the envs sharing a
-// wavefront.  Flattened into a queue, every 8-lane group of the row kernel always has a row to work on, and the
-// control kernels shrink to the genuinely serial part.  Semantics, operation order of every float64 expression and
-// the reference line ranges are those of orl_device.h / orl_device_g8.h; the parity suite runs against this path.
+// wavefront.  Flattened into queues, the row kernel is a flat loop over independent items and the control kernels
+// shrink to the genuinely serial part.  What bounds these kernels is not bytes but dependent memory round trips of
+// the slowest wavefront (a 8 192-env launch takes 60 % of the time of a 65 536-env one), so the design rules here are:
+// request everything a phase needs in one batch, keep stores behind the last load (they share the in-order memory
+// counter), no workgroup barriers, no per-slot searches (free-slot stack, soon list), branch-free selection.
+// Semantics, operation order of every float64 expression and the reference line ranges are those of orl_device.h /
+// orl_device_g8.h; the parity suite runs every case against this path and compares it with the monolithic one on
+// every env of full-size batches.
 #pragma once
 #include "orl_device_g8.h"
 
@@ -42,6 +50,15 @@ __device__ unsigned long long g_prof[ORL_PROF_WAVES * ORL_PROF_SLOTS];
 #define ORL_PROF_BEGIN() do { } while (0)
 #define ORL_PROF(k) do { } while (0)
 #define ORL_PROF_END() do { } while (0)
+#endif
+#if defined(ORL_TIMING) && ORL_TIMING == 4
+#define ORL_PROFR_BEGIN() ORL_PROF_BEGIN_()
+#define ORL_PROFR(k) ORL_PROF_(k)
+#define ORL_PROFR_END() ORL_PROF_END_()
+#else
+#define ORL_PROFR_BEGIN() do { } while (0)
+#define ORL_PROFR(k) do { } while (0)
+#define ORL_PROFR_END() do { } while (0)
 #endif
 #if defined(ORL_TIMING) && ORL_TIMING == 2
 #define ORL_PROFA_BEGIN() ORL_PROF_BEGIN_()
@@ -484,7 +501,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       // Item mode needs <= ORL_IMASKS releases meeting on one link.  The number of due releases is known exactly:
       // the whole list (now < t_soon: nothing outside is due) or the full scan just done.
       const int total = due_all >= 0 ? due_all : tot;
-      sink.active = total <= ORL_IMASKS;
+      sink.active = total <= P.item_masks;
       if (!sink.active && total < 200) {
         // More releases than one item holds masks for (the release count per step is geometric: ~0.2 % of env-steps
         // exceed 8).  What matters is the count PER LINK: tally the touches of every due release first — every lane
@@ -521,7 +538,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           m01 = m01 > m23 ? m01 : m23;
           mx = mx > m01 ? mx : m01;
         }
-        sink.active = g8_max((int)mx) <= ORL_IMASKS;
+        sink.active = g8_max((int)mx) <= P.item_masks;
       }
       if (!sink.active) {
         ORL_DBG(11, 1);
@@ -713,89 +730,12 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// row kernel: one 8-lane group per work item, lane w = word w of the link row
-// ---------------------------------------------------------------------------------------------------------------
-template <int ENV, int W>
-__device__ __forceinline__ void row_item(const DevParams& P, const Item it, int lane, int now_slot) {
-  const int w = lane & 7, E = P.E, S = P.S;
-  const i64 env = (i64)(u32)it.a.x;
-  const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
-  const bool release = ((it.a.x >> 44) & 1) != 0;
-  const u64 cores = it.b.y;
-  u64* bm = P.bitmap + env * P.bm_words;
-  int* cs = P.core_sums + env * P.cs_words;
-  double* ls = P.lstat + env * 4 * E;
-  // everything the item needs is requested before anything is used: clock, the four link statistics, the first
-  // mask's row word and that row's cached contribution to the compactness sums
-  const int core0 = (int)(cores & 0x1f);
-  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + now_slot]);
-  const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
-  double last_update = ls23.y;
-  double util = ls01.x, frag = ls01.y, comp = ls23.x;
-  u64 a_first = (w < W) ? bm[(size_t)(core0 * E + link) * W + w] : 0ull;
-  int pk_first = (ENV != ENV_RWA) ? cs[2 * P.C + core0 * E + link] : 0;
-  for (int k = 0; k < nmask; k++) {
-    const int core = (int)((cores >> (5 * k)) & 0x1f);
-    const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
-    const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
-    u64* wp = bm + (size_t)(core * E + link) * W + (w < W ? w : 0);
-    u64 a = (k == 0) ? a_first : ((w < W) ? *wp : 0ull);
-    const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
-    a = release ? (a | m) : (a & ~m);
-    if (w < W) *wp = a;
-    RowStat after;
-    if (ENV != ENV_RWA) {
-      row_stat<W, true>(a, w, S, after);
-      if (w == 0) {  // this row's contribution to the compactness sums of its core
-        int* sump = cs + 2 * P.C + core * E + link;
-        const int pk = (k == 0) ? pk_first : *sump;
-        const int d_occ = after.occ - (pk >> 16), d_fb = after.fb - (pk & 0xffff);
-        *sump = (after.occ << 16) | after.fb;
-        if (d_occ) atomicAdd(cs + 2 * core, d_occ);
-        if (d_fb) atomicAdd(cs + 2 * core + 1, d_fb);
-      }
-    } else {
-      after.free_ = g8_sum(__popcll(a));
-    }
-    if (now > 0) {
-      if (k == 0) {  // _update_link_stats on the row of the first touch (rmsa_env.py:464-543)
-        const double time_diff = now - last_update;
-        const int free_ = after.free_;
-        double cur_util = (double)(S - free_) / (double)S;
-        util = ((util * last_update) + (cur_util * time_diff)) / now;
-        if (ENV != ENV_RWA) {
-          double cur_frag = 0.0, cur_comp = 0.0;
-          const int top = (S - 1) - 64 * w;
-          const int edge = g8_sum(((w == 0 && (a & 1ull)) ? 1 : 0) + ((top >= 0 && top < 64 && ((a >> top) & 1ull)) ? 1 : 0));
-          const int max_empty = row_longest_run8<W>(a, w);
-          if (free_ > 0) {
-            int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
-            cur_frag = 1.0 - ((double)me / (double)free_);
-            if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
-            else cur_comp = 1.0;
-          }
-          frag = ((frag * last_update) + (cur_frag * time_diff)) / now;
-          comp = ((comp * last_update) + (cur_comp * time_diff)) / now;
-        }
-      } else {
-        // the same link touched again in the same step: the reference's update has last_update == now and
-        // time_diff == 0, i.e. new = ((old * now) + (cur * 0.0)) / now with a finite cur
-        util = ((util * now) + 0.0) / now;
-        if (ENV != ENV_RWA) { frag = ((frag * now) + 0.0) / now; comp = ((comp * now) + 0.0) / now; }
-      }
-    }
-  }
-  if (w == 0) {
-    if (now > 0) *(double2*)(ls + 4 * link) = make_double2(util, frag);
-    *(double2*)(ls + 4 * link + 2) = make_double2(comp, now);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// row kernel, one LANE per work item (the form the device uses): the whole link row (W words) sits in the lane's
-// registers, so the row statistics are plain per-lane bit arithmetic without cross-lane steps, a wavefront retires
-// 64 items instead of 8, and a 65 536-env launch is a single round of ~2 700 wavefronts instead of four rounds of
-// 6 144.  Same arithmetic, expression for expression, as row_item above.
+// row kernel, one LANE per work item: the whole link row (W words) sits in the lane's registers, so the row
+// statistics are plain per-lane bit arithmetic without cross-lane steps, a wavefront retires 64 items, and a
+// 65 536-env launch is a single round of ~2 700 wavefronts.  Same arithmetic, expression for expression, as
+// path_apply of the monolithic kernels (orl_device.h / orl_device_g8.h): _update_link_stats (rmsa_env.py:464-543) on
+// the first touch of a link in a step, the time_diff == 0 form on later touches, and the integer sums behind
+// _get_network_compactness kept per core with each row's cached contribution.
 // ---------------------------------------------------------------------------------------------------------------
 template <int W>
 __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat& st, int& max_empty, int& edge) {
@@ -846,7 +786,7 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
 }
 
 template <int ENV, int W>
-__device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it, int now_slot) {
+__device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it, int now_slot, Prof& prof) {
   const int E = P.E, S = P.S;
   const i64 env = (i64)(u32)it.a.x;
   const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
@@ -859,6 +799,8 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
   const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
   double last_update = ls23.y;
   double util = ls01.x, frag = ls01.y, comp = ls23.x;
+  if (last_update == -7.5 && util == 0.123) return;  // (keeps the loads ahead of the timing mark)
+  ORL_PROFR(3);
   u64 a[W];
   int pk = 0, prev_core = -1;
   for (int k = 0; k < nmask; k++) {
@@ -881,8 +823,10 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
     }
     RowStat after;
     int max_empty = 0, edge = 0;
+    ORL_PROFR(4);
     if (ENV != ENV_RWA) {
       row_stat_lane<W>(a, S, after, max_empty, edge);
+      ORL_PROFR(5);
       // this row's contribution to the compactness sums of its core
       const int d_occ = after.occ - (pk >> 16), d_fb = after.fb - (pk & 0xffff);
       pk = (after.occ << 16) | after.fb;
@@ -920,8 +864,10 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
       }
     }
   }
+  ORL_PROFR(6);
   if (now > 0) *(double2*)(ls + 4 * link) = make_double2(util, frag);
   *(double2*)(ls + 4 * link + 2) = make_double2(comp, now);
+  ORL_PROFR(7);
 }
 
 }  // namespace sp

@@ -315,28 +315,6 @@ __global__ void __launch_bounds__(256) k_ctrl_b2(DevParams P) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   sp::ctrl_b2<ENV, W>(P, env, env < P.B, lane_id(), s_tally, (sp::SinkEntry*)orl_lds_raw);  // 32 x E entries
 }
-#ifndef ORL_ROWS_SPLIT
-#define ORL_ROWS_SPLIT 3
-#endif
-template <int ENV, int W>
-__global__ void __launch_bounds__(256) k_rows(DevParams P, int phase) {
-  // ORL_ROWS_SPLIT workgroups per control workgroup (32 envs = four wavefront regions, ~75 items), taking interleaved
-  // chunks of 32 items of the dense index over the four regions: one workgroup alone would run 3 mostly serial passes
-  const u32 grp4 = blockIdx.x / ORL_ROWS_SPLIT, part = blockIdx.x % ORL_ROWS_SPLIT;
-  const ulonglong2* q = (phase ? P.q_b : P.q_a) + (size_t)grp4 * 4 * P.q_wave * 2;
-  const uint4 c = *(const uint4*)((phase ? P.q_cnt_b : P.q_cnt_a) + 4 * grp4);
-  const u32 p1 = c.x, p2 = p1 + c.y, p3 = p2 + c.z, n = p3 + c.w;
-  for (u32 idx = part * 32u + (threadIdx.x >> 3); idx < n; idx += 32u * ORL_ROWS_SPLIT) {
-    const u32 sub = (idx >= p1 ? 1u : 0u) + (idx >= p2 ? 1u : 0u) + (idx >= p3 ? 1u : 0u);
-    const u32 off = idx - (sub == 0 ? 0u : sub == 1 ? p1 : sub == 2 ? p2 : p3);
-    const size_t at = (size_t)sub * P.q_wave + off;
-    sp::Item it;
-    it.a = q[2 * at];
-    it.b = q[2 * at + 1];
-    sp::row_item<ENV, W>(P, it, lane_id(), phase ? SC_NOW : SC_NOWA);
-  }
-}
-
 // lane-per-item row kernel: one workgroup covers ORL_ROWS1_GROUPS control workgroups (32 envs each, ~75 items) and maps
 // its threads onto the dense item index over their 4 * ORL_ROWS1_GROUPS wavefront regions
 #ifndef ORL_ROWS1_GROUPS
@@ -345,6 +323,8 @@ __global__ void __launch_bounds__(256) k_rows(DevParams P, int phase) {
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_rows1(DevParams P, int phase) {
   constexpr int NR = 4 * ORL_ROWS1_GROUPS;
+  sp::Prof prof;
+  ORL_PROFR_BEGIN();
   const u32 r0 = blockIdx.x * NR;
   const u32 n_regions = (u32)((P.B + 31) / 32) * 4u;  // regions the control kernels of this launch wrote
   const u32* cnt = (phase ? P.q_cnt_b : P.q_cnt_a) + r0;
@@ -359,11 +339,15 @@ __global__ void __launch_bounds__(256) k_rows1(DevParams P, int phase) {
     for (int t = 1; t < NR; t++)
       if (idx >= cum[t]) { j = (u32)t; base = cum[t]; }
     const size_t at = (size_t)j * P.q_wave + (idx - base);
+    ORL_PROFR(1);
     sp::Item it;
     it.a = q[2 * at];
     it.b = q[2 * at + 1];
-    sp::row_item_lane<ENV, W>(P, it, phase ? SC_NOW : SC_NOWA);
+    if (it.a.x == 0x123456789abcdefull) return;
+    ORL_PROFR(2);
+    sp::row_item_lane<ENV, W>(P, it, phase ? SC_NOW : SC_NOWA, prof);
   }
+  ORL_PROFR(8);
   if (phase) {
     // serial tail: envs whose releases did not fit the item form (about one env-step in 10^7) release them in place,
     // 8 lanes per env; they have no items in this launch
@@ -371,6 +355,8 @@ __global__ void __launch_bounds__(256) k_rows1(DevParams P, int phase) {
     for (u32 d = blockIdx.x * 32u + (threadIdx.x >> 3); d < nd; d += gridDim.x * 32u)
       sp::rel_serial<ENV, W>(P, (i64)P.q_def[16 + d], lane_id());
   }
+  ORL_PROFR(9);
+  ORL_PROFR_END();
 }
 
 template <int ENV, int W>
@@ -759,6 +745,9 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     // a provision touches <= H links, the releases of a step <= E links (one item per link)
     const size_t waves = ((B + 31) / 32 + 16) * 4;  // +16 workgroups: sub-batch views start at multiples of 32 envs
     P.q_wave = 8 * (P.H > P.E ? P.H : P.E);
+    P.item_masks = ORL_IMASKS;
+    // test knob: a smaller limit sends far more env-steps through the tally pass and the serial tail
+    if (const char* mv = getenv("ORL_ITEM_MASKS")) { int v = atoi(mv); if (v >= 1 && v <= ORL_IMASKS) P.item_masks = v; }
     P.q_cap = (i64)waves * P.q_wave;
     rc |= dalloc(b, &P.q_a, (size_t)P.q_cap * 2);  // 32-byte items
     rc |= dalloc(b, &P.q_b, (size_t)P.q_cap * 2);

@@ -8,6 +8,16 @@ from tests.helpers import golden_names, load_golden, replay
 
 pytestmark = pytest.mark.gpu
 
+# The library picks the step implementation by batch size (split pipeline from 24 576 envs, one wavefront per env
+# below); the small parity cases run against both by forcing it (the variable is read when a batch is created).
+IMPLS = ["wave64", "split"]
+
+
+@pytest.fixture(params=IMPLS)
+def impl(request, monkeypatch):
+    monkeypatch.setenv("ORL_STEP_IMPL", {"wave64": "64", "split": "1"}[request.param])
+    return request.param
+
 
 def _product(meta, num_envs=1, seeds=None):
     import optical_rl_gym_amd as orl
@@ -30,7 +40,7 @@ def _exact(name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_hip_reproduces_reference_trace(name):
+def test_hip_reproduces_reference_trace(name, impl):
     g = load_golden(name)
     env = _product(g["meta"])
     replay(env, g, _exact(name))
@@ -53,7 +63,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("gname,policy,batch,steps", CASES)
-def test_hip_matches_oracle_on_batches(gname, policy, batch, steps):
+def test_hip_matches_oracle_on_batches(gname, policy, batch, steps, impl):
     from oracle.oracle import OracleBatch
 
     meta = load_golden(gname)["meta"]
@@ -87,7 +97,7 @@ def test_hip_matches_oracle_on_batches(gname, policy, batch, steps):
     dev.close()
 
 
-def test_device_resident_run_matches_stepwise():
+def test_device_resident_run_matches_stepwise(impl):
     """orl_batch_run (policy+step loop on the device, no host round trips) == host-driven policy()/step()."""
     meta = load_golden("g2_rmsa_cfg2_sapff")["meta"]
     kw = dict(meta["kwargs"])
@@ -164,6 +174,88 @@ def test_full_size_batch_sampled_envs_match_oracle(workload, batch):
     p, a = dev.totals()
     assert p == int(cd[:, 0].sum()) and a == int(cd[:, 1].sum())
     dev.close()
+
+
+@pytest.mark.parametrize("workload,batch,steps", [("cfg2", 65536, 700), ("cfg5", 32768, 300), ("cfg4", 16384, 300),
+                                                  ("cfg1", 32768, 300), ("cfg3", 32768, 200)])
+def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, steps, monkeypatch):
+    """Tens of millions of env-steps per case: the rare branches of the split pipeline (more releases in one step
+    than a work item holds masks for, several rebuild rounds, the serial tail) occur a few hundred times, in envs no
+    sample would pick.  The one-wavefront-per-env implementation is pinned to the oracle above; here every env of
+    the two implementations must agree on every integer and every float64 of its record."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    fam, topo, kw, policy = WORKLOADS[workload]
+    kw = dict(kw, episode_length=90)
+    seeds = [77 + 3 * i for i in range(batch)]
+    out = {}
+    for name, v in (("wave64", "64"), ("split", "1")):
+        monkeypatch.setenv("ORL_STEP_IMPL", v)
+        env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+        env.run(policy, steps)
+        pick = [0, 1, batch // 3, batch - 1]
+        out[name] = dict(counters=env.counters().copy(), services=env.services().copy(), active=env.active().copy(),
+                         flags=env.flags().copy(), slots=[env.slots(i).copy() for i in pick],
+                         link=[env.link_stats(i).copy() for i in pick], net=[env.net_stats(i).copy() for i in pick],
+                         serial=int(env.lib.orl_batch_debug_serial_count(env._h)))
+        env.close()
+    a, b = out["wave64"], out["split"]
+    chk = _exact(workload)
+    for key in ("counters", "services", "active", "flags"):
+        chk(0, key, b[key], a[key])
+    for j in range(4):
+        chk(j, "slots", b["slots"][j], a["slots"][j])
+        chk(j, "link_stats", b["link"][j], a["link"][j])
+        chk(j, "net_stats", b["net"][j], a["net"][j])
+
+
+def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
+    """The item form holds 8 releases per link and step; with the limit forced down to 1 the tally pass and the
+    serial tail of the release row kernel run thousands of times instead of once per 10^7 env-steps."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    out = {}
+    for workload, batch in (("cfg2", 4096), ("cfg4n", 1024)):
+        fam, topo, kw, policy = WORKLOADS[workload]
+        kw = dict(kw, episode_length=70)
+        seeds = [5 + 11 * i for i in range(batch)]
+        for name, v, masks in (("wave64", "64", None), ("split", "1", "1"), ("split2", "1", "2")):
+            monkeypatch.setenv("ORL_STEP_IMPL", v)
+            if masks:
+                monkeypatch.setenv("ORL_ITEM_MASKS", masks)
+            else:
+                monkeypatch.delenv("ORL_ITEM_MASKS", raising=False)
+            env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+            env.run(policy, 500)
+            out[name] = dict(counters=env.counters().copy(), services=env.services().copy(), active=env.active().copy(),
+                             slots=env.slots(batch - 1).copy(), link=env.link_stats(batch - 1).copy(),
+                             net=env.net_stats(batch - 1).copy(), serial=int(env.lib.orl_batch_debug_serial_count(env._h)))
+            assert not env.flags().any()
+            env.close()
+        chk = _exact(workload)
+        for name in ("split", "split2"):
+            for key in ("counters", "services", "active", "slots", "link", "net"):
+                chk(0, name + " " + key, out[name][key], out["wave64"][key])
+        assert out["split"]["serial"] > 100 and out["split2"]["serial"] > 0
+
+
+def test_run_reports_every_kernel_of_the_step(monkeypatch):
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    fam, topo, kw, policy = WORKLOADS["cfg2"]
+    for v, names in (("64", ["k_policy", "k_step"]),
+                     ("1", ["k_policy_ctrl_a", "k_rows(provision)", "k_ctrl_b2", "k_rows(release)"])):
+        monkeypatch.setenv("ORL_STEP_IMPL", v)
+        env = orl.make(fam, topology=topo, num_envs=2048, seeds=list(range(2048)), **kw)
+        st = env.run(policy, 20, time_kernels=1)
+        assert [n for n, _ in st.kernels()] == names
+        assert all(ms > 0 for _, ms in st.kernels()) and st.launches == 20 * len(names)
+        st2 = env.run(policy, 20, time_kernels=2)
+        assert st2.ms_policy > 0 and st2.ms_step > 0
+        env.close()
 
 
 def test_device_seeding_equals_cpython():
