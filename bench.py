@@ -156,7 +156,7 @@ def main():
     for name, k in kernels.items():
         ach = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
         roof[name] = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                          frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic.get(name), us_per_launch=round(k["ms"] * 1e3, 2),
+                          frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic.get(name.split("(")[0]), us_per_launch=round(k["ms"] * 1e3, 2),
                           algorithmic_bytes_per_launch=int(k["bytes"]))
         if k.get("standalone"):
             roof[name]["note"] = "stand-alone slot-scan kernel (orl_batch_policy); the device loop fuses it into k_policy_ctrl_a"

@@ -24,10 +24,12 @@ def mean_last(d, kern, n=20):
 known = 65536 * 110 * 8
 factor = known / (mean_last("tr_f", "k_calib", 4) * 1024)
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.py), cfg2 B=65536, mean of the last 20 "
-               "steady-state launches; FETCH_SIZE x the factor measured on k_calib_read (known byte count; 8-B and 16-B per-lane "
+               "steady-state launches of each kernel; FETCH_SIZE x the factor measured on k_calib_read (known byte count; 8-B and 16-B per-lane "
                "loads both give 2.0, as MI355X_MICROARCH.md states); WRITE_SIZE as is",
        "workload": "cfg2", "batch": 65536, "fetch_calibration_factor": round(factor, 4), "kernels": {}}
-for name, kern in (("slot_scan(k_policy)", "k_policy"), ("step(k_step)", "k_step")):
+# bench.py looks kernels up by these names; both launches of the row kernel (provision / release items) share one average
+for name, kern in (("k_policy_ctrl_a", "k_policy_ctrl_a<"), ("k_rows", "k_rows1<"), ("k_ctrl_b2", "k_ctrl_b2<"),
+                   ("k_policy", "void k_policy<")):
     f = mean_last("tr_f", kern) * 1024 * factor
     w = mean_last("tr_w", kern) * 1024
     out["kernels"][name] = {"fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w)}
@@ -37,3 +39,7 @@ shutil.copy(newest(O + "/stats1/**/*kernel_stats.csv"), "profiles/%s_bench_cfg2_
 for f in glob.glob(O + "/bench_*.json"):
     shutil.copy(f, "profiles/%s_%s" % (tag, os.path.basename(f)))
 print(json.dumps(out["kernels"]))
+# counter summaries (SQ issue/wait counters of the bench run, L2<->fabric request counts) as one text file
+import subprocess
+txt = subprocess.run([sys.executable, "tools/pmc_summary.py", O + "/sq", O + "/ea", O + "/tr_f", O + "/tr_w"], capture_output=True, text=True).stdout
+open("profiles/%s_pmc_summary.txt" % tag, "w").write(txt.replace(os.getcwd() + "/", ""))

@@ -19,5 +19,6 @@ done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/tr_f -- python3 $R/tools/pmc_traffic.py > $O/tr_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/tr_w -- python3 $R/tools/pmc_traffic.py > $O/tr_w.log 2>&1
 export ORL_STREAMS=1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $O/sq -- python3 $R/bench.py --steps 20 --warmup 1200 --no-cpu-baseline > $O/sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/sq -- python3 $R/bench.py --steps 20 --warmup 1200 --no-cpu-baseline > $O/sq.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $O/ea -- python3 $R/tools/pmc_traffic.py > $O/ea.log 2>&1
 ls $O
