@@ -101,6 +101,8 @@ struct DevParams {
   u32* q_cnt_b;     // same for q_b
   int q_wave;       // item slots per wavefront region
   int item_masks;   // releases of one step that may meet on one link before the env falls back to the serial tail (<= 8)
+  int* rel_sums;    // [B][2*C] two-kernel pipeline: what the releases of the current step added to core_sums[0..2C)
+  i64 q_def_stride; // two-kernel pipeline: second q_def buffer (steps alternate)
   u32* q_def;       // [0] = number of envs whose releases this step do not fit the item form, [16..] = their indices
   u32* q_stat;      // [1] env-steps that took the serial release path (statistics)
   double* soon_t;   // [B][ORL_SOON] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8, ...

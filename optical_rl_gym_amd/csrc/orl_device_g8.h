@@ -43,6 +43,7 @@ struct EnvG {
   u64* bm;
   double* ls;
   int* cs;
+  int* rs;  // two-kernel pipeline: per-core sums of what this step's releases added (nullptr otherwise)
   double* ev_time;
   u64* ev_info;
   double* soon_t;
@@ -80,6 +81,7 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
   e.bm = P.bitmap + env * P.bm_words;
   e.ls = P.lstat + env * 4 * P.E;
   e.cs = P.core_sums + env * P.cs_words;
+  e.rs = nullptr;
   e.ev_time = P.ev_time + env * P.ev_cap;
   e.ev_info = P.ev_info + env * P.ev_cap;
   e.soon_t = P.soon_t + env * ORL_SOON;
@@ -241,6 +243,7 @@ __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane,
   if (ENV != ENV_RWA) {
     int c0 = gget(e.cs[2 * core], 0, lane) + d_occ, c1 = gget(e.cs[2 * core + 1], 0, lane) + d_fb;
     if (w == 0) { e.cs[2 * core] = c0; e.cs[2 * core + 1] = c1; }
+    if (release && e.rs && w == 0) { e.rs[2 * core] += d_occ; e.rs[2 * core + 1] += d_fb; }
   }
   return hops;
 }
@@ -260,7 +263,7 @@ __device__ unsigned long long g_dbg[64];  // event counts of ev_push (orl_batch_
 #define ORL_DBG(k, v) do { } while (0)
 #endif
 // ---- pending releases: slot i belongs to lane i % 8 -------------------------------------------------
-__device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
+__device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
   const int gl = lane & 7;
   // a slot for the entry: the top of the free-slot stack (fed by the releases and by the rebuild scan of control
   // kernel B2); a dense table appends; only a table with holes nobody recorded is searched
@@ -287,7 +290,7 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
     }
   }
   if (idx < 0) {
-    if (e.ev_hwm >= P.ev_cap) { e.flags |= ORL_FLAG_EV_OVERFLOW; return; }
+    if (e.ev_hwm >= P.ev_cap) { e.flags |= ORL_FLAG_EV_OVERFLOW; return -1; }
     idx = e.ev_hwm++;
   }
   if (gl == (idx & 7)) { e.ev_time[idx] = t; e.ev_info[idx] = info; }
@@ -325,6 +328,7 @@ __device__ __forceinline__ void ev_push(const DevParams& P, EnvG& e, int lane, d
       }
     }
   }
+  return idx;
 }
 
 template <int ENV, int W>

@@ -75,8 +75,9 @@ using g8::gballot;
 using g8::gget;
 
 // work item (32 bytes, two 16-byte halves):
-//   a.x = env:32 | link:8 | nmask:4 | op:1 (1 = release/set)      a.y = masks 0..3, 16 bits each (s0:9 | n:7)
-//   b.x = masks 4..7                                                b.y = core of mask k, 5 bits each
+//   a.x = env:32 | link:8 | nmask:4 | op:2 (bit 0: masks are releases (set), bit 1: mask 0 is this step's
+//         provision (clear, at the provision clock) and the rest are releases — two-kernel pipeline)
+//   a.y = masks 0..3, 16 bits each (s0:9 | n:7)      b.x = masks 4..7      b.y = core of mask k, 5 bits each
 struct Item { ulonglong2 a, b; };
 __device__ __forceinline__ Item make_item(i64 env, u32 link, int nmask, u64 m0, u64 m1, u64 cores, int op) {
   Item it;
@@ -117,7 +118,7 @@ __device__ __forceinline__ size_t wave_reserve(const DevParams& P, int cnt, u32*
 struct SinkEntry {
   u64 mk0;  // masks 0..3: (s0 | n << 9), 16 bits each, in release order
   u64 mk1;  // masks 4..7
-  u64 crn;  // the core of each mask, 5 bits each (40 bits) | number of masks << 40
+  u64 crn;  // the core of each mask, 5 bits each (40 bits) | number of masks << 40 | mask 0 is a provision << 44
 };
 struct Sink {
   SinkEntry* tab;  // LDS, E entries of this env, crn zeroed
@@ -127,17 +128,38 @@ struct Sink {
   int cnt;         // links this LANE has opened an item for
 };
 // lane h of the group appends the mask to the item of hop h's link (the links of one path are distinct)
-__device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, int s0, int n, int lane) {
+__device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, int s0, int n, int lane, bool prov = false) {
   const int hops = path_rec_byte(rec, 0);
   const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
   for (int h = lane & 7; h < hops; h += 8) {
     SinkEntry* t = s.tab + path_rec_byte(rec, 2 + h);
-    const u64 crn = t->crn;
-    const int j = (int)(crn >> 40);
+    const u64 crn = t->crn | (prov ? (1ull << 44) : 0ull);  // (a provision is the first thing a step adds)
+    const int j = (int)((crn >> 40) & 15);
     if (j < 4) t->mk0 = (j == 0 ? 0ull : t->mk0) | (m << (16 * j));
     else t->mk1 = (j == 4 ? 0ull : t->mk1) | (m << (16 * (j - 4)));
-    t->crn = (crn & 0xffffffffffull) | ((u64)(u32)core << (5 * j)) | ((u64)(u32)(j + 1) << 40);
+    t->crn = (crn & ((1ull << 44) | 0xffffffffffull)) | ((u64)(u32)core << (5 * j)) | ((u64)(u32)(j + 1) << 40);
     s.cnt += (j == 0) ? 1 : 0;
+  }
+}
+
+// the env's items = the table entries that hold masks, in link order, into the wavefront's queue region
+__device__ __forceinline__ void emit_items(const DevParams& P, i64 env, const Sink& sink, bool any, int lane, ulonglong2* q, u32* counts) {
+  const int gl = lane & 7, E = P.E;
+  const int cnt = g8_sum(any ? sink.cnt : 0);
+  const size_t base = wave_reserve(P, cnt, counts, lane);
+  if (cnt) {
+    size_t at = base;
+    for (int l0 = 0; l0 < E; l0 += 8) {
+      const int l = l0 + gl;
+      const u64 crn = (l < E) ? sink.tab[l].crn : 0ull;
+      const int nm = (int)((crn >> 40) & 15);
+      const u32 fb = gballot(nm > 0, lane);
+      if (nm > 0)
+        item_store(q, at + __popc(fb & ((1u << gl) - 1u)),
+                   make_item(env, (u32)l, nm, sink.tab[l].mk0, nm > 4 ? sink.tab[l].mk1 : 0ull, crn & 0xffffffffffull,
+                             1 | (int)((crn >> 44) & 1) << 1));
+      at += __popc(fb);
+    }
   }
 }
 
@@ -147,20 +169,61 @@ __device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, 
 template <int ENV, int W, bool DEFER_GCOMP>
 __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
                                              double* info_out, Prof& prof);
+struct SoonRegs { double t[ORL_SOON_PER_LANE]; int i[ORL_SOON_PER_LANE]; bool dirty; };
+template <int ENV, int W>
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
+                                             int extra = 0, int pushed_idx = -1, u64 pushed_info = 0ull);
 
-// MERGE: device-resident loop without info — the work of control kernel B1 (next service) is done right here, on the env
-// record that is already in registers; only the network-compactness update has to wait for the row kernel (k_ctrl_b2).
-template <int ENV, int W, bool MERGE = false>
+// MERGE 1: device-resident loop without info — the work of control kernel B1 (next service) is done right here, on the
+// env record that is already in registers; only the network-compactness update has to wait for the row kernel
+// (k_ctrl_b2).
+// MERGE 2 (two-kernel pipeline): the release detection of control kernel B2 as well.  The provision and the releases of
+// the step go into ONE queue as mixed items (per link: the provision mask first, then the release masks) and one
+// row-kernel launch applies them.  The network-compactness average, which needs the sums between the provision and
+// the releases, is finished by the NEXT step's launch of this kernel from totals - (what the releases added): the row
+// kernel keeps the latter in rel_sums.
+template <int ENV, int W, int MERGE = 0>
 __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, Prof& prof,
-                                       const int4* given = nullptr) {
+                                       const int4* given = nullptr, u32* s_tally = nullptr, SinkEntry* s_tab = nullptr, int parity = 0) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
-  if (blockIdx.x == 0 && threadIdx.x == 0) P.q_def[0] = 0u;  // control kernel B2 of this step appends
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (MERGE == 2) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
+    else P.q_def[0] = 0u;                                                  // control kernel B2 of this step appends
+  }
   int cnt = 0, core = 0, slot = 0, n = 1;
   PathRec rec;
   rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
+  Sink sink;
+  sink.tab = nullptr; sink.tally = nullptr; sink.active = false; sink.deferred = false; sink.cnt = 0;
+  if (MERGE == 2) {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
+    u32* ty = s_tally + 32 * 8 * (int)(threadIdx.x >> 6);
+    SinkEntry* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
+    for (int i = lane; i < 8 * 32; i += 64) ty[i] = 0u;
+    for (int i = lane; i < 8 * P.E; i += 64) tb[i].crn = 0ull;
+    wave_fence();
+    sink.tab = s_tab + P.E * (int)(threadIdx.x >> 3);
+    sink.tally = s_tally + 32 * (int)(threadIdx.x >> 3);
+  }
   if (valid) {
     EnvG e;
     g8::env_load(P, e, env);
+    int* rs = nullptr;
+    if (MERGE == 2) {
+      rs = P.rel_sums + env * 2 * P.C;
+      const u64 acc0 = e.scal[SC_ACC];
+      if ((u32)acc0 & 2u) {
+        // network compactness update the previous step left pending: the sums right after ITS provision are the totals
+        // minus what its releases added (rmsa_env.py:439-462 with _get_network_compactness at provision time)
+        const int c0 = (int)((acc0 >> 32) & 31);
+        const i64 s_nh_prov = (i64)(acc0 >> 37);
+        const int occ = e.cs[2 * c0] - rs[2 * c0], fb = e.cs[2 * c0 + 1] - rs[2 * c0 + 1];
+        const double a0 = __longlong_as_double((i64)e.scal[SC_GC_A]), td = __longlong_as_double((i64)e.scal[SC_GC_TD]);
+        const double now_a = __longlong_as_double((i64)e.scal[SC_NOWA]);
+        const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
+        e.g_comp = (a0 + (cmp * td)) / now_a;
+      }
+      for (int i = gl; i < 2 * P.C; i += 8) rs[i] = 0;  // this step's releases start from zero
+    }
     const int4 av = given ? *given : *(const int4*)(P.actions + env * 4);
     int path, mod = 0;
     bool bad = false;
@@ -201,6 +264,8 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
       if (gl == 0) info_out[5] = pc;
     }
     bool accepted = false;
+    int pushed_idx = -1;
+    u64 pushed_info = 0ull;
     bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
     if (in_range && path < P.n_paths[e.src * P.N + e.dst]) {
       int pidx = pair_base(P, e.src, e.dst) + path;
@@ -244,7 +309,15 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         e.sa += 1;
         e.esa += 1;
         accepted = true;
-        g8::ev_push(P, e, lane, e.at + e.ht, ev_pack(pidx, slot, n, core, e.bit_rate));
+        pushed_info = ev_pack(pidx, slot, n, core, e.bit_rate);
+        pushed_idx = g8::ev_push(P, e, lane, e.at + e.ht, pushed_info);
+        if (MERGE == 2) {  // the provision's rows: first mask of their items; they also count towards the per-link limit
+          sink_add(sink, rec, core, slot, n, lane, true);
+          for (int h = gl; h < hops; h += 8) {
+            const int link = path_rec_byte(rec, 2 + h);
+            atomicAdd(sink.tally + (link >> 2), 1u << (8 * (link & 3)));
+          }
+        }
         ORL_PROFA(4);
       }
     }
@@ -270,10 +343,47 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     if (MERGE) service_part<ENV, W, true>(P, e, env, lane, 1, accepted, core, nullptr, prof);
     g8::env_store(P, e, gl);
     ORL_PROFA(8);
+    if (MERGE == 2) {
+      // due releases of the step (rmsa_env.py:590-597) -> masks behind the provision's in the same table.  The env record
+      // has gone back already (so that only the handful of release-related fields stays in registers through the
+      // detection); those fields are written again below when the detection changed them.
+      SoonRegs soon;
+      release_soon<ENV, W>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info);
+      if (sink.deferred) {
+        // more releases meet on one link than an item holds masks for: the release state stays as stored and the
+        // serial tail (k_rel_tail) releases them in place after this step's items
+        if (gl == 0) {
+          u32* dq = P.q_def + (size_t)parity * P.q_def_stride;
+          dq[16 + atomicAdd(dq, 1u)] = (u32)env;
+          e.scal[SC_ACC] = e.scal[SC_ACC] | (1ull << 16);
+          e.scal[SC_HINT] = pack2(e.nfree, 0);  // a rebuild may have rewritten the free-slot stack
+        }
+      } else {
+        if (soon.dirty) {
+#pragma unroll
+          for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+            e.soon_t[gl + 8 * k] = soon.t[k];
+            e.soon_i[gl + 8 * k] = (u32)soon.i[k];
+          }
+        }
+        if (gl == 0) {
+          e.scal[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
+          e.scal[SC_TSOON] = (u64)__double_as_longlong(e.t_soon);
+          e.scal[SC_SBR] = (u64)e.s_br;
+          e.scal[SC_SNH] = (u64)e.s_nh;
+          e.scal[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
+          e.scal[SC_HINT] = pack2(e.nfree, 0);
+        }
+      }
+    }
   }
-  const size_t base = wave_reserve(P, cnt, P.q_cnt_a, lane);
-  for (int h = gl; h < cnt; h += 8)
-    item_store(P.q_a, base + h, make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), 0ull, (u64)(u32)core, 0));
+  if (MERGE == 2) {
+    emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a);
+  } else {
+    const size_t base = wave_reserve(P, cnt, P.q_cnt_a, lane);
+    for (int h = gl; h < cnt; h += 8)
+      item_store(P.q_a, base + h, make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), 0ull, (u64)(u32)core, 0));
+  }
   ORL_PROFA(9);
 }
 
@@ -297,7 +407,7 @@ __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 en
         if (gl == 0) {
           e.scal[SC_GC_A] = (u64)__double_as_longlong(e.g_comp * last_update);
           e.scal[SC_GC_TD] = (u64)__double_as_longlong(time_diff);
-          e.scal[SC_ACC] = pack2(3, core);
+          e.scal[SC_ACC] = 3ull | ((u64)(u32)core << 32) | ((u64)e.s_nh << 37);  // s_nh at provision time (< 2^27)
         }
       } else {
         e.g_comp = ((e.g_comp * last_update) + (g8::net_compactness(P, e, core, lane) * time_diff)) / e.now;
@@ -356,7 +466,7 @@ __device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid,
   g8::env_load(P, e, env);
   const u64 acc = e.scal[SC_ACC];
   Prof prof;
-  service_part<ENV, W, false>(P, e, env, lane, auto_reset, ((u32)acc & 1u) != 0, (int)(acc >> 32),
+  service_part<ENV, W, false>(P, e, env, lane, auto_reset, ((u32)acc & 1u) != 0, (int)((acc >> 32) & 31),
                               want_info ? P.info + env * P.n_info : nullptr, prof);
   g8::env_store(P, e, lane & 7);
 }
@@ -368,10 +478,12 @@ __device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid,
 // t_soon is in the list"; while now < t_soon the due releases are found by looking at the lane's own list slots, and
 // only when the clock passes t_soon the list is rebuilt from a full scan.  Pushes keep the invariant (g8::ev_push).
 // ---------------------------------------------------------------------------------------------------------------
-struct SoonRegs { double t[ORL_SOON_PER_LANE]; int i[ORL_SOON_PER_LANE]; bool dirty; };
 // The list is returned in registers: the caller writes it back (when dirty) after everything that still loads.
 template <int ENV, int W>
-__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof) {
+// `extra`: masks this step already put on links (its provision, two-kernel pipeline); `pushed_idx / pushed_info`: the
+// release slot the same kernel has just written — its info word is taken from registers, not re-read through memory.
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
+                                             int extra, int pushed_idx, u64 pushed_info) {
   constexpr int NS = ORL_SOON_PER_LANE;
   out.dirty = false;
   // The rebuild scan costs the wavefront the same whether one of its 8 envs runs it or all of them (the other lanes
@@ -501,7 +613,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       // Item mode needs <= ORL_IMASKS releases meeting on one link.  The number of due releases is known exactly:
       // the whole list (now < t_soon: nothing outside is due) or the full scan just done.
       const int total = due_all >= 0 ? due_all : tot;
-      sink.active = total <= P.item_masks;
+      sink.active = total + extra <= P.item_masks;
       if (!sink.active && total < 200) {
         // More releases than one item holds masks for (the release count per step is geometric: ~0.2 % of env-steps
         // exceed 8).  What matters is the count PER LINK: tally the touches of every due release first — every lane
@@ -549,7 +661,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
     // info word + path record of this lane's candidate, requested by all lanes together
     u64 inf0 = 0;
     PathRec rc0 = PathRec();
-    if (ci != 0x7fffffff) { inf0 = e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
+    if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
     ORL_PROF(6);
     for (;;) {
       double bt = ct;
@@ -574,7 +686,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
         }
         ck = nk;
-        if (ci != 0x7fffffff) { inf0 = e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
+        if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
       }
       dirty = true;
       const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
@@ -649,7 +761,7 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
     e.ev_info = P.ev_info + env * P.ev_cap;
     const u64 acc = s[SC_ACC];
     if ((u32)acc & 2u) {  // network compactness update left pending by the merged control kernel (sums are final now)
-      const int core = (int)(acc >> 32);
+      const int core = (int)((acc >> 32) & 31);
       const double a0 = __longlong_as_double((i64)s[SC_GC_A]), td = __longlong_as_double((i64)s[SC_GC_TD]);
       const double now_a = __longlong_as_double((i64)s[SC_NOWA]);
       // s_nh at provision time = the value the merged kernel stored (this kernel has not released anything yet)
@@ -666,22 +778,8 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
     next_rel = e.next_rel; t_soon = e.t_soon; s_br = e.s_br; s_nh = e.s_nh; ev = pack2(e.ev_hwm, e.ev_cnt); nfree = e.nfree;
   }
   ORL_PROF(9);
-  const int cnt = g8_sum(sink.active ? sink.cnt : 0);
-  const size_t base = wave_reserve(P, cnt, P.q_cnt_b, lane);
+  emit_items(P, env, sink, sink.active, lane, P.q_b, P.q_cnt_b);
   ORL_PROF(10);
-  if (cnt) {  // the env's items = the table entries that hold masks, in link order
-    size_t at = base;
-    for (int l0 = 0; l0 < E; l0 += 8) {
-      const int l = l0 + gl;
-      const u64 crn = (l < E) ? sink.tab[l].crn : 0ull;
-      const int nm = (int)(crn >> 40);
-      const u32 fb = gballot(nm > 0, lane);
-      if (nm > 0)
-        item_store(P.q_b, at + __popc(fb & ((1u << gl) - 1u)),
-                   make_item(env, (u32)l, nm, sink.tab[l].mk0, nm > 4 ? sink.tab[l].mk1 : 0ull, crn & 0xffffffffffull, 1));
-      at += __popc(fb);
-    }
-  }
   // the env record goes back last: stores hold the memory counter, and nothing after this point waits on it
   if (valid) {
     u64* s = P.scal + env * ORL_SCAL_WORDS;
@@ -723,6 +821,7 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
   if (gl == 0) atomicAdd(P.q_stat, 1u);  // statistics: env-steps that took the serial path
   EnvG e;
   g8::env_load(P, e, env);
+  if (P.rel_sums) e.rs = P.rel_sums + env * 2 * P.C;  // two-kernel pipeline: the next step needs what releases added
   g8::release_due<ENV, W>(P, e, lane);
   e.t_soon = -__builtin_inf();  // released in place: the soon list is stale
   if (gl == 0) s[SC_ACC] = s[SC_ACC] & ~(1ull << 16);
@@ -785,17 +884,23 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
   edge = (int)(a[0] & 1ull) + top_bit;
 }
 
-template <int ENV, int W>
+// MIXED (two-kernel pipeline): mask 0 of an item may be this step's provision — slots cleared, statistics at the
+// provision clock (SC_NOWA) — followed by the step's releases at the new clock (SC_NOW); what the releases add to
+// the per-core sums is also accumulated in rel_sums (the next step needs the sums as they were in between).
+template <int ENV, int W, bool MIXED>
 __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it, int now_slot, Prof& prof) {
   const int E = P.E, S = P.S;
   const i64 env = (i64)(u32)it.a.x;
   const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
   const bool release = ((it.a.x >> 44) & 1) != 0;
+  const bool prov_first = MIXED && ((it.a.x >> 45) & 1) != 0;
   const u64 cores = it.b.y;
   u64* bm = P.bitmap + env * P.bm_words;
   int* cs = P.core_sums + env * P.cs_words;
+  int* rs = MIXED ? P.rel_sums + env * 2 * P.C : nullptr;
   double* ls = P.lstat + env * 4 * E;
-  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + now_slot]);
+  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + (MIXED ? (int)SC_NOW : now_slot)]);
+  const double now_prov = MIXED ? __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOWA]) : 0.0;
   const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
   double last_update = ls23.y;
   double util = ls01.x, frag = ls01.y, comp = ls23.x;
@@ -807,6 +912,11 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
     const int core = (int)((cores >> (5 * k)) & 0x1f);
     const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
     const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
+    const bool rel_k = MIXED ? !(k == 0 && prov_first) : release;
+    const double clock = (MIXED && !rel_k) ? now_prov : now;
+    // the first operation at a clock value is the reference's generic update; further touches of the link at the same
+    // clock have time_diff == 0
+    const bool first_at_clock = (k == 0) || (MIXED && k == 1 && prov_first);
     u64* row = bm + (size_t)(core * E + link) * W;
     int* sump = cs + 2 * P.C + core * E + link;
     if (core != prev_core) {  // several releases on the same core row keep working on the registers
@@ -818,7 +928,7 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
 #pragma unroll
     for (int w = 0; w < W; w++) {
       const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
-      a[w] = release ? (a[w] | m) : (a[w] & ~m);
+      a[w] = rel_k ? (a[w] | m) : (a[w] & ~m);
       if (m) row[w] = a[w];
     }
     RowStat after;
@@ -833,18 +943,22 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
       *sump = pk;
       if (d_occ) atomicAdd(cs + 2 * core, d_occ);
       if (d_fb) atomicAdd(cs + 2 * core + 1, d_fb);
+      if (MIXED && rel_k) {
+        if (d_occ) atomicAdd(rs + 2 * core, d_occ);
+        if (d_fb) atomicAdd(rs + 2 * core + 1, d_fb);
+      }
     } else {
       int f = 0;
 #pragma unroll
       for (int w = 0; w < W; w++) f += __popcll(a[w]);
       after.free_ = f;
     }
-    if (now > 0) {
-      if (k == 0) {  // _update_link_stats on the row of the first touch (rmsa_env.py:464-543)
-        const double time_diff = now - last_update;
+    if (clock > 0) {
+      if (first_at_clock) {  // _update_link_stats (rmsa_env.py:464-543)
+        const double time_diff = clock - last_update;
         const int free_ = after.free_;
         double cur_util = (double)(S - free_) / (double)S;
-        util = ((util * last_update) + (cur_util * time_diff)) / now;
+        util = ((util * last_update) + (cur_util * time_diff)) / clock;
         if (ENV != ENV_RWA) {
           double cur_frag = 0.0, cur_comp = 0.0;
           if (free_ > 0) {
@@ -853,20 +967,21 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
             if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
             else cur_comp = 1.0;
           }
-          frag = ((frag * last_update) + (cur_frag * time_diff)) / now;
-          comp = ((comp * last_update) + (cur_comp * time_diff)) / now;
+          frag = ((frag * last_update) + (cur_frag * time_diff)) / clock;
+          comp = ((comp * last_update) + (cur_comp * time_diff)) / clock;
         }
       } else {
-        // the same link touched again in the same step: the reference's update has last_update == now and
+        // the same link touched again at the same clock: the reference's update has last_update == now and
         // time_diff == 0, i.e. new = ((old * now) + (cur * 0.0)) / now with a finite cur
-        util = ((util * now) + 0.0) / now;
-        if (ENV != ENV_RWA) { frag = ((frag * now) + 0.0) / now; comp = ((comp * now) + 0.0) / now; }
+        util = ((util * clock) + 0.0) / clock;
+        if (ENV != ENV_RWA) { frag = ((frag * clock) + 0.0) / clock; comp = ((comp * clock) + 0.0) / clock; }
       }
     }
+    last_update = clock;
   }
   ORL_PROFR(6);
-  if (now > 0) *(double2*)(ls + 4 * link) = make_double2(util, frag);
-  *(double2*)(ls + 4 * link + 2) = make_double2(comp, now);
+  *(double2*)(ls + 4 * link) = make_double2(util, frag);
+  *(double2*)(ls + 4 * link + 2) = make_double2(comp, last_update);
   ORL_PROFR(7);
 }
 

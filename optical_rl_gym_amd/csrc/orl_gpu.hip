@@ -282,7 +282,7 @@ template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_a(DevParams P, int want_info) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   sp::Prof prof;
-  sp::ctrl_a<ENV, W, false>(P, env, env < P.B, lane_id(), want_info != 0, prof);
+  sp::ctrl_a<ENV, W, 0>(P, env, env < P.B, lane_id(), want_info != 0, prof);
 }
 // device-policy loop: slot-scan and control kernel A in one launch (same 8-lanes-per-env layout; the action never
 // leaves the registers, the link rows the scan just read are still in cache for the validation)
@@ -301,9 +301,101 @@ __global__ void __launch_bounds__(256) k_policy_ctrl_a(DevParams P, int pol) {
   const int4 av = make_int4(a[0], a[1], a[2], a[3]);
   if (valid && (lane & 7) == 0) *(int4*)(P.actions + env * 4) = av;
   ORL_PROFA(1);
-  sp::ctrl_a<ENV, W, true>(P, env, valid, lane, false, prof, &av);
+  sp::ctrl_a<ENV, W, 1>(P, env, valid, lane, false, prof, &av);
   ORL_PROFA_END();
 }
+#ifndef ORL_ROWS1_GROUPS
+#define ORL_ROWS1_GROUPS 3
+#endif
+// ---- two-kernel pipeline (step_impl 2): k_step_a2 ; k_rows2 -------------------------------------------------------
+// slot scan + everything of step() that is per-env control: validation, counters, release push, next service, the due
+// releases of the step; output = one queue of mixed work items (orl_device_split.h, ctrl_a<MERGE = 2>)
+template <int ENV, int W, bool FUSED_POLICY>
+__global__ void __launch_bounds__(256) k_step_a2(DevParams P, int pol, int parity) {
+  __shared__ u32 s_tally[32 * 32];
+  const int lane = lane_id();
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool valid = env < P.B;
+  sp::Prof prof;
+  ORL_PROFA_BEGIN();
+  if (FUSED_POLICY) {
+    const i64 env0 = env - ((lane >> 3));  // first env of this wavefront
+    u64 d = valid ? P.svc_desc[env] : 0ull;
+    int a[4];
+    policy_g<ENV, W, 8>(P, P.bitmap + env0 * P.bm_words + (size_t)(lane >> 3) * P.bm_words, valid, (int)(u32)d,
+                        (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane, pol, a);
+    const int4 av = make_int4(a[0], a[1], a[2], a[3]);
+    if (valid && (lane & 7) == 0) *(int4*)(P.actions + env * 4) = av;
+    ORL_PROFA(1);
+    sp::ctrl_a<ENV, W, 2>(P, env, valid, lane, false, prof, &av, s_tally, (sp::SinkEntry*)orl_lds_raw, parity);
+  } else {
+    sp::ctrl_a<ENV, W, 2>(P, env, valid, lane, false, prof, nullptr, s_tally, (sp::SinkEntry*)orl_lds_raw, parity);
+  }
+  ORL_PROFA_END();
+}
+// one lane per mixed item
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_rows2(DevParams P, int parity) {
+  constexpr int NR = 4 * ORL_ROWS1_GROUPS;
+  sp::Prof prof;
+  ORL_PROFR_BEGIN();
+  const u32 r0 = blockIdx.x * NR;
+  const u32 n_regions = (u32)((P.B + 31) / 32) * 4u;
+  const u32* cnt = P.q_cnt_a + r0;
+  u32 cum[NR + 1];
+  cum[0] = 0;
+#pragma unroll
+  for (int j = 0; j < NR; j++) cum[j + 1] = cum[j] + ((r0 + j < n_regions) ? cnt[j] : 0u);
+  const ulonglong2* q = P.q_a + (size_t)r0 * P.q_wave * 2;
+  for (u32 idx = threadIdx.x; idx < cum[NR]; idx += 256) {
+    u32 j = 0, base = 0;
+#pragma unroll
+    for (int t = 1; t < NR; t++)
+      if (idx >= cum[t]) { j = (u32)t; base = cum[t]; }
+    const size_t at = (size_t)j * P.q_wave + (idx - base);
+    ORL_PROFR(1);
+    sp::Item it;
+    it.a = q[2 * at];
+    it.b = q[2 * at + 1];
+    if (it.a.x == 0x123456789abcdefull) return;
+    ORL_PROFR(2);
+    sp::row_item_lane<ENV, W, true>(P, it, SC_NOW, prof);
+  }
+  ORL_PROFR(8);
+  ORL_PROFR(9);
+  ORL_PROFR_END();
+}
+// serial tail, one small workgroup per launch: the envs whose releases of this step did not fit the item form (about
+// one env-step in 10^7; control kernels append them to q_def) release them in place, 8 lanes per env.  A launch of its
+// own because inlined into the row kernels this code cost them half their occupancy.
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_rel_tail(DevParams P, int buffer) {
+  const u32* dq = P.q_def + (size_t)buffer * P.q_def_stride;
+  const u32 nd = dq[0];
+  for (u32 d = threadIdx.x >> 3; d < nd; d += 32u) sp::rel_serial<ENV, W>(P, (i64)dq[16 + d], lane_id());
+}
+// end of a device-resident run: the network-compactness update the last step left pending (one thread per env), so
+// that every host-visible state is final
+__global__ void k_finish2(DevParams P) {
+  const i64 env = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= P.B) return;
+  u64* s = P.scal + env * ORL_SCAL_WORDS;
+  int* rs = P.rel_sums + env * 2 * P.C;
+  const u64 acc = s[SC_ACC];
+  if ((u32)acc & 2u) {
+    const int* cs = P.core_sums + env * P.cs_words;
+    const int c0 = (int)((acc >> 32) & 31);
+    const i64 s_nh_prov = (i64)(acc >> 37);
+    const int occ = cs[2 * c0] - rs[2 * c0], fb = cs[2 * c0 + 1] - rs[2 * c0 + 1];
+    const double a0 = __longlong_as_double((i64)s[SC_GC_A]), td = __longlong_as_double((i64)s[SC_GC_TD]);
+    const double now_a = __longlong_as_double((i64)s[SC_NOWA]);
+    const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
+    s[SC_GCOMP] = (u64)__double_as_longlong((a0 + (cmp * td)) / now_a);
+    s[SC_ACC] = acc & ~2ull;
+  }
+  for (int i = 0; i < 2 * P.C; i++) rs[i] = 0;
+}
+
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_ctrl_b1(DevParams P, int auto_reset, int want_info) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -317,9 +409,6 @@ __global__ void __launch_bounds__(256) k_ctrl_b2(DevParams P) {
 }
 // lane-per-item row kernel: one workgroup covers ORL_ROWS1_GROUPS control workgroups (32 envs each, ~75 items) and maps
 // its threads onto the dense item index over their 4 * ORL_ROWS1_GROUPS wavefront regions
-#ifndef ORL_ROWS1_GROUPS
-#define ORL_ROWS1_GROUPS 3
-#endif
 template <int ENV, int W>
 __global__ void __launch_bounds__(256) k_rows1(DevParams P, int phase) {
   constexpr int NR = 4 * ORL_ROWS1_GROUPS;
@@ -345,16 +434,9 @@ __global__ void __launch_bounds__(256) k_rows1(DevParams P, int phase) {
     it.b = q[2 * at + 1];
     if (it.a.x == 0x123456789abcdefull) return;
     ORL_PROFR(2);
-    sp::row_item_lane<ENV, W>(P, it, phase ? SC_NOW : SC_NOWA, prof);
+    sp::row_item_lane<ENV, W, false>(P, it, phase ? SC_NOW : SC_NOWA, prof);
   }
   ORL_PROFR(8);
-  if (phase) {
-    // serial tail: envs whose releases did not fit the item form (about one env-step in 10^7) release them in place,
-    // 8 lanes per env; they have no items in this launch
-    const u32 nd = P.q_def[0];
-    for (u32 d = blockIdx.x * 32u + (threadIdx.x >> 3); d < nd; d += gridDim.x * 32u)
-      sp::rel_serial<ENV, W>(P, (i64)P.q_def[16 + d], lane_id());
-  }
   ORL_PROFR(9);
   ORL_PROFR_END();
 }
@@ -425,8 +507,9 @@ struct TkRec;
 struct orl_batch {
   DevParams P;
   TkRec* tk = nullptr;  // per-kernel timing of orl_batch_run(time_kernels = 1)
+  int parity[66] = {0};  // two-kernel pipeline: which deferred-env buffer the next step of view k writes (0 = whole batch)
   int device, wt;
-  int step_impl;  // ORL_STEP_IMPL: 64 = one wavefront per env, 8 = eight lanes per env (monolithic), 1 = split pipeline
+  int step_impl;  // 64 = one wavefront per env, 8 = eight lanes per env (monolithic), 1 = four-kernel split pipeline, 2 = two-kernel pipeline
   hipStream_t stream;
   std::vector<void*> allocs;
   hipEvent_t ev0, ev1;
@@ -557,10 +640,48 @@ static void launch_policy(orl_batch* b, int pol) {
 }
 static void launch_obs(orl_batch* b);
 static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_policy = -1);
+// two-kernel pipeline: (slot scan +) all per-env control -> one queue of mixed items -> row kernel
+static void launch_step2(orl_batch* b, int pol, bool wide) {
+  const DevParams& VP = b->view ? *b->view : b->P;
+  hipStream_t VS = b->view ? b->view_stream : b->stream;
+  int& par = b->parity[b->view ? (int)(b->view - b->subs.data()) + 1 : 0];
+  if (wide) launch_policy(b, pol);  // RMCSA / k > 8: the one-env-per-wavefront slot scan stays a launch of its own
+  dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
+  dim3 gr((gc.x + ORL_ROWS1_GROUPS - 1) / ORL_ROWS1_GROUPS);
+  const size_t lds_a = (size_t)32 * VP.E * sizeof(sp::SinkEntry);
+#define CALLW(WW)                                                                                                   \
+  do {                                                                                                              \
+    if (wide) {                                                                                                     \
+      if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_step_a2<EE, WW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
+      hipLaunchKernelGGL((k_step_a2<EE, WW, false>), gc, blk, lds_a, VS, VP, pol, par);                              \
+    } else {                                                                                                        \
+      if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_step_a2<EE, WW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
+      hipLaunchKernelGGL((k_step_a2<EE, WW, true>), gc, blk, lds_a, VS, VP, pol, par);                               \
+    }                                                                                                               \
+    ORL_TK("k_step_a2");                                                                                            \
+    hipLaunchKernelGGL((k_rows2<EE, WW>), gr, blk, 0, VS, VP, par);                                                 \
+    ORL_TK("k_rows2");                                                                                              \
+    hipLaunchKernelGGL((k_rel_tail<EE, WW>), dim3(1), blk, 0, VS, VP, par);                                         \
+    ORL_TK("k_rel_tail");                                                                                           \
+  } while (0)
+#define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
+  ORL_FOR_ENV(PER_ENV)
+#undef PER_ENV
+#undef CALLW
+  par ^= 1;
+  if (VP.obs_dim) launch_obs(b);
+}
+// after the last step of a device-resident run (every view): nothing pending is left for the host to see
+static void launch_finish2(orl_batch* b) {
+  const DevParams& VP = b->view ? *b->view : b->P;
+  hipStream_t VS = b->view ? b->view_stream : b->stream;
+  hipLaunchKernelGGL(k_finish2, dim3((unsigned)((VP.B + 255) / 256)), dim3(256), 0, VS, VP);
+}
 // policy + step of the device-resident loop; the split pipeline fuses the slot-scan with its first control kernel
 static void launch_policy_step(orl_batch* b, int pol) {
   const DevParams& VP = b->view ? *b->view : b->P;
   const bool wide = (VP.env_type == ENV_RMCSA) || VP.K > 8;
+  if (b->step_impl == 2) { launch_step2(b, pol, wide); return; }
   if (b->step_impl == 1 && !wide) { launch_step(b, 1, 0, pol); return; }
   launch_policy(b, pol);
   launch_step(b, 1, 0);
@@ -568,7 +689,7 @@ static void launch_policy_step(orl_batch* b, int pol) {
 static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_policy) {
   const DevParams& VP = b->view ? *b->view : b->P;
   hipStream_t VS = b->view ? b->view_stream : b->stream;
-  if (b->step_impl == 1) {
+  if (b->step_impl == 1 || b->step_impl == 2) {  // host-driven steps of the two-kernel pipeline use the four-kernel form
     dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
     dim3 gr((gc.x + ORL_ROWS1_GROUPS - 1) / ORL_ROWS1_GROUPS);  // lane-per-item row kernel
     const size_t lds_b2 = (size_t)32 * VP.E * sizeof(sp::SinkEntry);
@@ -584,6 +705,8 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
     ORL_TK("k_ctrl_b2");                                                                               \
     hipLaunchKernelGGL((k_rows1<EE, WW>), gr, blk, 0, VS, VP, 1);                                       \
     ORL_TK("k_rows(release)");                                                                         \
+    hipLaunchKernelGGL((k_rel_tail<EE, WW>), dim3(1), blk, 0, VS, VP, 0);                              \
+    ORL_TK("k_rel_tail");                                                                              \
   } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
     ORL_FOR_ENV(PER_ENV)
@@ -662,13 +785,13 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   b->view = nullptr;
   b->view_stream = nullptr;
   {
-    // Measured on MI355X (tools/compare_impls.sh): the split pipeline wins once the batch fills the chip several
-    // times over (cfg2 65 536 envs: 3.5e8 vs 2.5e8 env-steps/s; cfg5 32 768: 1.64e8 vs 1.23e8; RMCSA 16 384: 1.17e8 vs
-    // 1.04e8); below that its six launches per step cost more than they save (cfg2 16 384: 1.83e8 vs 2.04e8).
+    // Measured on MI355X (tools/compare_impls.sh, env-steps/s of the device loop): the two-kernel pipeline wins once the
+    // batch fills the chip (cfg2 65 536 envs: 4.9e8 vs 4.4e8 four-kernel split vs 2.5e8 one wavefront per env; cfg5
+    // 32 768: 2.4e8 / 2.1e8 / 1.2e8; RMCSA 16 384: 2.1e8 / 1.6e8 / 1.0e8; cfg2 16 384: 2.0e8 / 1.9e8 / 2.0e8); below
+    // that the per-env kernel's two launches win (cfg2 4 096: 5.6e7 vs 7.1e7).  ORL_STEP_IMPL = 64 | 8 | 1 | 2 overrides.
     const char* impl = getenv("ORL_STEP_IMPL");
-    const int64_t split_from = (c->env_type == ORL_ENV_RMCSA) ? 16384 : 24576;
-    b->step_impl = impl ? atoi(impl) : (n_envs >= split_from ? 1 : 64);
-    if (b->step_impl != 8 && b->step_impl != 1) b->step_impl = 64;
+    b->step_impl = impl ? atoi(impl) : (n_envs >= 16384 ? 2 : 64);
+    if (b->step_impl != 8 && b->step_impl != 1 && b->step_impl != 2) b->step_impl = 64;
   }
   DevParams& P = b->P;
   P.env_type = c->env_type;
@@ -697,7 +820,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     cap = (int)(load + 10.0 * sqrt(load) + 64.0);
   }
   P.ev_cap = (cap + 63) / 64 * 64;
-  if (b->step_impl == 1 && P.ev_cap > 2048) b->step_impl = 64;  // the split pipeline indexes release slots with 8 + 3 bits
+  if ((b->step_impl == 1 || b->step_impl == 2) && P.ev_cap > 2048) b->step_impl = 64;  // the split pipeline indexes release slots with 8 + 3 bits
   int words = C * P.E * b->wt;
   P.bm_words = (words + 1) & ~1;
   int rej = P.allow_rejection;
@@ -754,11 +877,18 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     rc |= dalloc(b, &P.q_cnt_a, waves);
     rc |= dalloc(b, &P.q_cnt_b, waves);
     rc |= dalloc(b, &P.q_stat, 16);
-    rc |= dalloc(b, &P.q_def, 2 * B + 16 * 80);  // [B + 16] for the whole batch, then one region per sub-batch
+    // deferred-env lists: [B + 16] for the whole batch, then one region per sub-batch; two buffers (steps alternate)
+    P.q_def_stride = (i64)(2 * B + 16 * 80);
+    rc |= dalloc(b, &P.q_def, 2 * (size_t)P.q_def_stride);
+    if (b->step_impl == 2) {
+      rc |= dalloc(b, &P.rel_sums, B * 2 * C);
+      if (!rc) hipMemset(P.rel_sums, 0, B * 2 * C * sizeof(int));
+    }
+    if (!rc) hipMemset(P.q_def, 0, 2 * (size_t)P.q_def_stride * sizeof(u32));
     rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
     rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
     if (!rc) hipMemset(P.q_stat, 0, 16 * sizeof(u32));
-    if (!rc) hipMemset(P.q_def, 0, (2 * B + 16 * 80) * sizeof(u32));
+
   }
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
   rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
@@ -802,6 +932,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
       q.q_def = P.q_def + (B + 16) + lo + 16 * b->subs.size();
+      if (q.rel_sums) q.rel_sums += lo * 2 * C;
       if (q.obs) { q.obs += lo * P.obs_dim; q.term_obs += lo * P.obs_dim; }
       b->sub_streams.push_back(b->owned_streams[b->subs.size() % (size_t)n_streams]);
       b->subs.push_back(q);
@@ -945,6 +1076,12 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
         launch_policy_step(b, policy_id);
       }
     }
+    if (b->step_impl == 2)
+      for (size_t k = 0; k < b->subs.size(); k++) {
+        b->view = &b->subs[k];
+        b->view_stream = b->sub_streams[k];
+        launch_finish2(b);
+      }
     b->view = nullptr;
     b->view_stream = nullptr;
     for (hipStream_t st : b->owned_streams) {
@@ -963,9 +1100,14 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
       launch_policy_step(b, policy_id);
       b->tk = nullptr;
     }
+    if (b->step_impl == 2) launch_finish2(b);
   } else {
+    if (!time_kernels) {
+      for (int64_t s = 0; s < n_steps; s++) launch_policy_step(b, policy_id);
+      if (b->step_impl == 2) launch_finish2(b);
+    }
     for (int64_t s = 0; s < n_steps; s++) {
-      if (!time_kernels) { launch_policy_step(b, policy_id); continue; }
+      if (!time_kernels) break;
       HIPCHK(hipEventRecord(evs[3 * s], b->stream));
       launch_policy(b, policy_id);
       HIPCHK(hipEventRecord(evs[3 * s + 1], b->stream));

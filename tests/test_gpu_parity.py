@@ -10,12 +10,12 @@ pytestmark = pytest.mark.gpu
 
 # The library picks the step implementation by batch size (split pipeline from 24 576 envs, one wavefront per env
 # below); the small parity cases run against both by forcing it (the variable is read when a batch is created).
-IMPLS = ["wave64", "split"]
+IMPLS = ["wave64", "split", "split2"]
 
 
 @pytest.fixture(params=IMPLS)
 def impl(request, monkeypatch):
-    monkeypatch.setenv("ORL_STEP_IMPL", {"wave64": "64", "split": "1"}[request.param])
+    monkeypatch.setenv("ORL_STEP_IMPL", {"wave64": "64", "split": "1", "split2": "2"}[request.param])
     return request.param
 
 
@@ -190,24 +190,27 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
     kw = dict(kw, episode_length=90)
     seeds = [77 + 3 * i for i in range(batch)]
     out = {}
-    for name, v in (("wave64", "64"), ("split", "1")):
+    for name, v in (("wave64", "64"), ("split", "1"), ("split2", "2")):
         monkeypatch.setenv("ORL_STEP_IMPL", v)
         env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
-        env.run(policy, steps)
+        env.run(policy, steps // 2)  # two calls: the two-kernel pipeline finishes its pending update between them
+        env.run(policy, steps - steps // 2)
         pick = [0, 1, batch // 3, batch - 1]
         out[name] = dict(counters=env.counters().copy(), services=env.services().copy(), active=env.active().copy(),
                          flags=env.flags().copy(), slots=[env.slots(i).copy() for i in pick],
                          link=[env.link_stats(i).copy() for i in pick], net=[env.net_stats(i).copy() for i in pick],
                          serial=int(env.lib.orl_batch_debug_serial_count(env._h)))
         env.close()
-    a, b = out["wave64"], out["split"]
+    a = out["wave64"]
     chk = _exact(workload)
-    for key in ("counters", "services", "active", "flags"):
-        chk(0, key, b[key], a[key])
-    for j in range(4):
-        chk(j, "slots", b["slots"][j], a["slots"][j])
-        chk(j, "link_stats", b["link"][j], a["link"][j])
-        chk(j, "net_stats", b["net"][j], a["net"][j])
+    for other in ("split", "split2"):
+        b = out[other]
+        for key in ("counters", "services", "active", "flags"):
+            chk(0, other + " " + key, b[key], a[key])
+        for j in range(4):
+            chk(j, other + " slots", b["slots"][j], a["slots"][j])
+            chk(j, other + " link_stats", b["link"][j], a["link"][j])
+            chk(j, other + " net_stats", b["net"][j], a["net"][j])
 
 
 def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
@@ -221,7 +224,7 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         fam, topo, kw, policy = WORKLOADS[workload]
         kw = dict(kw, episode_length=70)
         seeds = [5 + 11 * i for i in range(batch)]
-        for name, v, masks in (("wave64", "64", None), ("split", "1", "1"), ("split2", "1", "2")):
+        for name, v, masks in (("wave64", "64", None), ("split", "1", "1"), ("split2", "1", "2"), ("two", "2", "1"), ("two2", "2", "2")):
             monkeypatch.setenv("ORL_STEP_IMPL", v)
             if masks:
                 monkeypatch.setenv("ORL_ITEM_MASKS", masks)
@@ -235,10 +238,10 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
             assert not env.flags().any()
             env.close()
         chk = _exact(workload)
-        for name in ("split", "split2"):
+        for name in ("split", "split2", "two", "two2"):
             for key in ("counters", "services", "active", "slots", "link", "net"):
                 chk(0, name + " " + key, out[name][key], out["wave64"][key])
-        assert out["split"]["serial"] > 100 and out["split2"]["serial"] > 0
+        assert out["split"]["serial"] > 100 and out["split2"]["serial"] > 0 and out["two"]["serial"] > 100
 
 
 def test_run_reports_every_kernel_of_the_step(monkeypatch):
@@ -247,7 +250,8 @@ def test_run_reports_every_kernel_of_the_step(monkeypatch):
 
     fam, topo, kw, policy = WORKLOADS["cfg2"]
     for v, names in (("64", ["k_policy", "k_step"]),
-                     ("1", ["k_policy_ctrl_a", "k_rows(provision)", "k_ctrl_b2", "k_rows(release)"])):
+                     ("1", ["k_policy_ctrl_a", "k_rows(provision)", "k_ctrl_b2", "k_rows(release)", "k_rel_tail"]),
+                     ("2", ["k_step_a2", "k_rows2", "k_rel_tail"])):
         monkeypatch.setenv("ORL_STEP_IMPL", v)
         env = orl.make(fam, topology=topo, num_envs=2048, seeds=list(range(2048)), **kw)
         st = env.run(policy, 20, time_kernels=1)
