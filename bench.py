@@ -3,8 +3,9 @@
 envs per MI355X, on-device KSP-FF policy (BASELINE.json `metric`; SURVEY.md §8d cfg2 at B = 65 536).
 
 One "step" = one batched policy + env.step() over the whole batch, entirely on the device: at this batch size
-the split pipeline (slot-scan fused with control kernel A; row kernel; control kernel B2; row kernel; serial
-fallback), launched back to back on the batch's streams; inputs are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
+the two-kernel pipeline (k_step_a2: slot scan + all per-env control + release detection -> mixed work items;
+k_rows2: one lane per touched link row; k_rel_tail: one-workgroup serial fallback), launched back to back on the
+batch's two streams (half the envs each); inputs are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
 collective on the data path; torch.distributed is used only for the barrier and the max-over-ranks time).
 
     python bench.py --gpus 1 --steps 300 --warmup 1500
@@ -63,7 +64,10 @@ def algorithmic_bytes(env, mean_hops, active):
         "k_rows(provision)": 64 * mean_hops,               # link rows + per-link statistics, read and written
         "k_rows(release)": 64 * mean_hops,
         "k_ctrl_b2": lg / 2,                                # due-release detection
-        "k_rel_serial": 0.0,
+        "k_rel_tail": 0.0,
+        # two-kernel pipeline: all per-env control in one kernel; provision + release rows in one launch
+        "k_step_a2": scan + 32 * mean_hops + fixed + lg,
+        "k_rows2": 128 * mean_hops,
         "k_obs": 8 * env.obs_dim if env.obs_dim else 0.0,
     }
 

@@ -27,9 +27,8 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/
                "steady-state launches of each kernel; FETCH_SIZE x the factor measured on k_calib_read (known byte count; 8-B and 16-B per-lane "
                "loads both give 2.0, as MI355X_MICROARCH.md states); WRITE_SIZE as is",
        "workload": "cfg2", "batch": 65536, "fetch_calibration_factor": round(factor, 4), "kernels": {}}
-# bench.py looks kernels up by these names; both launches of the row kernel (provision / release items) share one average
-for name, kern in (("k_policy_ctrl_a", "k_policy_ctrl_a<"), ("k_rows", "k_rows1<"), ("k_ctrl_b2", "k_ctrl_b2<"),
-                   ("k_policy", "void k_policy<")):
+# bench.py looks kernels up by these names
+for name, kern in (("k_step_a2", "k_step_a2<"), ("k_rows2", "k_rows2<"), ("k_policy", "void k_policy<")):
     f = mean_last("tr_f", kern) * 1024 * factor
     w = mean_last("tr_w", kern) * 1024
     out["kernels"][name] = {"fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w)}
