@@ -349,6 +349,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
       // detection); those fields are written again below when the detection changed them.
       SoonRegs soon;
       release_soon<ENV, W>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info);
+      ORL_PROFA(10);
       if (sink.deferred) {
         // more releases meet on one link than an item holds masks for: the release state stays as stored and the
         // serial tail (k_rel_tail) releases them in place after this step's items
@@ -377,6 +378,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
       }
     }
   }
+  ORL_PROFA(11);
   if (MERGE == 2) {
     emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a);
   } else {

@@ -334,9 +334,19 @@ __global__ void __launch_bounds__(256) k_step_a2(DevParams P, int pol, int parit
   ORL_PROFA_END();
 }
 // one lane per mixed item
+// One workgroup per control workgroup (32 envs, ~140 mixed items, 192 threads): a thread handles at most one item in
+// all but one launch in 10^3, so the kernel's duration is one item's dependent chain.  Measured, us per 65 536-env launch
+// between events: 1 group x 192 threads 55.9, x 256 57.8, x 128 66.2; 2 groups x 256 62.6, 3: 63.8, 4: 70.5, 6: 80.1.  (A
+// static thread -> slot map that requests the item together with the fill count was slower: 62.9.)
+#ifndef ORL_ROWS2_GROUPS
+#define ORL_ROWS2_GROUPS 1
+#endif
+#ifndef ORL_ROWS2_THREADS
+#define ORL_ROWS2_THREADS 192
+#endif
 template <int ENV, int W>
-__global__ void __launch_bounds__(256) k_rows2(DevParams P, int parity) {
-  constexpr int NR = 4 * ORL_ROWS1_GROUPS;
+__global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int parity) {
+  constexpr int NR = 4 * ORL_ROWS2_GROUPS;
   sp::Prof prof;
   ORL_PROFR_BEGIN();
   const u32 r0 = blockIdx.x * NR;
@@ -347,7 +357,7 @@ __global__ void __launch_bounds__(256) k_rows2(DevParams P, int parity) {
 #pragma unroll
   for (int j = 0; j < NR; j++) cum[j + 1] = cum[j] + ((r0 + j < n_regions) ? cnt[j] : 0u);
   const ulonglong2* q = P.q_a + (size_t)r0 * P.q_wave * 2;
-  for (u32 idx = threadIdx.x; idx < cum[NR]; idx += 256) {
+  for (u32 idx = threadIdx.x; idx < cum[NR]; idx += ORL_ROWS2_THREADS) {
     u32 j = 0, base = 0;
 #pragma unroll
     for (int t = 1; t < NR; t++)
@@ -647,7 +657,7 @@ static void launch_step2(orl_batch* b, int pol, bool wide) {
   int& par = b->parity[b->view ? (int)(b->view - b->subs.data()) + 1 : 0];
   if (wide) launch_policy(b, pol);  // RMCSA / k > 8: the one-env-per-wavefront slot scan stays a launch of its own
   dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
-  dim3 gr((gc.x + ORL_ROWS1_GROUPS - 1) / ORL_ROWS1_GROUPS);
+  dim3 gr((gc.x + ORL_ROWS2_GROUPS - 1) / ORL_ROWS2_GROUPS), blk_r(ORL_ROWS2_THREADS);
   const size_t lds_a = (size_t)32 * VP.E * sizeof(sp::SinkEntry);
 #define CALLW(WW)                                                                                                   \
   do {                                                                                                              \
@@ -659,7 +669,7 @@ static void launch_step2(orl_batch* b, int pol, bool wide) {
       hipLaunchKernelGGL((k_step_a2<EE, WW, true>), gc, blk, lds_a, VS, VP, pol, par);                               \
     }                                                                                                               \
     ORL_TK("k_step_a2");                                                                                            \
-    hipLaunchKernelGGL((k_rows2<EE, WW>), gr, blk, 0, VS, VP, par);                                                 \
+    hipLaunchKernelGGL((k_rows2<EE, WW>), gr, blk_r, 0, VS, VP, par);                                               \
     ORL_TK("k_rows2");                                                                                              \
     hipLaunchKernelGGL((k_rel_tail<EE, WW>), dim3(1), blk, 0, VS, VP, par);                                         \
     ORL_TK("k_rel_tail");                                                                                           \

@@ -1,7 +1,7 @@
 """Per-phase shader-clock breakdown of the split control kernels (needs a -DORL_TIMING build: ORL_HIPCC_EXTRA)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-os.environ["ORL_STEP_IMPL"] = "1"; os.environ["ORL_STREAMS"] = "1"
+os.environ.setdefault("ORL_STEP_IMPL", "2"); os.environ["ORL_STREAMS"] = "1"
 import numpy as np
 import optical_rl_gym_amd as orl
 from bench import WORKLOADS
