@@ -180,6 +180,25 @@ def main():
                    sample="%d envs x %d steps after %d warm-up steps, same workload and seeds, oracle/orl_oracle.c, 1 thread"
                           % (n_cpu, timed, warm))
 
+    host = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # SURVEY 8(d) second variant: host-supplied uniform-random actions, reward/done/info fetched every step — the
+        # PCIe-inclusive rate of an agent on the host (never `value`)
+        import numpy as np
+
+        rng = np.random.RandomState(3)
+        n_host = 30
+        acts = [np.stack([rng.randint(0, env.k_paths + 1, B), rng.randint(0, env.num_spectrum_resources + 1, B)], 1).astype(np.int32)
+                for _ in range(4)]
+        env.step(acts[0], auto_reset=True)
+        h0 = time.perf_counter()
+        for s_ in range(n_host):
+            env.step(acts[s_ % 4], auto_reset=True)
+        hdt = time.perf_counter() - h0
+        host = dict(value=round(B * n_host / hdt, 1), unit="env-steps/s", steps=n_host,
+                    note="host-driven step(): 16 B/env of actions in, reward+done+info (%d B/env) out per step over PCIe, "
+                         "synchronous; four-kernel form with info" % (8 + 1 + 8 * env.n_info))
+
     if rank == 0:
         total_steps = B * world * args.steps
         out = {
@@ -203,6 +222,7 @@ def main():
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_by_kernel": roof,
             "cpu_baseline": cpu,
+            "host_driven": host,
             "state": {"mean_active_services": round(active, 1),
                       "blocking": round(1.0 - accepted / max(processed, 1), 5)},
         }

@@ -154,6 +154,19 @@ int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels
 
 int orl_batch_sync(orl_batch* b);
 
+/* Zero-copy access for an agent that lives on the same GPU (the reference hands numpy arrays to SB3,
+ * DeepRMSA.ipynb:272-302).  Device pointers of the batch's I/O arrays: write actions there, call
+ * orl_batch_step(b, NULL, auto_reset, NULL, NULL, NULL, NULL) (no copies, no synchronisation: the launches are queued
+ * on the batch's stream), orl_batch_sync(b), read reward / done / info / obs in place.  The pointers stay valid until
+ * orl_batch_destroy.  `which`: */
+#define ORL_BUF_ACTIONS 0  /* int32 [n_envs][4] */
+#define ORL_BUF_REWARD 1   /* f64   [n_envs] */
+#define ORL_BUF_DONE 2     /* u8    [n_envs] */
+#define ORL_BUF_INFO 3     /* f64   [n_envs][info_dim] */
+#define ORL_BUF_OBS 4      /* f64   [n_envs][obs_dim] (DeepRMSA) */
+#define ORL_BUF_TERM_OBS 5 /* f64   [n_envs][obs_dim]: observation before an auto reset */
+int orl_batch_device_buffer(orl_batch* b, int which, void** device_ptr, int64_t* n_elements);
+
 /* state read-back (parity tests, Python attribute surface) */
 int orl_batch_get_counters(orl_batch* b, int64_t* out /*[n_envs][ORL_N_COUNTERS]*/);
 int orl_batch_get_services(orl_batch* b, double* out /*[n_envs][ORL_N_SERVICE]*/);

@@ -1052,6 +1052,21 @@ extern "C" int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_res
   return ORL_OK;
 }
 
+extern "C" int orl_batch_device_buffer(orl_batch* b, int which, void** device_ptr, int64_t* n_elements) {
+  if (!b || !device_ptr || !n_elements) return fail(ORL_E_INVALID, "null argument");
+  const int64_t B = b->P.B;
+  switch (which) {
+    case ORL_BUF_ACTIONS: *device_ptr = b->P.actions; *n_elements = B * 4; break;
+    case ORL_BUF_REWARD: *device_ptr = b->P.reward; *n_elements = B; break;
+    case ORL_BUF_DONE: *device_ptr = b->P.done; *n_elements = B; break;
+    case ORL_BUF_INFO: *device_ptr = b->P.info; *n_elements = B * b->P.n_info; break;
+    case ORL_BUF_OBS: *device_ptr = b->P.obs; *n_elements = B * b->P.obs_dim; break;
+    case ORL_BUF_TERM_OBS: *device_ptr = b->P.term_obs; *n_elements = B * b->P.obs_dim; break;
+    default: return fail(ORL_E_INVALID, "unknown buffer %d", which);
+  }
+  return ORL_OK;
+}
+
 extern "C" int orl_batch_observation(orl_batch* b, double* obs_out) {
   if (!b || !obs_out) return fail(ORL_E_INVALID, "null argument");
   if (!b->P.obs_dim) return fail(ORL_E_INVALID, "this env family has no array observation");

@@ -237,6 +237,35 @@ class BatchedOpticalEnv:
     def sync(self):
         _lib.check(self.lib.orl_batch_sync(self._h))
 
+    # ---- zero-copy device views (an agent on the same GPU: no PCIe in the loop) -------------------------
+    _BUFFERS = {"actions": (0, "<i4", 4), "reward": (1, "<f8", 0), "done": (2, "|u1", 0), "info": (3, "<f8", -1),
+                "obs": (4, "<f8", -2), "terminal_obs": (5, "<f8", -2)}
+
+    def device_array(self, name):
+        """The batch's device-resident I/O array `name` as an object with `__cuda_array_interface__` (what
+        `torch.as_tensor(x, device="cuda")` and CuPy consume without a copy).  Write actions into "actions", call
+        `step(None, fetch=False)`, `sync()`, read "reward" / "done" / "info" / "obs" in place."""
+        which, typestr, cols = self._BUFFERS[name]
+        ptr, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.orl_batch_device_buffer(self._h, which, C.byref(ptr), C.byref(n)))
+        cols = {-1: self.n_info, -2: self.obs_dim}.get(cols, cols)
+        if n.value == 0 or not ptr.value:
+            raise _lib.OrlError("this env family has no '%s' array" % name)
+        shape = (self.num_envs, cols) if cols else (self.num_envs,)
+
+        class _DeviceArray:
+            __cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr.value), False), "version": 2,
+                                        "strides": None}
+            owner = self  # keeps the batch alive
+
+        return _DeviceArray()
+
+    def device_tensor(self, name):
+        """`device_array(name)` wrapped as a torch tensor on this batch's GPU (no copy)."""
+        import torch
+
+        return torch.as_tensor(self.device_array(name), device="cuda:%d" % self.device_id)
+
     def observation(self):
         if not self.obs_dim:
             return None

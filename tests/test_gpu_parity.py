@@ -262,6 +262,33 @@ def test_run_reports_every_kernel_of_the_step(monkeypatch):
         env.close()
 
 
+def test_zero_copy_device_tensors_drive_the_batch():
+    """An agent on the same GPU: actions written into the batch's device array through torch, step without copies,
+    reward / done / info read in place — same numbers as the host-driven path."""
+    import torch
+
+    meta = load_golden("g2_rmsa_cfg2_sapff")["meta"]
+    kw = dict(meta["kwargs"])
+    kw.pop("seed")
+    kw["episode_length"] = 40
+    seeds = list(range(900, 900 + 96))
+    a = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=96, seeds=seeds)
+    b = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=96, seeds=seeds)
+    act, rew, done, info = (a.device_tensor(n) for n in ("actions", "reward", "done", "info"))
+    assert act.is_cuda and act.shape == (96, 4) and act.dtype == torch.int32 and info.shape == (96, a.n_info)
+    for t in range(120):
+        acts = b.policy("SAP_FF").copy()
+        act.copy_(torch.from_numpy(acts))
+        torch.cuda.synchronize()
+        a.step(None, auto_reset=True, fetch=False)
+        a.sync()
+        _, r, d, i = b.step(acts, auto_reset=True)
+        assert np.array_equal(rew.cpu().numpy(), r) and np.array_equal(done.cpu().numpy(), d), t
+        assert np.array_equal(info.cpu().numpy(), i), t
+    a.close()
+    b.close()
+
+
 def test_device_seeding_equals_cpython():
     """random.Random(seed) expanded on the device (init_by_array) vs CPython's getstate(), incl. negative and >32-bit seeds."""
     import optical_rl_gym_amd as orl
