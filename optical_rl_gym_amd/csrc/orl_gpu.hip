@@ -452,13 +452,16 @@ __global__ void __launch_bounds__(256) k_rows1(DevParams P, int phase) {
 }
 
 template <int ENV, int W>
-__global__ void __launch_bounds__(64) k_obs(DevParams P) {
+__global__ void __launch_bounds__(64) k_obs(DevParams P, int with_terminal) {
   const i64 env = blockIdx.x;
   const int lane = lane_id();
   Env e;
   env_load(P, e, env, lane);
   stage_in(P, e, (u64*)orl_lds_raw, lane);
-  if (ENV == ENV_DEEPRMSA) deep_observation<W>(P, e, lane, P.obs + env * P.obs_dim, nullptr);
+  // after a step: an env that just finished its episode also gets the observation as `terminal_observation` (the soft
+  // reset keeps the pending service, so the values are the same; SB3 VecEnv convention)
+  if (ENV == ENV_DEEPRMSA)
+    deep_observation<W>(P, e, lane, P.obs + env * P.obs_dim, (with_terminal && P.done[env]) ? P.term_obs + env * P.obs_dim : nullptr);
 }
 
 // Counter calibration: streams the whole slot-map array once with a known byte count (FETCH_SIZE on gfx950 is
@@ -648,7 +651,7 @@ static void launch_policy(orl_batch* b, int pol) {
 #undef CALLW
   ORL_TK("k_policy");
 }
-static void launch_obs(orl_batch* b);
+static void launch_obs(orl_batch* b, int with_terminal = 1);
 static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_policy = -1);
 // two-kernel pipeline: (slot scan +) all per-env control -> one queue of mixed items -> row kernel
 static void launch_step2(orl_batch* b, int pol, bool wide) {
@@ -751,12 +754,12 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
 #undef CALLW
   ORL_TK("k_step");
 }
-static void launch_obs(orl_batch* b) {
+static void launch_obs(orl_batch* b, int with_terminal) {
   const DevParams& VP = b->view ? *b->view : b->P;
   hipStream_t VS = b->view ? b->view_stream : b->stream;
   dim3 g((unsigned)VP.B), blk(64);
   size_t lds = VP.lds_bytes;
-#define CALLW(WW) hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, VS, VP)
+#define CALLW(WW) hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, VS, VP, with_terminal)
   ORL_FOR_W(CALLW)
 #undef CALLW
   ORL_TK("k_obs");
@@ -962,7 +965,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   HIPCHK(hipMemsetAsync(P.actions, 0, B * 4 * sizeof(int), b->stream));
   hipLaunchKernelGGL(k_init_mt, dim3((unsigned)B), dim3(64), 624 * 4, b->stream, P, raw);
   launch_reset(b, 1, nullptr);
-  if (P.obs_dim) launch_obs(b);
+  if (P.obs_dim) launch_obs(b, 0);
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   hipFree(raw);
@@ -1013,7 +1016,7 @@ extern "C" int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask) 
     HIPCHK(hipMemcpyAsync(dmask, env_mask, (size_t)b->P.B, hipMemcpyHostToDevice, b->stream));
   }
   launch_reset(b, full ? 1 : 0, dmask);
-  if (b->P.obs_dim) launch_obs(b);
+  if (b->P.obs_dim) launch_obs(b, 0);
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   if (dmask) hipFree(dmask);
@@ -1071,7 +1074,7 @@ extern "C" int orl_batch_observation(orl_batch* b, double* obs_out) {
   if (!b || !obs_out) return fail(ORL_E_INVALID, "null argument");
   if (!b->P.obs_dim) return fail(ORL_E_INVALID, "this env family has no array observation");
   HIPCHK(hipSetDevice(b->device));
-  launch_obs(b);
+  launch_obs(b, 0);
   HIPCHK(hipMemcpyAsync(obs_out, b->P.obs, (size_t)b->P.B * b->P.obs_dim * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
@@ -1342,7 +1345,7 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
   HIPCHK(hipStreamSynchronize(b->stream));
   const unsigned char* o = (const unsigned char*)in;
   for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(s.ptr, o, s.bytes, hipMemcpyHostToDevice)); o += s.bytes; }
-  if (b->P.obs_dim) launch_obs(b);
+  if (b->P.obs_dim) launch_obs(b, 0);
   HIPCHK(hipStreamSynchronize(b->stream));
   return ORL_OK;
 }

@@ -289,6 +289,28 @@ def test_zero_copy_device_tensors_drive_the_batch():
     b.close()
 
 
+def test_terminal_observation_on_device(impl):
+    """DeepRMSA: the env that reports done gets its observation also as terminal_observation (device array)."""
+    meta = load_golden("g4_deeprmsa_j2_sap")["meta"]
+    kw = dict(meta["kwargs"])
+    kw.pop("seed")
+    kw["episode_length"] = 12
+    env = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=64, seeds=list(range(64)))
+    obs, tobs, done = env.device_tensor("obs"), env.device_tensor("terminal_obs"), env.device_tensor("done")
+    seen = 0
+    for t in range(40):
+        env.policy("SAP", fetch=False)
+        env.step(None, auto_reset=True, fetch=False)
+        env.sync()
+        d = done.cpu().numpy().astype(bool)
+        if d.any():
+            seen += int(d.sum())
+            assert np.array_equal(tobs.cpu().numpy()[d], obs.cpu().numpy()[d])
+            assert np.array_equal(obs.cpu().numpy(), env.observation())
+    assert seen >= 64
+    env.close()
+
+
 def test_device_seeding_equals_cpython():
     """random.Random(seed) expanded on the device (init_by_array) vs CPython's getstate(), incl. negative and >32-bit seeds."""
     import optical_rl_gym_amd as orl
