@@ -464,6 +464,65 @@ __global__ void __launch_bounds__(64) k_obs(DevParams P, int with_terminal) {
     deep_observation<W>(P, e, lane, P.obs + env * P.obs_dim, (with_terminal && P.done[env]) ? P.term_obs + env * P.obs_dim : nullptr);
 }
 
+// DeepRMSAEnv.observation (deeprmsa_env.py:60-121) with 8 lanes per env, lane = path (k <= 8), 8 envs per wavefront: rows
+// are read straight from global memory (the form of the slot scan), every lane writes its own path block.  The
+// one-wavefront-per-env k_obs above staged the whole slot map in LDS and took 26.7 us per 32 768-env launch (cfg3).
+template <int W>
+__global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
+  const int lane = lane_id(), gl = lane & 7;
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (env >= P.B) return;
+  const u64* s = P.scal + env * ORL_SCAL_WORDS;
+  u64 t = s[SC_SRC_DST];
+  const int src = (int)(u32)t, dst = (int)(t >> 32);
+  t = s[SC_BR_IDX];
+  const int bit_rate = (int)(u32)t, br_idx = (int)(t >> 32);
+  const int N = P.N, J = P.J, S = P.S, WD = 2 * J + 3;
+  double* o = P.obs + env * P.obs_dim;
+  double* o2 = (with_terminal && P.done[env]) ? P.term_obs + env * P.obs_dim : nullptr;
+  const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
+  for (int i = gl; i < 1 + 2 * N; i += 8) {
+    const double v = (i == 0) ? (double)bit_rate / 100 : ((i == 1 + mn || i == 1 + N + mx) ? 1.0 : 0.0);
+    o[i] = v;
+    if (o2) o2[i] = v;
+  }
+  if (gl < P.K) {
+    double f[19];  // 2 * J + 3 <= 19
+#pragma unroll
+    for (int i = 0; i < 19; i++) f[i] = -1.0;
+    if (gl < P.n_paths[src * N + dst]) {
+      const int pidx = (src * N + dst) * P.K + gl;
+      const Row<W> m = path_and_rec<W>(path_rec_load(P, pidx), P.bitmap + env * P.bm_words, P.E, S, 0);
+      const int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
+      Row<W> r = row_runs_ge<W>(m, n);
+      const Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        if (b < J && row_any<W>(r)) {
+          const int st = row_ctz<W>(r);
+          const Row<W> z = row_andn<W>(zeros, row_mask_lo<W>(st));
+          const int end = row_any<W>(z) ? row_ctz<W>(z) : S;
+          f[2 * b] = 2 * ((double)st - 0.5 * (double)S) / (double)S;
+          f[2 * b + 1] = (double)(end - st - 8) / 8;
+          r = row_andn<W>(r, row_mask_lo<W>(end));
+        }
+      }
+      const double fn = ((double)n - 5.5) / 3.5;
+      const int tot = row_popc<W>(m);
+      const double ft = 2 * ((double)tot - 0.5 * (double)S) / (double)S;
+      const int nruns = row_popc<W>(row_starts<W>(m));
+      const double fr = (nruns > 0) ? ((double)tot / (double)nruns - 4) / 4 : -1.0;
+      // f[2J], f[2J+1], f[2J+2] with a run-time J: written below by position
+#pragma unroll
+      for (int i = 0; i < 19; i++) f[i] = (i == 2 * J) ? fn : (i == 2 * J + 1) ? ft : (i == 2 * J + 2) ? fr : f[i];
+    }
+    double* sp = o + 1 + 2 * N + gl * WD;
+#pragma unroll
+    for (int i = 0; i < 19; i++)
+      if (i < WD) { sp[i] = f[i]; if (o2) o2[1 + 2 * N + gl * WD + i] = f[i]; }
+  }
+}
+
 // Counter calibration: streams the whole slot-map array once with a known byte count (FETCH_SIZE on gfx950 is
 // documented to under-report wide coalesced reads; this gives the factor for our own access widths).
 __global__ void k_calib_read(const u64* __restrict__ src, i64 n_words, int width16, u64* sink) {
@@ -759,7 +818,10 @@ static void launch_obs(orl_batch* b, int with_terminal) {
   hipStream_t VS = b->view ? b->view_stream : b->stream;
   dim3 g((unsigned)VP.B), blk(64);
   size_t lds = VP.lds_bytes;
-#define CALLW(WW) hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, VS, VP, with_terminal)
+  const bool g8form = VP.K <= 8 && VP.J <= 8;
+  dim3 g8((unsigned)((VP.B + 31) / 32)), blk8(256);
+#define CALLW(WW) do { if (g8form) hipLaunchKernelGGL((k_obs8<WW>), g8, blk8, 0, VS, VP, with_terminal); \
+                       else hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, WW>), g, blk, lds, VS, VP, with_terminal); } while (0)
   ORL_FOR_W(CALLW)
 #undef CALLW
   ORL_TK("k_obs");
