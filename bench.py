@@ -170,7 +170,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import OracleBatch
 
-        n_cpu, warm, timed = 64, 1500, 2500
+        n_cpu, warm, timed = 128, 1500, 3500  # ~14 s of one host core
         ora = OracleBatch(fam, topo, seeds[:n_cpu], **kw)
         ora.run(policy, warm)
         c0 = time.perf_counter()

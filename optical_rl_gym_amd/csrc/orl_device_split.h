@@ -1,25 +1,28 @@
-// orl_device_split.h — step() as a pipeline of kernels ("split" implementation; the default from 24 576 envs).
+// orl_device_split.h — step() as a pipeline of kernels: per-env control -> work items -> one lane per touched link row.
 //
-// One policy + step of the batch (device-resident loop) =
-//   k_policy_ctrl_a  8 lanes per env: the slot scan (policy), then — the action still in registers — decode + validate,
-//                    counters, reward, the release push, network throughput, the next service (RNG, node pair, bit
-//                    rate), done / auto reset; every link row the provision touches becomes a 32-byte work item
-//   k_rows1(A)       one lane per item: clear the slots, per-link statistics, compactness sums (integer atomics)
-//   k_ctrl_b2        8 lanes per env: finish the network-compactness average (needs the sums after the provision),
-//                    find the due releases through the env's soon list -> one work item per touched link
-//   k_rows1(B)       one lane per item: set the slots, statistics, sums; tail: the rare envs whose releases did not
-//                    fit the item form release them in place (8 lanes per env)
-// Host-driven step() (agent in the loop, info wanted) launches k_ctrl_a / k_ctrl_b1 instead of the merged kernel.
+// Two-kernel pipeline (step_impl 2; the default from 16 384 envs), one policy + step of the device-resident loop:
+//   k_step_a2   8 lanes per env: the slot scan (policy), then — the action still in registers — decode + validate,
+//               counters, reward, the release push, network throughput, the next service (RNG, node pair, bit rate),
+//               done / auto reset, and the due releases of the step through the env's soon list.  Output: one queue of
+//               32-byte MIXED work items, one per touched link: the provision's mask first, then the release masks.
+//   k_rows2     one lane per item: clear / set the slots, per-link statistics, compactness sums (integer atomics)
+//   k_rel_tail  one workgroup: the rare envs whose releases did not fit the item form release them in place
+//   The network-compactness average needs the sums between the provision and the releases: the next launch of k_step_a2
+//   finishes it from totals - rel_sums (k_finish2 at the end of a run).
+// Four-kernel split (step_impl 1; also the host-driven step() of large batches, where info needs the compactness right
+// after the provision): k_policy_ctrl_a | k_ctrl_a (+ k_ctrl_b1), k_rows1(provision items), k_ctrl_b2 (release
+// detection), k_rows1(release items), k_rel_tail.
 //
 // Why: in the monolithic kernels the row work (bit tricks + float64 running averages) ran under per-env control
 // flow — one or two link rows per pass, multiplied by the worst hop count and release count among the envs sharing a
 // wavefront.  Flattened into queues, the row kernel is a flat loop over independent items and the control kernels
 // shrink to the genuinely serial part.  What bounds these kernels is not bytes but dependent memory round trips of
-// the slowest wavefront (a 8 192-env launch takes 60 % of the time of a 65 536-env one), so the design rules here are:
-// request everything a phase needs in one batch, keep stores behind the last load (they share the in-order memory
-// counter), no workgroup barriers, no per-slot searches (free-slot stack, soon list), branch-free selection.
+// the slowest wavefront (an 8 192-env launch takes 60 % of the time of a 65 536-env one) and, at full batch, the number
+// of scattered DRAM requests; so the design rules here are: request everything a phase needs in one batch, keep
+// stores behind the last load (they share the in-order memory counter), no workgroup barriers, no per-slot searches
+// (free-slot stack, soon list), branch-free selection, rare paths out of line (a launch of their own).
 // Semantics, operation order of every float64 expression and the reference line ranges are those of orl_device.h /
-// orl_device_g8.h; the parity suite runs every case against this path and compares it with the monolithic one on
+// orl_device_g8.h; the parity suite runs every case against these paths and compares them with the monolithic one on
 // every env of full-size batches.
 #pragma once
 #include "orl_device_g8.h"
@@ -124,7 +127,7 @@ struct Sink {
   SinkEntry* tab;  // LDS, E entries of this env, crn zeroed
   u32* tally;      // LDS, 32 words per env, zeroed: per-link touch counters (4 x 8 bit per word) for the capacity check
   bool active;     // item mode decided: the releases of this step fit the item form
-  bool deferred;   // they do not: nothing has been touched, k_rel_serial releases them in place
+  bool deferred;   // they do not: nothing has been touched, k_rel_tail releases them in place
   int cnt;         // links this LANE has opened an item for
 };
 // lane h of the group appends the mask to the item of hop h's link (the links of one path are distinct)
@@ -656,7 +659,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       }
       if (!sink.active) {
         ORL_DBG(11, 1);
-        sink.deferred = true;  // nothing has been touched: k_rel_serial takes this env
+        sink.deferred = true;  // nothing has been touched: k_rel_tail takes this env
         return;
       }
     }
@@ -787,7 +790,7 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
     u64* s = P.scal + env * ORL_SCAL_WORDS;
     if (gl == 0) {
       // deferred: more releases meet on one link than an item holds masks for; the pending-release state is left
-      // untouched and k_rel_serial (flag bit 16) releases them in place
+      // untouched and k_rel_tail (flag bit 16) releases them in place
       if (gc_pending) s[SC_GCOMP] = (u64)__double_as_longlong(gc);
       if (gc_pending || sink.deferred) s[SC_ACC] = acc_word | (sink.deferred ? (1ull << 16) : 0ull);
       if (sink.deferred) P.q_def[16 + atomicAdd(P.q_def, 1u)] = (u32)env;  // rare: the row kernel's serial tail takes it
@@ -906,7 +909,9 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
   const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
   double last_update = ls23.y;
   double util = ls01.x, frag = ls01.y, comp = ls23.x;
+#if defined(ORL_TIMING) && ORL_TIMING == 4
   if (last_update == -7.5 && util == 0.123) return;  // (keeps the loads ahead of the timing mark)
+#endif
   ORL_PROFR(3);
   u64 a[W];
   int pk = 0, prev_core = -1;
