@@ -150,12 +150,13 @@ def main():
     kernels.setdefault("k_policy", dict(ms=st2.ms_policy, bytes=alg["k_policy"] * B, standalone=True))
     # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x calibration + WRITE_SIZE), collected offline with
     # tools/pmc_traffic.py for exactly this workload/batch and committed under profiles/; null otherwise.
-    traffic = {}
+    traffic, requests = {}, {}
     tpath = os.path.join(ROOT, "profiles", "traffic_cfg2.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("workload") == args.workload and tj.get("batch") == B:
             traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
+            requests = {k: v.get("dram_requests_per_launch") for k, v in tj["kernels"].items()}
     roof = {}
     for name, k in kernels.items():
         ach = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
@@ -165,6 +166,14 @@ def main():
         if k.get("standalone"):
             roof[name]["note"] = "stand-alone slot-scan kernel (orl_batch_policy); the device loop fuses it into k_policy_ctrl_a"
     dominant = max((n for n in kernels if not kernels[n].get("standalone")), key=lambda n: kernels[n]["ms"])
+    # The bound these scattered-access kernels actually run into: L2<->fabric requests per batched step
+    # (PMC, profiles/) against the random 64-byte-line access rate measured with tools/micro/gather_bench.hip
+    req_roof = None
+    step_req = [requests.get(n.split("(")[0]) for n in kernels if not kernels[n].get("standalone") and n != "k_rel_tail"]
+    if step_req and all(step_req):
+        RANDOM_ACCESS_PEAK = 43.7e9  # read+write mix; 53.6e9 read-only (profiles/r1f_gather_bench.txt)
+        per_step = float(sum(step_req))
+        req_roof = dict(bound="dram_requests", requests_per_step=int(per_step), peak=RANDOM_ACCESS_PEAK, unit="requests/s")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -221,6 +230,9 @@ def main():
                        "step_kernels": [n for n, _ in st.kernels()]},
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_by_kernel": roof,
+            "request_roofline": None if req_roof is None else dict(
+                req_roof, achieved=round(req_roof["requests_per_step"] / elapsed * args.steps, 1),
+                frac=round(req_roof["requests_per_step"] / elapsed * args.steps / req_roof["peak"], 4)),
             "cpu_baseline": cpu,
             "host_driven": host,
             "state": {"mean_active_services": round(active, 1),

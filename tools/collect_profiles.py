@@ -32,6 +32,14 @@ for name, kern in (("k_step_a2", "k_step_a2<"), ("k_rows2", "k_rows2<"), ("k_pol
     f = mean_last("tr_f", kern) * 1024 * factor
     w = mean_last("tr_w", kern) * 1024
     out["kernels"][name] = {"fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w)}
+    try:  # L2 <-> fabric requests (TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum), the quantity the random-access roofline counts
+        fe = newest("%s/ea/**/*counter_collection.csv" % O)
+        rows = [r for r in csv.DictReader(open(fe)) if kern in r["Kernel_Name"]]
+        rd = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "TCC_EA0_RDREQ_sum"][-20:]
+        wr = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "TCC_EA0_WRREQ_sum"][-20:]
+        out["kernels"][name]["dram_requests_per_launch"] = int(sum(rd) / len(rd) + sum(wr) / len(wr))
+    except Exception as exc:  # noqa: BLE001
+        print("no request counters for", name, exc)
 json.dump(out, open("profiles/traffic_cfg2.json", "w"), indent=1)
 shutil.copy(newest(O + "/stats/**/*kernel_stats.csv"), "profiles/%s_bench_cfg2_kernel_stats.csv" % tag)
 shutil.copy(newest(O + "/stats1/**/*kernel_stats.csv"), "profiles/%s_bench_cfg2_single_stream_kernel_stats.csv" % tag)
