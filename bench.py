@@ -188,6 +188,16 @@ def main():
         cpu = dict(value=round(n_cpu * timed / cdt, 1), unit="env-steps/s", cores=1, kind="port",
                    sample="%d envs x %d steps after %d warm-up steps, same workload and seeds, oracle/orl_oracle.c, 1 thread"
                           % (n_cpu, timed, warm))
+        try:  # the same restatement over all host cores (OpenMP over env ranges), a bounded sample too
+            n_mt = 64 * (os.cpu_count() or 1)
+            omt = OracleBatch(fam, topo, [10 + i for i in range(n_mt)], omp=True, **kw)
+            omt.run(policy, 300)
+            c0 = time.perf_counter()
+            omt.run(policy, 1200)
+            cpu["all_cores"] = dict(value=round(n_mt * 1200 / (time.perf_counter() - c0), 1), unit="env-steps/s",
+                                    cores=os.cpu_count(), sample="%d envs x 1200 steps after 300, OpenMP" % n_mt)
+        except Exception as exc:  # the OpenMP build of the oracle is optional
+            cpu["all_cores"] = dict(error=str(exc))
 
     host = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

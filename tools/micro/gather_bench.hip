@@ -23,6 +23,16 @@ __global__ void k_gather(u64* buf, u64 n_lines, int mode, u64 seed, u64* sink) {
   }
   if (acc == 0x1234567ull) *sink = acc;
 }
+// streaming read / copy over the same buffer (16-byte loads, grid-stride): what "HBM peak" means in practice on this GPU
+__global__ void k_stream(const ulonglong2* __restrict__ src, ulonglong2* __restrict__ dst, u64 n, u64* sink) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 acc = 0;
+  for (u64 j = i; j < n; j += (u64)gridDim.x * blockDim.x) {
+    ulonglong2 v = src[j];
+    if (dst) dst[j] = v; else acc ^= v.x ^ v.y;
+  }
+  if (!dst && acc == 0x1234567ull) *sink = acc;
+}
 int main() {
   const u64 bytes = 2ull << 30, n_lines = bytes / 64;
   u64 *buf, *sink;
@@ -44,5 +54,20 @@ int main() {
       printf("%s threads 2^%d x %d accesses: %.2f us per launch, %.1f G accesses/s (64-B lines over a 2 GiB buffer)\n",
              mode ? "read+write" : "read      ", threads_log, R, ms * 1e3 / reps, acc / (ms * 1e-3) / 1e9);
     }
+  for (int copy = 0; copy < 2; copy++) {
+    const u64 half = bytes / 2, n = (copy ? half : bytes) / 16;
+    ulonglong2* src = (ulonglong2*)buf;
+    ulonglong2* dst = copy ? (ulonglong2*)((char*)buf + half) : nullptr;
+    hipLaunchKernelGGL(k_stream, dim3(256 * 32), dim3(256), 0, 0, src, dst, n, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_stream, dim3(256 * 32), dim3(256), 0, 0, src, dst, n, sink);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double moved = (double)n * 16 * reps * (copy ? 2 : 1);
+    printf("%s: %.2f TB/s (%s)\n", copy ? "stream copy 1 GiB -> 1 GiB" : "stream read 2 GiB", moved / (ms * 1e-3) / 1e12,
+           copy ? "read + write bytes" : "read bytes");
+  }
   return 0;
 }
