@@ -925,11 +925,18 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
     // clock have time_diff == 0
     const bool first_at_clock = (k == 0) || (MIXED && k == 1 && prov_first);
     u64* row = bm + (size_t)(core * E + link) * W;
-    int* sump = cs + 2 * P.C + core * E + link;
     if (core != prev_core) {  // several releases on the same core row keep working on the registers
 #pragma unroll
       for (int w = 0; w < W; w++) a[w] = row[w];
-      pk = (ENV != ENV_RWA) ? *sump : 0;
+      if (ENV != ENV_RWA) {
+        // the row's contribution to the compactness sums BEFORE the change, recomputed from the row itself: the
+        // kernel is bound by scattered memory requests, not ALU — the cached copy the per-env kernels keep
+        // (core_sums[2C + ...]) would cost a read and a write of one more line per item
+        RowStat b4;
+        int me_, ed_;
+        row_stat_lane<W>(a, S, b4, me_, ed_);
+        pk = (b4.occ << 16) | b4.fb;
+      }
       prev_core = core;
     }
 #pragma unroll
@@ -947,7 +954,6 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
       // this row's contribution to the compactness sums of its core
       const int d_occ = after.occ - (pk >> 16), d_fb = after.fb - (pk & 0xffff);
       pk = (after.occ << 16) | after.fb;
-      *sump = pk;
       if (d_occ) atomicAdd(cs + 2 * core, d_occ);
       if (d_fb) atomicAdd(cs + 2 * core + 1, d_fb);
       if (MIXED && rel_k) {

@@ -386,6 +386,24 @@ __global__ void __launch_bounds__(256) k_rel_tail(DevParams P, int buffer) {
   const u32 nd = dq[0];
   for (u32 d = threadIdx.x >> 3; d < nd; d += 32u) sp::rel_serial<ENV, W>(P, (i64)dq[16 + d], lane_id());
 }
+// After a snapshot restore: the per-row cache of compactness contributions (core_sums[2C + ...]) that the
+// one-wavefront-per-env kernel differences against is recomputed from the slot map, one thread per (env, core, link) row
+// — the pipelines do not maintain it, and a snapshot may come from a batch that ran them.
+template <int W>
+__global__ void k_rebuild_row_cache(DevParams P) {
+  const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 rows = (i64)P.C * P.E;
+  if (t >= P.B * rows) return;
+  const i64 env = t / rows, r = t % rows;
+  const u64* row = P.bitmap + env * P.bm_words + r * W;
+  u64 a[W];
+#pragma unroll
+  for (int w = 0; w < W; w++) a[w] = row[w];
+  RowStat st;
+  int me, ed;
+  sp::row_stat_lane<W>(a, P.S, st, me, ed);
+  P.core_sums[env * P.cs_words + 2 * P.C + r] = (st.occ << 16) | st.fb;
+}
 // end of a device-resident run: the network-compactness update the last step left pending (one thread per env), so
 // that every host-visible state is final
 __global__ void k_finish2(DevParams P) {
@@ -1411,6 +1429,13 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
   HIPCHK(hipStreamSynchronize(b->stream));
   const unsigned char* o = (const unsigned char*)in;
   for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(s.ptr, o, s.bytes, hipMemcpyHostToDevice)); o += s.bytes; }
+  if (b->P.env_type != ENV_RWA) {
+    const i64 n = b->P.B * b->P.C * b->P.E;
+    dim3 g((unsigned)((n + 255) / 256)), blk(256);
+#define CALLW(WW) hipLaunchKernelGGL((k_rebuild_row_cache<WW>), g, blk, 0, b->stream, b->P)
+    ORL_FOR_W(CALLW)
+#undef CALLW
+  }
   if (b->P.obs_dim) launch_obs(b, 0);
   HIPCHK(hipStreamSynchronize(b->stream));
   return ORL_OK;

@@ -358,6 +358,38 @@ def test_matrix_observation_and_snapshot_restore():
     dev.close()
 
 
+def test_snapshot_moves_between_step_implementations(monkeypatch):
+    """A snapshot taken from a batch driven by the two-kernel pipeline continues bit-identically in a batch driven by the
+    one-wavefront-per-env kernel, and the other way round (the per-row cache only the latter keeps is rebuilt on restore)."""
+    import optical_rl_gym_amd as orl
+
+    kw = dict(load=300, mean_service_holding_time=25, episode_length=50, num_spectrum_resources=320)
+    seeds = list(range(200, 296))
+    envs = {}
+    for name, v in (("wave64", "64"), ("two", "2")):
+        monkeypatch.setenv("ORL_STEP_IMPL", v)
+        envs[name] = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=96, seeds=seeds, **kw)
+    envs["two"].run("SAP_FF", 300)
+    envs["wave64"].set_state(envs["two"].get_state())
+    envs["two"].run("SAP_FF", 200)
+    envs["wave64"].run("SAP_FF", 200)
+    chk = _exact("snapshot")
+    for rnd in range(2):
+        a, b = envs["two"], envs["wave64"]
+        chk(rnd, "counters", a.counters(), b.counters())
+        chk(rnd, "services", a.services(), b.services())
+        for e in (0, 50, 95):
+            chk(rnd, "slots", a.slots(e), b.slots(e))
+            chk(rnd, "link_stats", a.link_stats(e), b.link_stats(e))
+            chk(rnd, "net_stats", a.net_stats(e), b.net_stats(e))
+        if rnd == 0:  # and back
+            envs["two"].set_state(envs["wave64"].get_state())
+            envs["two"].run("SAP_FF", 150)
+            envs["wave64"].run("SAP_FF", 150)
+    for e in envs.values():
+        e.close()
+
+
 def test_gym_front_end_rwa_and_rmcsa_script_numbers():
     """tests/test_rwa.py and tests/test_rmcsa.py of the reference through the product's gym-shaped classes (episode
     rewards as captured from the reference in tests/golden)."""
