@@ -176,9 +176,11 @@ def test_full_size_batch_sampled_envs_match_oracle(workload, batch):
     dev.close()
 
 
-@pytest.mark.parametrize("workload,batch,steps", [("cfg2", 65536, 700), ("cfg5", 32768, 300), ("cfg4", 16384, 300),
-                                                  ("cfg1", 32768, 300), ("cfg3", 32768, 200)])
-def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, steps, monkeypatch):
+@pytest.mark.parametrize("workload,batch,steps,pol", [("cfg2", 65536, 700, None), ("cfg5", 32768, 300, None), ("cfg4", 16384, 300, None),
+                                                      ("cfg1", 32768, 300, None), ("cfg3", 32768, 200, None),
+                                                      ("cfg2", 16384, 300, "LLP_FF"), ("cfg2", 16384, 300, "SP_FF"),
+                                                      ("cfg1", 16384, 300, "SAP_LF"), ("cfg1", 16384, 300, "LLP_FF")])
+def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, steps, pol, monkeypatch):
     """Tens of millions of env-steps per case: the rare branches of the split pipeline (more releases in one step
     than a work item holds masks for, several rebuild rounds, the serial tail) occur a few hundred times, in envs no
     sample would pick.  The one-wavefront-per-env implementation is pinned to the oracle above; here every env of
@@ -187,6 +189,7 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
     from bench import WORKLOADS
 
     fam, topo, kw, policy = WORKLOADS[workload]
+    policy = pol or policy
     kw = dict(kw, episode_length=90)
     seeds = [77 + 3 * i for i in range(batch)]
     out = {}
