@@ -6,7 +6,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --gpus 1 --steps 300 --warmup 1500 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 tail -c 2500 $O/bench_cfg2.json
-rm -rf $O/stats $O/stats1 $O/tr_f $O/tr_w $O/sq
+rm -rf $O/stats $O/stats1 $O/tr_f $O/tr_w $O/sq $O/ea
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --gpus 1 --steps 300 --warmup 1500 --no-cpu-baseline > $O/stats.log 2>&1
 export ORL_STREAMS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --gpus 1 --steps 300 --warmup 1500 --no-cpu-baseline > $O/stats1.log 2>&1
