@@ -101,14 +101,15 @@ struct DevParams {
   u32* q_cnt_b;     // same for q_b
   int q_wave;       // item slots per wavefront region
   int item_masks;   // releases of one step that may meet on one link before the env falls back to the serial tail (<= 8)
-  int* rel_sums;    // [B][2*C] two-kernel pipeline: what the releases of the current step added to core_sums[0..2C)
+  int pipeline2;    // two-kernel pipeline: core_sums[2C..4C) accumulates what the current step's releases add to the sums
   i64 q_def_stride; // two-kernel pipeline: second q_def buffer (steps alternate)
   u32* q_def;       // [0] = number of envs whose releases this step do not fit the item form, [16..] = their indices
   u32* q_stat;      // [1] env-steps that took the serial release path (statistics)
   double* soon_t;   // [B][ORL_SOON] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8, ...
   u32* soon_i;      // [B][ORL_SOON] their slots in ev_time / ev_info
   i64 q_cap;
-  int* core_sums;   // [B][cs_words]      [2*C] per core: sum(lambda_max-lambda_min), sum(free blocks inside);
+  int* core_sums;   // [B][cs_words]      [2*C] per core: sum(lambda_max-lambda_min), sum(free blocks inside); [2*C] the part
+                    //                    of them this step's releases added (two-kernel pipeline; same 64-byte line);
                     //                    then [C*E] per (core, link): that row's own contribution, (occ << 16) | fb
   i64* br_hist;     // [B][2*n_br]        discrete mode: requested / provisioned histograms
   i64* act_hist;    // [B][(K+1)+(S+1)]   RWA: marginals of actions_output
@@ -655,7 +656,7 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
     u64* wp = e.bm + (core * E + link) * W + (w < W ? w : 0);
     u64 a = v ? *wp : 0ull;
     RowStat before, after;
-    int* sump = e.cs + 2 * P.C + core * E + link;  // this row's contribution as of its last modification
+    int* sump = e.cs + 4 * P.C + core * E + link;  // this row's contribution as of its last modification
     if (ENV != ENV_RWA) { int pk = *sump; before.occ = pk >> 16; before.fb = pk & 0xffff; }
     const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
     a = release ? (a | m) : (a & ~m);

@@ -172,7 +172,7 @@ __device__ __forceinline__ void emit_items(const DevParams& P, i64 env, const Si
 template <int ENV, int W, bool DEFER_GCOMP>
 __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
                                              double* info_out, Prof& prof);
-struct SoonRegs { double t[ORL_SOON_PER_LANE]; int i[ORL_SOON_PER_LANE]; bool dirty; };
+struct SoonRegs { double t[ORL_SOON_PER_LANE]; int i[ORL_SOON_PER_LANE]; int dirty; };  // dirty: bit k = entry k of this lane changed
 template <int ENV, int W>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
                                              int extra = 0, int pushed_idx = -1, u64 pushed_info = 0ull);
@@ -212,7 +212,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     g8::env_load(P, e, env);
     int* rs = nullptr;
     if (MERGE == 2) {
-      rs = P.rel_sums + env * 2 * P.C;
+      rs = e.cs + 2 * P.C;
       const u64 acc0 = e.scal[SC_ACC];
       if ((u32)acc0 & 2u) {
         // network compactness update the previous step left pending: the sums right after ITS provision are the totals
@@ -363,13 +363,12 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
           e.scal[SC_HINT] = pack2(e.nfree, 0);  // a rebuild may have rewritten the free-slot stack
         }
       } else {
-        if (soon.dirty) {
 #pragma unroll
-          for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+        for (int k = 0; k < ORL_SOON_PER_LANE; k++)
+          if ((soon.dirty >> k) & 1) {
             e.soon_t[gl + 8 * k] = soon.t[k];
             e.soon_i[gl + 8 * k] = (u32)soon.i[k];
           }
-        }
         if (gl == 0) {
           e.scal[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
           e.scal[SC_TSOON] = (u64)__double_as_longlong(e.t_soon);
@@ -490,7 +489,7 @@ template <int ENV, int W>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
                                              int extra, int pushed_idx, u64 pushed_info) {
   constexpr int NS = ORL_SOON_PER_LANE;
-  out.dirty = false;
+  out.dirty = 0;
   // The rebuild scan costs the wavefront the same whether one of its 8 envs runs it or all of them (the other lanes
   // idle meanwhile), so when any env's horizon has passed, every env of the wavefront rebuilds: their horizons
   // stay in phase and the wavefront pays for a scan far less often.
@@ -502,7 +501,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
   int si[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) { st[k] = e.soon_t[gl + 8 * k]; si[k] = (int)e.soon_i[gl + 8 * k]; }
-  bool dirty = false;
+  int dirty = 0;  // which of this lane's entries changed (only those go back to memory: a release touches one)
   ORL_PROF(4);
   for (int round = 0; round < 64; round++) {
     int due_all = -1;  // number of due entries overall, known when this round scanned everything
@@ -579,7 +578,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 #pragma unroll
       for (int k = 0; k < NS; k++) { st[k] = bt[k] < T ? bt[k] : INF; si[k] = bi[k]; }
       e.t_soon = T;
-      dirty = true;
+      dirty = (1 << NS) - 1;
       due_all = g8_sum(nd);
       // the scan saw every slot: shrink the window to the highest occupied one (a stale larger window is harmless, so
       // the steps between two rebuilds do not bother)
@@ -682,6 +681,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       rec.q[2] = gget(rc0.q[2], bl, lane); rec.q[3] = gget(rc0.q[3], bl, lane);
       if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
       if (gl == bl) {  // the holder drops the entry from its list and moves to its next due entry, if any (rare)
+        dirty |= 1 << ck;
         ct = INF; ci = 0x7fffffff;
         int nk = 0;
 #pragma unroll
@@ -693,7 +693,6 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         ck = nk;
         if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
       }
-      dirty = true;
       const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
       const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
       e.ev_cnt--;
@@ -737,7 +736,7 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
   sink.tally = s_tally + 32 * (int)(threadIdx.x >> 3);
   sink.active = false; sink.deferred = false; sink.cnt = 0;
   SoonRegs soon;
-  soon.dirty = false;
+  soon.dirty = 0;
   double next_rel = 0.0, t_soon = 0.0;
   i64 s_br = 0, s_nh = 0;
   u64 ev = 0, acc_word = 0;
@@ -797,13 +796,12 @@ __device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid,
       s[SC_HINT] = pack2(nfree, 0);  // also when deferred: a rebuild may have rewritten the free-slot stack
     }
     if (!sink.deferred) {
-      if (soon.dirty) {
 #pragma unroll
-        for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+      for (int k = 0; k < ORL_SOON_PER_LANE; k++)
+        if ((soon.dirty >> k) & 1) {
           P.soon_t[env * ORL_SOON + gl + 8 * k] = soon.t[k];
           P.soon_i[env * ORL_SOON + gl + 8 * k] = (u32)soon.i[k];
         }
-      }
       if (gl == 0) {
         s[SC_NEXTREL] = (u64)__double_as_longlong(next_rel);
         s[SC_TSOON] = (u64)__double_as_longlong(t_soon);
@@ -826,7 +824,7 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
   if (gl == 0) atomicAdd(P.q_stat, 1u);  // statistics: env-steps that took the serial path
   EnvG e;
   g8::env_load(P, e, env);
-  if (P.rel_sums) e.rs = P.rel_sums + env * 2 * P.C;  // two-kernel pipeline: the next step needs what releases added
+  if (P.pipeline2) e.rs = e.cs + 2 * P.C;  // two-kernel pipeline: the next step needs what releases added
   g8::release_due<ENV, W>(P, e, lane);
   e.t_soon = -__builtin_inf();  // released in place: the soon list is stale
   if (gl == 0) s[SC_ACC] = s[SC_ACC] & ~(1ull << 16);
@@ -902,7 +900,7 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
   const u64 cores = it.b.y;
   u64* bm = P.bitmap + env * P.bm_words;
   int* cs = P.core_sums + env * P.cs_words;
-  int* rs = MIXED ? P.rel_sums + env * 2 * P.C : nullptr;
+  int* rs = MIXED ? cs + 2 * P.C : nullptr;
   double* ls = P.lstat + env * 4 * E;
   const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + (MIXED ? (int)SC_NOW : now_slot)]);
   const double now_prov = MIXED ? __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOWA]) : 0.0;

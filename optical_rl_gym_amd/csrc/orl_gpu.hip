@@ -402,7 +402,7 @@ __global__ void k_rebuild_row_cache(DevParams P) {
   RowStat st;
   int me, ed;
   sp::row_stat_lane<W>(a, P.S, st, me, ed);
-  P.core_sums[env * P.cs_words + 2 * P.C + r] = (st.occ << 16) | st.fb;
+  P.core_sums[env * P.cs_words + 4 * P.C + r] = (st.occ << 16) | st.fb;
 }
 // end of a device-resident run: the network-compactness update the last step left pending (one thread per env), so
 // that every host-visible state is final
@@ -410,7 +410,7 @@ __global__ void k_finish2(DevParams P) {
   const i64 env = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= P.B) return;
   u64* s = P.scal + env * ORL_SCAL_WORDS;
-  int* rs = P.rel_sums + env * 2 * P.C;
+  int* rs = P.core_sums + env * P.cs_words + 2 * P.C;
   const u64 acc = s[SC_ACC];
   if ((u32)acc & 2u) {
     const int* cs = P.core_sums + env * P.cs_words;
@@ -925,7 +925,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   else if (c->env_type == ORL_ENV_RMCSA) P.n_info = 4;
   else P.n_info = 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
   P.obs_dim = c->env_type == ORL_ENV_DEEPRMSA ? 1 + 2 * P.N + (2 * P.J + 3) * P.K : 0;
-  P.cs_words = 2 * C + C * P.E;
+  P.cs_words = (4 * C + C * P.E + 15) & ~15;  // sums, release part, per-row cache; whole 64-byte lines per env
   P.lds_bytes = ((P.bm_words + 4 * P.E + P.E + P.obs_dim) * 8 + P.cs_words * 4 + 15) & ~15;
   if (P.lds_bytes < 624 * 4) P.lds_bytes = 624 * 4;  // k_init_mt stages the MT state in the same window
   if (P.lds_bytes > 64 * 1024) { delete b; return fail(ORL_E_INVALID, "per-env LDS window too large (%d B)", P.lds_bytes); }
@@ -977,10 +977,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     // deferred-env lists: [B + 16] for the whole batch, then one region per sub-batch; two buffers (steps alternate)
     P.q_def_stride = (i64)(2 * B + 16 * 80);
     rc |= dalloc(b, &P.q_def, 2 * (size_t)P.q_def_stride);
-    if (b->step_impl == 2) {
-      rc |= dalloc(b, &P.rel_sums, B * 2 * C);
-      if (!rc) hipMemset(P.rel_sums, 0, B * 2 * C * sizeof(int));
-    }
+    P.pipeline2 = (b->step_impl == 2) ? 1 : 0;
     if (!rc) hipMemset(P.q_def, 0, 2 * (size_t)P.q_def_stride * sizeof(u32));
     rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
     rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
@@ -1029,7 +1026,6 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (S + 1));
       q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
       q.q_def = P.q_def + (B + 16) + lo + 16 * b->subs.size();
-      if (q.rel_sums) q.rel_sums += lo * 2 * C;
       if (q.obs) { q.obs += lo * P.obs_dim; q.term_obs += lo * P.obs_dim; }
       b->sub_streams.push_back(b->owned_streams[b->subs.size() % (size_t)n_streams]);
       b->subs.push_back(q);
