@@ -172,6 +172,9 @@ __device__ __forceinline__ void emit_items(const DevParams& P, i64 env, const Si
 template <int ENV, int W, bool DEFER_GCOMP>
 __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
                                              double* info_out, Prof& prof);
+#ifndef ORL_SCAN_BATCH
+#define ORL_SCAN_BATCH 8  // release times a lane requests per round of the rebuild scan
+#endif
 struct SoonRegs { double t[ORL_SOON_PER_LANE]; int i[ORL_SOON_PER_LANE]; int dirty; };  // dirty: bit k = entry k of this lane changed
 template <int ENV, int W>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
@@ -517,16 +520,16 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       for (int k = 0; k <= NS; k++) kb[k] = 0xffffffffu;
       int nd = 0, top = -1, h0 = 0x7fffffff, h1 = 0x7fffffff;  // h0 < h1: the first two empty slots this lane sees
       const int hwm = e.ev_hwm;
-      for (int base = gl, ord = 0; base < hwm; base += 64, ord += 8) {
-        double tt[8];
+      for (int base = gl, ord = 0; base < hwm; base += 8 * ORL_SCAN_BATCH, ord += ORL_SCAN_BATCH) {
+        double tt[ORL_SCAN_BATCH];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < ORL_SCAN_BATCH; k++) {
           const int i = base + 8 * k;
           const double v = e.ev_time[i < hwm ? i : hwm - 1];
           tt[k] = (i < hwm) ? v : INF;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < ORL_SCAN_BATCH; k++) {
           const double t = tt[k];
           const int i = base + 8 * k;
           nd += (t <= e.now) ? 1 : 0;
