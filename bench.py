@@ -145,8 +145,12 @@ def main():
     mean_hops = float(h0[h0 > 0].mean())
     alg = algorithmic_bytes(env, mean_hops, active)
     kernels = {}
+    step_names = [n for n, _ in st.kernels()]
     for name, ms in st.kernels():
-        kernels[name] = dict(ms=ms, bytes=alg.get(name, 0.0) * B)
+        bpe = alg.get(name, 0.0)
+        if name in ("k_step", "k_step8") and "k_policy" not in step_names:
+            bpe += alg["k_policy"]  # the device loop of the per-env kernel runs the slot scan inside k_step
+        kernels[name] = dict(ms=ms, bytes=bpe * B)
     kernels.setdefault("k_policy", dict(ms=st2.ms_policy, bytes=alg["k_policy"] * B, standalone=True))
     # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x calibration + WRITE_SIZE), collected offline with
     # tools/pmc_traffic.py for exactly this workload/batch and committed under profiles/; null otherwise.

@@ -191,20 +191,28 @@ __global__ void __launch_bounds__(64 * ORL_POLICY_WAVES) k_policy(DevParams P, i
 #define ORL_STEP_WAVES 5  // waves per SIMD the register allocator must leave room for (measured: 4 -> 428 us, 5 -> 389 us, 6 -> 436 us)
 #endif
 template <int ENV, int W, bool EVL>
-__global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int auto_reset, int want_info) {
+__global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int auto_reset, int want_info, int pol) {
   const i64 env = blockIdx.x;
   const int lane = lane_id();
   Env e;
   // Round trip 1: everything addressed by the env index alone is requested before anything is waited for — the
   // scalar record, the action, the slot map / link statistics / per-core sums (into LDS), the source-node table.
   const u64 sv = env_fetch(P, env, lane);
-  const int4 av = *(const int4*)(P.actions + env * 4);
+  int4 av = (pol < 0) ? *(const int4*)(P.actions + env * 4) : make_int4(0, 0, 0, 0);
   Prefetch pf;
   pf.have_cum = P.N <= 64;
   pf.cum_my = pf.have_cum ? P.cum_src[lane < P.N - 1 ? lane : P.N - 1] : 0.0;
   e.env = env;
   stage_in(P, e, (u64*)orl_lds_raw, lane);
   env_unpack(P, e, env, lane, sv);
+  if (pol >= 0) {
+    // device-resident loop: the slot scan runs right here on the LDS copy of the slot map (lanes = paths, or (path, core)
+    // pairs) — one launch and one read of the map per policy + step instead of two
+    int a[4];
+    policy_g<ENV, W, 64>(P, e.bm, true, pair_base(P, e.src, e.dst), e.br_idx, P.n_paths[e.src * P.N + e.dst], lane, pol, a);
+    av = make_int4(a[0], a[1], a[2], a[3]);
+    if (lane == 0) *(int4*)(P.actions + env * 4) = av;
+  }
   // Round trip 2: what the scalar record addresses — the MT window of the next service, the pending release times
   // (EVL: into LDS for all scans) and the path record + slot count of the action's path.
   Rng pre;
@@ -777,6 +785,7 @@ static void launch_policy_step(orl_batch* b, int pol) {
   const bool wide = (VP.env_type == ENV_RMCSA) || VP.K > 8;
   if (b->step_impl == 2) { launch_step2(b, pol, wide); return; }
   if (b->step_impl == 1 && !wide) { launch_step(b, 1, 0, pol); return; }
+  if (b->step_impl == 64 && !getenv("ORL_UNFUSED_POLICY")) { launch_step(b, 1, 0, pol); return; }  // slot scan inside k_step
   launch_policy(b, pol);
   launch_step(b, 1, 0);
 }
@@ -827,8 +836,8 @@ static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_p
   const bool evl = (VP.lds_bytes + ev_bytes) <= 8 * 1024;
   size_t lds = VP.lds_bytes + (evl ? ev_bytes : 0);
 #define CALLW(WW) \
-  do { if (evl) hipLaunchKernelGGL((k_step<EE, WW, true>), g, blk, lds, VS, VP, auto_reset, want_info); \
-       else hipLaunchKernelGGL((k_step<EE, WW, false>), g, blk, lds, VS, VP, auto_reset, want_info); } while (0)
+  do { if (evl) hipLaunchKernelGGL((k_step<EE, WW, true>), g, blk, lds, VS, VP, auto_reset, want_info, fused_policy); \
+       else hipLaunchKernelGGL((k_step<EE, WW, false>), g, blk, lds, VS, VP, auto_reset, want_info, fused_policy); } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
   ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV

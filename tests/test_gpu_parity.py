@@ -252,7 +252,7 @@ def test_run_reports_every_kernel_of_the_step(monkeypatch):
     from bench import WORKLOADS
 
     fam, topo, kw, policy = WORKLOADS["cfg2"]
-    for v, names in (("64", ["k_policy", "k_step"]),
+    for v, names in (("64", ["k_step"]),
                      ("1", ["k_policy_ctrl_a", "k_rows(provision)", "k_ctrl_b2", "k_rows(release)", "k_rel_tail"]),
                      ("2", ["k_step_a2", "k_rows2", "k_rel_tail"])):
         monkeypatch.setenv("ORL_STEP_IMPL", v)
