@@ -1,6 +1,6 @@
 // orl_device_split.h — step() as a pipeline of kernels: per-env control -> work items -> one lane per touched link row.
 //
-// Two-kernel pipeline (step_impl 2; the default from 16 384 envs), one policy + step of the device-resident loop:
+// Two-kernel pipeline (step_impl 2; the default for large batches), one policy + step of the device-resident loop:
 //   k_step_a2   8 lanes per env: the slot scan (policy), then — the action still in registers — decode + validate,
 //               counters, reward, the release push, network throughput, the next service (RNG, node pair, bit rate),
 //               done / auto reset, and the due releases of the step through the env's soon list.  Output: one queue of

@@ -891,12 +891,16 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   b->view = nullptr;
   b->view_stream = nullptr;
   {
-    // Measured on MI355X (tools/compare_impls.sh, env-steps/s of the device loop): the two-kernel pipeline wins once the
-    // batch fills the chip (cfg2 65 536 envs: 4.9e8 vs 4.4e8 four-kernel split vs 2.5e8 one wavefront per env; cfg5
-    // 32 768: 2.4e8 / 2.1e8 / 1.2e8; RMCSA 16 384: 2.1e8 / 1.6e8 / 1.0e8; cfg2 16 384: 2.0e8 / 1.9e8 / 2.0e8); below
-    // that the per-env kernel's two launches win (cfg2 4 096: 5.6e7 vs 7.1e7).  ORL_STEP_IMPL = 64 | 8 | 1 | 2 overrides.
+    // Measured on MI355X (tools/compare_impls.sh, env-steps/s of the device loop; two-kernel pipeline / four-kernel split /
+    // one wavefront per env): cfg2 65 536 envs 5.3e8 / 4.4e8 / 2.5e8; cfg5 32 768: 2.6e8 / 2.1e8 / 1.2e8; RMCSA 16 384:
+    // 2.0e8 / 1.6e8 / 1.0e8.  The pipeline wins once the batch fills the chip; the heavier the env, the earlier:
+    // RMSA NSFNET 12 288 envs 1.74e8 vs 1.37e8, 10 240: 1.53e8 vs 1.62e8, 8 192: 1.28e8 vs 1.39e8; RWA 8 192: 1.78e8 vs
+    // 1.42e8; Germany50 8 192: 0.96e8 vs 0.89e8; RMCSA 4 096: 0.70e8 vs 0.59e8.  ORL_STEP_IMPL = 64 | 8 | 1 | 2 overrides.
     const char* impl = getenv("ORL_STEP_IMPL");
-    b->step_impl = impl ? atoi(impl) : (n_envs >= 16384 ? 2 : 64);
+    int64_t from = 12288;
+    if (c->env_type == ORL_ENV_RWA || t->E >= 64) from = 8192;
+    if (c->env_type == ORL_ENV_RMCSA) from = 4096;
+    b->step_impl = impl ? atoi(impl) : (n_envs >= from ? 2 : 64);
     if (b->step_impl != 8 && b->step_impl != 1 && b->step_impl != 2) b->step_impl = 64;
   }
   DevParams& P = b->P;
@@ -1013,8 +1017,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   HIPCHK(hipEventCreate(&b->ev0));
   HIPCHK(hipEventCreate(&b->ev1));
   {
-    // measured on MI355X, cfg2, B = 65 536: 1 stream 2.02e8 env-steps/s, 2 streams 2.38e8, 4 streams 2.27e8, 8 streams 2.09e8
-    int n_streams = (n_envs >= 2 * 8192) ? 2 : 1;
+    // Two env sub-ranges on two streams: one range's kernel fills the other's tail.  Measured on MI355X, cfg2: pipeline at
+    // 65 536 envs 1 stream 4.2e8, 2 streams 5.3e8, 3+ slower; at 8 192 envs no gain (RWA: 1.78e8 -> 1.42e8), so from 16 384;
+    // per-env kernel at 8 192 envs 1.12e8 -> 1.39e8 (10 240: 1.27e8 -> 1.62e8), so from 8 192.
+    int n_streams = (n_envs >= (b->step_impl == 64 || b->step_impl == 8 ? 8192 : 16384)) ? 2 : 1;
     if (const char* sv = getenv("ORL_STREAMS")) { int v = atoi(sv); if (v >= 1 && v <= 16) n_streams = v; }
     int n_sub = n_streams;  // ORL_SUBS > ORL_STREAMS: sub-batch k runs on stream k % n_streams
     if (const char* sv = getenv("ORL_SUBS")) { int v = atoi(sv); if (v >= n_streams && v <= 64) n_sub = v; }
