@@ -8,8 +8,9 @@ from tests.helpers import golden_names, load_golden, replay
 
 pytestmark = pytest.mark.gpu
 
-# The library picks the step implementation by batch size (split pipeline from 24 576 envs, one wavefront per env
-# below); the small parity cases run against both by forcing it (the variable is read when a batch is created).
+# The library picks the step implementation by batch size and env family (two-kernel pipeline for large batches, one
+# wavefront per env below); the small parity cases run against all of them by forcing it (the variable is read when a
+# batch is created).
 IMPLS = ["wave64", "split", "split2"]
 
 
