@@ -154,6 +154,11 @@ int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels
 
 int orl_batch_sync(orl_batch* b);
 
+/* Page-locked host memory for the buffers handed to orl_batch_step / orl_batch_policy: copies to and from it run at the
+ * full PCIe rate (pageable numpy memory is staged through a bounce buffer by the runtime). */
+int orl_host_alloc(size_t bytes, void** out);
+int orl_host_free(void* p);
+
 /* Zero-copy access for an agent that lives on the same GPU (the reference hands numpy arrays to SB3,
  * DeepRMSA.ipynb:272-302).  Device pointers of the batch's I/O arrays: write actions there, call
  * orl_batch_step(b, NULL, auto_reset, NULL, NULL, NULL, NULL) (no copies, no synchronisation: the launches are queued

@@ -1150,6 +1150,17 @@ extern "C" int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_res
   return ORL_OK;
 }
 
+extern "C" int orl_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  memset(*out, 0, bytes);
+  return ORL_OK;
+}
+extern "C" int orl_host_free(void* p) {
+  if (p) HIPCHK(hipHostFree(p));
+  return ORL_OK;
+}
+
 extern "C" int orl_batch_device_buffer(orl_batch* b, int which, void** device_ptr, int64_t* n_elements) {
   if (!b || !device_ptr || !n_elements) return fail(ORL_E_INVALID, "null argument");
   const int64_t B = b->P.B;

@@ -39,6 +39,20 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+
+class _PinnedBlock:
+    """Owner of one page-locked host allocation (orl_host_alloc); numpy views keep it alive through their base chain."""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.orl_host_free(self.ptr)
+        except Exception:
+            pass
+
+
 class BatchedOpticalEnv:
     """Common machinery; use one of the four family classes below."""
 
@@ -176,11 +190,21 @@ class BatchedOpticalEnv:
         self.n_info = self.lib.orl_batch_info_dim(self._h)
         self.obs_dim = self.lib.orl_batch_obs_dim(self._h)
         n = self.num_envs
-        self._act = np.zeros((n, 4), np.int32)
-        self._reward = np.zeros(n, np.float64)
-        self._done = np.zeros(n, np.uint8)
-        self._info = np.zeros((n, self.n_info), np.float64)
-        self._obs = np.zeros((n, self.obs_dim), np.float64) if self.obs_dim else None
+        # host-side I/O arrays in page-locked memory: every step() moves actions in and reward/done/info(/obs) out
+        self._act = self._host_array((n, 4), np.int32)
+        self._act_in = self._host_array((n, 4), np.int32)
+        self._reward = self._host_array((n,), np.float64)
+        self._done = self._host_array((n,), np.uint8)
+        self._info = self._host_array((n, self.n_info), np.float64)
+        self._obs = self._host_array((n, self.obs_dim), np.float64) if self.obs_dim else None
+
+    def _host_array(self, shape, dtype):
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        _lib.check(self.lib.orl_host_alloc(max(nbytes, 1), C.byref(ptr)))
+        buf = (C.c_ubyte * max(nbytes, 1)).from_address(ptr.value)
+        buf._block = _PinnedBlock(self.lib, ptr)  # freed when the last numpy view of it is gone, not at close()
+        return np.frombuffer(buf, dtype=np.uint8, count=nbytes).view(dtype).reshape(shape)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -218,7 +242,8 @@ class BatchedOpticalEnv:
             actions = np.asarray(actions)
             if actions.ndim == 1:
                 actions = actions[:, None]
-            a = np.zeros((self.num_envs, 4), np.int32)
+            a = self._act_in
+            a[:] = 0
             a[:, : actions.shape[1]] = actions
         if fetch:
             _lib.check(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), _ptr(self._obs), self._reward.ctypes.data,
