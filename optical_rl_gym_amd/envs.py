@@ -242,8 +242,7 @@ class BatchedOpticalEnv:
             actions = np.asarray(actions)
             if actions.ndim == 1:
                 actions = actions[:, None]
-            a = self._act_in
-            a[:] = 0
+            a = self._act_in  # columns beyond the family's action width stay zero from allocation
             a[:, : actions.shape[1]] = actions
         if fetch:
             _lib.check(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), _ptr(self._obs), self._reward.ctypes.data,
