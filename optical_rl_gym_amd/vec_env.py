@@ -55,6 +55,19 @@ class OpticalVecEnv:
         self.step_async(actions)
         return self.step_wait()
 
+    def save_monitor_csv(self, path, env_id=None):
+        """The episode log in stable-baselines3's Monitor file format — a JSON header line, then `r,l,t` plus the info
+        keywords (cf. the reference's examples/heuristics/bkp/rmsa-heu/sap_ff.monitor.csv) — so that SB3's
+        `load_results` / plotting read a batched run like a DummyVecEnv one."""
+        import json
+
+        with open(path, "w") as f:
+            f.write("#%s\n" % json.dumps({"t_start": self._t0, "env_id": env_id or type(self.batch).__name__}))
+            cols = ("r", "l", "t") + self.info_keywords
+            f.write(",".join(cols) + "\n")
+            for row in self.episode_log:
+                f.write(",".join(str(row[c]) for c in cols) + "\n")
+
     def info_array(self):
         """Last step's info as [num_envs, len(info_keys)] (cheaper than per-env dicts for large batches)."""
         return self.batch._info

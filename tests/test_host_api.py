@@ -88,3 +88,15 @@ def test_vecenv_auto_reset_and_monitor_rows():
     assert n_done == 6
     # env 0 saw the same episodes as the single-env golden (seed 10)
     assert [r["r"] for r in venv.episode_log if True][0::3][:2] == g["meta"]["episode_rewards"][:2]
+    import csv
+    import json
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:  # SB3 Monitor file format
+        path = d + "/run.monitor.csv"
+        venv.save_monitor_csv(path, env_id="DeepRMSA-v0")
+        lines = open(path).read().splitlines()
+        assert lines[0].startswith("#") and json.loads(lines[0][1:])["env_id"] == "DeepRMSA-v0"
+        rows = list(csv.DictReader(lines[1:]))
+        assert len(rows) == 6 and list(rows[0])[:3] == ["r", "l", "t"] and int(rows[0]["l"]) == 49
+        assert "episode_service_blocking_rate" in rows[0]
