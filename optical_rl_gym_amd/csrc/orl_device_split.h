@@ -346,6 +346,10 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
       e.scal[SC_NOWA] = (u64)__double_as_longlong(e.now);
     }
     ORL_PROFA(5);
+    // the word service_part leaves in SC_ACC (recomputed here so that the deferral below need not read it back)
+    const u64 acc_after = (MERGE && accepted && ENV != ENV_RWA && e.now > 0)
+                              ? (3ull | ((u64)(u32)core << 32) | ((u64)e.s_nh << 37))
+                              : pack2(accepted ? 1 : 0, core);
     if (MERGE) service_part<ENV, W, true>(P, e, env, lane, 1, accepted, core, nullptr, prof);
     g8::env_store(P, e, gl);
     ORL_PROFA(8);
@@ -362,7 +366,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         if (gl == 0) {
           u32* dq = P.q_def + (size_t)parity * P.q_def_stride;
           dq[16 + atomicAdd(dq, 1u)] = (u32)env;
-          e.scal[SC_ACC] = e.scal[SC_ACC] | (1ull << 16);
+          e.scal[SC_ACC] = acc_after | (1ull << 16);
           e.scal[SC_HINT] = pack2(e.nfree, 0);  // a rebuild may have rewritten the free-slot stack
         }
       } else {
