@@ -1203,7 +1203,28 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
   if (multi) {
     // every sub-batch runs its own policy -> step -> policy -> ... chain on its own stream
     for (hipStream_t st : b->owned_streams) HIPCHK(hipStreamWaitEvent(st, b->ev0, 0));
-    for (int64_t s = 0; s < n_steps; s++) {
+    int64_t s0 = 0;
+    if (getenv("ORL_GRAPH") && b->subs.size() == b->owned_streams.size() && n_steps >= 64) {
+      // experiment (off by default): 16 steps of every sub-batch captured into one hipGraph per stream
+      constexpr int GS_ = 16;
+      std::vector<hipGraphExec_t> ex(b->subs.size());
+      bool ok = true;
+      for (size_t k = 0; k < b->subs.size() && ok; k++) {
+        b->view = &b->subs[k];
+        b->view_stream = b->sub_streams[k];
+        hipGraph_t g;
+        ok = hipStreamBeginCapture(b->view_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        for (int i = 0; i < GS_ && ok; i++) launch_policy_step(b, policy_id);
+        ok = ok && hipStreamEndCapture(b->view_stream, &g) == hipSuccess;
+        ok = ok && hipGraphInstantiate(&ex[k], g, nullptr, nullptr, 0) == hipSuccess;
+        if (ok) hipGraphDestroy(g);
+      }
+      if (!ok) return fail(ORL_E_HIP, "hipGraph capture failed");
+      for (; s0 + GS_ <= n_steps; s0 += GS_)
+        for (size_t k = 0; k < b->subs.size(); k++) HIPCHK(hipGraphLaunch(ex[k], b->sub_streams[k]));
+      for (auto& e : ex) hipGraphExecDestroy(e);
+    }
+    for (int64_t s = s0; s < n_steps; s++) {
       for (size_t k = 0; k < b->subs.size(); k++) {
         b->view = &b->subs[k];
         b->view_stream = b->sub_streams[k];
