@@ -5,7 +5,7 @@ envs per MI355X, on-device KSP-FF policy (BASELINE.json `metric`; SURVEY.md §8d
 One "step" = one batched policy + env.step() over the whole batch, entirely on the device: at this batch size
 the two-kernel pipeline (k_step_a2: slot scan + all per-env control + release detection -> mixed work items;
 k_rows2: one lane per touched link row; k_rel_tail: one-workgroup serial fallback), launched back to back on the
-batch's two streams (half the envs each); inputs are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
+batch's three streams (a third of the envs each); inputs are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
 collective on the data path; torch.distributed is used only for the barrier and the max-over-ranks time).
 
     python bench.py --gpus 1 --steps 300 --warmup 1500

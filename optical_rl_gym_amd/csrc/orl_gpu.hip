@@ -1017,14 +1017,20 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   HIPCHK(hipEventCreate(&b->ev0));
   HIPCHK(hipEventCreate(&b->ev1));
   {
-    // Two env sub-ranges on two streams: one range's kernel fills the other's tail.  Measured on MI355X, cfg2: pipeline at
-    // 65 536 envs 1 stream 4.2e8, 2 streams 5.3e8, 3+ slower; at 8 192 envs no gain (RWA: 1.78e8 -> 1.42e8), so from 16 384;
+    // Env sub-ranges on separate streams: one range's kernel fills the other's tail.  Measured on MI355X, cfg2: pipeline at
+    // 65 536 envs 1 stream 4.2e8, 2 streams 5.3e8; at 8 192 envs no gain (RWA: 1.78e8 -> 1.42e8), so from 16 384;
     // per-env kernel at 8 192 envs 1.12e8 -> 1.39e8 (10 240: 1.27e8 -> 1.62e8), so from 8 192.
-    int n_streams = (n_envs >= (b->step_impl == 64 || b->step_impl == 8 ? 8192 : 16384)) ? 2 : 1;
+    // Three sub-ranges (the batch's own stream + two more) beat two for the heavier env families: cfg2 65 536 envs
+    // 5.3e8 -> 5.7e8, cfg5 32 768: 2.69e8 -> 2.80e8, RMCSA 16 384: 2.12e8 -> 2.20e8; RWA / DeepRMSA 32 768: 4.75e8 -> 4.57e8.
+    const int many = (c->env_type == ORL_ENV_RWA || c->env_type == ORL_ENV_DEEPRMSA) ? 2 : 3;
+    int n_streams = (n_envs >= (b->step_impl == 64 || b->step_impl == 8 ? 8192 : 16384)) ? many : 1;
     if (const char* sv = getenv("ORL_STREAMS")) { int v = atoi(sv); if (v >= 1 && v <= 16) n_streams = v; }
     int n_sub = n_streams;  // ORL_SUBS > ORL_STREAMS: sub-batch k runs on stream k % n_streams
     if (const char* sv = getenv("ORL_SUBS")) { int v = atoi(sv); if (v >= n_streams && v <= 64) n_sub = v; }
-    for (int i = 0; i < n_streams; i++) {
+    // The batch's own stream carries the first sub-batch: the runtime maps streams onto 4 hardware queues by default, and
+    // with one more stream than queues the sub-batches serialise (3 extra streams: 3.5e8 env-steps/s; 3 streams in all: 5.7e8).
+    b->owned_streams.push_back(b->stream);
+    for (int i = 1; i < n_streams; i++) {
       hipStream_t st;
       HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       b->owned_streams.push_back(st);
@@ -1084,7 +1090,8 @@ extern "C" void orl_batch_destroy(orl_batch* b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
-  for (hipStream_t st : b->owned_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  for (hipStream_t st : b->owned_streams)
+    if (st != b->stream) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   for (void* p : b->allocs) hipFree(p);
@@ -1202,7 +1209,8 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   if (multi) {
     // every sub-batch runs its own policy -> step -> policy -> ... chain on its own stream
-    for (hipStream_t st : b->owned_streams) HIPCHK(hipStreamWaitEvent(st, b->ev0, 0));
+    for (hipStream_t st : b->owned_streams)
+      if (st != b->stream) HIPCHK(hipStreamWaitEvent(st, b->ev0, 0));
     int64_t s0 = 0;
     if (getenv("ORL_GRAPH") && b->subs.size() == b->owned_streams.size() && n_steps >= 64) {
       // experiment (off by default): 16 steps of every sub-batch captured into one hipGraph per stream
@@ -1240,6 +1248,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     b->view = nullptr;
     b->view_stream = nullptr;
     for (hipStream_t st : b->owned_streams) {
+      if (st == b->stream) continue;
       hipEvent_t e;
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       HIPCHK(hipEventRecord(e, st));
