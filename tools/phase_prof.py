@@ -1,4 +1,6 @@
-"""Per-phase shader-clock breakdown of the split control kernels (needs a -DORL_TIMING build: ORL_HIPCC_EXTRA)."""
+"""Per-phase shader-clock breakdown of the pipeline kernels.  Build with ORL_HIPCC_EXTRA=-DORL_TIMING=<n> and run with
+the same variable exported: n = 2 -> k_step_a2 / k_policy_ctrl_a, 4 -> the row kernels (default ORL_STEP_IMPL=2);
+n = 1 -> k_ctrl_b2 (run with ORL_STEP_IMPL=1); n = 3 -> event counts, see tools/push_dbg.py."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 os.environ.setdefault("ORL_STEP_IMPL", "2"); os.environ["ORL_STREAMS"] = "1"
