@@ -248,6 +248,43 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         assert out["split"]["serial"] > 100 and out["split2"]["serial"] > 0 and out["two"]["serial"] > 100
 
 
+CORNERS = [
+    ("RWA", "cost239", "SAP_LF", 3000, dict(load=450.0, mean_service_holding_time=25.0, episode_length=7, num_spectrum_resources=17,
+                                            allow_rejection=True)),
+    ("RMSA", "nsfnet_chen", "LLP_FF", 1500, dict(load=700.0, mean_service_holding_time=25.0, episode_length=40,
+                                                 num_spectrum_resources=500, allow_rejection=True, bit_rate_selection="discrete")),
+    ("RMSA", "cost239", "SP_FF", 2048, dict(load=60.0, mean_service_holding_time=5.0, episode_length=1000, num_spectrum_resources=64)),
+    ("DeepRMSA", "germany50", "SAP", 1024, dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=0.25, j=4,
+                                                episode_length=9, num_spectrum_resources=200)),
+    ("RMCSA", "cost239", "SAP_BM_FC_FF", 700, dict(load=300.0, mean_service_holding_time=5.0, episode_length=40,
+                                                   num_spectrum_resources=100, num_spatial_resources=7, allow_rejection=True)),
+]
+
+
+@pytest.mark.parametrize("fam,topo,policy,batch,kw", CORNERS)
+def test_corner_configurations_agree_across_step_implementations(fam, topo, policy, batch, kw, monkeypatch):
+    """Row widths of 1, 2, 4 and 8 words, slot counts that are no multiple of 64, discrete bit rates, rejection, very short
+    episodes, 7 cores, the 88-link topology: every env ends in the same state under all three default-path implementations
+    (a sample of tools/fuzz_cross.py, which drew 62 random configurations without a mismatch)."""
+    import optical_rl_gym_amd as orl
+
+    seeds = [int(x) for x in np.random.RandomState(len(topo) + batch).randint(0, 2**31 - 1, batch)]
+    out = {}
+    for v in ("64", "1", "2"):
+        monkeypatch.setenv("ORL_STEP_IMPL", v)
+        env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+        env.run(policy, 130)
+        env.run(policy, 170)
+        pick = (0, batch // 2, batch - 1)
+        out[v] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy()] + \
+                 [env.slots(i).copy() for i in pick] + [env.link_stats(i).copy() for i in pick] + [env.net_stats(i).copy() for i in pick]
+        env.close()
+    chk = _exact(fam + "/" + topo)
+    for v in ("1", "2"):
+        for k, (x, y) in enumerate(zip(out[v], out["64"])):
+            chk(k, "impl " + v, x, y)
+
+
 def test_run_reports_every_kernel_of_the_step(monkeypatch):
     import optical_rl_gym_amd as orl
     from bench import WORKLOADS
