@@ -283,6 +283,17 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
     for v in ("1", "2"):
         for k, (x, y) in enumerate(zip(out[v], out["64"])):
             chk(k, "impl " + v, x, y)
+    # ... and that state is the reference's: the first envs against the oracle
+    from oracle.oracle import OracleBatch
+
+    ora = OracleBatch(fam, topo, seeds[:5], **kw)
+    ora.run(policy, 300)
+    ref = out["64"]
+    chk(0, "oracle counters", ref[0][:5], ora.counters())
+    chk(0, "oracle services", ref[1][:5], ora.services())
+    chk(0, "oracle slots", ref[4], ora.slots(0))
+    chk(0, "oracle link_stats", ref[7], ora.link_stats(0))
+    chk(0, "oracle net_stats", ref[10], ora.net_stats(0))
 
 
 def test_run_reports_every_kernel_of_the_step(monkeypatch):
