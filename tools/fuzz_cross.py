@@ -10,8 +10,8 @@ bad = 0
 for case in range(n_cases):
     fam = rng.choice(["RMSA", "RMSA", "DeepRMSA", "RWA", "RMCSA"])
     topo = rng.choice(["nsfnet_chen", "nsfnet_chen", "germany50", "cost239"])
-    B = int(rng.choice([600, 2048, 5000]))
-    steps = int(rng.choice([150, 400]))
+    B = int(rng.choice([600, 2048, 5000, 20000]))
+    steps = int(rng.choice([150, 400, 1200]))
     kw = dict(episode_length=int(rng.choice([7, 40, 1000])), mean_service_holding_time=float(rng.choice([5.0, 25.0])))
     if fam == "RWA":
         kw.update(load=float(rng.choice([50, 450])), num_spectrum_resources=int(rng.choice([17, 80, 130])),
