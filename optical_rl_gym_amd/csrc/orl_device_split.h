@@ -190,7 +190,8 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 // kernel keeps the latter in rel_sums.
 template <int ENV, int W, int MERGE = 0>
 __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, Prof& prof,
-                                       const int4* given = nullptr, u32* s_tally = nullptr, SinkEntry* s_tab = nullptr, int parity = 0) {
+                                       const int4* given = nullptr, u32* s_tally = nullptr, SinkEntry* s_tab = nullptr, int parity = 0,
+                                       int* s_deferred = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (MERGE == 2) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
@@ -222,13 +223,25 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         // minus what its releases added (rmsa_env.py:439-462 with _get_network_compactness at provision time)
         const int c0 = (int)((acc0 >> 32) & 31);
         const i64 s_nh_prov = (i64)(acc0 >> 37);
-        const int occ = e.cs[2 * c0] - rs[2 * c0], fb = e.cs[2 * c0 + 1] - rs[2 * c0 + 1];
+        // (the sums are updated by L2 atomics: in the persistent kernel, where no kernel boundary invalidates the L1 in
+        // between, they are read through L2 as well)
+        int occ, fb;
+        if (s_deferred) {
+          occ = atomicAdd(e.cs + 2 * c0, 0) - atomicAdd(rs + 2 * c0, 0);
+          fb = atomicAdd(e.cs + 2 * c0 + 1, 0) - atomicAdd(rs + 2 * c0 + 1, 0);
+        } else {
+          occ = e.cs[2 * c0] - rs[2 * c0];
+          fb = e.cs[2 * c0 + 1] - rs[2 * c0 + 1];
+        }
         const double a0 = __longlong_as_double((i64)e.scal[SC_GC_A]), td = __longlong_as_double((i64)e.scal[SC_GC_TD]);
         const double now_a = __longlong_as_double((i64)e.scal[SC_NOWA]);
         const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
         e.g_comp = (a0 + (cmp * td)) / now_a;
       }
-      for (int i = gl; i < 2 * P.C; i += 8) rs[i] = 0;  // this step's releases start from zero
+      for (int i = gl; i < 2 * P.C; i += 8) {  // this step's releases start from zero
+        if (s_deferred) atomicExch(rs + i, 0);
+        else rs[i] = 0;
+      }
     }
     const int4 av = given ? *given : *(const int4*)(P.actions + env * 4);
     int path, mod = 0;
@@ -366,6 +379,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         if (gl == 0) {
           u32* dq = P.q_def + (size_t)parity * P.q_def_stride;
           dq[16 + atomicAdd(dq, 1u)] = (u32)env;
+          if (s_deferred) *s_deferred = 1;  // persistent kernel: this workgroup stops after the row phase
           e.scal[SC_ACC] = acc_after | (1ull << 16);
           e.scal[SC_HINT] = pack2(e.nfree, 0);  // a rebuild may have rewritten the free-slot stack
         }

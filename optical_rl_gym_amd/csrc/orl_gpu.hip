@@ -385,6 +385,81 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
   ORL_PROFR(9);
   ORL_PROFR_END();
 }
+// ---- persistent form of the two-kernel pipeline (step_impl 3) ----------------------------------------------------------
+// Envs never interact, so a workgroup can own its 32 envs for a whole run: control phase (the body of k_step_a2) ->
+// barrier -> row phase over the items its own wavefronts just emitted (the body of k_rows2) -> barrier -> next step, with
+// no kernel boundary and no grid-wide tail between the phases; the workgroups of a launch drift out of phase and keep
+// the memory system uniformly busy (what only a 10^6-env batch achieves with separate launches).  Data written in one
+// phase and read in the next stays within the workgroup: same CU, same L1.  A workgroup in which an env's releases did
+// not fit the item form (one env-step in 10^7) leaves the loop after that step's row phase; the host runs k_rel_tail
+// and relaunches, every workgroup resuming from its own step count.
+#ifndef ORL_PERSIST_WAVES
+#define ORL_PERSIST_WAVES 4   // waves per SIMD the register allocator must leave room for
+#endif
+#ifndef ORL_PERSIST_WG
+#define ORL_PERSIST_WG 1      // wavefronts (8 envs each) per workgroup of the persistent kernel
+#endif
+template <int ENV, int W>
+__global__ void __launch_bounds__(64 * ORL_PERSIST_WG) __attribute__((amdgpu_waves_per_eu(ORL_PERSIST_WAVES, ORL_PERSIST_WAVES)))
+k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
+  constexpr int NW = ORL_PERSIST_WG;
+  __shared__ u32 s_tally[32 * 8 * NW];
+  __shared__ int s_deferred[2];  // alternating by step: a flag is cleared only after every thread has passed the next barrier
+  const int lane = lane_id();
+  const i64 env = (i64)blockIdx.x * (8 * NW) + (threadIdx.x >> 3);
+  int step = wg_step[blockIdx.x];
+  sp::Prof prof;
+  if (threadIdx.x == 0) s_deferred[0] = s_deferred[1] = 0;
+  while (step < target) {
+    __syncthreads();  // the previous row phase's writes are visible to every wavefront of the workgroup
+    if (threadIdx.x == 0) s_deferred[(step + 1) & 1] = 0;
+    // per-iteration opaque copies: without them the compiler hoists every per-lane address out of the loop and keeps
+    // them all live across both phases (199 VGPRs instead of ~128)
+    int env_lo = (int)env, lane_i = lane;
+    asm volatile("" : "+v"(env_lo), "+v"(lane_i));
+    const i64 env_i = (i64)env_lo;
+    const bool valid_i = env_i < P.B;
+    const i64 env0_i = env_i - (lane_i >> 3);
+    {
+      u64 d = valid_i ? P.svc_desc[env_i] : 0ull;
+      int a[4];
+      policy_g<ENV, W, 8>(P, P.bitmap + env0_i * P.bm_words + (size_t)(lane_i >> 3) * P.bm_words, valid_i, (int)(u32)d,
+                          (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane_i, pol, a);
+      const int4 av = make_int4(a[0], a[1], a[2], a[3]);
+      if (valid_i && (lane_i & 7) == 0) *(int4*)(P.actions + env_i * 4) = av;
+      sp::ctrl_a<ENV, W, 2>(P, env_i, valid_i, lane_i, false, prof, &av, s_tally, (sp::SinkEntry*)orl_lds_raw, 0, &s_deferred[step & 1]);
+    }
+    __syncthreads();  // items, fill counts, env records
+    {
+      u32 r0 = blockIdx.x * (u32)NW, tid = threadIdx.x;
+      asm volatile("" : "+s"(r0), "+v"(tid));
+      const u32* cnt = P.q_cnt_a + r0;
+      u32 cum[NW + 1];
+      cum[0] = 0;
+#pragma unroll
+      for (int j = 0; j < NW; j++) cum[j + 1] = cum[j] + cnt[j];
+      const ulonglong2* q = P.q_a + (size_t)r0 * P.q_wave * 2;
+      for (u32 idx = tid; idx < cum[NW]; idx += 64 * NW) {
+        u32 j = 0, base = 0;
+#pragma unroll
+        for (int t = 1; t < NW; t++)
+          if (idx >= cum[t]) { j = (u32)t; base = cum[t]; }
+        const size_t at = (size_t)j * P.q_wave + (idx - base);
+        sp::Item it;
+        it.a = q[2 * at];
+        it.b = q[2 * at + 1];
+        sp::row_item_lane<ENV, W, true>(P, it, SC_NOW, prof);
+      }
+    }
+    step++;
+    if (s_deferred[(step - 1) & 1]) break;  // set before the barrier in front of the row phase
+  }
+  if (threadIdx.x == 0) {
+    wg_step[blockIdx.x] = step;
+    if (step < target) atomicAdd(n_unfinished, 1u);
+  }
+}
+
 // serial tail, one small workgroup per launch: the envs whose releases of this step did not fit the item form (about
 // one env-step in 10^7; control kernels append them to q_def) release them in place, 8 lanes per env.  A launch of its
 // own because inlined into the row kernels this code cost them half their occupancy.
@@ -610,6 +685,9 @@ struct orl_batch {
   DevParams P;
   TkRec* tk = nullptr;  // per-kernel timing of orl_batch_run(time_kernels = 1)
   int parity[66] = {0};  // two-kernel pipeline: which deferred-env buffer the next step of view k writes (0 = whole batch)
+  int persist = 0;       // device-resident runs through the persistent kernel (k_persist)
+  int* d_wg_step = nullptr;        // [ceil(B/32)] steps each workgroup of the persistent kernel has completed in this run
+  unsigned int* d_unfinished = nullptr;
   int device, wt;
   int step_impl;  // 64 = one wavefront per env, 8 = eight lanes per env (monolithic), 1 = four-kernel split pipeline, 2 = two-kernel pipeline
   hipStream_t stream;
@@ -991,6 +1069,12 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     P.q_def_stride = (i64)(2 * B + 16 * 80);
     rc |= dalloc(b, &P.q_def, 2 * (size_t)P.q_def_stride);
     P.pipeline2 = (b->step_impl == 2) ? 1 : 0;
+    if (b->step_impl == 2) {
+      rc |= dalloc(b, &b->d_wg_step, (B + 7) / 8 + 16);
+      rc |= dalloc(b, &b->d_unfinished, 16);
+      const bool wide_policy = (c->env_type == ORL_ENV_RMCSA) || t->K > 8;
+      if (const char* pv = getenv("ORL_PERSIST")) b->persist = atoi(pv) != 0 && !wide_policy && c->env_type != ORL_ENV_DEEPRMSA;
+    }
     if (!rc) hipMemset(P.q_def, 0, 2 * (size_t)P.q_def_stride * sizeof(u32));
     rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
     rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
@@ -1207,7 +1291,34 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
   HIPCHK(hipStreamSynchronize(b->stream));
   const bool multi = !time_kernels && b->subs.size() > 1;
   HIPCHK(hipEventRecord(b->ev0, b->stream));
-  if (multi) {
+  if (!time_kernels && b->persist) {
+    // one launch for the whole run (plus a relaunch whenever a workgroup had to leave its loop for the serial tail)
+    const DevParams& VP = b->P;
+    hipStream_t VS = b->stream;
+    constexpr int EPW_ = 8 * ORL_PERSIST_WG;  // envs per workgroup
+    dim3 gc((unsigned)((VP.B + EPW_ - 1) / EPW_)), blk(64 * ORL_PERSIST_WG), blk_tail(256);
+    const size_t lds_a = (size_t)EPW_ * VP.E * sizeof(sp::SinkEntry);
+    HIPCHK(hipMemsetAsync(b->d_wg_step, 0, gc.x * sizeof(int), VS));
+    for (;;) {
+      HIPCHK(hipMemsetAsync(VP.q_def, 0, sizeof(u32), VS));
+      HIPCHK(hipMemsetAsync(b->d_unfinished, 0, sizeof(unsigned int), VS));
+#define CALLW(WW)                                                                                                     \
+  do {                                                                                                                \
+    if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<EE, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
+    hipLaunchKernelGGL((k_persist<EE, WW>), gc, blk, lds_a, VS, VP, policy_id, (int)n_steps, b->d_wg_step, b->d_unfinished); \
+    hipLaunchKernelGGL((k_rel_tail<EE, WW>), dim3(1), blk_tail, 0, VS, VP, 0);                                        \
+  } while (0)
+#define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
+      ORL_FOR_ENV(PER_ENV)
+#undef PER_ENV
+#undef CALLW
+      unsigned int left = 0;
+      HIPCHK(hipMemcpyAsync(&left, b->d_unfinished, sizeof left, hipMemcpyDeviceToHost, VS));
+      HIPCHK(hipStreamSynchronize(VS));
+      if (!left) break;
+    }
+    launch_finish2(b);
+  } else if (multi) {
     // every sub-batch runs its own policy -> step -> policy -> ... chain on its own stream
     for (hipStream_t st : b->owned_streams)
       if (st != b->stream) HIPCHK(hipStreamWaitEvent(st, b->ev0, 0));

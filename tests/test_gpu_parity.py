@@ -11,12 +11,13 @@ pytestmark = pytest.mark.gpu
 # The library picks the step implementation by batch size and env family (two-kernel pipeline for large batches, one
 # wavefront per env below); the small parity cases run against all of them by forcing it (the variable is read when a
 # batch is created).
-IMPLS = ["wave64", "split", "split2"]
+IMPLS = ["wave64", "split", "split2", "persist"]
 
 
 @pytest.fixture(params=IMPLS)
 def impl(request, monkeypatch):
-    monkeypatch.setenv("ORL_STEP_IMPL", {"wave64": "64", "split": "1", "split2": "2"}[request.param])
+    monkeypatch.setenv("ORL_STEP_IMPL", {"wave64": "64", "split": "1", "split2": "2", "persist": "2"}[request.param])
+    monkeypatch.setenv("ORL_PERSIST", "1" if request.param == "persist" else "0")
     return request.param
 
 
@@ -194,8 +195,9 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
     kw = dict(kw, episode_length=90)
     seeds = [77 + 3 * i for i in range(batch)]
     out = {}
-    for name, v in (("wave64", "64"), ("split", "1"), ("split2", "2")):
+    for name, v in (("wave64", "64"), ("split", "1"), ("split2", "2"), ("persist", "2")):
         monkeypatch.setenv("ORL_STEP_IMPL", v)
+        monkeypatch.setenv("ORL_PERSIST", "1" if name == "persist" else "0")
         env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
         env.run(policy, steps // 2)  # two calls: the two-kernel pipeline finishes its pending update between them
         env.run(policy, steps - steps // 2)
@@ -207,7 +209,7 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
         env.close()
     a = out["wave64"]
     chk = _exact(workload)
-    for other in ("split", "split2"):
+    for other in ("split", "split2", "persist"):
         b = out[other]
         for key in ("counters", "services", "active", "flags"):
             chk(0, other + " " + key, b[key], a[key])
@@ -228,8 +230,10 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         fam, topo, kw, policy = WORKLOADS[workload]
         kw = dict(kw, episode_length=70)
         seeds = [5 + 11 * i for i in range(batch)]
-        for name, v, masks in (("wave64", "64", None), ("split", "1", "1"), ("split2", "1", "2"), ("two", "2", "1"), ("two2", "2", "2")):
+        for name, v, masks in (("wave64", "64", None), ("split", "1", "1"), ("split2", "1", "2"), ("two", "2", "1"), ("two2", "2", "2"),
+                               ("persist", "2", "1"), ("persist2", "2", "2")):
             monkeypatch.setenv("ORL_STEP_IMPL", v)
+            monkeypatch.setenv("ORL_PERSIST", "1" if name.startswith("persist") else "0")
             if masks:
                 monkeypatch.setenv("ORL_ITEM_MASKS", masks)
             else:
@@ -242,7 +246,7 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
             assert not env.flags().any()
             env.close()
         chk = _exact(workload)
-        for name in ("split", "split2", "two", "two2"):
+        for name in ("split", "split2", "two", "two2", "persist", "persist2"):
             for key in ("counters", "services", "active", "slots", "link", "net"):
                 chk(0, name + " " + key, out[name][key], out["wave64"][key])
         assert out["split"]["serial"] > 100 and out["split2"]["serial"] > 0 and out["two"]["serial"] > 100
@@ -270,8 +274,9 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
 
     seeds = [int(x) for x in np.random.RandomState(len(topo) + batch).randint(0, 2**31 - 1, batch)]
     out = {}
-    for v in ("64", "1", "2"):
-        monkeypatch.setenv("ORL_STEP_IMPL", v)
+    for v in ("64", "1", "2", "p"):
+        monkeypatch.setenv("ORL_STEP_IMPL", "2" if v == "p" else v)
+        monkeypatch.setenv("ORL_PERSIST", "1" if v == "p" else "0")
         env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
         env.run(policy, 130)
         env.run(policy, 170)
@@ -280,7 +285,7 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
                  [env.slots(i).copy() for i in pick] + [env.link_stats(i).copy() for i in pick] + [env.net_stats(i).copy() for i in pick]
         env.close()
     chk = _exact(fam + "/" + topo)
-    for v in ("1", "2"):
+    for v in ("1", "2", "p"):
         for k, (x, y) in enumerate(zip(out[v], out["64"])):
             chk(k, "impl " + v, x, y)
     # ... and that state is the reference's: the first envs against the oracle
