@@ -393,6 +393,8 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 // phase and read in the next stays within the workgroup: same CU, same L1.  A workgroup in which an env's releases did
 // not fit the item form (one env-step in 10^7) leaves the loop after that step's row phase; the host runs k_rel_tail
 // and relaunches, every workgroup resuming from its own step count.
+template <int W>
+__device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, int with_terminal);
 #ifndef ORL_PERSIST_WAVES
 #define ORL_PERSIST_WAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
@@ -450,6 +452,10 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
         it.b = q[2 * at + 1];
         sp::row_item_lane<ENV, W, true>(P, it, SC_NOW, prof);
       }
+    }
+    if (ENV == ENV_DEEPRMSA) {  // the observation of the new pending service, from the rows as they are now
+      __syncthreads();
+      if (valid_i) obs8_env<W>(P, env_i, lane_i, 1);
     }
     step++;
     if (s_deferred[(step - 1) & 1]) break;  // set before the barrier in front of the row phase
@@ -573,10 +579,8 @@ __global__ void __launch_bounds__(64) k_obs(DevParams P, int with_terminal) {
 // are read straight from global memory (the form of the slot scan), every lane writes its own path block.  The
 // one-wavefront-per-env k_obs above staged the whole slot map in LDS and took 26.7 us per 32 768-env launch (cfg3).
 template <int W>
-__global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
-  const int lane = lane_id(), gl = lane & 7;
-  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
-  if (env >= P.B) return;
+__device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, int with_terminal) {
+  const int gl = lane & 7;
   const u64* s = P.scal + env * ORL_SCAL_WORDS;
   u64 t = s[SC_SRC_DST];
   const int src = (int)(u32)t, dst = (int)(t >> 32);
@@ -626,6 +630,12 @@ __global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
     for (int i = 0; i < 19; i++)
       if (i < WD) { sp[i] = f[i]; if (o2) o2[1 + 2 * N + gl * WD + i] = f[i]; }
   }
+}
+template <int W>
+__global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (env >= P.B) return;
+  obs8_env<W>(P, env, lane_id(), with_terminal);
 }
 
 // Counter calibration: streams the whole slot-map array once with a known byte count (FETCH_SIZE on gfx950 is
@@ -978,7 +988,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     int64_t from = 12288;
     if (c->env_type == ORL_ENV_RWA || t->E >= 64) from = 8192;
     if (c->env_type == ORL_ENV_RMCSA) from = 4096;
-    b->step_impl = impl ? atoi(impl) : (n_envs >= from ? 2 : 64);
+    // The persistent kernel (k_persist) wins at every batch size where it applies (slot scan with 8 lanes per env):
+    // cfg2 64 envs 2.6e6 vs 2.1e6; 4 096: 1.6e8 vs 7.6e7; 32 768: 6.3e8 vs 4.0e8; RWA 4 096: 2.4e8 vs 8.3e7.
+    const bool persist_ok = c->env_type != ORL_ENV_RMCSA && t->K <= 8;
+    b->step_impl = impl ? atoi(impl) : ((persist_ok || n_envs >= from) ? 2 : 64);
     if (b->step_impl != 8 && b->step_impl != 1 && b->step_impl != 2) b->step_impl = 64;
   }
   DevParams& P = b->P;
@@ -1073,7 +1086,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       rc |= dalloc(b, &b->d_wg_step, (B + 7) / 8 + 16);
       rc |= dalloc(b, &b->d_unfinished, 16);
       const bool wide_policy = (c->env_type == ORL_ENV_RMCSA) || t->K > 8;
-      if (const char* pv = getenv("ORL_PERSIST")) b->persist = atoi(pv) != 0 && !wide_policy && c->env_type != ORL_ENV_DEEPRMSA;
+      b->persist = !wide_policy && !(c->env_type == ORL_ENV_DEEPRMSA && c->j > 8);
+      if (const char* pv = getenv("ORL_PERSIST")) b->persist = b->persist && atoi(pv) != 0;
     }
     if (!rc) hipMemset(P.q_def, 0, 2 * (size_t)P.q_def_stride * sizeof(u32));
     rc |= dalloc(b, &P.soon_t, B * ORL_SOON);

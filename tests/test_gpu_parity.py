@@ -202,6 +202,10 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
         env.run(policy, steps // 2)  # two calls: the two-kernel pipeline finishes its pending update between them
         env.run(policy, steps - steps // 2)
         pick = [0, 1, batch // 3, batch - 1]
+        if env.obs_dim:  # the observation the run left in the device buffer is the one a fresh evaluation gives
+            in_loop = env.device_tensor("obs").cpu().numpy().copy()
+            chk0 = _exact(workload)
+            chk0(0, name + " obs left by run()", in_loop, env.observation())
         out[name] = dict(counters=env.counters().copy(), services=env.services().copy(), active=env.active().copy(),
                          flags=env.flags().copy(), slots=[env.slots(i).copy() for i in pick],
                          link=[env.link_stats(i).copy() for i in pick], net=[env.net_stats(i).copy() for i in pick],
