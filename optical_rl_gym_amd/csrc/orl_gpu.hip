@@ -871,7 +871,9 @@ static void launch_finish2(orl_batch* b) {
 static void launch_policy_step(orl_batch* b, int pol) {
   const DevParams& VP = b->view ? *b->view : b->P;
   const bool wide = (VP.env_type == ENV_RMCSA) || VP.K > 8;
-  if (b->step_impl == 2) { launch_step2(b, pol, wide); return; }
+  // (the pipelines scan with 8 lanes per env also for RMCSA: the (path, core) pairs are walked 8 at a time in the
+  // reference's order and the walk stops at the first batch that fits — usually the first)
+  if (b->step_impl == 2) { launch_step2(b, pol, VP.K > 8); return; }
   if (b->step_impl == 1 && !wide) { launch_step(b, 1, 0, pol); return; }
   if (b->step_impl == 64 && !getenv("ORL_UNFUSED_POLICY")) { launch_step(b, 1, 0, pol); return; }  // slot scan inside k_step
   launch_policy(b, pol);
@@ -990,7 +992,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     if (c->env_type == ORL_ENV_RMCSA) from = 4096;
     // The persistent kernel (k_persist) wins at every batch size where it applies (slot scan with 8 lanes per env):
     // cfg2 64 envs 2.6e6 vs 2.1e6; 4 096: 1.6e8 vs 7.6e7; 32 768: 6.3e8 vs 4.0e8; RWA 4 096: 2.4e8 vs 8.3e7.
-    const bool persist_ok = c->env_type != ORL_ENV_RMCSA && t->K <= 8;
+    const bool persist_ok = t->K <= 8;
     b->step_impl = impl ? atoi(impl) : ((persist_ok || n_envs >= from) ? 2 : 64);
     if (b->step_impl != 8 && b->step_impl != 1 && b->step_impl != 2) b->step_impl = 64;
   }
@@ -1085,7 +1087,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     if (b->step_impl == 2) {
       rc |= dalloc(b, &b->d_wg_step, (B + 7) / 8 + 16);
       rc |= dalloc(b, &b->d_unfinished, 16);
-      const bool wide_policy = (c->env_type == ORL_ENV_RMCSA) || t->K > 8;
+      const bool wide_policy = t->K > 8;
       b->persist = !wide_policy && !(c->env_type == ORL_ENV_DEEPRMSA && c->j > 8);
       if (const char* pv = getenv("ORL_PERSIST")) b->persist = b->persist && atoi(pv) != 0;
     }
