@@ -2,10 +2,10 @@
 """Headline benchmark: env-steps/s of RMSA-v0 on NSFNET (320 slots, k=5, load 300 Erlang), batch 65 536
 envs per MI355X, on-device KSP-FF policy (BASELINE.json `metric`; SURVEY.md §8d cfg2 at B = 65 536).
 
-One "step" = one batched policy + env.step() over the whole batch, entirely on the device: at this batch size
-the two-kernel pipeline (k_step_a2: slot scan + all per-env control + release detection -> mixed work items;
-k_rows2: one lane per touched link row; k_rel_tail: one-workgroup serial fallback), launched back to back on the
-batch's three streams (a third of the envs each); inputs are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
+One "step" = one batched policy + env.step() over the whole batch, entirely on the device: the persistent kernel
+k_persist — one wavefront owns 8 envs for the whole run and alternates a control phase (slot scan + all per-env control +
+release detection -> work items) with a row phase (one lane per touched link row); the K timed steps are one launch.
+Inputs are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
 collective on the data path; torch.distributed is used only for the barrier and the max-over-ranks time).
 
     python bench.py --gpus 1 --steps 300 --warmup 1500
@@ -125,7 +125,7 @@ def main():
     env.run(policy, args.warmup)  # untimed: brings every env to its steady-state occupancy
     barrier()
     t0 = time.perf_counter()
-    env.run(policy, args.steps)   # EXACTLY K steps: K x (slot-scan kernel ; step kernel) on the stream
+    st_run = env.run(policy, args.steps)   # EXACTLY K steps of policy + step, entirely on the device
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -152,6 +152,14 @@ def main():
             bpe += alg["k_policy"]  # the device loop of the per-env kernel runs the slot scan inside k_step
         kernels[name] = dict(ms=ms, bytes=bpe * B)
     kernels.setdefault("k_policy", dict(ms=st2.ms_policy, bytes=alg["k_policy"] * B, standalone=True))
+    persistent = st_run.n_kernels == 1 and st_run.kernels()[0][0] == "k_persist"
+    if persistent:
+        # the timed run was ONE launch of the persistent kernel covering all K steps (live HIP-event duration of that
+        # launch); the kernels above are the same work as separate launches (the form time_kernels=1 runs), kept as a breakdown
+        for k in kernels.values():
+            k["breakdown"] = True
+        kernels["k_persist"] = dict(ms=st_run.kernels()[0][1], bytes=(alg["k_policy"] + alg["k_step"]) * B * args.steps,
+                                    steps_per_launch=args.steps)
     # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x calibration + WRITE_SIZE), collected offline with
     # tools/pmc_traffic.py for exactly this workload/batch and committed under profiles/; null otherwise.
     traffic, requests = {}, {}
@@ -161,6 +169,10 @@ def main():
         if tj.get("workload") == args.workload and tj.get("batch") == B:
             traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
             requests = {k: v.get("dram_requests_per_launch") for k, v in tj["kernels"].items()}
+            for k, v in tj["kernels"].items():  # kernels whose launch spans several steps: per-step figures
+                if v.get("steps_per_launch"):
+                    traffic[k + "_per_step"] = v["hbm_bytes_per_launch"] / v["steps_per_launch"]
+                    requests[k + "_per_step"] = (v.get("dram_requests_per_launch") or 0) / v["steps_per_launch"] or None
     roof = {}
     for name, k in kernels.items():
         ach = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
@@ -168,12 +180,21 @@ def main():
                           frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic.get(name.split("(")[0]), us_per_launch=round(k["ms"] * 1e3, 2),
                           algorithmic_bytes_per_launch=int(k["bytes"]))
         if k.get("standalone"):
-            roof[name]["note"] = "stand-alone slot-scan kernel (orl_batch_policy); the device loop fuses it into k_policy_ctrl_a"
-    dominant = max((n for n in kernels if not kernels[n].get("standalone")), key=lambda n: kernels[n]["ms"])
+            roof[name]["note"] = "stand-alone slot-scan kernel (orl_batch_policy); the device loop runs the scan inside its step kernel"
+        elif k.get("breakdown"):
+            roof[name]["note"] = "separate-launch form of the same work (one stream, whole batch): breakdown only"
+        if k.get("steps_per_launch"):
+            roof[name]["steps_per_launch"] = k["steps_per_launch"]
+            t_ps = traffic.get(name + "_per_step")
+            roof[name]["traffic"] = None if t_ps is None else int(t_ps * k["steps_per_launch"])
+    dominant = "k_persist" if persistent else max((n for n in kernels if not kernels[n].get("standalone")), key=lambda n: kernels[n]["ms"])
     # The bound these scattered-access kernels actually run into: L2<->fabric requests per batched step
     # (PMC, profiles/) against the random 64-byte-line access rate measured with tools/micro/gather_bench.hip
     req_roof = None
-    step_req = [requests.get(n.split("(")[0]) for n in kernels if not kernels[n].get("standalone") and n != "k_rel_tail"]
+    if persistent:
+        step_req = [requests.get("k_persist_per_step")]
+    else:
+        step_req = [requests.get(n.split("(")[0]) for n in kernels if not kernels[n].get("standalone") and n != "k_rel_tail"]
     if step_req and all(step_req):
         RANDOM_ACCESS_PEAK = 43.7e9  # read+write mix; 53.6e9 read-only (profiles/r1f_gather_bench.txt)
         per_step = float(sum(step_req))
@@ -240,8 +261,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %s-v0 %s, %d slots, k=%d, batch %d envs/GPU, on-device %s policy, seeds 10+i"
                                    % (args.workload, fam, topo, env.num_spectrum_resources, env.k_paths, B, policy),
-                       "envs_per_gpu": B, "kernels_per_step": st.n_kernels,
-                       "step_kernels": [n for n, _ in st.kernels()]},
+                       "envs_per_gpu": B,
+                       "step_kernels": ["k_persist (one launch for all %d steps)" % args.steps] if persistent else [n for n, _ in st.kernels()]},
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_by_kernel": roof,
             "request_roofline": None if req_roof is None else dict(

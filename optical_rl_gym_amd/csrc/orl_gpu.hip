@@ -1415,6 +1415,12 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     memset(stats, 0, sizeof *stats);
     stats->ms_total = ms;
     stats->launches = 2 * n_steps;
+    if (!time_kernels && b->persist && n_steps > 0) {  // the whole run was (re)launches of one kernel
+      stats->n_kernels = 1;
+      stats->ms_kernel[0] = ms;  // duration of the run: one k_persist launch covers all n_steps
+      snprintf(stats->kernel_name[0], sizeof stats->kernel_name[0], "k_persist");
+      stats->launches = 1;
+    }
     if (time_kernels == 2 && n_steps > 0) {
       double sp = 0, ss = 0;
       for (int64_t s = 0; s < n_steps; s++) {

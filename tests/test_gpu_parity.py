@@ -310,6 +310,7 @@ def test_run_reports_every_kernel_of_the_step(monkeypatch):
     from bench import WORKLOADS
 
     fam, topo, kw, policy = WORKLOADS["cfg2"]
+    monkeypatch.setenv("ORL_PERSIST", "0")
     for v, names in (("64", ["k_step"]),
                      ("1", ["k_policy_ctrl_a", "k_rows(provision)", "k_ctrl_b2", "k_rows(release)", "k_rel_tail"]),
                      ("2", ["k_step_a2", "k_rows2", "k_rel_tail"])):
@@ -321,6 +322,12 @@ def test_run_reports_every_kernel_of_the_step(monkeypatch):
         st2 = env.run(policy, 20, time_kernels=2)
         assert st2.ms_policy > 0 and st2.ms_step > 0
         env.close()
+    monkeypatch.setenv("ORL_PERSIST", "1")  # the default: the production run is one launch of the persistent kernel
+    monkeypatch.setenv("ORL_STEP_IMPL", "2")
+    env = orl.make(fam, topology=topo, num_envs=2048, seeds=list(range(2048)), **kw)
+    st = env.run(policy, 20)
+    assert [n for n, _ in st.kernels()] == ["k_persist"] and st.kernels()[0][1] > 0
+    env.close()
 
 
 def test_zero_copy_device_tensors_drive_the_batch():

@@ -28,15 +28,19 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/
                "loads both give 2.0, as MI355X_MICROARCH.md states); WRITE_SIZE as is",
        "workload": "cfg2", "batch": 65536, "fetch_calibration_factor": round(factor, 4), "kernels": {}}
 # bench.py looks kernels up by these names
-for name, kern in (("k_step_a2", "k_step_a2<"), ("k_rows2", "k_rows2<"), ("k_policy", "void k_policy<")):
-    f = mean_last("tr_f", kern) * 1024 * factor
-    w = mean_last("tr_w", kern) * 1024
+STEPS = {"k_persist": 20}  # tools/pmc_traffic.py measures launches of env.run(policy, 20)
+for name, kern in (("k_persist", "k_persist<"), ("k_policy", "void k_policy<")):
+    last = 5 if name in STEPS else 20  # (the run before the measured launches is one long launch of the same kernel)
+    f = mean_last("tr_f", kern, last) * 1024 * factor
+    w = mean_last("tr_w", kern, last) * 1024
     out["kernels"][name] = {"fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w)}
+    if name in STEPS:
+        out["kernels"][name]["steps_per_launch"] = STEPS[name]
     try:  # L2 <-> fabric requests (TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum), the quantity the random-access roofline counts
         fe = newest("%s/ea/**/*counter_collection.csv" % O)
         rows = [r for r in csv.DictReader(open(fe)) if kern in r["Kernel_Name"]]
-        rd = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "TCC_EA0_RDREQ_sum"][-20:]
-        wr = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "TCC_EA0_WRREQ_sum"][-20:]
+        rd = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "TCC_EA0_RDREQ_sum"][-last:]
+        wr = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "TCC_EA0_WRREQ_sum"][-last:]
         out["kernels"][name]["dram_requests_per_launch"] = int(sum(rd) / len(rd) + sum(wr) / len(wr))
     except Exception as exc:  # noqa: BLE001
         print("no request counters for", name, exc)

@@ -18,7 +18,8 @@ env.run(policy, 1200)
 for w in (0, 1, 0, 1):
     n = env.lib.orl_batch_debug_stream_read(env._h, w)
 print("calibration bytes", n)
-env.run(policy, 20)
+for _ in range(6):  # six launches of the persistent kernel, 20 steps each (tools/collect_profiles.py: STEPS)
+    env.run(policy, 20)
 for _ in range(20):  # the stand-alone slot-scan kernel (orl_batch_policy), on the same steady-state slot maps
     env.policy(policy)
 env.close()
