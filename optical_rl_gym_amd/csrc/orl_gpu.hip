@@ -1315,23 +1315,34 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     dim3 gc((unsigned)((VP.B + EPW_ - 1) / EPW_)), blk(64 * ORL_PERSIST_WG), blk_tail(256);
     const size_t lds_a = (size_t)EPW_ * VP.E * sizeof(sp::SinkEntry);
     HIPCHK(hipMemsetAsync(b->d_wg_step, 0, gc.x * sizeof(int), VS));
-    for (;;) {
-      HIPCHK(hipMemsetAsync(VP.q_def, 0, sizeof(u32), VS));
-      HIPCHK(hipMemsetAsync(b->d_unfinished, 0, sizeof(unsigned int), VS));
+    // The run is cut into chunks of steps: a workgroup that had to leave its loop for the serial tail resumes in the next
+    // launch and is at most one chunk behind (left to one launch per run, it would finish its remaining steps alone on
+    // the GPU: 3 000-step runs measured 5.6e8 env-steps/s against 6.3e8 for 100-step runs).  No host synchronisation
+    // between chunks; only the last launch is checked for stragglers.
+    int chunk = 64;
+    if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
+    for (int64_t tgt = 0; tgt < n_steps || tgt == 0;) {
+      tgt = (tgt + chunk < n_steps) ? tgt + chunk : n_steps;
+      for (;;) {
+        HIPCHK(hipMemsetAsync(VP.q_def, 0, sizeof(u32), VS));
+        HIPCHK(hipMemsetAsync(b->d_unfinished, 0, sizeof(unsigned int), VS));
 #define CALLW(WW)                                                                                                     \
   do {                                                                                                                \
     if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<EE, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
-    hipLaunchKernelGGL((k_persist<EE, WW>), gc, blk, lds_a, VS, VP, policy_id, (int)n_steps, b->d_wg_step, b->d_unfinished); \
+    hipLaunchKernelGGL((k_persist<EE, WW>), gc, blk, lds_a, VS, VP, policy_id, (int)tgt, b->d_wg_step, b->d_unfinished); \
     hipLaunchKernelGGL((k_rel_tail<EE, WW>), dim3(1), blk_tail, 0, VS, VP, 0);                                        \
   } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
-      ORL_FOR_ENV(PER_ENV)
+        ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
 #undef CALLW
-      unsigned int left = 0;
-      HIPCHK(hipMemcpyAsync(&left, b->d_unfinished, sizeof left, hipMemcpyDeviceToHost, VS));
-      HIPCHK(hipStreamSynchronize(VS));
-      if (!left) break;
+        if (tgt < n_steps) break;  // stragglers catch up in the next chunk's launch
+        unsigned int left = 0;
+        HIPCHK(hipMemcpyAsync(&left, b->d_unfinished, sizeof left, hipMemcpyDeviceToHost, VS));
+        HIPCHK(hipStreamSynchronize(VS));
+        if (!left) break;
+      }
+      if (tgt >= n_steps) break;
     }
     launch_finish2(b);
   } else if (multi) {
