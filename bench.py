@@ -4,7 +4,7 @@ envs per MI355X, on-device KSP-FF policy (BASELINE.json `metric`; SURVEY.md §8d
 
 One "step" = one batched policy + env.step() over the whole batch, entirely on the device: the persistent kernel
 k_persist — one wavefront owns 8 envs for the whole run and alternates a control phase (slot scan + all per-env control +
-release detection -> work items) with a row phase (one lane per touched link row); the K timed steps are one launch.
+release detection -> work items) with a row phase (one lane per touched link row); the K timed steps are ceil(K/64) launches.
 Inputs are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no
 collective on the data path; torch.distributed is used only for the barrier and the max-over-ranks time).
 
@@ -158,8 +158,9 @@ def main():
         # launch); the kernels above are the same work as separate launches (the form time_kernels=1 runs), kept as a breakdown
         for k in kernels.values():
             k["breakdown"] = True
-        kernels["k_persist"] = dict(ms=st_run.kernels()[0][1], bytes=(alg["k_policy"] + alg["k_step"]) * B * args.steps,
-                                    steps_per_launch=args.steps)
+        spl = args.steps / max(int(st_run.launches), 1)  # the run is cut into launches of 64 steps (the last one shorter)
+        kernels["k_persist"] = dict(ms=st_run.kernels()[0][1], bytes=(alg["k_policy"] + alg["k_step"]) * B * spl,
+                                    steps_per_launch=round(spl, 2))
     # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x calibration + WRITE_SIZE), collected offline with
     # tools/pmc_traffic.py for exactly this workload/batch and committed under profiles/; null otherwise.
     traffic, requests = {}, {}
@@ -262,7 +263,7 @@ def main():
             "config": {"workload": "%s: %s-v0 %s, %d slots, k=%d, batch %d envs/GPU, on-device %s policy, seeds 10+i"
                                    % (args.workload, fam, topo, env.num_spectrum_resources, env.k_paths, B, policy),
                        "envs_per_gpu": B,
-                       "step_kernels": ["k_persist (one launch for all %d steps)" % args.steps] if persistent else [n for n, _ in st.kernels()]},
+                       "step_kernels": ["k_persist (%d launches for the %d steps)" % (int(st_run.launches), args.steps)] if persistent else [n for n, _ in st.kernels()]},
             "roofline": dict(roof[dominant], kernel=dominant),
             "roofline_by_kernel": roof,
             "request_roofline": None if req_roof is None else dict(

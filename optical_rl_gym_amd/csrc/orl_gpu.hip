@@ -696,6 +696,7 @@ struct orl_batch {
   TkRec* tk = nullptr;  // per-kernel timing of orl_batch_run(time_kernels = 1)
   int parity[66] = {0};  // two-kernel pipeline: which deferred-env buffer the next step of view k writes (0 = whole batch)
   int persist = 0;       // device-resident runs through the persistent kernel (k_persist)
+  int64_t persist_launches = 0;
   int* d_wg_step = nullptr;        // [ceil(B/32)] steps each workgroup of the persistent kernel has completed in this run
   unsigned int* d_unfinished = nullptr;
   int device, wt;
@@ -1321,6 +1322,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     // between chunks; only the last launch is checked for stragglers.
     int chunk = 64;
     if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
+    b->persist_launches = 0;
     for (int64_t tgt = 0; tgt < n_steps || tgt == 0;) {
       tgt = (tgt + chunk < n_steps) ? tgt + chunk : n_steps;
       for (;;) {
@@ -1333,6 +1335,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     hipLaunchKernelGGL((k_rel_tail<EE, WW>), dim3(1), blk_tail, 0, VS, VP, 0);                                        \
   } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
+        b->persist_launches++;
         ORL_FOR_ENV(PER_ENV)
 #undef PER_ENV
 #undef CALLW
@@ -1428,9 +1431,9 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     stats->launches = 2 * n_steps;
     if (!time_kernels && b->persist && n_steps > 0) {  // the whole run was (re)launches of one kernel
       stats->n_kernels = 1;
-      stats->ms_kernel[0] = ms;  // duration of the run: one k_persist launch covers all n_steps
+      stats->launches = b->persist_launches > 0 ? b->persist_launches : 1;  // chunks of ORL_PERSIST_CHUNK steps
+      stats->ms_kernel[0] = ms / (double)stats->launches;                   // average duration of one launch
       snprintf(stats->kernel_name[0], sizeof stats->kernel_name[0], "k_persist");
-      stats->launches = 1;
     }
     if (time_kernels == 2 && n_steps > 0) {
       double sp = 0, ss = 0;
