@@ -1,6 +1,7 @@
 // orl_device_split.h — step() as a pipeline of kernels: per-env control -> work items -> one lane per touched link row.
 //
-// Two-kernel pipeline (step_impl 2; the default for large batches), one policy + step of the device-resident loop:
+// Persistent kernel k_persist (orl_gpu.hip; the default of the device-resident loop): one wavefront owns 8 envs for a whole
+// run and alternates the control phase and the row phase below, which the two-kernel pipeline runs as separate launches:
 //   k_step_a2   8 lanes per env: the slot scan (policy), then — the action still in registers — decode + validate,
 //               counters, reward, the release push, network throughput, the next service (RNG, node pair, bit rate),
 //               done / auto reset, and the due releases of the step through the env's soon list.  Output: one queue of
