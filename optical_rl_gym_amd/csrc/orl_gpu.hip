@@ -402,8 +402,7 @@ __device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, 
 #define ORL_PERSIST_WG 1      // wavefronts (8 envs each) per workgroup of the persistent kernel
 #endif
 template <int ENV, int W>
-__global__ void __launch_bounds__(64 * ORL_PERSIST_WG) __attribute__((amdgpu_waves_per_eu(ORL_PERSIST_WAVES, ORL_PERSIST_WAVES)))
-k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
+__device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr int NW = ORL_PERSIST_WG;
   __shared__ u32 s_tally[32 * 8 * NW];
   __shared__ int s_deferred[2];  // alternating by step: a flag is cleared only after every thread has passed the next barrier
@@ -464,6 +463,19 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
     wg_step[blockIdx.x] = step;
     if (step < target) atomicAdd(n_unfinished, 1u);
   }
+}
+// Two register budgets of the same body: 4 waves/SIMD (128 VGPRs, a few spills) is the better trade for NSFNET-sized
+// RMSA / RWA / DeepRMSA (cfg2 6.7e8 vs 6.2e8, cfg1 7.1e8 vs 6.1e8, cfg3 7.1e8 vs 5.8e8), 3 waves/SIMD (168 VGPRs, no spills)
+// for the heavier RMCSA and Germany50 steps (cfg4 5.0e8 vs 4.6e8, cfg5 3.4e8 vs 3.2e8).
+template <int ENV, int W>
+__global__ void __launch_bounds__(64 * ORL_PERSIST_WG) __attribute__((amdgpu_waves_per_eu(ORL_PERSIST_WAVES, ORL_PERSIST_WAVES)))
+k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
+  persist_body<ENV, W>(P, pol, target, wg_step, n_unfinished);
+}
+template <int ENV, int W>
+__global__ void __launch_bounds__(64 * ORL_PERSIST_WG) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_persist3(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
+  persist_body<ENV, W>(P, pol, target, wg_step, n_unfinished);
 }
 
 // serial tail, one small workgroup per launch: the envs whose releases of this step did not fit the item form (about
@@ -1320,6 +1332,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     // launch and is at most one chunk behind (left to one launch per run, it would finish its remaining steps alone on
     // the GPU: 3 000-step runs measured 5.6e8 env-steps/s against 6.3e8 for 100-step runs).  No host synchronisation
     // between chunks; only the last launch is checked for stragglers.
+    const bool roomy = VP.env_type == ENV_RMCSA || VP.E >= 64;  // 3 waves/SIMD without spills (see k_persist3)
     int chunk = 64;
     if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
     b->persist_launches = 0;
@@ -1330,8 +1343,13 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
         HIPCHK(hipMemsetAsync(b->d_unfinished, 0, sizeof(unsigned int), VS));
 #define CALLW(WW)                                                                                                     \
   do {                                                                                                                \
-    if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<EE, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
-    hipLaunchKernelGGL((k_persist<EE, WW>), gc, blk, lds_a, VS, VP, policy_id, (int)tgt, b->d_wg_step, b->d_unfinished); \
+    if (roomy) {                                                                                                      \
+      if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist3<EE, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
+      hipLaunchKernelGGL((k_persist3<EE, WW>), gc, blk, lds_a, VS, VP, policy_id, (int)tgt, b->d_wg_step, b->d_unfinished); \
+    } else {                                                                                                          \
+      if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<EE, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
+      hipLaunchKernelGGL((k_persist<EE, WW>), gc, blk, lds_a, VS, VP, policy_id, (int)tgt, b->d_wg_step, b->d_unfinished); \
+    }                                                                                                                 \
     hipLaunchKernelGGL((k_rel_tail<EE, WW>), dim3(1), blk_tail, 0, VS, VP, 0);                                        \
   } while (0)
 #define PER_ENV(E_) { constexpr int EE = E_; ORL_FOR_W(CALLW) }
