@@ -74,6 +74,32 @@ class OrlError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  If this library pulled in the system copies
+    first, a later `import torch` would bring a second HIP runtime into the process and find "No HIP GPUs"; so when torch
+    is installed (it need not be imported), its copies are loaded first and both sides share one runtime — the order
+    bench.py and the tests have anyway by importing torch before this package."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load (building if the sources are newer) liborlgpu.so."""
     global _LIB
@@ -83,6 +109,7 @@ def lib():
             path = _build.build()
         if not os.path.exists(path):
             raise OrlError("liborlgpu.so is missing and could not be built; the HIP path is the only path")
+        _share_hip_runtime_with_torch()
         handle = C.CDLL(path)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(handle, name)  # AttributeError = ABI mismatch, fail loudly
