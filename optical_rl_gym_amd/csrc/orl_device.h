@@ -109,7 +109,7 @@ struct DevParams {
   u32* soon_i;      // [B][ORL_SOON] their slots in ev_time / ev_info
   i64 q_cap;
   int* core_sums;   // [B][cs_words]      [2*C] per core: sum(lambda_max-lambda_min), sum(free blocks inside); [2*C] the part
-                    //                    of them this step's releases added (two-kernel pipeline; same 64-byte line);
+                    //                    of them this step's releases added (pipelines; same 64-byte line)
                     //                    then [C*E] per (core, link): that row's own contribution, (occ << 16) | fb
   i64* br_hist;     // [B][2*n_br]        discrete mode: requested / provisioned histograms
   i64* act_hist;    // [B][(K+1)+(S+1)]   RWA: marginals of actions_output
@@ -656,14 +656,15 @@ __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, 
     u64* wp = e.bm + (core * E + link) * W + (w < W ? w : 0);
     u64 a = v ? *wp : 0ull;
     RowStat before, after;
-    int* sump = e.cs + 4 * P.C + core * E + link;  // this row's contribution as of its last modification
-    if (ENV != ENV_RWA) { int pk = *sump; before.occ = pk >> 16; before.fb = pk & 0xffff; }
+    // the row's contribution to the compactness sums before the change (a cached copy used to save this summary; it
+    // tied this kernel to being the only one that steps the batch — the pipelines do not maintain such a cache)
+    if (ENV != ENV_RWA) row_stat<W, false>(a, w, S, before);
     const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
     a = release ? (a | m) : (a & ~m);
     if (v) *wp = a;
     if (ENV != ENV_RWA) {
       row_stat<W, true>(a, w, S, after);
-      if (rowv && w == 0) { d_occ += after.occ - before.occ; d_fb += after.fb - before.fb; *sump = (after.occ << 16) | after.fb; }
+      if (rowv && w == 0) { d_occ += after.occ - before.occ; d_fb += after.fb - before.fb; }
     } else {
       after.free_ = g8_sum(__popcll(a));
     }

@@ -206,7 +206,6 @@ __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane,
       row_stat<W, true>(a, w, S, after);
       d_occ += after.occ - before.occ;
       d_fb += after.fb - before.fb;
-      if (w == 0) e.cs[4 * P.C + core * E + link] = (after.occ << 16) | after.fb;  // keep the per-row cache of k_step valid
     } else {
       after.free_ = g8_sum(__popcll(a));
     }

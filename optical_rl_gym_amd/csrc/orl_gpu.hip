@@ -487,24 +487,6 @@ __global__ void __launch_bounds__(256) k_rel_tail(DevParams P, int buffer) {
   const u32 nd = dq[0];
   for (u32 d = threadIdx.x >> 3; d < nd; d += 32u) sp::rel_serial<ENV, W>(P, (i64)dq[16 + d], lane_id());
 }
-// After a snapshot restore: the per-row cache of compactness contributions (core_sums[2C + ...]) that the
-// one-wavefront-per-env kernel differences against is recomputed from the slot map, one thread per (env, core, link) row
-// — the pipelines do not maintain it, and a snapshot may come from a batch that ran them.
-template <int W>
-__global__ void k_rebuild_row_cache(DevParams P) {
-  const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const i64 rows = (i64)P.C * P.E;
-  if (t >= P.B * rows) return;
-  const i64 env = t / rows, r = t % rows;
-  const u64* row = P.bitmap + env * P.bm_words + r * W;
-  u64 a[W];
-#pragma unroll
-  for (int w = 0; w < W; w++) a[w] = row[w];
-  RowStat st;
-  int me, ed;
-  sp::row_stat_lane<W>(a, P.S, st, me, ed);
-  P.core_sums[env * P.cs_words + 4 * P.C + r] = (st.occ << 16) | st.fb;
-}
 // end of a device-resident run: the network-compactness update the last step left pending (one thread per env), so
 // that every host-visible state is final
 __global__ void k_finish2(DevParams P) {
@@ -708,6 +690,7 @@ struct orl_batch {
   TkRec* tk = nullptr;  // per-kernel timing of orl_batch_run(time_kernels = 1)
   int parity[66] = {0};  // two-kernel pipeline: which deferred-env buffer the next step of view k writes (0 = whole batch)
   int persist = 0;       // device-resident runs through the persistent kernel (k_persist)
+  int host_wave64 = 0;   // host-driven step() launches the one-wavefront-per-env kernel (small batches)
   int64_t persist_launches = 0;
   int* d_wg_step = nullptr;        // [ceil(B/32)] steps each workgroup of the persistent kernel has completed in this run
   unsigned int* d_unfinished = nullptr;
@@ -895,7 +878,7 @@ static void launch_policy_step(orl_batch* b, int pol) {
 static void launch_step(orl_batch* b, int auto_reset, int want_info, int fused_policy) {
   const DevParams& VP = b->view ? *b->view : b->P;
   hipStream_t VS = b->view ? b->view_stream : b->stream;
-  if (b->step_impl == 1 || b->step_impl == 2) {  // host-driven steps of the two-kernel pipeline use the four-kernel form
+  if ((b->step_impl == 1 || b->step_impl == 2) && !(b->host_wave64 && fused_policy < 0)) {  // host-driven steps: the four-kernel form
     dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256);
     dim3 gr((gc.x + ORL_ROWS1_GROUPS - 1) / ORL_ROWS1_GROUPS);  // lane-per-item row kernel
     const size_t lds_b2 = (size_t)32 * VP.E * sizeof(sp::SinkEntry);
@@ -1007,6 +990,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     // cfg2 64 envs 2.6e6 vs 2.1e6; 4 096: 1.6e8 vs 7.6e7; 32 768: 6.3e8 vs 4.0e8; RWA 4 096: 2.4e8 vs 8.3e7.
     const bool persist_ok = t->K <= 8;
     b->step_impl = impl ? atoi(impl) : ((persist_ok || n_envs >= from) ? 2 : 64);
+    // Host-driven step() of small batches: two launches of the per-env kernel beat the six of the split form (1 env: 18 500 vs
+    // 11 200 steps/s; 4 096 envs: 3.3e7 vs 2.7e7 env-steps/s).  Every kernel leaves the state in the common layout (the
+    // 8-lane kernels' caches are marked unknown by the per-env kernel), so the forms can alternate on one batch.
+    b->host_wave64 = (!impl && n_envs < from) ? 1 : 0;
     if (b->step_impl != 8 && b->step_impl != 1 && b->step_impl != 2) b->step_impl = 64;
   }
   DevParams& P = b->P;
@@ -1044,7 +1031,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   else if (c->env_type == ORL_ENV_RMCSA) P.n_info = 4;
   else P.n_info = 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
   P.obs_dim = c->env_type == ORL_ENV_DEEPRMSA ? 1 + 2 * P.N + (2 * P.J + 3) * P.K : 0;
-  P.cs_words = (4 * C + C * P.E + 15) & ~15;  // sums, release part, per-row cache; whole 64-byte lines per env
+  P.cs_words = (4 * C + 15) & ~15;  // sums and their release part; whole 64-byte lines per env
   P.lds_bytes = ((P.bm_words + 4 * P.E + P.E + P.obs_dim) * 8 + P.cs_words * 4 + 15) & ~15;
   if (P.lds_bytes < 624 * 4) P.lds_bytes = 624 * 4;  // k_init_mt stages the MT state in the same window
   if (P.lds_bytes > 64 * 1024) { delete b; return fail(ORL_E_INVALID, "per-env LDS window too large (%d B)", P.lds_bytes); }
@@ -1646,13 +1633,6 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
   HIPCHK(hipStreamSynchronize(b->stream));
   const unsigned char* o = (const unsigned char*)in;
   for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(s.ptr, o, s.bytes, hipMemcpyHostToDevice)); o += s.bytes; }
-  if (b->P.env_type != ENV_RWA) {
-    const i64 n = b->P.B * b->P.C * b->P.E;
-    dim3 g((unsigned)((n + 255) / 256)), blk(256);
-#define CALLW(WW) hipLaunchKernelGGL((k_rebuild_row_cache<WW>), g, blk, 0, b->stream, b->P)
-    ORL_FOR_W(CALLW)
-#undef CALLW
-  }
   if (b->P.obs_dim) launch_obs(b, 0);
   HIPCHK(hipStreamSynchronize(b->stream));
   return ORL_OK;

@@ -426,6 +426,45 @@ def test_matrix_observation_and_snapshot_restore():
     dev.close()
 
 
+@pytest.mark.parametrize("gname,policy", [("g2_rmsa_cfg2_sapff", "SAP_FF"), ("g4_deeprmsa_j2_sap", "SAP"),
+                                          ("g6_rmcsa_7x320_sapff", "SAP_BM_FC_FF"), ("g5_rwa_testcfg_sapff", "SAP_FF")])
+def test_device_runs_and_host_steps_alternate_on_one_batch(gname, policy):
+    """Default configuration: run() goes through the persistent kernel, host-driven step() of a small batch through the
+    one-wavefront-per-env kernel; they alternate on the same state (each leaves what the other needs, caches marked
+    unknown) and the result is the oracle's."""
+    from oracle.oracle import OracleBatch
+
+    meta = load_golden(gname)["meta"]
+    kw = dict(meta["kwargs"])
+    kw.pop("seed")
+    kw["episode_length"] = 45
+    seeds = [3000 + 5 * i for i in range(72)]
+    ora = OracleBatch(meta["env"], meta["topology"], seeds, **kw)
+    dev = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=72, seeds=seeds)
+    chk = _exact(gname)
+    for rnd in range(4):
+        dev.run(policy, 37)
+        ora.run(policy, 37)
+        for t in range(23):
+            a_o, a_d = ora.policy(policy), dev.policy(policy)
+            chk(t, "actions", a_d, a_o)
+            obs_o, r_o, d_o, i_o = ora.step(a_o, auto_reset=True)
+            obs_d, r_d, d_d, i_d = dev.step(a_d, auto_reset=True)
+            chk(t, "reward", r_d, r_o)
+            chk(t, "done", d_d, d_o)
+            chk(t, "info", i_d, i_o)
+            if obs_o is not None:
+                chk(t, "obs", obs_d, obs_o)
+        chk(rnd, "counters", dev.counters(), ora.counters())
+        chk(rnd, "services", dev.services(), ora.services())
+        for e in (0, 35, 71):
+            chk(rnd, "slots", dev.slots(e), ora.slots(e))
+            chk(rnd, "link_stats", dev.link_stats(e), ora.link_stats(e))
+            chk(rnd, "net_stats", dev.net_stats(e), ora.net_stats(e))
+    assert not dev.flags().any()
+    dev.close()
+
+
 def test_snapshot_moves_between_step_implementations(monkeypatch):
     """A snapshot taken from a batch driven by the two-kernel pipeline continues bit-identically in a batch driven by the
     one-wavefront-per-env kernel, and the other way round (the per-row cache only the latter keeps is rebuilt on restore)."""
