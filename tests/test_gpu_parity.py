@@ -467,7 +467,7 @@ def test_device_runs_and_host_steps_alternate_on_one_batch(gname, policy):
 
 def test_snapshot_moves_between_step_implementations(monkeypatch):
     """A snapshot taken from a batch driven by the two-kernel pipeline continues bit-identically in a batch driven by the
-    one-wavefront-per-env kernel, and the other way round (the per-row cache only the latter keeps is rebuilt on restore)."""
+    one-wavefront-per-env kernel, and the other way round."""
     import optical_rl_gym_amd as orl
 
     kw = dict(load=300, mean_service_holding_time=25, episode_length=50, num_spectrum_resources=320)
