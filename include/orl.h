@@ -45,6 +45,10 @@ extern "C" {
 #define ORL_POLICY_SAP_FF 1 /* k-shortest-path first-fit (KSP-FF) */
 #define ORL_POLICY_LLP_FF 2
 #define ORL_POLICY_SAP_LF 3 /* RWA only */
+/* PathOnlyFirstFitAction (rmsa_env.py:840-874, rwa_env.py:505-536): the agent chose the path (Discrete(k + reject)), the
+ * device finds the first fitting slot on it.  The per-env path column is set with orl_batch_set_paths() or written into
+ * the ORL_BUF_PATHS device array.  RMSA and RWA. */
+#define ORL_POLICY_PATH_FF 4
 
 /* Flattened topology: what the reference keeps in topology.graph["ksp"] / ["modulations"] and in the
  * networkx edge attributes (examples/create_topology.py:96-147).  All arrays are copied. */
@@ -72,7 +76,7 @@ typedef struct {
   int32_t bit_rate_lo, bit_rate_hi;
   int32_t n_bit_rates;         /* rows of the bit-rate tables: hi-lo+1 (continuous) or len(bit_rates) */
   int32_t event_capacity;      /* pending releases per env (0 = derive from load) */
-  int32_t reserved;
+  int32_t action_histograms;   /* != 0: keep the 2-D actions_output / actions_taken arrays (rmsa_env.py:126-137, rwa_env.py:52-58) */
   double lambda_arrival;       /* 1 / mean_service_inter_arrival_time  (rmsa_env.py:548-550) */
   double lambda_holding;       /* 1 / mean_service_holding_time        (rmsa_env.py:553) */
   const double* cum_src;       /* [n_nodes]          accumulate(node_request_probabilities) */
@@ -132,6 +136,14 @@ int orl_batch_obs_dim(const orl_batch* b);  /* DeepRMSA observation length, else
  * env_mask: NULL = all envs, else [n_envs] bytes. */
 int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask);
 
+/* seed(seed) (optical_network_env.py:205-210): env i (of the envs selected by env_mask, NULL = all) continues with the
+ * random stream of random.Random(seeds[i]); nothing else of its state changes.  seeds: [n_envs] (entries of unselected
+ * envs are ignored). */
+int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_t* env_mask);
+
+/* ORL_POLICY_PATH_FF: the path index chosen for every env, [n_envs] int32 (>= k_paths = reject). */
+int orl_batch_set_paths(orl_batch* b, const int32_t* paths);
+
 /* Heuristic decision for the pending service of every env.  actions_out: [n_envs][4] int32 or NULL to keep the
  * result on the device for the next orl_batch_step(actions = NULL).
  * Columns: RMSA/RWA (path, slot, -, -); DeepRMSA (action, -, -, -); RMCSA (path, modulation, core, slot). */
@@ -142,7 +154,14 @@ int orl_batch_policy(orl_batch* b, int policy_id, int32_t* actions_out);
  * auto_reset != 0: an env that returns done is soft-reset right away (what SB3's VecEnv does).
  * Any output pointer may be NULL (result stays on the device).  reward_out/[n_envs] double, done_out/[n_envs] u8,
  * info_out/[n_envs][info_dim] double, obs_out/[n_envs][obs_dim] double (DeepRMSA).
- * Synchronous on return when any output pointer is given. */
+ * Synchronous on return when any output pointer is given.
+ * Errors, mirroring the reference's exceptions:
+ *   ORL_E_ACTION    host-supplied `actions` hold an index outside the reference's actions_output array (IndexError at
+ *                   rmsa_env.py:167, rwa_env.py:103, rmcsa_env.py:219): returned BEFORE anything is modified.  With
+ *                   device-resident actions (actions = NULL) the kernel treats such an action as a rejection and the
+ *                   error is reported by the next synchronous call (or orl_batch_check).
+ *   ORL_E_OVERFLOW  an env needed more than event_capacity pending releases: that env's state is invalid from then on
+ *                   (the reference's heap is unbounded); recreate the batch with a larger event_capacity. */
 int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, double* reward_out,
                    uint8_t* done_out, double* info_out);
 
@@ -150,11 +169,15 @@ int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double*
 int orl_batch_observation(orl_batch* b, double* obs_out);
 
 /* n_steps x { policy ; step(auto_reset) } entirely on the device (the loop of utils.evaluate_heuristic,
- * utils.py:113-128, with VecEnv-style auto reset).  time_kernels: 0 = production run (sub-batches on their streams), 1 = the same launches on one stream with every kernel
- * bracketed by HIP events (stats->ms_kernel), 2 = stand-alone slot-scan kernel + step launches (ms_policy, ms_step). */
+ * utils.py:113-128, with VecEnv-style auto reset).  time_kernels: 0 = production run (the persistent kernel where it
+ * applies, else the per-env kernel with the slot scan inside), 1 = the separate-launch form with every kernel bracketed by
+ * HIP events (stats->ms_kernel), 2 = stand-alone slot-scan kernel + per-env step launches (ms_policy, ms_step).
+ * Returns ORL_E_OVERFLOW / ORL_E_ACTION like orl_batch_step. */
 int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels, orl_run_stats* stats);
 
 int orl_batch_sync(orl_batch* b);
+/* Synchronises and returns ORL_E_OVERFLOW / ORL_E_ACTION if any env flagged it since the last report (see orl_batch_step). */
+int orl_batch_check(orl_batch* b);
 
 /* Page-locked host memory for the buffers handed to orl_batch_step / orl_batch_policy: copies to and from it run at the
  * full PCIe rate (pageable numpy memory is staged through a bounce buffer by the runtime). */
@@ -172,6 +195,7 @@ int orl_host_free(void* p);
 #define ORL_BUF_INFO 3     /* f64   [n_envs][info_dim] */
 #define ORL_BUF_OBS 4      /* f64   [n_envs][obs_dim] (DeepRMSA) */
 #define ORL_BUF_TERM_OBS 5 /* f64   [n_envs][obs_dim]: observation before an auto reset */
+#define ORL_BUF_PATHS 6    /* int32 [n_envs]: path column of ORL_POLICY_PATH_FF */
 int orl_batch_device_buffer(orl_batch* b, int which, void** device_ptr, int64_t* n_elements);
 
 /* state read-back (parity tests, Python attribute surface) */
@@ -182,6 +206,14 @@ int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out /*[4][links]
 int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out /*[4]: throughput, compactness, last_update, current_time*/);
 int orl_batch_get_active(orl_batch* b, int32_t* out /*[n_envs] pending releases*/);
 int orl_batch_get_flags(orl_batch* b, int32_t* out /*[n_envs] bit0 event overflow, bit1 bad action*/);
+/* actions_output and actions_taken of one env (batch created with action_histograms): int32 [2][k_paths+1][slots+1]
+ * (rmsa_env.py:126-137, 167, 201, 211-212; rwa_env.py:52-58, 103, 125, 132-133 — RWA uses the top-left
+ * [k+reject][slots+reject] corner) */
+int orl_batch_get_action_histograms(orl_batch* b, int64_t env, int32_t* out);
+/* The pending releases of one env (the reference's heap `_events`, optical_network_env.py:143-154, unordered): returns
+ * their number; fills up to `capacity` entries of time_out[] (release time) and rec_out[][6] = (src*n_nodes+dst, path
+ * index, initial slot, number of slots, core, bit rate) when both pointers are given. */
+int orl_batch_get_pending(orl_batch* b, int64_t env, int32_t capacity, double* time_out, int32_t* rec_out);
 /* summed over envs: services_processed, services_accepted (for throughput/blocking reports) */
 int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted);
 
@@ -199,10 +231,11 @@ int orl_batch_set_state(orl_batch* b, const void* in);
 /* Profiling aid: reads the whole slot-map array once with 8-B (width16 = 0) or 16-B (1) loads per lane and returns the
  * number of bytes read, so that rocprofv3's FETCH_SIZE can be calibrated on a known byte count. */
 int64_t orl_batch_debug_stream_read(orl_batch* b, int width16);
-/* Statistics: env-steps of the split pipeline whose releases took the serial path (more than 8 in one step). */
+/* Statistics: env-steps whose releases took the serial tail (more than 8 of one step meeting on one link). */
 int64_t orl_batch_debug_serial_count(orl_batch* b);
-/* Builds with -DORL_TIMING only (zeros otherwise): shader-clock cycles per phase of the split control kernels. */
-int orl_batch_debug_prof(orl_batch* b, uint64_t* out32, int reset);
+/* 1 when the library was built with -DORL_ALT_IMPLS (the two-kernel form of the persistent kernel's phases, used by
+ * the cross-implementation tests), else 0. */
+int orl_build_has_alt(void);
 
 #ifdef __cplusplus
 }

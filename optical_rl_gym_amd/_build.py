@@ -1,21 +1,33 @@
 """Build liborlgpu.so (HIP, gfx950) in-tree with hipcc.  No JIT cache: the .so sits next to this file so it
-travels with the source tree to the GPU box.  Staleness is decided by a content hash of the sources (file times do
-not survive being copied to another machine); concurrent builders (one process per GPU) serialise on a file lock."""
+travels with the source tree to the GPU box.  Staleness is decided by a content hash of EVERY file under csrc/ plus
+include/orl.h, the flags and the compiler version (file times do not survive being copied to another machine);
+concurrent builders (one process per GPU) serialise on a file lock.
+
+The library is five translation units compiled in parallel: orl_api.hip (C ABI, W-independent kernels) and
+orl_kernels.hip once per row width W in {1, 2, 5, 8} (the env kernels are templates over the number of 64-bit words of
+a link row).  `variant="alt"` builds liborlgpu_alt.so with -DORL_ALT_IMPLS: the same library plus the two-kernel form of
+the persistent kernel's phases, used only by the cross-implementation tests."""
 import fcntl
+import glob
 import hashlib
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "liborlgpu.so")
-STAMP = LIB + ".stamp"
-SOURCES = ["orl_gpu.hip", "orl_device.h", "orl_device_g8.h", "orl_log.h", "orl_log_data.h",
-           os.path.join("..", "..", "include", "orl.h")]
+INCLUDE = os.path.join(HERE, "..", "include", "orl.h")
+ROW_WIDTHS = (1, 2, 5, 8)
+VARIANTS = {"default": ("liborlgpu.so", []), "alt": ("liborlgpu_alt.so", ["-DORL_ALT_IMPLS"])}
+LIB = os.path.join(HERE, VARIANTS["default"][0])
 
 # -ffp-contract=off: float64 statistics and the log restatement must round exactly like the reference
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
+
+
+def lib_path(variant="default"):
+    return os.path.join(HERE, VARIANTS[variant][0])
 
 
 def hipcc_path():
@@ -29,41 +41,91 @@ def _extra():
     return os.environ.get("ORL_HIPCC_EXTRA", "").split()  # tuning experiments only (e.g. -DORL_STEP_WAVES=6)
 
 
-def source_hash():
+def sources():
+    """Every file the build reads: all of csrc/ (headers included by the .hip units) and the public header."""
+    files = sorted(p for p in glob.glob(os.path.join(CSRC, "*")) if os.path.isfile(p) and p.endswith((".h", ".hip")))
+    return files + [INCLUDE]
+
+
+_HIPCC_VERSION = None
+
+
+def hipcc_version():
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            _HIPCC_VERSION = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True).stdout.strip()
+        except Exception as exc:  # no compiler: an existing library with a matching stamp is still usable
+            _HIPCC_VERSION = "unavailable: %s" % type(exc).__name__
+    return _HIPCC_VERSION
+
+
+def source_hash(variant="default", with_compiler=True):
     h = hashlib.sha256()
-    for s in SOURCES:
-        with open(os.path.join(CSRC, s), "rb") as f:
+    for s in sources():
+        h.update(os.path.basename(s).encode())
+        with open(s, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(HIPCC_FLAGS + _extra()).encode())
-    return h.hexdigest()
+    h.update(" ".join(HIPCC_FLAGS + VARIANTS[variant][1] + _extra()).encode())
+    text = h.hexdigest()
+    if with_compiler:
+        text += " " + hashlib.sha256(hipcc_version().encode()).hexdigest()[:16]
+    return text
 
 
-def stale():
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+def stale(variant="default"):
+    lib = lib_path(variant)
+    if not os.path.exists(lib) or not os.path.exists(lib + ".stamp"):
         return True
-    return open(STAMP).read().strip() != source_hash()
+    have = open(lib + ".stamp").read().split()
+    want = source_hash(variant).split()
+    if not have or have[0] != want[0]:
+        return True
+    # the compiler half of the stamp only counts where a compiler exists to rebuild with (the GPU box has the same image)
+    return len(have) > 1 and len(want) > 1 and not hipcc_version().startswith("unavailable") and have[1] != want[1]
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
-    with open(LIB + ".lock", "w") as lock:
+def build(force=False, verbose=False, variant="default"):
+    lib = lib_path(variant)
+    if not force and not stale(variant):
+        return lib
+    with open(lib + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not stale():  # another process built it while we waited
-                return LIB
-            tmp = LIB + ".tmp.%d" % os.getpid()
-            cmd = [hipcc_path()] + HIPCC_FLAGS + _extra() + [os.path.join(CSRC, "orl_gpu.hip"), "-o", tmp]
+            if not force and not stale(variant):  # another process built it while we waited
+                return lib
+            hipcc = hipcc_path()
+            flags = HIPCC_FLAGS + VARIANTS[variant][1] + _extra()
+            objdir = os.path.join(HERE, "build", variant)
+            os.makedirs(objdir, exist_ok=True)
+            units = [(os.path.join(CSRC, "orl_api.hip"), os.path.join(objdir, "orl_api.o"), [])]
+            for w in ROW_WIDTHS:
+                units.append((os.path.join(CSRC, "orl_kernels.hip"), os.path.join(objdir, "orl_kernels_w%d.o" % w), ["-DORL_W=%d" % w]))
+
+            def compile_unit(u):
+                src, obj, extra = u
+                cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                return obj
+
+            with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(compile_unit, units))
+            tmp = lib + ".tmp.%d" % os.getpid()
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
             if verbose:
-                print(" ".join(cmd))
+                print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            os.replace(tmp, LIB)
-            with open(STAMP, "w") as f:
-                f.write(source_hash() + "\n")
+            os.replace(tmp, lib)
+            with open(lib + ".stamp", "w") as f:
+                f.write(source_hash(variant) + "\n")
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    print(build(force=True, verbose=True, variant=sys.argv[1] if len(sys.argv) > 1 else "default"))

@@ -5,7 +5,7 @@ import os
 
 from . import _build
 
-_LIB = None
+_LIBS = {}
 
 
 class TopologyDesc(C.Structure):
@@ -16,7 +16,7 @@ class TopologyDesc(C.Structure):
 class EnvConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "env_type", "num_spectrum_resources", "num_spatial_resources", "episode_length", "allow_rejection", "j",
-        "bit_rate_mode", "bit_rate_lo", "bit_rate_hi", "n_bit_rates", "event_capacity", "reserved")] + [
+        "bit_rate_mode", "bit_rate_lo", "bit_rate_hi", "n_bit_rates", "event_capacity", "action_histograms")] + [
         ("lambda_arrival", C.c_double), ("lambda_holding", C.c_double)] + [
         (n, C.c_void_p) for n in ("cum_src", "cum_dst", "bit_rates", "cum_bit_rate", "n_slots", "lmax_snr", "lmax_xt")]
 
@@ -65,7 +65,12 @@ EXPORTS = {
     "orl_host_free": (C.c_int, [C.c_void_p]),
     "orl_batch_device_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "orl_batch_debug_serial_count": (C.c_int64, [C.c_void_p]),
-    "orl_batch_debug_prof": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "orl_build_has_alt": (C.c_int, []),
+    "orl_batch_reseed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orl_batch_set_paths": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_check": (C.c_int, [C.c_void_p]),
+    "orl_batch_get_action_histograms": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "orl_batch_get_pending": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "orl_batch_totals": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
@@ -100,15 +105,16 @@ def _share_hip_runtime_with_torch():
                 return
 
 
-def lib():
-    """Load (building if the sources are newer) liborlgpu.so."""
-    global _LIB
-    if _LIB is None:
-        path = _build.LIB
-        if _build.stale():
-            path = _build.build()
+def lib(variant=None):
+    """Load (building if the sources changed) liborlgpu.so.  variant "alt" (or ORL_LIB_VARIANT=alt in the environment
+    when the batch is created) is the -DORL_ALT_IMPLS build the cross-implementation tests use."""
+    variant = variant or os.environ.get("ORL_LIB_VARIANT", "default")
+    if variant not in _LIBS:
+        path = _build.lib_path(variant)
+        if _build.stale(variant):
+            path = _build.build(variant=variant)
         if not os.path.exists(path):
-            raise OrlError("liborlgpu.so is missing and could not be built; the HIP path is the only path")
+            raise OrlError("%s is missing and could not be built; the HIP path is the only path" % os.path.basename(path))
         _share_hip_runtime_with_torch()
         handle = C.CDLL(path)
         for name, (res, args) in EXPORTS.items():
@@ -117,11 +123,18 @@ def lib():
             fn.argtypes = args
         if handle.orl_abi_version() != 1:
             raise OrlError("ABI version mismatch")
-        _LIB = handle
-    return _LIB
+        _LIBS[variant] = handle
+    return _LIBS[variant]
 
 
-def check(rc):
+def check(rc, handle=None):
+    """0 -> nothing; else the exception the reference would have raised: ORL_E_ACTION -> IndexError (rmsa_env.py:167),
+    ORL_E_OVERFLOW -> OverflowError (the reference's heap is unbounded), anything else -> OrlError."""
     if rc != 0:
-        msg = lib().orl_last_error()
-        raise OrlError("liborlgpu: error %d: %s" % (rc, msg.decode() if msg else "?"))
+        msg = (handle or lib()).orl_last_error()
+        text = "liborlgpu: error %d: %s" % (rc, msg.decode() if msg else "?")
+        if rc == -3:
+            raise IndexError(text)
+        if rc == -4:
+            raise OverflowError(text)
+        raise OrlError(text)

@@ -1,0 +1,1047 @@
+// orl_api.hip — the C ABI (include/orl.h) of liborlgpu.so: topology / batch construction, dispatch to the per-W kernel units
+// (orl_kernels.hip through orl_host.h), the small W-independent kernels, state read-back.  gfx950 only.
+// Host side: plain HIP runtime, one stream per batch, no torch types.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <limits.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "orl_host.h"
+
+using namespace orl;
+
+// =============================================================================================
+// W-independent kernels
+// =============================================================================================
+extern __shared__ __attribute__((aligned(16))) unsigned char orl_lds_api[];
+
+// CPython MT19937 state -> in-place "update-behind" form (orl_device.h, Rng).  keep_record: reseeding a live env
+// (optical_network_env.py:205-210 replaces only self.rng) — the scalar record keeps everything but the stream position.
+__global__ void __launch_bounds__(64) k_init_mt(DevParams P, const u32* raw, const unsigned char* mask, int keep_record) {
+  const i64 env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  const int lane = lane_id();
+  u32* m = (u32*)orl_lds_api;
+  const u32* src = raw + env * 625;
+  for (int i = lane; i < 624; i += 64) m[i] = src[i];
+  int p0 = (int)src[624];
+  if (p0 > 624) p0 = 624;
+  wave_fence();
+  // positions < p0 were already handed out by CPython: advance them to the next generation
+  for (int base = 0; base < p0; base += 64) {
+    int i = base + lane;
+    u32 nw = 0;
+    if (i < p0) {
+      int i1 = i + 1 >= 624 ? i + 1 - 624 : i + 1;
+      int im = i + 397 >= 624 ? i + 397 - 624 : i + 397;
+      u32 y = (m[i] & 0x80000000u) | (m[i1] & 0x7fffffffu);
+      nw = m[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    wave_fence();
+    if (i < p0) m[i] = nw;
+    wave_fence();
+  }
+  u32* dst = P.mt + env * 624;
+  for (int i = lane; i < 624; i += 64) dst[i] = m[i];
+  const int pos = p0 >= 624 ? 0 : p0;
+  if (keep_record) {
+    if (lane == 0) {
+      u64* w = P.scal + env * ORL_SCAL_WORDS + SC_ID_MTPOS;
+      *w = (*w & 0xffffffffull) | ((u64)(u32)pos << 32);
+    }
+    return;
+  }
+  u64 v = 0;
+  if (lane == SC_ID_MTPOS) v = pack2(0, pos);
+  if (lane < ORL_SCAL_WORDS) P.scal[env * ORL_SCAL_WORDS + lane] = v;
+}
+
+// random.Random(seed) on the device: CPython's random_seed() takes abs(seed), splits it into 32-bit words
+// (little-endian, at least one) and calls init_by_array (Modules/_randommodule.c).  One thread per env; the
+// resulting 624 words + index 624 go to the same raw buffer k_init_mt converts.
+__global__ void k_seed_mt(const long long* seeds, i64 n, u32* raw) {
+  i64 env = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  u32* mt = raw + env * 625;
+  long long sv = seeds[env];
+  u64 a = sv < 0 ? (u64)(-(sv + 1)) + 1ull : (u64)sv;
+  u32 key[2] = {(u32)a, (u32)(a >> 32)};
+  const int klen = key[1] ? 2 : 1;
+  mt[0] = 19650218u;
+  for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (u32)i;
+  int i = 1, j = 0;
+  for (int k = 624; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (u32)j;
+    i++; j++;
+    if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    if (j >= klen) j = 0;
+  }
+  for (int k = 623; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (u32)i;
+    i++;
+    if (i >= 624) { mt[0] = mt[623]; i = 1; }
+  }
+  mt[0] = 0x80000000u;
+  mt[624] = 624u;
+}
+
+// SimpleMatrixObservation (rmsa_env.py:806-837, rmcsa_env.py:914-947): [one-hot(min(src,dst)) | one-hot(max(src,dst)) |
+// available_slots.flatten()] as uint8, one workgroup per env, bits unpacked one per thread-iteration.
+__global__ void k_matrix_obs(DevParams P, unsigned char* out) {
+  const i64 env = blockIdx.x;
+  const int N = P.N, S = P.S, rows = P.C * P.E;
+  const int dim = 2 * N + rows * S;
+  unsigned char* o = out + env * dim;
+  const u64 sd = P.scal[env * ORL_SCAL_WORDS + SC_SRC_DST];
+  const int src = (int)(u32)sd, dst = (int)(sd >> 32);
+  const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
+  for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) o[i] = (i == mn || i == N + mx) ? 1 : 0;
+  const u64* bm = P.bitmap + env * P.bm_words;
+  for (int i = threadIdx.x; i < rows * S; i += blockDim.x) {
+    int r = i / S, sl = i - r * S;
+    o[2 * N + i] = (unsigned char)((bm[r * P.W + (sl >> 6)] >> (sl & 63)) & 1ull);
+  }
+}
+
+// end of a device-resident run: the network-compactness update the last step left pending (one thread per env), so
+// that every host-visible state is final; also the OR of every env's flag word (as k_flags_or) — one launch, and
+// orl_batch_run fetches its result together with the straggler count in a single copy
+__global__ void k_finish2(DevParams P, int finish, unsigned int* flag_or) {
+  const i64 env = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  u32 f = 0;
+  if (env < P.B) {
+    u64* s = P.scal + env * ORL_SCAL_WORDS;
+    if (finish) {
+      int* rs = P.core_sums + env * P.cs_words + 2 * P.C;
+      const u64 acc = s[SC_ACC];
+      if ((u32)acc & 2u) {
+        const int* cs = P.core_sums + env * P.cs_words;
+        const int c0 = (int)((acc >> 32) & 31);
+        const i64 s_nh_prov = (i64)(acc >> 37);
+        const int occ = cs[2 * c0] - rs[2 * c0], fb = cs[2 * c0 + 1] - rs[2 * c0 + 1];
+        const double a0 = __longlong_as_double((i64)s[SC_GC_A]), td = __longlong_as_double((i64)s[SC_GC_TD]);
+        const double now_a = __longlong_as_double((i64)s[SC_NOWA]);
+        const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
+        s[SC_GCOMP] = (u64)__double_as_longlong((a0 + (cmp * td)) / now_a);
+        s[SC_ACC] = acc & ~2ull;
+      }
+      for (int i = 0; i < 2 * P.C; i++) rs[i] = 0;
+    }
+    const u64 v = s[SC_FLAGS];
+    f = (u32)(v >> 32);
+    if (f & ORL_FLAG_BAD_ACTION) s[SC_FLAGS] = v & ~((u64)ORL_FLAG_BAD_ACTION << 32);
+  }
+  for (int o = 32; o > 0; o >>= 1) f |= (u32)__shfl_xor((int)f, o, 64);
+  if ((threadIdx.x & 63) == 0 && f) atomicOr(flag_or, f);
+}
+
+// Counter calibration: streams the whole slot-map array once with a known byte count (FETCH_SIZE on gfx950 is
+// documented to under-report wide coalesced reads; this gives the factor for our own access widths).
+__global__ void k_calib_read(const u64* __restrict__ src, i64 n_words, int width16, u64* sink) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 acc = 0;
+  if (width16) {
+    const ulonglong2* s2 = (const ulonglong2*)src;
+    for (i64 j = i; j < n_words / 2; j += (i64)gridDim.x * blockDim.x) { ulonglong2 v = s2[j]; acc ^= v.x ^ v.y; }
+  } else {
+    for (i64 j = i; j < n_words; j += (i64)gridDim.x * blockDim.x) acc ^= src[j];
+  }
+  if (acc == 0x123456789abcdefull) *sink = acc;  // keep the loads alive
+}
+
+// sums of services_processed / services_accepted over the batch (two atomics per wave)
+__global__ void k_totals(DevParams P, unsigned long long* out) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  i64 sp = 0, sa = 0;
+  if (i < P.B) { sp = (i64)P.scal[i * ORL_SCAL_WORDS + SC_SP]; sa = (i64)P.scal[i * ORL_SCAL_WORDS + SC_SA]; }
+  for (int o = 32; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); sa += __shfl_xor(sa, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(out, (unsigned long long)sp); atomicAdd(out + 1, (unsigned long long)sa); }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                                     \
+  do {                                                                                                \
+    hipError_t _e = (x);                                                                              \
+    if (_e != hipSuccess) return fail(ORL_E_HIP, "%s failed: %s", #x, hipGetErrorString(_e));         \
+  } while (0)
+
+template <typename T, typename S>
+static int upload_conv(T** out, const S* src, size_t n, std::vector<void*>* track) {
+  std::vector<T> tmp(n);
+  for (size_t i = 0; i < n; i++) tmp[i] = (T)src[i];
+  HIPCHK(hipMalloc((void**)out, n * sizeof(T) + 16));
+  if (track) track->push_back(*out);
+  HIPCHK(hipMemcpy(*out, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int orl_abi_version(void) { return ORL_ABI_VERSION; }
+extern "C" const char* orl_last_error(void) { return g_err.c_str(); }
+extern "C" int orl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" int orl_build_has_alt(void) {
+#ifdef ORL_ALT_IMPLS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, orl_topology** out) {
+  if (!d || !out) return fail(ORL_E_INVALID, "null argument");
+  if (d->n_nodes < 2 || d->n_nodes > 512 || d->n_links < 1 || d->n_links > 128 || d->k_paths < 1 || d->k_paths > 64 ||
+      d->max_hops < 1 || d->max_hops > 30 || d->n_modulations < 1 || d->n_modulations > 255)
+    return fail(ORL_E_INVALID, "topology out of supported range (N<=512, E<=128, k<=64, hops<=30)");
+  if (!d->n_paths || !d->path_hops || !d->path_links || !d->path_length || !d->path_modulation || !d->edge_iter_order)
+    return fail(ORL_E_INVALID, "null topology table");
+  const int N = d->n_nodes, E = d->n_links, K = d->k_paths, H = d->max_hops, M = d->n_modulations;
+  const size_t nn = (size_t)N * N, npk = nn * K;
+  for (size_t i = 0; i < nn; i++)
+    if (d->n_paths[i] < 0 || d->n_paths[i] > K) return fail(ORL_E_INVALID, "n_paths[%zu] out of range", i);
+  for (size_t i = 0; i < npk; i++) {
+    const int hops = d->path_hops[i];
+    if (hops < 0 || hops > H || d->path_modulation[i] >= M) return fail(ORL_E_INVALID, "bad path table entry %zu", i);
+    for (int h = 0; h < hops; h++) {
+      const int l = d->path_links[i * H + h];
+      if (l < 0 || l >= E) return fail(ORL_E_INVALID, "bad link index %d at hop %d of path %zu", l, h, i);
+    }
+  }
+  {
+    std::vector<char> seen((size_t)E, 0);
+    for (int i = 0; i < E; i++) {
+      const int l = d->edge_iter_order[i];
+      if (l < 0 || l >= E || seen[(size_t)l]) return fail(ORL_E_INVALID, "edge_iter_order is not a permutation of the links");
+      seen[(size_t)l] = 1;
+    }
+  }
+  HIPCHK(hipSetDevice(device_id));
+  orl_topology* t = new orl_topology();
+  t->n_paths = nullptr;
+  t->path_length = nullptr; t->edge_iter_order = nullptr; t->link_pos = nullptr;
+  t->device = device_id;
+  t->N = N; t->E = E; t->K = K; t->H = H; t->M = M;
+  int rc = 0;
+  std::vector<int32_t> mod(npk);
+  for (size_t i = 0; i < npk; i++) mod[i] = d->path_modulation[i] < 0 ? 0 : d->path_modulation[i];
+  t->h_hops.assign(d->path_hops, d->path_hops + npk);
+  t->h_links.assign(d->path_links, d->path_links + npk * H);
+  t->h_mod = mod;
+  rc |= upload_conv(&t->n_paths, d->n_paths, nn, nullptr);
+  rc |= upload_conv(&t->path_length, d->path_length, npk, nullptr);
+  rc |= upload_conv(&t->edge_iter_order, d->edge_iter_order, (size_t)E, nullptr);
+  {
+    std::vector<int32_t> pos((size_t)E, 0);
+    for (int i = 0; i < E; i++) pos[(size_t)d->edge_iter_order[i]] = i;
+    rc |= upload_conv(&t->link_pos, pos.data(), (size_t)E, nullptr);
+  }
+  if (rc) { orl_topology_destroy(t); return ORL_E_HIP; }
+  *out = t;
+  return ORL_OK;
+}
+
+extern "C" void orl_topology_destroy(orl_topology* t) {
+  if (!t) return;
+  hipSetDevice(t->device);
+  if (t->n_paths) hipFree(t->n_paths);
+  if (t->path_length) hipFree(t->path_length);
+  if (t->edge_iter_order) hipFree(t->edge_iter_order);
+  if (t->link_pos) hipFree(t->link_pos);
+  delete t;
+}
+
+// ---- launch dispatch over the row width ---------------------------------------------------------------
+static void launch_reset(orl_batch* b, int full, const unsigned char* dmask) {
+#define CALL(WW) orl_launch::reset<WW>(b, full, dmask)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+}
+static void launch_policy(orl_batch* b, int pol) {
+#define CALL(WW) orl_launch::policy<WW>(b, pol)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+}
+static void launch_step64(orl_batch* b, int auto_reset, int want_info, int fused_policy) {
+#define CALL(WW) orl_launch::step64<WW>(b, auto_reset, want_info, fused_policy)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+}
+static void launch_obs(orl_batch* b, int with_terminal) {
+#define CALL(WW) orl_launch::obs<WW>(b, with_terminal)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+}
+static void launch_persist(orl_batch* b, int pol, int target) {
+#define CALL(WW) orl_launch::persist<WW>(b, pol, target)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+}
+static void launch_step2(orl_batch* b, int pol) {
+#define CALL(WW) orl_launch::step2<WW>(b, pol)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+}
+// d_unfinished[0] = straggler workgroups of the last persistent launch, d_unfinished[1] = OR of the env flag words
+static void launch_finish2(orl_batch* b, int finish) {
+  hipLaunchKernelGGL(k_finish2, dim3((unsigned)((b->P.B + 255) / 256)), dim3(256), 0, b->stream, b->P, finish, b->d_unfinished + 1);
+}
+static int flags_to_rc(const orl_batch* b, unsigned int f);
+
+template <typename T> static int dalloc(orl_batch* b, T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T) + 64));
+  b->allocs.push_back(*p);
+  return 0;
+}
+
+static int policy_ok(const orl_batch* b, int policy_id) {
+  if (policy_id < 0 || policy_id > ORL_POLICY_PATH_FF) return 0;
+  if (policy_id == ORL_POLICY_PATH_FF && b->P.env_type != ENV_RMSA && b->P.env_type != ENV_RWA) return 0;
+  return 1;
+}
+
+static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
+                             const int64_t* seeds, orl_batch** out) {
+  if (!c || !t || !out || (!mt_state && !seeds) || n_envs < 1) return fail(ORL_E_INVALID, "null/invalid argument");
+  if (n_envs > (int64_t)1 << 30) return fail(ORL_E_INVALID, "n_envs must be <= 2^30");
+  if (c->env_type < 0 || c->env_type > 3) return fail(ORL_E_INVALID, "unknown env_type %d", c->env_type);
+  const int S = c->num_spectrum_resources, C = c->num_spatial_resources;
+  if (S < 2 || S > 512) return fail(ORL_E_INVALID, "num_spectrum_resources must be in [2, 512]");
+  if (C < 1 || C > 31 || (c->env_type != ORL_ENV_RMCSA && C != 1)) return fail(ORL_E_INVALID, "bad num_spatial_resources");
+  if (c->env_type == ORL_ENV_DEEPRMSA && (c->j < 1 || c->j > 8)) return fail(ORL_E_INVALID, "j must be in [1, 8]");
+  if (c->n_bit_rates < 1 || c->n_bit_rates > 4096) return fail(ORL_E_INVALID, "bad n_bit_rates");
+  if (c->episode_length < 1) return fail(ORL_E_INVALID, "episode_length must be positive");
+  if (!c->cum_src || !c->cum_dst) return fail(ORL_E_INVALID, "node probability tables missing");
+  if (c->env_type != ORL_ENV_RWA && (!c->n_slots || !c->bit_rates)) return fail(ORL_E_INVALID, "bit-rate tables missing");
+  if (c->env_type == ORL_ENV_RMCSA && (!c->lmax_snr || !c->lmax_xt)) return fail(ORL_E_INVALID, "RMCSA reach tables missing");
+  if (c->bit_rate_mode == 1 && !c->cum_bit_rate) return fail(ORL_E_INVALID, "cum_bit_rate missing");
+  if (c->env_type != ORL_ENV_RWA) {
+    for (int i = 0; i < c->n_bit_rates * t->M; i++)
+      if (c->n_slots[i] < 1 || c->n_slots[i] > 64) return fail(ORL_E_INVALID, "n_slots entries must be in [1, 64]");
+    for (int i = 0; i < c->n_bit_rates; i++)
+      if (c->bit_rates[i] < 0 || c->bit_rates[i] > 32767) return fail(ORL_E_INVALID, "bit rates must be < 32768");
+  }
+  const int rand_n = c->bit_rate_hi + 1 - c->bit_rate_lo;
+  if (c->bit_rate_mode == 0 && c->env_type != ORL_ENV_RWA && (rand_n < 1 || rand_n != c->n_bit_rates))
+    return fail(ORL_E_INVALID, "continuous mode needs n_bit_rates == hi - lo + 1");
+  if (!(c->lambda_arrival > 0) || !(c->lambda_holding > 0)) return fail(ORL_E_INVALID, "rates must be positive");
+  if (c->action_histograms && c->env_type == ORL_ENV_RMCSA) return fail(ORL_E_INVALID, "action histograms are not kept for RMCSA");
+  HIPCHK(hipSetDevice(t->device));
+  // every early return below goes through orl_batch_destroy (frees what has been allocated so far)
+  orl_batch* b = new orl_batch();
+  memset(&b->P, 0, sizeof b->P);
+  b->device = t->device;
+#define FAIL_B(...) do { int rc_ = fail(__VA_ARGS__); orl_batch_destroy(b); return rc_; } while (0)
+#define HIPCHK_B(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL_B(ORL_E_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+  DevParams& P = b->P;
+  P.env_type = c->env_type;
+  P.N = t->N; P.E = t->E; P.K = t->K; P.H = t->H; P.M = t->M;
+  P.S = S; P.C = C;
+  b->wt = S <= 64 ? 1 : (S <= 128 ? 2 : (S <= 320 ? 5 : 8));
+  P.W = b->wt;
+  P.episode_length = c->episode_length;
+  P.allow_rejection = c->allow_rejection ? 1 : 0;
+  P.J = c->env_type == ORL_ENV_DEEPRMSA ? c->j : 1;
+  P.bit_rate_mode = c->bit_rate_mode;
+  P.br_lo = c->bit_rate_lo;
+  P.n_br = c->n_bit_rates;
+  P.rand_n = rand_n;
+  P.rand_bits = 0;
+  for (int v = P.rand_n; v > 0; v >>= 1) P.rand_bits++;
+  P.lambda_a = c->lambda_arrival;
+  P.lambda_h = c->lambda_holding;
+  P.B = n_envs;
+  int cap = c->event_capacity;
+  if (cap <= 0) {
+    double load = P.lambda_a / P.lambda_h;
+    cap = (int)(load + 10.0 * sqrt(load) + 64.0);
+  }
+  P.ev_cap = (cap + 63) / 64 * 64;
+  int words = C * P.E * b->wt;
+  P.bm_words = (words + 1) & ~1;
+  int rej = P.allow_rejection;
+  if (c->env_type == ORL_ENV_RWA) P.n_info = 2 + (P.K + rej) + (S + rej);
+  else if (c->env_type == ORL_ENV_RMCSA) P.n_info = 4;
+  else P.n_info = 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
+  P.obs_dim = c->env_type == ORL_ENV_DEEPRMSA ? 1 + 2 * P.N + (2 * P.J + 3) * P.K : 0;
+  P.cs_words = (4 * C + 15) & ~15;  // sums and their release part; whole 64-byte lines per env
+  P.lds_bytes = ((P.bm_words + 4 * P.E + P.E + P.obs_dim) * 8 + P.cs_words * 4 + 15) & ~15;
+  if (P.lds_bytes < 624 * 4) P.lds_bytes = 624 * 4;
+  if (P.lds_bytes > 64 * 1024) FAIL_B(ORL_E_INVALID, "per-env LDS window too large (%d B)", P.lds_bytes);
+  {
+    // The persistent kernel (k_persist) serves the device-resident loop wherever its 8-lanes-per-env slot scan applies
+    // (k <= 8 paths, release slots indexed with 8 + 3 bits): cfg2 64 envs 2.6e6 vs 2.1e6 env-steps/s for the per-env kernel;
+    // 4 096: 1.6e8 vs 7.6e7; 32 768: 6.3e8 vs 4.0e8; RWA 4 096: 2.4e8 vs 8.3e7.  ORL_STEP_IMPL=64 forces the per-env kernel
+    // (cross-checks); ORL_STEP_IMPL=2 with ORL_PERSIST=0 selects the two-kernel form in ORL_ALT_IMPLS builds.
+    const char* impl = getenv("ORL_STEP_IMPL");
+    const bool pipeline_ok = t->K <= 8 && P.ev_cap <= 2048;
+    b->persist = pipeline_ok && !(impl && atoi(impl) == 64);
+    if (const char* pv = getenv("ORL_PERSIST")) {
+      if (atoi(pv) == 0 && b->persist) {
+        b->persist = 0;
+#ifdef ORL_ALT_IMPLS
+        b->two_kernel = (impl && atoi(impl) == 2) ? 1 : 0;
+#endif
+      }
+    }
+  }
+  P.pipeline2 = (b->persist || b->two_kernel) ? 1 : 0;
+
+  P.n_paths = t->n_paths;
+  P.path_length = t->path_length; P.edge_iter_order = t->edge_iter_order; P.link_pos = t->link_pos;
+  int rc = 0;
+  {
+    double* p; int* q; unsigned char* u;
+    rc |= upload_conv(&p, c->cum_src, (size_t)P.N, &b->allocs); P.cum_src = p;
+    rc |= upload_conv(&p, c->cum_dst, (size_t)P.N * P.N, &b->allocs); P.cum_dst = p;
+    if (c->bit_rates) { rc |= upload_conv(&q, c->bit_rates, (size_t)P.n_br, &b->allocs); P.bit_rates = q; }
+    if (c->cum_bit_rate) { rc |= upload_conv(&p, c->cum_bit_rate, (size_t)P.n_br, &b->allocs); P.cum_br = p; }
+    if (c->n_slots) { rc |= upload_conv(&u, c->n_slots, (size_t)P.n_br * P.M, &b->allocs); P.nslots = u; }
+    if (c->lmax_snr) { rc |= upload_conv(&p, c->lmax_snr, (size_t)P.n_br * P.M, &b->allocs); P.lmax_snr = p; }
+    if (c->lmax_xt) { rc |= upload_conv(&p, c->lmax_xt, (size_t)P.M, &b->allocs); P.lmax_xt = p; }
+  }
+  {
+    // derived shared tables: 32-B path records and slots-per-path-per-bit-rate
+    size_t npk = (size_t)P.N * P.N * P.K;
+    std::vector<unsigned char> rec(npk * 32, 0), nsp(npk * (size_t)P.n_br, 1);
+    for (size_t i = 0; i < npk; i++) {
+      rec[i * 32 + 0] = (unsigned char)t->h_hops[i];
+      rec[i * 32 + 1] = (unsigned char)t->h_mod[i];
+      for (int h = 0; h < t->h_hops[i]; h++) rec[i * 32 + 2 + h] = (unsigned char)t->h_links[i * P.H + h];
+      if (c->n_slots)
+        for (int r = 0; r < P.n_br; r++) nsp[i * P.n_br + r] = c->n_slots[(size_t)r * P.M + t->h_mod[i]];
+    }
+    unsigned char* u;
+    rc |= upload_conv(&u, rec.data(), rec.size(), &b->allocs); P.path_rec = u;
+    rc |= upload_conv(&u, nsp.data(), nsp.size(), &b->allocs); P.nslots_path = u;
+  }
+  size_t B = (size_t)n_envs;
+  rc |= dalloc(b, &P.svc_desc, B);
+  {
+    // one queue region per control wavefront (8 envs), sized for the most items its envs can produce in a step:
+    // a provision touches <= H links, the releases of a step <= E links (one item per link)
+    const size_t waves = ((B + 31) / 32 + 16) * 4;
+    P.q_wave = 8 * (P.H > P.E ? P.H : P.E);
+    P.item_masks = ORL_IMASKS;
+    // test knob: a smaller limit sends far more env-steps through the tally pass and the serial tail
+    if (const char* mv = getenv("ORL_ITEM_MASKS")) { int v = atoi(mv); if (v >= 1 && v <= ORL_IMASKS) P.item_masks = v; }
+    P.q_cap = (i64)waves * P.q_wave;
+    rc |= dalloc(b, &P.q_a, (size_t)P.q_cap * 2);  // 32-byte items
+    rc |= dalloc(b, &P.q_cnt_a, waves);
+    rc |= dalloc(b, &P.q_stat, 16);
+    // deferred-env lists: count at [0], env indices from [16]; two buffers (the steps of the two-kernel form alternate)
+    P.q_def_stride = (i64)(B + 16);
+    rc |= dalloc(b, &P.q_def, 2 * (size_t)P.q_def_stride);
+    rc |= dalloc(b, &b->d_wg_step, (B + 7) / 8 + 16);
+    rc |= dalloc(b, &b->d_unfinished, 16);
+    rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
+    rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
+  }
+  rc |= dalloc(b, &P.bitmap, B * P.bm_words);
+  rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
+  rc |= dalloc(b, &P.ev_info, B * P.ev_cap);
+  rc |= dalloc(b, &P.mt, B * 624);
+  rc |= dalloc(b, &P.lstat, B * 4 * P.E);
+  rc |= dalloc(b, &P.scal, B * ORL_SCAL_WORDS);
+  rc |= dalloc(b, &P.core_sums, B * P.cs_words);
+  if (c->bit_rate_mode == 1 && c->env_type != ORL_ENV_RWA) rc |= dalloc(b, &P.br_hist, B * 2 * P.n_br);
+  if (c->env_type == ORL_ENV_RWA) rc |= dalloc(b, &P.act_hist, B * ((P.K + 1) + (S + 1)));
+  if (c->action_histograms) {
+    P.act2d_words = 2 * (P.K + 1) * (S + 1);
+    rc |= dalloc(b, &P.act2d, B * (size_t)P.act2d_words);
+  }
+  rc |= dalloc(b, &P.path_col, B);
+  rc |= dalloc(b, &P.actions, B * 4);
+  rc |= dalloc(b, &P.reward, B);
+  rc |= dalloc(b, &P.done, B);
+  rc |= dalloc(b, &P.info, B * P.n_info);
+  if (P.obs_dim) { rc |= dalloc(b, &P.obs, B * P.obs_dim); rc |= dalloc(b, &P.term_obs, B * P.obs_dim); }
+  rc |= dalloc(b, &b->d_totals, 2);
+  if (rc) { orl_batch_destroy(b); return ORL_E_HIP; }
+  HIPCHK_B(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  HIPCHK_B(hipEventCreate(&b->ev0));
+  HIPCHK_B(hipEventCreate(&b->ev1));
+  // everything below is ordered on the batch's own stream
+  HIPCHK_B(hipMemsetAsync(P.q_def, 0, 2 * (size_t)P.q_def_stride * sizeof(u32), b->stream));
+  HIPCHK_B(hipMemsetAsync(P.q_stat, 0, 16 * sizeof(u32), b->stream));
+  HIPCHK_B(hipMemsetAsync(P.path_col, 0, B * sizeof(int), b->stream));
+  HIPCHK_B(hipMemsetAsync(P.actions, 0, B * 4 * sizeof(int), b->stream));
+  // MT state upload + conversion, then the constructor's full reset
+  u32* raw = nullptr;
+  HIPCHK_B(hipMalloc((void**)&raw, B * 625 * sizeof(u32)));
+  b->allocs.push_back(raw);
+  long long* dseeds = nullptr;
+  if (mt_state) {
+    HIPCHK_B(hipMemcpyAsync(raw, mt_state, B * 625 * sizeof(u32), hipMemcpyHostToDevice, b->stream));
+  } else {
+    HIPCHK_B(hipMalloc((void**)&dseeds, B * sizeof(long long)));
+    b->allocs.push_back(dseeds);
+    HIPCHK_B(hipMemcpyAsync(dseeds, seeds, B * sizeof(long long), hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_seed_mt, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, b->stream, dseeds, (i64)B, raw);
+  }
+  hipLaunchKernelGGL(k_init_mt, dim3((unsigned)B), dim3(64), 624 * 4, b->stream, P, raw, (const unsigned char*)nullptr, 0);
+  launch_reset(b, 1, nullptr);
+  if (P.obs_dim) launch_obs(b, 0);
+  HIPCHK_B(hipStreamSynchronize(b->stream));
+  HIPCHK_B(hipGetLastError());
+  hipFree(raw);
+  b->allocs.erase(std::find(b->allocs.begin(), b->allocs.end(), (void*)raw));
+  if (dseeds) { hipFree(dseeds); b->allocs.erase(std::find(b->allocs.begin(), b->allocs.end(), (void*)dseeds)); }
+#undef FAIL_B
+#undef HIPCHK_B
+  *out = b;
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
+                                orl_batch** out) {
+  if (!mt_state) return fail(ORL_E_INVALID, "mt_state is null");
+  return batch_create_impl(c, t, n_envs, mt_state, nullptr, out);
+}
+extern "C" int orl_batch_create_seeded(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const int64_t* seeds,
+                                       orl_batch** out) {
+  if (!seeds) return fail(ORL_E_INVALID, "seeds is null");
+  return batch_create_impl(c, t, n_envs, nullptr, seeds, out);
+}
+
+extern "C" void orl_batch_destroy(orl_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  for (void* p : b->allocs) hipFree(p);
+  delete b;
+}
+
+extern "C" int orl_batch_info_dim(const orl_batch* b) { return b ? b->P.n_info : 0; }
+extern "C" int orl_batch_obs_dim(const orl_batch* b) { return b ? b->P.obs_dim : 0; }
+
+extern "C" int orl_batch_sync(orl_batch* b) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+
+// device copy of a host env mask for the duration of one call
+struct DevMask {
+  unsigned char* d = nullptr;
+  ~DevMask() { if (d) hipFree(d); }
+  int upload(const orl_batch* b, const uint8_t* host) {
+    if (!host) return 0;
+    HIPCHK(hipMalloc((void**)&d, (size_t)b->P.B));
+    HIPCHK(hipMemcpyAsync(d, host, (size_t)b->P.B, hipMemcpyHostToDevice, b->stream));
+    return 0;
+  }
+};
+
+extern "C" int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  DevMask m;
+  if (m.upload(b, env_mask)) return ORL_E_HIP;
+  launch_reset(b, full ? 1 : 0, m.d);
+  if (b->P.obs_dim) launch_obs(b, 0);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_t* env_mask) {
+  if (!b || !seeds) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t B = (size_t)b->P.B;
+  DevMask m;
+  if (m.upload(b, env_mask)) return ORL_E_HIP;
+  u32* raw = nullptr;
+  long long* dseeds = nullptr;
+  HIPCHK(hipMalloc((void**)&raw, B * 625 * sizeof(u32)));
+  if (hipMalloc((void**)&dseeds, B * sizeof(long long)) != hipSuccess) { hipFree(raw); return fail(ORL_E_HIP, "hipMalloc failed"); }
+  hipError_t e = hipMemcpyAsync(dseeds, seeds, B * sizeof(long long), hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_seed_mt, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, b->stream, dseeds, (i64)B, raw);
+    hipLaunchKernelGGL(k_init_mt, dim3((unsigned)B), dim3(64), 624 * 4, b->stream, b->P, raw, (const unsigned char*)m.d, 1);
+    e = hipStreamSynchronize(b->stream);
+  }
+  hipFree(raw);
+  hipFree(dseeds);
+  if (e != hipSuccess) return fail(ORL_E_HIP, "reseed failed: %s", hipGetErrorString(e));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_set_paths(orl_batch* b, const int32_t* paths) {
+  if (!b || !paths) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemcpyAsync(b->P.path_col, paths, (size_t)b->P.B * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_policy(orl_batch* b, int policy_id, int32_t* actions_out) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  if (!policy_ok(b, policy_id)) return fail(ORL_E_INVALID, "policy %d is not defined for this env family", policy_id);
+  HIPCHK(hipSetDevice(b->device));
+  launch_policy(b, policy_id);
+  if (actions_out) {
+    HIPCHK(hipMemcpyAsync(actions_out, b->P.actions, (size_t)b->P.B * 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+  }
+  return ORL_OK;
+}
+
+// the index ranges of the reference's actions_output arrays (rmsa_env.py:126-137, 167; rwa_env.py:52-58, 103;
+// rmcsa_env.py:145-153, 219); DeepRMSA takes any integer (deeprmsa_env.py:48-58)
+static int64_t first_bad_action(const orl_batch* b, const int32_t* a) {
+  const DevParams& P = b->P;
+  const int rej = P.allow_rejection ? 1 : 0;
+  for (i64 i = 0; i < P.B; i++) {
+    const int32_t* r = a + 4 * i;
+    bool bad = false;
+    if (P.env_type == ENV_RMSA) bad = r[0] < 0 || r[0] > P.K || r[1] < 0 || r[1] > P.S;
+    else if (P.env_type == ENV_RWA) bad = r[0] < 0 || r[0] >= P.K + rej || r[1] < 0 || r[1] >= P.S + rej;
+    else if (P.env_type == ENV_RMCSA) bad = r[0] < 0 || r[0] > P.K || r[1] < 0 || r[1] > P.M || r[2] < 0 || r[2] > P.C || r[3] < 0 || r[3] > P.S;
+    if (bad) return i;
+  }
+  return -1;
+}
+
+static int flags_to_rc(const orl_batch* b, unsigned int f) {
+  if (f & ORL_FLAG_EV_OVERFLOW)
+    return fail(ORL_E_OVERFLOW, "an env ran out of pending-release slots (event_capacity %d): its state is no longer valid", b->P.ev_cap);
+  if (f & ORL_FLAG_BAD_ACTION)
+    return fail(ORL_E_ACTION, "a device-resident action was outside the action space (it was treated as a rejection)");
+  return ORL_OK;
+}
+// after a synchronous call: report what the kernels flagged (device-resident actions cannot be checked beforehand)
+static int report_flags(orl_batch* b) {
+  unsigned int f[2] = {0, 0};
+  HIPCHK(hipMemsetAsync(b->d_unfinished, 0, 2 * sizeof(unsigned int), b->stream));
+  launch_finish2(b, 0);
+  HIPCHK(hipMemcpyAsync(f, b->d_unfinished, sizeof f, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return flags_to_rc(b, f[1]);
+}
+
+extern "C" int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, double* reward_out,
+                              uint8_t* done_out, double* info_out) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t B = (size_t)b->P.B;
+  if (actions) {
+    const int64_t bad = first_bad_action(b, actions);
+    if (bad >= 0)  // like the reference's IndexError at its first statement: nothing has been modified
+      return fail(ORL_E_ACTION, "action (%d, %d, %d, %d) of env %lld is outside the action space", actions[4 * bad],
+                  actions[4 * bad + 1], actions[4 * bad + 2], actions[4 * bad + 3], (long long)bad);
+    HIPCHK(hipMemcpyAsync(b->P.actions, actions, B * 4 * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  }
+  launch_step64(b, auto_reset ? 1 : 0, 1, -1);
+  bool any = false;
+  if (reward_out) { HIPCHK(hipMemcpyAsync(reward_out, b->P.reward, B * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (done_out) { HIPCHK(hipMemcpyAsync(done_out, b->P.done, B, hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (info_out) { HIPCHK(hipMemcpyAsync(info_out, b->P.info, B * b->P.n_info * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (obs_out && b->P.obs_dim) { HIPCHK(hipMemcpyAsync(obs_out, b->P.obs, B * b->P.obs_dim * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (any) return report_flags(b);  // synchronises
+  if (actions) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+  }
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_check(orl_batch* b) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  return report_flags(b);
+}
+
+extern "C" int orl_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  memset(*out, 0, bytes);
+  return ORL_OK;
+}
+extern "C" int orl_host_free(void* p) {
+  if (p) HIPCHK(hipHostFree(p));
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_device_buffer(orl_batch* b, int which, void** device_ptr, int64_t* n_elements) {
+  if (!b || !device_ptr || !n_elements) return fail(ORL_E_INVALID, "null argument");
+  const int64_t B = b->P.B;
+  switch (which) {
+    case ORL_BUF_ACTIONS: *device_ptr = b->P.actions; *n_elements = B * 4; break;
+    case ORL_BUF_REWARD: *device_ptr = b->P.reward; *n_elements = B; break;
+    case ORL_BUF_DONE: *device_ptr = b->P.done; *n_elements = B; break;
+    case ORL_BUF_INFO: *device_ptr = b->P.info; *n_elements = B * b->P.n_info; break;
+    case ORL_BUF_OBS: *device_ptr = b->P.obs; *n_elements = B * b->P.obs_dim; break;
+    case ORL_BUF_TERM_OBS: *device_ptr = b->P.term_obs; *n_elements = B * b->P.obs_dim; break;
+    case ORL_BUF_PATHS: *device_ptr = b->P.path_col; *n_elements = B; break;
+    default: return fail(ORL_E_INVALID, "unknown buffer %d", which);
+  }
+  return ORL_OK;
+}
+
+extern "C" int orl_batch_observation(orl_batch* b, double* obs_out) {
+  if (!b || !obs_out) return fail(ORL_E_INVALID, "null argument");
+  if (!b->P.obs_dim) return fail(ORL_E_INVALID, "this env family has no array observation");
+  HIPCHK(hipSetDevice(b->device));
+  launch_obs(b, 0);
+  HIPCHK(hipMemcpyAsync(obs_out, b->P.obs, (size_t)b->P.B * b->P.obs_dim * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+
+// events created for one call, destroyed on every exit path
+struct EventPool {
+  std::vector<hipEvent_t> ev;
+  ~EventPool() { for (auto& e : ev) hipEventDestroy(e); }
+};
+
+extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels, orl_run_stats* stats) {
+  if (!b || n_steps < 0) return fail(ORL_E_INVALID, "bad argument");
+  if (n_steps > INT_MAX) return fail(ORL_E_INVALID, "n_steps must be <= %d per call", INT_MAX);
+  if (!policy_ok(b, policy_id)) return fail(ORL_E_INVALID, "policy %d is not defined for this env family", policy_id);
+  HIPCHK(hipSetDevice(b->device));
+  EventPool pool;
+  TkRec tk;
+  struct TkGuard { TkRec& t; orl_batch* b; ~TkGuard() { b->tk = nullptr; for (auto& e : t.ev) hipEventDestroy(e); } } tkg{tk, b};
+  if (time_kernels == 2) {
+    pool.ev.resize((size_t)n_steps * 3);
+    for (auto& e : pool.ev) HIPCHK(hipEventCreate(&e));
+  }
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  unsigned int tail[2] = {0, 0};  // straggler workgroups, OR of the env flags
+  bool have_flags = false;
+  if (!time_kernels && b->persist) {
+    // The run is cut into chunks of steps: a wavefront that had to leave its loop for the serial tail resumes in the next
+    // launch and is at most one chunk behind (left to one launch per run, it would finish its remaining steps alone on
+    // the GPU: 3 000-step runs measured 5.6e8 env-steps/s against 6.3e8 for 100-step runs).  No host synchronisation
+    // between chunks; after the last one k_finish2 finalises the state and reduces the flags, and ONE 8-byte copy tells
+    // the host whether stragglers are left (then: relaunch) and what the envs flagged.
+    const unsigned n_wg = (unsigned)((b->P.B + 7) / 8);
+    HIPCHK(hipMemsetAsync(b->d_wg_step, 0, n_wg * sizeof(int), b->stream));
+    int chunk = 64;
+    if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
+    b->persist_launches = 0;
+    for (int64_t tgt = 0; tgt < n_steps;) {
+      tgt = (tgt + chunk < n_steps) ? tgt + chunk : n_steps;
+      for (;;) {
+        HIPCHK(hipMemsetAsync(b->d_unfinished, 0, 2 * sizeof(unsigned int), b->stream));
+        b->persist_launches++;
+        launch_persist(b, policy_id, (int)tgt);
+        if (tgt < n_steps) break;  // stragglers catch up in the next chunk's launch
+        launch_finish2(b, 1);  // (harmless for a straggler: it does what that env's next control phase would do first)
+        HIPCHK(hipEventRecord(b->ev1, b->stream));
+        HIPCHK(hipMemcpyAsync(tail, b->d_unfinished, sizeof tail, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (!tail[0]) break;
+      }
+    }
+    if (n_steps == 0) HIPCHK(hipEventRecord(b->ev1, b->stream));
+    have_flags = n_steps > 0;
+  } else if (time_kernels == 2) {
+    for (int64_t s = 0; s < n_steps; s++) {
+      HIPCHK(hipEventRecord(pool.ev[3 * s], b->stream));
+      launch_policy(b, policy_id);
+      HIPCHK(hipEventRecord(pool.ev[3 * s + 1], b->stream));
+      launch_step64(b, 1, 0, -1);
+      HIPCHK(hipEventRecord(pool.ev[3 * s + 2], b->stream));
+    }
+  } else {
+    // the per-env kernel with the slot scan inside it (one launch per policy + step), or — ORL_ALT_IMPLS builds — the
+    // two-kernel form of the persistent kernel's phases; time_kernels == 1: an event after every kernel
+    for (int64_t s = 0; s < n_steps; s++) {
+      if (time_kernels == 1) { b->tk = &tk; ORL_TK(b, ""); }
+      if (b->two_kernel) launch_step2(b, policy_id);
+      else launch_step64(b, 1, 0, policy_id);
+      b->tk = nullptr;
+    }
+    if (b->two_kernel) launch_finish2(b, 1);
+  }
+  if (!(!time_kernels && b->persist)) HIPCHK(hipEventRecord(b->ev1, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  if (stats) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    memset(stats, 0, sizeof *stats);
+    stats->ms_total = ms;
+    stats->launches = n_steps;
+    if (!time_kernels && b->persist && n_steps > 0) {  // the whole run was (re)launches of one kernel
+      stats->n_kernels = 1;
+      stats->launches = b->persist_launches > 0 ? b->persist_launches : 1;  // chunks of ORL_PERSIST_CHUNK steps
+      stats->ms_kernel[0] = ms / (double)stats->launches;                   // average duration of one launch (+ its k_rel_tail)
+      snprintf(stats->kernel_name[0], sizeof stats->kernel_name[0], "k_persist");
+    }
+    if (time_kernels == 2 && n_steps > 0) {
+      double sp = 0, ss = 0;
+      for (int64_t s = 0; s < n_steps; s++) {
+        float a = 0, c2 = 0;
+        HIPCHK(hipEventElapsedTime(&a, pool.ev[3 * s], pool.ev[3 * s + 1]));
+        HIPCHK(hipEventElapsedTime(&c2, pool.ev[3 * s + 1], pool.ev[3 * s + 2]));
+        sp += a; ss += c2;
+      }
+      stats->ms_policy = sp / (double)n_steps;
+      stats->ms_step = ss / (double)n_steps;
+      stats->launches = 2 * n_steps;
+    }
+    if (time_kernels == 1 && n_steps > 0) {
+      const size_t per = tk.ev.size() / (size_t)n_steps;  // 1 start mark + one event per kernel
+      const int nk = (int)per - 1 < ORL_MAX_STEP_KERNELS ? (int)per - 1 : ORL_MAX_STEP_KERNELS;
+      stats->n_kernels = nk;
+      stats->launches = (int64_t)(per - 1) * n_steps;
+      for (int k = 0; k < nk; k++) {
+        double sum = 0;
+        for (int64_t s = 0; s < n_steps; s++) {
+          float a = 0;
+          HIPCHK(hipEventElapsedTime(&a, tk.ev[(size_t)s * per + k], tk.ev[(size_t)s * per + k + 1]));
+          sum += a;
+        }
+        stats->ms_kernel[k] = sum / (double)n_steps;
+        snprintf(stats->kernel_name[k], sizeof stats->kernel_name[k], "%s", tk.name[k + 1]);
+      }
+    }
+  }
+  return have_flags ? flags_to_rc(b, tail[1]) : report_flags(b);
+}
+
+// ---- read-back ----------------------------------------------------------------------------------
+static int fetch_scal(orl_batch* b, std::vector<u64>& host) {
+  host.resize((size_t)b->P.B * ORL_SCAL_WORDS);
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(host.data(), b->P.scal, host.size() * sizeof(u64), hipMemcpyDeviceToHost));
+  return 0;
+}
+static double as_f64(u64 v) { double d; memcpy(&d, &v, 8); return d; }
+
+extern "C" int orl_batch_get_counters(orl_batch* b, int64_t* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) {
+    const u64* s = &h[(size_t)i * ORL_SCAL_WORDS];
+    int64_t* o = out + i * ORL_N_COUNTERS;
+    o[0] = (int64_t)s[SC_SP]; o[1] = (int64_t)s[SC_SA]; o[2] = (int64_t)s[SC_ESP]; o[3] = (int64_t)s[SC_ESA];
+    o[4] = (int64_t)s[SC_BRQ]; o[5] = (int64_t)s[SC_BRP]; o[6] = (int64_t)s[SC_EBRQ]; o[7] = (int64_t)s[SC_EBRP];
+  }
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_services(orl_batch* b, double* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) {
+    const u64* s = &h[(size_t)i * ORL_SCAL_WORDS];
+    double* o = out + i * ORL_N_SERVICE;
+    o[0] = as_f64(s[SC_AT]); o[1] = as_f64(s[SC_HT]);
+    o[2] = (double)(int)(u32)s[SC_SRC_DST]; o[3] = (double)(int)(s[SC_SRC_DST] >> 32);
+    o[4] = (double)(int)(u32)s[SC_BR_IDX]; o[5] = (double)(int)(u32)s[SC_ID_MTPOS];
+  }
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_active(orl_batch* b, int32_t* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) out[i] = (int32_t)(h[(size_t)i * ORL_SCAL_WORDS + SC_EV] >> 32);
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_flags(orl_batch* b, int32_t* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) out[i] = (int32_t)(h[(size_t)i * ORL_SCAL_WORDS + SC_FLAGS] >> 32);
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out) {
+  if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  std::vector<u64> h((size_t)b->P.bm_words);
+  HIPCHK(hipMemcpy(h.data(), b->P.bitmap + env * b->P.bm_words, h.size() * 8, hipMemcpyDeviceToHost));
+  const int W = b->wt, S = b->P.S, rows = b->P.C * b->P.E;
+  for (int r = 0; r < rows; r++)
+    for (int s = 0; s < S; s++) out[(size_t)r * S + s] = (uint8_t)((h[(size_t)r * W + (s >> 6)] >> (s & 63)) & 1ull);
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out) {
+  if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const int E = b->P.E;
+  std::vector<double> h((size_t)4 * E);  // device layout [E][4] (one 32-byte record per link) -> ABI layout [4][E]
+  HIPCHK(hipMemcpy(h.data(), b->P.lstat + env * 4 * E, h.size() * 8, hipMemcpyDeviceToHost));
+  for (int l = 0; l < E; l++)
+    for (int k = 0; k < 4; k++) out[(size_t)k * E + l] = h[(size_t)4 * l + k];
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out) {
+  if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  u64 s[ORL_SCAL_WORDS];
+  HIPCHK(hipMemcpy(s, b->P.scal + env * ORL_SCAL_WORDS, sizeof s, hipMemcpyDeviceToHost));
+  out[0] = as_f64(s[SC_GTHR]); out[1] = as_f64(s[SC_GCOMP]); out[2] = as_f64(s[SC_GLAST]); out[3] = as_f64(s[SC_NOW]);
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_action_histograms(orl_batch* b, int64_t env, int32_t* out) {
+  if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
+  if (!b->P.act2d) return fail(ORL_E_INVALID, "the batch was created without action_histograms");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out, b->P.act2d + env * b->P.act2d_words, (size_t)b->P.act2d_words * sizeof(int), hipMemcpyDeviceToHost));
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_pending(orl_batch* b, int64_t env, int32_t capacity, double* time_out, int32_t* rec_out) {
+  if (!b || env < 0 || env >= b->P.B || capacity < 0) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const int cap = b->P.ev_cap;
+  std::vector<double> t((size_t)cap);
+  std::vector<u64> inf((size_t)cap);
+  HIPCHK(hipMemcpy(t.data(), b->P.ev_time + env * cap, (size_t)cap * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(inf.data(), b->P.ev_info + env * cap, (size_t)cap * 8, hipMemcpyDeviceToHost));
+  u64 ev = 0;
+  HIPCHK(hipMemcpy(&ev, b->P.scal + env * ORL_SCAL_WORDS + SC_EV, 8, hipMemcpyDeviceToHost));
+  const int hwm = (int)(u32)ev;
+  int n = 0;
+  for (int i = 0; i < hwm && i < cap; i++) {
+    if (!(t[(size_t)i] < INFINITY)) continue;
+    if (n < capacity && time_out && rec_out) {
+      const u64 v = inf[(size_t)i];
+      const int pidx = (int)(v & 0xffffffu);
+      time_out[n] = t[(size_t)i];
+      int32_t* r = rec_out + 6 * n;
+      r[0] = pidx / b->P.K;                  // src * N + dst
+      r[1] = pidx % b->P.K;                  // path index within the pair
+      r[2] = (int)((v >> 24) & 0xfffu);      // initial slot
+      r[3] = (int)((v >> 36) & 0xffu);       // number of slots
+      r[4] = (int)((v >> 44) & 0x1fu);       // core
+      r[5] = (int)((v >> 49) & 0x7fffu);     // bit rate
+    }
+    n++;
+  }
+  return n;
+}
+extern "C" int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemsetAsync(b->d_totals, 0, 16, b->stream));
+  unsigned blocks = (unsigned)((b->P.B + 255) / 256);
+  hipLaunchKernelGGL(k_totals, dim3(blocks), dim3(256), 0, b->stream, b->P, b->d_totals);
+  unsigned long long h[2];
+  HIPCHK(hipMemcpyAsync(h, b->d_totals, 16, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (processed) *processed = (int64_t)h[0];
+  if (accepted) *accepted = (int64_t)h[1];
+  return ORL_OK;
+}
+
+/* debug: stream the slot-map array (n_envs * bm_words * 8 bytes) once; returns that byte count */
+extern "C" int64_t orl_batch_debug_stream_read(orl_batch* b, int width16) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  if (hipSetDevice(b->device) != hipSuccess) return ORL_E_HIP;
+  i64 n_words = b->P.B * b->P.bm_words;
+  hipLaunchKernelGGL(k_calib_read, dim3(2048), dim3(256), 0, b->stream, b->P.bitmap, n_words, width16, (u64*)b->d_totals);
+  if (hipStreamSynchronize(b->stream) != hipSuccess) return ORL_E_HIP;
+  return n_words * 8;
+}
+
+extern "C" int orl_batch_matrix_obs_dim(const orl_batch* b) { return b ? 2 * b->P.N + b->P.C * b->P.E * b->P.S : 0; }
+
+extern "C" int orl_batch_matrix_observation(orl_batch* b, uint8_t* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t dim = (size_t)orl_batch_matrix_obs_dim(b), B = (size_t)b->P.B;
+  unsigned char* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, B * dim));
+  hipLaunchKernelGGL(k_matrix_obs, dim3((unsigned)B), dim3(256), 0, b->stream, b->P, d);
+  hipError_t e = hipMemcpyAsync(out, d, B * dim, hipMemcpyDeviceToHost, b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  hipFree(d);
+  if (e != hipSuccess) return fail(ORL_E_HIP, "matrix observation failed: %s", hipGetErrorString(e));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+
+// ---- snapshot / restore: the per-env arrays, concatenated in a fixed order -------------------------
+struct Section { void* ptr; size_t bytes; };
+static std::vector<Section> state_sections(orl_batch* b) {
+  const DevParams& P = b->P;
+  const size_t B = (size_t)P.B;
+  std::vector<Section> v;
+  v.push_back({P.scal, B * ORL_SCAL_WORDS * 8});
+  v.push_back({P.svc_desc, B * 8});
+  v.push_back({P.bitmap, B * P.bm_words * 8});
+  v.push_back({P.ev_time, B * P.ev_cap * 8});
+  v.push_back({P.ev_info, B * P.ev_cap * 8});
+  v.push_back({P.mt, B * 624 * 4});
+  v.push_back({P.lstat, B * 4 * P.E * 8});
+  v.push_back({P.core_sums, B * P.cs_words * 4});
+  v.push_back({P.soon_t, B * ORL_SOON * 8});
+  v.push_back({P.soon_i, B * ORL_SOON * 4});
+  if (P.br_hist) v.push_back({P.br_hist, B * 2 * P.n_br * 8});
+  if (P.act_hist) v.push_back({P.act_hist, B * ((P.K + 1) + (P.S + 1)) * 8});
+  if (P.act2d) v.push_back({P.act2d, B * (size_t)P.act2d_words * 4});
+  return v;
+}
+extern "C" int64_t orl_batch_state_bytes(orl_batch* b) {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  int64_t n = 0;
+  for (auto& s : state_sections(b)) n += (int64_t)s.bytes;
+  return n;
+}
+extern "C" int orl_batch_get_state(orl_batch* b, void* out) {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  unsigned char* o = (unsigned char*)out;
+  for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(o, s.ptr, s.bytes, hipMemcpyDeviceToHost)); o += s.bytes; }
+  return ORL_OK;
+}
+extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
+  if (!b || !in) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const unsigned char* o = (const unsigned char*)in;
+  for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(s.ptr, o, s.bytes, hipMemcpyHostToDevice)); o += s.bytes; }
+  if (b->P.obs_dim) launch_obs(b, 0);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ORL_OK;
+}
+
+extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
+  if (!b) return -1;
+  if (hipSetDevice(b->device) != hipSuccess) return -1;
+  hipStreamSynchronize(b->stream);
+  u32 v = 0;
+  if (hipMemcpy(&v, b->P.q_stat, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)v;
+}

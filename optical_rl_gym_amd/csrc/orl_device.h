@@ -38,7 +38,8 @@ typedef long long i64;
 typedef unsigned int u32;
 
 enum { ENV_RMSA = 0, ENV_DEEPRMSA = 1, ENV_RWA = 2, ENV_RMCSA = 3 };
-enum { POL_SP_FF = 0, POL_SAP_FF = 1, POL_LLP_FF = 2, POL_SAP_LF = 3 };
+enum { POL_SP_FF = 0, POL_SAP_FF = 1, POL_LLP_FF = 2, POL_SAP_LF = 3,
+       POL_PATH_FF = 4 };  // PathOnlyFirstFitAction (rmsa_env.py:840-874, rwa_env.py:505-536): first fit on the path the agent chose
 
 // scalar-record slots (one 8-byte word each; 32 per env = one 256-B line, lane l owns word l)
 enum {
@@ -57,6 +58,7 @@ enum {
 };
 #define ORL_SCAL_WORDS 32
 #define ORL_FREE_SLOTS 16
+#define ORL_IMASKS 8  // masks one work item can carry = releases of one step that may meet on one link (orl_device_split.h)
 #define ORL_FLAG_EV_OVERFLOW 1
 #define ORL_FLAG_BAD_ACTION 2
 
@@ -94,15 +96,13 @@ struct DevParams {
   double* lstat;    // [B][E][4]          utilization, external_fragmentation, compactness, last_update
   u64* scal;        // [B][32]
   u64* svc_desc;    // [B]  pending service for the slot-scan kernel: pair_base:32 | br_idx:16 | n_paths:8
-  // split pipeline (orl_device_split.h): row-update work items produced by the control kernels
-  ulonglong2* q_a;  // [q_cap] provision items of this step
-  ulonglong2* q_b;  // [q_cap] release items of this step
-  u32* q_cnt_a;     // [4 * ceil(B/32)] items each control wavefront (8 envs) put into its region of q_a
-  u32* q_cnt_b;     // same for q_b
+  // control phase -> row phase (orl_device_split.h): work items, one per link a step touches
+  ulonglong2* q_a;  // [q_cap] mixed items of this step, one region of q_wave slots per control wavefront (8 envs)
+  u32* q_cnt_a;     // [ceil(B/8)] items each control wavefront put into its region
   int q_wave;       // item slots per wavefront region
   int item_masks;   // releases of one step that may meet on one link before the env falls back to the serial tail (<= 8)
-  int pipeline2;    // two-kernel pipeline: core_sums[2C..4C) accumulates what the current step's releases add to the sums
-  i64 q_def_stride; // two-kernel pipeline: second q_def buffer (steps alternate)
+  int pipeline2;    // core_sums[2C..4C) accumulates what the current step's releases add to the sums (persistent kernel)
+  i64 q_def_stride; // second q_def buffer (the steps of the two-kernel form alternate)
   u32* q_def;       // [0] = number of envs whose releases this step do not fit the item form, [16..] = their indices
   u32* q_stat;      // [1] env-steps that took the serial release path (statistics)
   double* soon_t;   // [B][ORL_SOON] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8, ...
@@ -113,6 +113,9 @@ struct DevParams {
                     //                    then [C*E] per (core, link): that row's own contribution, (occ << 16) | fb
   i64* br_hist;     // [B][2*n_br]        discrete mode: requested / provisioned histograms
   i64* act_hist;    // [B][(K+1)+(S+1)]   RWA: marginals of actions_output
+  int* act2d;       // [B][2][(K+1)*(S+1)] opt-in: actions_output, actions_taken (rmsa_env.py:126-137, rwa_env.py:52-58); else null
+  int act2d_words;  // 2*(K+1)*(S+1)
+  int* path_col;    // [B] POL_PATH_FF: the path index each env's agent chose (Discrete(k + reject) action)
   // I/O (device resident; the C-ABI copies to/from host buffers)
   int* actions;            // [B][4]
   double* reward;          // [B]
@@ -948,6 +951,15 @@ __device__ __forceinline__ double link_mean(const DevParams& P, const double* va
   return res / (double)E;
 }
 
+// opt-in 2-D action histograms (rmsa_env.py:126-137, 167, 201, 211-212; rwa_env.py:52-58, 103, 125, 132-133):
+// actions_output[path, slot] counts every action, actions_taken[path, slot] the accepted ones and [k, S] the rejections
+__device__ __forceinline__ void act2d_count(const DevParams& P, i64 env, int path, int slot, bool accepted) {
+  int* h = P.act2d + env * P.act2d_words;
+  const int S1 = P.S + 1, half = (P.K + 1) * S1;
+  h[path * S1 + slot] += 1;
+  h[half + (accepted ? path * S1 + slot : P.K * S1 + P.S)] += 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // heuristics (the policy side) — the slot-scan.
 //
@@ -966,7 +978,7 @@ template <int GS> __device__ __forceinline__ int group_get(int v, int src, int l
 
 template <int ENV, int W, int GS>
 __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool valid, int pb, int br_idx, int np_,
-                                         int lane, int pol, int* a) {
+                                         int lane, int pol, int pcol, int* a) {
   const int K = P.K, S = P.S;
   const int p = lane & (GS - 1);
   a[0] = a[1] = a[2] = a[3] = 0;
@@ -975,7 +987,9 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     a[0] = K; a[1] = S;
     int slot = -1, freec = 0;
     int limit = (pol == POL_SP_FF) ? 1 : np_;
-    if (valid && p < limit) {
+    // PathOnlyFirstFitAction: only the chosen path is scanned (a choice >= k, or beyond the pair's paths, rejects)
+    const bool mine = (pol == POL_PATH_FF) ? (p == pcol && pcol < K) : true;
+    if (valid && p < limit && mine) {
       int pidx = pb + p;
       PathRec rec = path_rec_load(P, pidx);
       int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
@@ -1010,7 +1024,8 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     a[0] = K; a[1] = S;
     int slot = -1, cap = 0, hops = 0;
     int limit = (pol == POL_SP_FF) ? 1 : np_;
-    if (valid && p < limit) {
+    const bool mine = (pol == POL_PATH_FF) ? (p == pcol && pcol < K) : true;
+    if (valid && p < limit && mine) {
       int pidx = pb + p;
       PathRec rec = path_rec_load(P, pidx);
       Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
@@ -1026,6 +1041,9 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     int best = -1;
     if (pol == POL_SP_FF) {
       best = (group_ballot<GS>(slot >= 0, lane) & 1ull) ? 0 : -1;
+    } else if (pol == POL_PATH_FF) {
+      const u64 fit = group_ballot<GS>(slot >= 0, lane);
+      best = fit ? (int)__builtin_ctzll(fit) : -1;
     } else if (pol == POL_LLP_FF) {
       // cap > best_load with best_load = -DBL_MAX initially: the first path with the largest positive capacity
       int mx = group_max<GS>(slot >= 0 ? cap : -1);
@@ -1148,6 +1166,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
   if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
   if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
   if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && info_out) cur_comp = net_compactness(P, e, 0);
+  if (ENV != ENV_RMCSA && P.act2d && !bad && lane == 0) act2d_count(P, e.env, path0, slot0, accepted);
 
   if (ENV == ENV_RWA) {
     // actions_output marginals (rwa_env.py:103, 148-151).  Each lane owns histogram entries, applies this

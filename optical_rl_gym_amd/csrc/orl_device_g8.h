@@ -164,22 +164,6 @@ __device__ __forceinline__ int rng_choice(EnvG& e, RngG& r, int lane, const doub
 }
 
 // ---- slot rows: lane w owns word w -------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ bool path_is_free(const DevParams& P, const EnvG& e, int lane, int pidx, int core, int s0, int n) {
-  if (s0 + n > P.S) return false;
-  const PathRec rec = path_rec_load(P, pidx);
-  const int hops = path_rec_byte(rec, 0), w = lane & 7;
-  bool busy = false;
-  if (w < W) {
-    const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
-    for (int h = 0; h < hops; h++) {
-      int link = path_rec_byte(rec, 2 + h);
-      busy = busy || ((m & ~e.bm[(core * P.E + link) * W + w]) != 0ull);
-    }
-  }
-  return gballot(busy, lane) == 0u;
-}
-
 __device__ __forceinline__ double net_compactness(const DevParams& P, const EnvG& e, int core, int lane) {
   // lane 0 of the group is the only writer of cs[]: take its copy
   int occ = gget(e.cs[2 * core], 0, lane), fb = gget(e.cs[2 * core + 1], 0, lane);
@@ -402,7 +386,9 @@ __device__ __forceinline__ void release_due(const DevParams& P, EnvG& e, int lan
   }
 }
 
-template <int ENV, int W, bool REL = true>
+// (the due releases are detected by sp::release_soon afterwards; RWA / RMCSA release before creating the service in the
+// reference, which touches disjoint state, so the order within the kernel does not matter)
+template <int ENV, int W>
 __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int lane, RngG& r) {
   if (e.new_service) return;
   const int gl = lane & 7;
@@ -424,7 +410,6 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
     }
   }
   rng_commit(e, r, gl);
-  if (REL && (ENV == ENV_RWA || ENV == ENV_RMCSA)) release_due<ENV, W>(P, e, lane);
   e.id = (int)e.esp;
   e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
   e.new_service = 1;
@@ -434,163 +419,12 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
     e.ebrq += bit_rate;
     if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;
   }
-  if (REL && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA)) release_due<ENV, W>(P, e, lane);
-}
-
-// np.mean over the links in topology.edges() order (numpy pairwise sum); lane j reads the statistics it owns
-__device__ __forceinline__ double link_mean(const DevParams& P, const double* vals, int lane) {
-  const int E = P.E, gl = lane & 7;
-  double res;
-  if (E < 8) {
-    res = 0.;
-    for (int i = 0; i < E; i++) res += gget((gl == i) ? vals[4 * P.edge_iter_order[i]] : 0.0, i, lane);
-  } else {
-    double r = vals[4 * P.edge_iter_order[gl]];
-    int i;
-    for (i = 8; i < E - (E % 8); i += 8) r += vals[4 * P.edge_iter_order[i + gl]];
-    double r0 = gget(r, 0, lane), r1 = gget(r, 1, lane), r2 = gget(r, 2, lane), r3 = gget(r, 3, lane);
-    double r4 = gget(r, 4, lane), r5 = gget(r, 5, lane), r6 = gget(r, 6, lane), r7 = gget(r, 7, lane);
-    res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < E; i++) res += gget((gl == (i & 7)) ? vals[4 * P.edge_iter_order[i]] : 0.0, i & 7, lane);
-  }
-  return res / (double)E;
 }
 
 // lane-private AND of a path's rows, only valid BEFORE this kernel modified the slot map (DeepRMSA action decode)
 template <int W>
 __device__ __forceinline__ Row<W> path_and_global(const DevParams& P, const EnvG& e, int pidx) {
   return path_and_rec<W>(path_rec_load(P, pidx), e.bm, P.E, P.S, 0);
-}
-
-template <int ENV, int W>
-__device__ __forceinline__ void step(const DevParams& P, EnvG& e, int lane, const int* act, int auto_reset, bool want_info) {
-  const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
-  RngG rng;
-  rng_fill(e, rng, gl);  // requested first: consumed only in next_service
-  int path, slot, mod = 0, core = 0;
-  bool bad = false;
-  if (ENV == ENV_DEEPRMSA) {
-    int aa = act[0];
-    path = K; slot = S;
-    if (aa >= 0 && aa < K * P.J) {
-      int route = aa / P.J, block = aa - route * P.J;
-      int starts[8], lens[8];
-      int pidx = pair_base(P, e.src, e.dst) + route;
-      int nb = 0;
-      if (route < P.n_paths[e.src * P.N + e.dst]) {
-        Row<W> m = path_and_global<W>(P, e, pidx);
-        nb = first_blocks<W>(m, S, P.nslots_path[(size_t)pidx * P.n_br + e.br_idx], block + 1, starts, lens);
-      }
-      if (block < nb) { path = route; slot = starts[block]; }
-    }
-  } else if (ENV == ENV_RMCSA) {
-    path = act[0]; mod = act[1]; core = act[2]; slot = act[3];
-    bad = path < 0 || path > K || mod < 0 || mod > P.M || core < 0 || core > P.C || slot < 0 || slot > S;
-  } else if (ENV == ENV_RWA) {
-    path = act[0]; slot = act[1];
-    bad = path < 0 || path >= K + rej || slot < 0 || slot >= S + rej;
-  } else {
-    path = act[0]; slot = act[1];
-    bad = path < 0 || path > K || slot < 0 || slot > S;
-  }
-  if (bad) {
-    e.flags |= ORL_FLAG_BAD_ACTION;
-    path = K; slot = S; mod = P.M; core = P.C;
-  }
-  const int path0 = path, slot0 = slot;
-  double prev_comp = 0.0, cur_comp = 0.0;
-  if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && want_info) prev_comp = net_compactness(P, e, 0, lane);
-  bool accepted = false;
-  bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
-  if (in_range && path < P.n_paths[e.src * P.N + e.dst]) {
-    int pidx = pair_base(P, e.src, e.dst) + path;
-    int n = 1;
-    if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
-    else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
-    bool ok = path_is_free<W>(P, e, lane, pidx, core, slot, n);
-    if (ok && ENV == ENV_RMCSA) {
-      double len = P.path_length[pidx];
-      ok = (len < P.lmax_xt[mod]) && (len < P.lmax_snr[mod * P.n_br + e.br_idx]);
-    }
-    if (ok) {
-      int hops_p = path_apply<ENV, W>(P, e, lane, pidx, core, slot, n, false);
-      e.s_br += e.bit_rate;
-      e.s_nh += (i64)n * hops_p;
-      if (ENV != ENV_RWA) {
-        double last_update = e.g_last, time_diff = e.now - last_update;
-        if (e.now > 0) {
-          double cur_thr = (double)e.s_br;
-          e.g_thr = ((e.g_thr * last_update) + (cur_thr * time_diff)) / e.now;
-          e.g_comp = ((e.g_comp * last_update) + (net_compactness(P, e, core, lane) * time_diff)) / e.now;
-        }
-        e.g_last = e.now;
-        e.brp += e.bit_rate;
-        e.ebrp += e.bit_rate;
-        if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[e.env * 2 * P.n_br + P.n_br + e.br_idx] += 1;
-      }
-      e.sa += 1;
-      e.esa += 1;
-      accepted = true;
-      ev_push(P, e, lane, e.at + e.ht, ev_pack(pidx, slot, n, core, e.bit_rate));
-    }
-  }
-  if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
-  if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
-  if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && want_info) cur_comp = net_compactness(P, e, 0, lane);
-
-  double* info_out = want_info ? P.info + e.env * P.n_info : nullptr;
-  if (ENV == ENV_RWA) {
-    i64* h = P.act_hist + e.env * ((K + 1) + (S + 1));
-    const int npa = K + rej, nsa = S + rej;
-    for (int i = gl; i < npa + nsa; i += 8) {
-      int hi = (i < npa) ? i : (K + 1) + (i - npa);
-      bool hit = !bad && ((i < npa) ? (i == path0) : (i - npa == slot0));
-      i64 v = h[hi] + (hit ? 1 : 0);
-      if (hit) h[hi] = v;
-      if (info_out) info_out[2 + i] = (double)v / (double)e.sp;
-    }
-  }
-  double reward = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
-  if (info_out) {
-    double i0 = (double)(e.sp - e.sa) / (double)e.sp;
-    double i1 = (double)(e.esp - e.esa) / (double)e.esp;
-    if (gl == 0) { info_out[0] = i0; info_out[1] = i1; }
-    if (ENV != ENV_RWA) {
-      double i2 = (double)(e.brq - e.brp) / (double)e.brq;
-      double i3 = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
-      if (gl == 0) { info_out[2] = i2; info_out[3] = i3; }
-    }
-    if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
-      double mc = link_mean(P, e.ls + 2, lane);
-      double mu = link_mean(P, e.ls, lane);
-      if (gl == 0) { info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu; }
-      if (P.bit_rate_mode == 1 && gl == 0) {
-        const i64* rq = P.br_hist + e.env * 2 * P.n_br;
-        const i64* pv = rq + P.n_br;
-        double mxv = -__builtin_inf(), mnv = __builtin_inf();
-        for (int i = 0; i < P.n_br; i++) {
-          double bl = 0.0;
-          if (rq[i] > 0) bl = (double)(rq[i] - pv[i]) / (double)rq[i];
-          info_out[8 + i] = bl;
-          mxv = bl > mxv ? bl : mxv;
-          mnv = bl < mnv ? bl : mnv;
-        }
-        info_out[8 + P.n_br] = mxv - mnv;
-      }
-    }
-  }
-  e.new_service = 0;
-  next_service<ENV, W>(P, e, lane, rng);
-  e.t_soon = -__builtin_inf();  // the in-kernel releases do not maintain the soon list
-  bool done = (e.esp == (i64)P.episode_length);
-  if (done && auto_reset) {
-    e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
-    if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
-  }
-  if (gl == 0) {
-    P.reward[e.env] = reward;
-    P.done[e.env] = done ? 1 : 0;
-  }
 }
 
 }  // namespace g8

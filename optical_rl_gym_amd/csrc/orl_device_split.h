@@ -118,7 +118,6 @@ __device__ __forceinline__ size_t wave_reserve(const DevParams& P, int cnt, u32*
 // [s0, s0+n) masks in release order, each with its core.  While collecting, the items live in an LDS table indexed
 // by the link (24 bytes per link and env): appending a mask is one LDS read-modify-write by the lane that owns the
 // hop, with no search and no per-lane registers.
-#define ORL_IMASKS 8  // masks one item can carry = releases of one step that may meet on one link
 struct SinkEntry {
   u64 mk0;  // masks 0..3: (s0 | n << 9), 16 bits each, in release order
   u64 mk1;  // masks 4..7
@@ -170,9 +169,9 @@ __device__ __forceinline__ void emit_items(const DevParams& P, i64 env, const Si
 // ---------------------------------------------------------------------------------------------------------------
 // control kernel A: everything of step() up to (and excluding) the effects of the provision on the link rows
 // ---------------------------------------------------------------------------------------------------------------
-template <int ENV, int W, bool DEFER_GCOMP>
+template <int ENV, int W>
 __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             double* info_out, Prof& prof);
+                                             Prof& prof);
 #ifndef ORL_SCAN_BATCH
 #define ORL_SCAN_BATCH 8  // release times a lane requests per round of the rebuild scan
 #endif
@@ -181,29 +180,22 @@ template <int ENV, int W>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
                                              int extra = 0, int pushed_idx = -1, u64 pushed_info = 0ull);
 
-// MERGE 1: device-resident loop without info — the work of control kernel B1 (next service) is done right here, on the
-// env record that is already in registers; only the network-compactness update has to wait for the row kernel
-// (k_ctrl_b2).
-// MERGE 2 (two-kernel pipeline): the release detection of control kernel B2 as well.  The provision and the releases of
-// the step go into ONE queue as mixed items (per link: the provision mask first, then the release masks) and one
-// row-kernel launch applies them.  The network-compactness average, which needs the sums between the provision and
-// the releases, is finished by the NEXT step's launch of this kernel from totals - (what the releases added): the row
-// kernel keeps the latter in rel_sums.
-template <int ENV, int W, int MERGE = 0>
-__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, bool want_info, Prof& prof,
-                                       const int4* given = nullptr, u32* s_tally = nullptr, SinkEntry* s_tab = nullptr, int parity = 0,
+// The provision and the releases of the step go into ONE queue as mixed items (per link: the provision mask first, then the
+// release masks) and one row phase applies them.  The network-compactness average, which needs the sums between the
+// provision and the releases, is finished by the NEXT step from totals - (what the releases added): the row phase keeps
+// the latter in rel_sums.
+template <int ENV, int W>
+__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, Prof& prof,
+                                       const int4* given, u32* s_tally, SinkEntry* s_tab, int parity = 0,
                                        int* s_deferred = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (MERGE == 2) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
-    else P.q_def[0] = 0u;                                                  // control kernel B2 of this step appends
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
   int cnt = 0, core = 0, slot = 0, n = 1;
   PathRec rec;
   rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
   Sink sink;
   sink.tab = nullptr; sink.tally = nullptr; sink.active = false; sink.deferred = false; sink.cnt = 0;
-  if (MERGE == 2) {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
+  {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
     u32* ty = s_tally + 32 * 8 * (int)(threadIdx.x >> 6);
     SinkEntry* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
     for (int i = lane; i < 8 * 32; i += 64) ty[i] = 0u;
@@ -215,9 +207,8 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
   if (valid) {
     EnvG e;
     g8::env_load(P, e, env);
-    int* rs = nullptr;
-    if (MERGE == 2) {
-      rs = e.cs + 2 * P.C;
+    int* rs = e.cs + 2 * P.C;
+    {
       const u64 acc0 = e.scal[SC_ACC];
       if ((u32)acc0 & 2u) {
         // network compactness update the previous step left pending: the sums right after ITS provision are the totals
@@ -277,12 +268,6 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     }
     const int path0 = path, slot0 = slot;
     ORL_PROFA(2);
-    double* info_out = want_info ? P.info + env * P.n_info : nullptr;
-    if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && info_out) {
-      // compactness before the provision; k_ctrl_b turns it into the difference (rmsa_env.py:168-170, 250-251)
-      double pc = g8::net_compactness(P, e, 0, lane);
-      if (gl == 0) info_out[5] = pc;
-    }
     bool accepted = false;
     int pushed_idx = -1;
     u64 pushed_info = 0ull;
@@ -331,7 +316,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         accepted = true;
         pushed_info = ev_pack(pidx, slot, n, core, e.bit_rate);
         pushed_idx = g8::ev_push(P, e, lane, e.at + e.ht, pushed_info);
-        if (MERGE == 2) {  // the provision's rows: first mask of their items; they also count towards the per-link limit
+        {  // the provision's rows: first mask of their items; they also count towards the per-link limit
           sink_add(sink, rec, core, slot, n, lane, true);
           for (int h = gl; h < hops; h += 8) {
             const int link = path_rec_byte(rec, 2 + h);
@@ -343,15 +328,14 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     }
     if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
     if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
+    if (ENV != ENV_RMCSA && P.act2d && !bad && gl == 0) act2d_count(P, env, path0, slot0, accepted);
     if (ENV == ENV_RWA) {  // actions_output marginals (rwa_env.py:103, 148-151)
       i64* h = P.act_hist + env * ((K + 1) + (S + 1));
       const int npa = K + rej, nsa = S + rej;
       for (int i = gl; i < npa + nsa; i += 8) {
         int hi = (i < npa) ? i : (K + 1) + (i - npa);
         bool hit = !bad && ((i < npa) ? (i == path0) : (i - npa == slot0));
-        i64 v = h[hi] + (hit ? 1 : 0);
-        if (hit) h[hi] = v;
-        if (info_out) info_out[2 + i] = (double)v / (double)e.sp;
+        if (hit) h[hi] += 1;
       }
     }
     if (gl == 0) {
@@ -361,13 +345,13 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     }
     ORL_PROFA(5);
     // the word service_part leaves in SC_ACC (recomputed here so that the deferral below need not read it back)
-    const u64 acc_after = (MERGE && accepted && ENV != ENV_RWA && e.now > 0)
+    const u64 acc_after = (accepted && ENV != ENV_RWA && e.now > 0)
                               ? (3ull | ((u64)(u32)core << 32) | ((u64)e.s_nh << 37))
                               : pack2(accepted ? 1 : 0, core);
-    if (MERGE) service_part<ENV, W, true>(P, e, env, lane, 1, accepted, core, nullptr, prof);
+    service_part<ENV, W>(P, e, env, lane, 1, accepted, core, prof);
     g8::env_store(P, e, gl);
     ORL_PROFA(8);
-    if (MERGE == 2) {
+    {
       // due releases of the step (rmsa_env.py:590-597) -> masks behind the provision's in the same table.  The env record
       // has gone back already (so that only the handful of release-related fields stays in registers through the
       // detection); those fields are written again below when the detection changed them.
@@ -403,22 +387,16 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     }
   }
   ORL_PROFA(11);
-  if (MERGE == 2) {
-    emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a);
-  } else {
-    const size_t base = wave_reserve(P, cnt, P.q_cnt_a, lane);
-    for (int h = gl; h < cnt; h += 8)
-      item_store(P.q_a, base + h, make_item(env, (u32)path_rec_byte(rec, 2 + h), 1, (u64)(u32)slot | ((u64)(u32)n << 9), 0ull, (u64)(u32)core, 0));
-  }
+  emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a);
   ORL_PROFA(9);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// control kernel B: what step() does after the provision: network statistics, info, next service, due releases
+// what step() does after the provision, except the link rows: network statistics, next service, done / auto reset
 // ---------------------------------------------------------------------------------------------------------------
-template <int ENV, int W, bool DEFER_GCOMP>
+template <int ENV, int W>
 __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             double* info_out, Prof& prof) {
+                                             Prof& prof) {
   const int gl = lane & 7;
   g8::RngG rng;
   g8::rng_fill(e, rng, gl);
@@ -427,55 +405,19 @@ __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 en
     if (e.now > 0) {
       double cur_thr = (double)e.s_br;
       e.g_thr = ((e.g_thr * last_update) + (cur_thr * time_diff)) / e.now;
-      if (DEFER_GCOMP) {
-        // the compactness term needs the sums after the provision's row updates: k_ctrl_b2 finishes
-        // g_comp = (g_comp * last_update + compactness * time_diff) / now from these two stashed factors
-        if (gl == 0) {
-          e.scal[SC_GC_A] = (u64)__double_as_longlong(e.g_comp * last_update);
-          e.scal[SC_GC_TD] = (u64)__double_as_longlong(time_diff);
-          e.scal[SC_ACC] = 3ull | ((u64)(u32)core << 32) | ((u64)e.s_nh << 37);  // s_nh at provision time (< 2^27)
-        }
-      } else {
-        e.g_comp = ((e.g_comp * last_update) + (g8::net_compactness(P, e, core, lane) * time_diff)) / e.now;
+      // the compactness term needs the sums after the provision's row updates: the next step finishes
+      // g_comp = (g_comp * last_update + compactness * time_diff) / now from these two stashed factors
+      if (gl == 0) {
+        e.scal[SC_GC_A] = (u64)__double_as_longlong(e.g_comp * last_update);
+        e.scal[SC_GC_TD] = (u64)__double_as_longlong(time_diff);
+        e.scal[SC_ACC] = 3ull | ((u64)(u32)core << 32) | ((u64)e.s_nh << 37);  // s_nh at provision time (< 2^27)
       }
     }
     e.g_last = e.now;
   }
-  if (info_out) {
-    double i0 = (double)(e.sp - e.sa) / (double)e.sp;
-    double i1 = (double)(e.esp - e.esa) / (double)e.esp;
-    if (gl == 0) { info_out[0] = i0; info_out[1] = i1; }
-    if (ENV != ENV_RWA) {
-      double i2 = (double)(e.brq - e.brp) / (double)e.brq;
-      double i3 = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
-      if (gl == 0) { info_out[2] = i2; info_out[3] = i3; }
-    }
-    if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) {
-      double cur_comp = g8::net_compactness(P, e, 0, lane);
-      double mc = g8::link_mean(P, e.ls + 2, lane);
-      double mu = g8::link_mean(P, e.ls, lane);
-      if (gl == 0) {
-        double prev_comp = info_out[5];
-        info_out[4] = cur_comp; info_out[5] = prev_comp - cur_comp; info_out[6] = mc; info_out[7] = mu;
-      }
-      if (P.bit_rate_mode == 1 && gl == 0) {
-        const i64* rq = P.br_hist + env * 2 * P.n_br;
-        const i64* pv = rq + P.n_br;
-        double mxv = -__builtin_inf(), mnv = __builtin_inf();
-        for (int i = 0; i < P.n_br; i++) {
-          double bl = 0.0;
-          if (rq[i] > 0) bl = (double)(rq[i] - pv[i]) / (double)rq[i];
-          info_out[8 + i] = bl;
-          mxv = bl > mxv ? bl : mxv;
-          mnv = bl < mnv ? bl : mnv;
-        }
-        info_out[8 + P.n_br] = mxv - mnv;
-      }
-    }
-  }
   e.new_service = 0;
   ORL_PROFA(6);
-  g8::next_service<ENV, W, false>(P, e, lane, rng);  // the due releases are k_ctrl_b2's job
+  g8::next_service<ENV, W>(P, e, lane, rng);  // the due releases are release_soon's job
   ORL_PROFA(7);
   bool done = (e.esp == (i64)P.episode_length);
   if (done && auto_reset) {
@@ -483,18 +425,6 @@ __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 en
     if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
   }
   if (gl == 0) P.done[env] = done ? 1 : 0;
-}
-
-template <int ENV, int W>
-__device__ __forceinline__ void ctrl_b1(const DevParams& P, i64 env, bool valid, int lane, int auto_reset, bool want_info) {
-  if (!valid) return;
-  EnvG e;
-  g8::env_load(P, e, env);
-  const u64 acc = e.scal[SC_ACC];
-  Prof prof;
-  service_part<ENV, W, false>(P, e, env, lane, auto_reset, ((u32)acc & 1u) != 0, (int)((acc >> 32) & 31),
-                              want_info ? P.info + env * P.n_info : nullptr, prof);
-  g8::env_store(P, e, lane & 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -739,104 +669,6 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
   ORL_PROF(8);
 }
 
-// control kernel B2: the due releases of the step (rmsa_env.py:590-597) -> work items.  Only the clock, the
-// pending-release bookkeeping and the two running sums of the env record are touched.
-template <int ENV, int W>
-__device__ __forceinline__ void ctrl_b2(const DevParams& P, i64 env, bool valid, int lane, u32* s_tally, SinkEntry* s_tab) {
-  const int gl = lane & 7, E = P.E;
-  Prof prof;
-  ORL_PROF_BEGIN();
-  {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
-    u32* ty = s_tally + 32 * 8 * (int)(threadIdx.x >> 6);
-    SinkEntry* tb = s_tab + E * 8 * (int)(threadIdx.x >> 6);
-    for (int i = lane; i < 8 * 32; i += 64) ty[i] = 0u;
-    for (int i = lane; i < 8 * E; i += 64) tb[i].crn = 0ull;
-    wave_fence();
-  }
-  Sink sink;
-  sink.tab = s_tab + E * (int)(threadIdx.x >> 3);
-  sink.tally = s_tally + 32 * (int)(threadIdx.x >> 3);
-  sink.active = false; sink.deferred = false; sink.cnt = 0;
-  SoonRegs soon;
-  soon.dirty = 0;
-  double next_rel = 0.0, t_soon = 0.0;
-  i64 s_br = 0, s_nh = 0;
-  u64 ev = 0, acc_word = 0;
-  int nfree = 0;
-  double gc = 0.0;
-  bool gc_pending = false;
-  ORL_PROF(1);
-  if (valid) {
-    EnvG e;
-    u64* s = P.scal + env * ORL_SCAL_WORDS;
-    e.scal = s;
-    e.env = env;
-    e.now = __longlong_as_double((i64)s[SC_NOW]);
-    e.next_rel = __longlong_as_double((i64)s[SC_NEXTREL]);
-    e.s_br = (i64)s[SC_SBR];
-    e.s_nh = (i64)s[SC_SNH];
-    u64 t = s[SC_EV];
-    e.ev_hwm = (int)(u32)t; e.ev_cnt = (int)(t >> 32);
-    e.nfree = (int)(u32)s[SC_HINT];
-    e.pop_idx = -1;
-    e.flags = 0;
-    e.bm = P.bitmap + env * P.bm_words;
-    e.ls = P.lstat + env * 4 * P.E;
-    e.cs = P.core_sums + env * P.cs_words;
-    e.ev_time = P.ev_time + env * P.ev_cap;
-    e.ev_info = P.ev_info + env * P.ev_cap;
-    const u64 acc = s[SC_ACC];
-    if ((u32)acc & 2u) {  // network compactness update left pending by the merged control kernel (sums are final now)
-      const int core = (int)((acc >> 32) & 31);
-      const double a0 = __longlong_as_double((i64)s[SC_GC_A]), td = __longlong_as_double((i64)s[SC_GC_TD]);
-      const double now_a = __longlong_as_double((i64)s[SC_NOWA]);
-      // s_nh at provision time = the value the merged kernel stored (this kernel has not released anything yet)
-      gc = (a0 + (g8::net_compactness(P, e, core, lane) * td)) / now_a;
-      gc_pending = true;
-    }
-    acc_word = acc & ~2ull;
-    ORL_PROF(2);
-    e.t_soon = __longlong_as_double((i64)s[SC_TSOON]);
-    e.soon_t = P.soon_t + env * ORL_SOON;
-    e.soon_i = P.soon_i + env * ORL_SOON;
-    ORL_PROF(3);
-    release_soon<ENV, W>(P, e, lane, sink, soon, prof);
-    next_rel = e.next_rel; t_soon = e.t_soon; s_br = e.s_br; s_nh = e.s_nh; ev = pack2(e.ev_hwm, e.ev_cnt); nfree = e.nfree;
-  }
-  ORL_PROF(9);
-  emit_items(P, env, sink, sink.active, lane, P.q_b, P.q_cnt_b);
-  ORL_PROF(10);
-  // the env record goes back last: stores hold the memory counter, and nothing after this point waits on it
-  if (valid) {
-    u64* s = P.scal + env * ORL_SCAL_WORDS;
-    if (gl == 0) {
-      // deferred: more releases meet on one link than an item holds masks for; the pending-release state is left
-      // untouched and k_rel_tail (flag bit 16) releases them in place
-      if (gc_pending) s[SC_GCOMP] = (u64)__double_as_longlong(gc);
-      if (gc_pending || sink.deferred) s[SC_ACC] = acc_word | (sink.deferred ? (1ull << 16) : 0ull);
-      if (sink.deferred) P.q_def[16 + atomicAdd(P.q_def, 1u)] = (u32)env;  // rare: the row kernel's serial tail takes it
-      s[SC_HINT] = pack2(nfree, 0);  // also when deferred: a rebuild may have rewritten the free-slot stack
-    }
-    if (!sink.deferred) {
-#pragma unroll
-      for (int k = 0; k < ORL_SOON_PER_LANE; k++)
-        if ((soon.dirty >> k) & 1) {
-          P.soon_t[env * ORL_SOON + gl + 8 * k] = soon.t[k];
-          P.soon_i[env * ORL_SOON + gl + 8 * k] = (u32)soon.i[k];
-        }
-      if (gl == 0) {
-        s[SC_NEXTREL] = (u64)__double_as_longlong(next_rel);
-        s[SC_TSOON] = (u64)__double_as_longlong(t_soon);
-        s[SC_SBR] = (u64)s_br;
-        s[SC_SNH] = (u64)s_nh;
-        s[SC_EV] = ev;
-      }
-    }
-  }
-  ORL_PROF(11);
-  ORL_PROF_END();
-}
-
 // rare path: envs whose due releases did not fit the item form (flag bit 16 of SC_ACC) release them in place
 template <int ENV, int W>
 __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane) {
@@ -912,8 +744,9 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
 // MIXED (two-kernel pipeline): mask 0 of an item may be this step's provision — slots cleared, statistics at the
 // provision clock (SC_NOWA) — followed by the step's releases at the new clock (SC_NOW); what the releases add to
 // the per-core sums is also accumulated in rel_sums (the next step needs the sums as they were in between).
-template <int ENV, int W, bool MIXED>
-__device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it, int now_slot, Prof& prof) {
+template <int ENV, int W>
+__device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it, Prof& prof) {
+  constexpr bool MIXED = true;
   const int E = P.E, S = P.S;
   const i64 env = (i64)(u32)it.a.x;
   const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
@@ -924,7 +757,7 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
   int* cs = P.core_sums + env * P.cs_words;
   int* rs = MIXED ? cs + 2 * P.C : nullptr;
   double* ls = P.lstat + env * 4 * E;
-  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + (MIXED ? (int)SC_NOW : now_slot)]);
+  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
   const double now_prov = MIXED ? __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOWA]) : 0.0;
   const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
   double last_update = ls23.y;

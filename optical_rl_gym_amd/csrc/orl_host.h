@@ -1,0 +1,73 @@
+// orl_host.h — host-side structures shared by the translation units of liborlgpu.so.
+//
+// The library is built from one W-independent unit (orl_api.hip: the C ABI of include/orl.h, batch construction, the small
+// utility kernels) and one unit per row width W in {1, 2, 5, 8} 64-bit words (orl_kernels.hip compiled with -DORL_W=W: the
+// env kernels, which keep a whole link row in registers and are therefore templates over W).  The units compile in
+// parallel (optical_rl_gym_amd/_build.py); the API unit reaches the kernels through the launchers declared below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/orl.h"
+#include "orl_device.h"
+
+struct orl_topology {
+  int device;
+  int N, E, K, H, M;
+  std::vector<int32_t> h_hops, h_links, h_mod;  // host copies (per-batch derived tables are built from them)
+  int* n_paths;
+  double* path_length;
+  int* edge_iter_order;
+  int* link_pos;
+};
+
+// per-kernel timing (orl_batch_run, time_kernels == 1): an event after every launch
+struct TkRec { std::vector<hipEvent_t> ev; std::vector<const char*> name; };
+
+struct orl_batch {
+  orl::DevParams P;
+  TkRec* tk = nullptr;
+  int parity = 0;        // two-kernel form (ORL_ALT_IMPLS): which deferred-env buffer the next step writes
+  int persist = 0;       // device-resident runs go through the persistent kernel (k_persist)
+  int lds_state = 0;     // ... with the slot maps and link statistics of a wavefront's envs resident in LDS
+  int two_kernel = 0;    // ORL_ALT_IMPLS builds, ORL_STEP_IMPL=2 ORL_PERSIST=0: the phases of k_persist as separate launches
+  int64_t persist_launches = 0;
+  int* d_wg_step = nullptr;        // [ceil(B/8)] steps each workgroup of the persistent kernel has completed in this run
+  unsigned int* d_unfinished = nullptr;  // [0] straggler workgroups of the last persistent launch, [1] OR of the env flag words (k_finish2)
+  int device = 0, wt = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long* d_totals = nullptr;
+};
+
+#define ORL_TK(B_, NAME)                                                                 \
+  do {                                                                                   \
+    if ((B_)->tk) {                                                                      \
+      hipEvent_t e_;                                                                     \
+      hipEventCreate(&e_);                                                               \
+      hipEventRecord(e_, (B_)->stream);                                                  \
+      (B_)->tk->ev.push_back(e_);                                                        \
+      (B_)->tk->name.push_back(NAME);                                                    \
+    }                                                                                    \
+  } while (0)
+
+// ---- launchers, one explicit instantiation per W (orl_kernels.hip) ----------------------------------------------------
+namespace orl_launch {
+template <int W> void reset(orl_batch* b, int full, const unsigned char* dmask);
+template <int W> void policy(orl_batch* b, int pol);                       // stand-alone slot scan -> P.actions
+template <int W> void step64(orl_batch* b, int auto_reset, int want_info, int fused_policy);  // one wavefront per env
+template <int W> void obs(orl_batch* b, int with_terminal);                // DeepRMSA observation
+template <int W> void persist(orl_batch* b, int pol, int target);          // k_persist up to step `target` of this run, then k_rel_tail
+template <int W> void step2(orl_batch* b, int pol);                        // ORL_ALT_IMPLS: k_step_a2 ; k_rows2 ; k_rel_tail
+}  // namespace orl_launch
+
+#define ORL_DISPATCH_W(B_, CALL)      \
+  switch ((B_)->wt) {                 \
+    case 1: CALL(1); break;           \
+    case 2: CALL(2); break;           \
+    case 5: CALL(5); break;           \
+    default: CALL(8); break;          \
+  }

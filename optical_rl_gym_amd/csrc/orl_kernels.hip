@@ -1,0 +1,490 @@
+// orl_kernels.hip — the env kernels of liborlgpu.so for ONE row width W (compiled once per -DORL_W=1|2|5|8; gfx950 only).
+//
+//   k_reset     full reset (clear network, draw first service) or soft reset (episode counters)     one wavefront per env
+//   k_policy    stand-alone slot scan: AND the link rows of each of the k paths, log-step run detection, first fit -> action
+//               [the HBM-streaming kernel; 8 lanes per env, lane = path]
+//   k_step      host-driven step(): apply action, statistics, reward/info, next service, observation   one wavefront per env
+//   k_persist   device-resident loop: one wavefront owns 8 envs for a whole run and alternates a control phase (slot scan,
+//               validation, counters, next service, due releases -> work items) and a row phase (one lane per touched link)
+//   k_rel_tail  the rare envs whose releases of a step did not fit the item form release them in place
+//   k_obs8/k_obs DeepRMSA observation of the pending service
+// Launchers (orl_launch::*<W>) are explicitly instantiated at the end; orl_api.hip dispatches on the batch's W.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "orl_host.h"
+#include "orl_device_g8.h"
+#include "orl_device_split.h"
+
+#ifndef ORL_W
+#error "compile with -DORL_W=1|2|5|8"
+#endif
+
+using namespace orl;
+
+extern __shared__ __attribute__((aligned(16))) unsigned char orl_lds_raw[];
+
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsigned char* mask) {
+  const i64 env = blockIdx.x;
+  const int lane = lane_id();
+  if (mask && !mask[env]) return;
+  Env e;
+  env_load(P, e, env, lane);
+  if (!full) {
+    soft_reset<ENV>(e);
+    env_store(P, e, lane);
+    return;
+  }
+  u64* lds = (u64*)orl_lds_raw;
+  e.bm = lds;
+  e.ls = (double*)(lds + P.bm_words);
+  e.scratch = e.ls + 4 * P.E;
+  e.obs_l = e.scratch + P.E;
+  e.cs = (int*)(e.obs_l + P.obs_dim);
+  // available_slots = ones (rmsa_env.py:337-339); bits >= S stay 0
+  for (int i = lane; i < P.bm_words; i += 64) {
+    int w = i % W;
+    int c = P.S - 64 * w;
+    u64 v = c >= 64 ? ~0ull : (c <= 0 ? 0ull : ((1ull << c) - 1ull));
+    lds[i] = (i < P.C * P.E * W) ? v : 0ull;
+  }
+  for (int i = lane; i < 4 * P.E; i += 64) e.ls[i] = 0.0;
+  for (int i = lane; i < P.cs_words; i += 64) e.cs[i] = 0;
+  for (int i = lane; i < P.ev_cap; i += 64) e.ev_time[i] = __builtin_inf();
+  if (P.br_hist) for (int i = lane; i < 2 * P.n_br; i += 64) P.br_hist[env * 2 * P.n_br + i] = 0;
+  if (P.act_hist) for (int i = lane; i < (P.K + 1) + (P.S + 1); i += 64) P.act_hist[env * ((P.K + 1) + (P.S + 1)) + i] = 0;
+  if (P.act2d) for (int i = lane; i < P.act2d_words; i += 64) P.act2d[env * P.act2d_words + i] = 0;
+  wave_fence();
+  e.now = 0; e.at = 0; e.ht = 0; e.g_thr = 0; e.g_comp = 0; e.g_last = 0;
+  e.sp = e.sa = e.esp = e.esa = e.brq = e.brp = e.ebrq = e.ebrp = e.s_br = e.s_nh = 0;
+  e.src = e.dst = e.bit_rate = e.br_idx = e.id = 0;
+  e.ev_hwm = 0; e.ev_cnt = 0; e.new_service = 0; e.flags = 0;
+  next_service<ENV, W, false>(P, e, lane, nullptr);
+  stage_out(P, e, lane);
+  env_store(P, e, lane);
+}
+
+// Slot-scan kernel.  GS lanes per env: a wavefront serves 64/GS envs whose slot maps are contiguous in HBM.  Link rows are
+// read straight from global memory (each lane the 8W-byte rows of its own path).  A/B on MI355X, cfg2, B = 65 536: 17.2 us per
+// launch vs 19.4 us with the maps staged through LDS first — the 28 KB/workgroup LDS window capped residency at 5
+// workgroups/CU and cost a second dispatch round, while the 7-KB-per-wave footprint stays L2/TCP resident.
+#ifndef ORL_POLICY_WAVES
+#define ORL_POLICY_WAVES 4  // wavefronts per workgroup in the slot-scan kernel
+#endif
+template <int ENV, int W, int GS>
+__global__ void __launch_bounds__(64 * ORL_POLICY_WAVES) k_policy(DevParams P, int pol) {
+  constexpr int EPW = 64 / GS;  // envs per wavefront
+  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+  const i64 env0 = ((i64)blockIdx.x * ORL_POLICY_WAVES + wave) * EPW;
+  if (env0 >= P.B) return;
+  const u64* maps = P.bitmap + env0 * P.bm_words;
+  const int grp = lane / GS;
+  const i64 env = env0 + grp;
+  const bool valid = env < P.B;
+  u64 d = valid ? P.svc_desc[env] : 0ull;
+  int a[4];
+  policy_g<ENV, W, GS>(P, maps + (size_t)grp * P.bm_words, valid, (int)(u32)d, (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu),
+                       lane, pol, valid ? P.path_col[env] : 0, a);
+  if (valid && (lane & (GS - 1)) == 0) *(int4*)(P.actions + env * 4) = make_int4(a[0], a[1], a[2], a[3]);
+}
+
+#ifndef ORL_STEP_WAVES
+#define ORL_STEP_WAVES 5  // waves per SIMD the register allocator must leave room for (measured: 4 -> 428 us, 5 -> 389 us, 6 -> 436 us)
+#endif
+template <int ENV, int W, bool EVL>
+__global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int auto_reset, int want_info, int pol) {
+  const i64 env = blockIdx.x;
+  const int lane = lane_id();
+  Env e;
+  // Round trip 1: everything addressed by the env index alone is requested before anything is waited for — the
+  // scalar record, the action, the slot map / link statistics / per-core sums (into LDS), the source-node table.
+  const u64 sv = env_fetch(P, env, lane);
+  int4 av = (pol < 0) ? *(const int4*)(P.actions + env * 4) : make_int4(0, 0, 0, 0);
+  Prefetch pf;
+  pf.have_cum = P.N <= 64;
+  pf.cum_my = pf.have_cum ? P.cum_src[lane < P.N - 1 ? lane : P.N - 1] : 0.0;
+  e.env = env;
+  stage_in(P, e, (u64*)orl_lds_raw, lane);
+  env_unpack(P, e, env, lane, sv);
+  if (pol >= 0) {
+    // device-resident loop of the batches the persistent kernel does not take: the slot scan runs right here on the LDS copy
+    // of the slot map (lanes = paths, or (path, core) pairs) — one launch and one read of the map per policy + step
+    int a[4];
+    policy_g<ENV, W, 64>(P, e.bm, true, pair_base(P, e.src, e.dst), e.br_idx, P.n_paths[e.src * P.N + e.dst], lane, pol,
+                         P.path_col[env], a);
+    av = make_int4(a[0], a[1], a[2], a[3]);
+    if (lane == 0) *(int4*)(P.actions + env * 4) = av;
+  }
+  // Round trip 2: what the scalar record addresses — the MT window of the next service, the pending release times
+  // (EVL: into LDS for all scans) and the path record + slot count of the action's path.
+  Rng pre;
+  rng_fill(e, pre, lane);
+  {
+    const int route = (ENV == ENV_DEEPRMSA) ? (av.x >= 0 ? av.x / P.J : P.K) : av.x;
+    pf.have_rec = route >= 0 && route < P.K;
+    pf.pidx = pair_base(P, e.src, e.dst) + (pf.have_rec ? route : 0);
+    const PathRec r0 = path_rec_load(P, pf.pidx);
+    pf.rq0 = r0.q[0]; pf.rq1 = r0.q[1]; pf.rq2 = r0.q[2]; pf.rq3 = r0.q[3];
+    pf.nslots = P.nslots_path[(size_t)pf.pidx * P.n_br + e.br_idx];
+  }
+  if (EVL) {
+    e.evl = (double*)((unsigned char*)orl_lds_raw + P.lds_bytes);
+    for (int i = lane; i < e.ev_hwm; i += 64) e.evl[i] = e.ev_time[i];
+    wave_fence();
+  }
+  int act[4] = {av.x, av.y, av.z, av.w};
+  step<ENV, W, EVL>(P, e, lane, act, auto_reset, P.reward + env, P.done + env,
+                    want_info ? P.info + env * P.n_info : nullptr,
+                    P.obs_dim ? P.obs + env * P.obs_dim : nullptr,
+                    P.obs_dim ? P.term_obs + env * P.obs_dim : nullptr, &pre, &pf);
+  stage_out(P, e, lane);
+  env_store(P, e, lane);
+}
+
+template <int W>
+__device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, int with_terminal);
+
+#ifdef ORL_ALT_IMPLS
+// ---- two-kernel form of the persistent kernel's phases (cross-checks, per-kernel timing): k_step_a2 ; k_rows2 ------------
+template <int ENV, int W, bool FUSED_POLICY>
+__global__ void __launch_bounds__(256) k_step_a2(DevParams P, int pol, int parity) {
+  __shared__ u32 s_tally[32 * 32];
+  const int lane = lane_id();
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool valid = env < P.B;
+  sp::Prof prof;
+  ORL_PROFA_BEGIN();
+  if (FUSED_POLICY) {
+    const i64 env0 = env - ((lane >> 3));  // first env of this wavefront
+    u64 d = valid ? P.svc_desc[env] : 0ull;
+    int a[4];
+    policy_g<ENV, W, 8>(P, P.bitmap + env0 * P.bm_words + (size_t)(lane >> 3) * P.bm_words, valid, (int)(u32)d,
+                        (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane, pol, valid ? P.path_col[env] : 0, a);
+    const int4 av = make_int4(a[0], a[1], a[2], a[3]);
+    if (valid && (lane & 7) == 0) *(int4*)(P.actions + env * 4) = av;
+    ORL_PROFA(1);
+    sp::ctrl_a<ENV, W>(P, env, valid, lane, prof, &av, s_tally, (sp::SinkEntry*)orl_lds_raw, parity);
+  } else {
+    sp::ctrl_a<ENV, W>(P, env, valid, lane, prof, nullptr, s_tally, (sp::SinkEntry*)orl_lds_raw, parity);
+  }
+  ORL_PROFA_END();
+}
+// One lane per mixed item; one 192-thread workgroup per control workgroup (32 envs, ~140 items): a thread handles at most one
+// item in all but one launch in 10^3, so the kernel's duration is one item's dependent chain.
+#define ORL_ROWS2_THREADS 192
+template <int ENV, int W>
+__global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int parity) {
+  constexpr int NR = 4;
+  sp::Prof prof;
+  ORL_PROFR_BEGIN();
+  const u32 r0 = blockIdx.x * NR;
+  const u32 n_regions = (u32)((P.B + 31) / 32) * 4u;
+  const u32* cnt = P.q_cnt_a + r0;
+  u32 cum[NR + 1];
+  cum[0] = 0;
+#pragma unroll
+  for (int j = 0; j < NR; j++) cum[j + 1] = cum[j] + ((r0 + j < n_regions) ? cnt[j] : 0u);
+  const ulonglong2* q = P.q_a + (size_t)r0 * P.q_wave * 2;
+  for (u32 idx = threadIdx.x; idx < cum[NR]; idx += ORL_ROWS2_THREADS) {
+    u32 j = 0, base = 0;
+#pragma unroll
+    for (int t = 1; t < NR; t++)
+      if (idx >= cum[t]) { j = (u32)t; base = cum[t]; }
+    const size_t at = (size_t)j * P.q_wave + (idx - base);
+    ORL_PROFR(1);
+    sp::Item it;
+    it.a = q[2 * at];
+    it.b = q[2 * at + 1];
+    ORL_PROFR(2);
+    sp::row_item_lane<ENV, W>(P, it, prof);
+  }
+  ORL_PROFR(8);
+  ORL_PROFR_END();
+}
+#endif  // ORL_ALT_IMPLS
+
+// ---- persistent kernel -------------------------------------------------------------------------------------------------
+// Envs never interact, so a wavefront can own its 8 envs for a whole run: control phase -> row phase over the items the
+// wavefront itself just emitted (one lane per item) -> next step, with no kernel boundary and no grid-wide tail between the
+// phases; the wavefronts of a launch drift out of phase and keep the memory system uniformly busy.  What one phase writes and
+// the next reads stays within the wavefront's CU (same L1).  A wavefront in which an env's releases did not fit the item form
+// (one env-step in 10^7) leaves the loop after that step's row phase; k_rel_tail follows every launch, and the wavefront
+// resumes from its own step count in the next launch.
+#ifndef ORL_PERSIST_WAVES
+#define ORL_PERSIST_WAVES 4   // waves per SIMD the register allocator must leave room for
+#endif
+template <int ENV, int W>
+__device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
+  __shared__ u32 s_tally[32 * 8];
+  __shared__ int s_deferred[2];  // alternating by step
+  const int lane = lane_id();
+  const i64 env = (i64)blockIdx.x * 8 + (threadIdx.x >> 3);
+  int step = wg_step[blockIdx.x];
+  sp::Prof prof;
+  if (threadIdx.x == 0) s_deferred[0] = s_deferred[1] = 0;
+  while (step < target) {
+    __syncthreads();  // (one wavefront: a compiler-level ordering point) the previous row phase's writes are done
+    if (threadIdx.x == 0) s_deferred[(step + 1) & 1] = 0;
+    // per-iteration opaque copies: without them the compiler hoists every per-lane address out of the loop and keeps
+    // them all live across both phases (199 VGPRs instead of ~128)
+    int env_lo = (int)env, lane_i = lane;
+    asm volatile("" : "+v"(env_lo), "+v"(lane_i));
+    const i64 env_i = (i64)env_lo;
+    const bool valid_i = env_i < P.B;
+    const i64 env0_i = env_i - (lane_i >> 3);
+    {
+      u64 d = valid_i ? P.svc_desc[env_i] : 0ull;
+      int a[4];
+      policy_g<ENV, W, 8>(P, P.bitmap + env0_i * P.bm_words + (size_t)(lane_i >> 3) * P.bm_words, valid_i, (int)(u32)d,
+                          (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane_i, pol, valid_i ? P.path_col[env_i] : 0, a);
+      const int4 av = make_int4(a[0], a[1], a[2], a[3]);
+      if (valid_i && (lane_i & 7) == 0) *(int4*)(P.actions + env_i * 4) = av;
+      sp::ctrl_a<ENV, W>(P, env_i, valid_i, lane_i, prof, &av, s_tally, (sp::SinkEntry*)orl_lds_raw, 0, &s_deferred[step & 1]);
+    }
+    __syncthreads();  // items, fill counts, env records
+    {
+      u32 r0 = blockIdx.x, tid = threadIdx.x;
+      asm volatile("" : "+s"(r0), "+v"(tid));
+      const u32 n_items = P.q_cnt_a[r0];
+      const ulonglong2* q = P.q_a + (size_t)r0 * P.q_wave * 2;
+      for (u32 idx = tid; idx < n_items; idx += 64) {
+        sp::Item it;
+        it.a = q[2 * idx];
+        it.b = q[2 * idx + 1];
+        sp::row_item_lane<ENV, W>(P, it, prof);
+      }
+    }
+    if (ENV == ENV_DEEPRMSA) {  // the observation of the new pending service, from the rows as they are now
+      __syncthreads();
+      if (valid_i) obs8_env<W>(P, env_i, lane_i, 1);
+    }
+    step++;
+    if (s_deferred[(step - 1) & 1]) break;  // set before the barrier in front of the row phase
+  }
+  if (threadIdx.x == 0) {
+    wg_step[blockIdx.x] = step;
+    if (step < target) atomicAdd(n_unfinished, 1u);
+  }
+}
+// Two register budgets of the same body: 4 waves/SIMD (128 VGPRs) for NSFNET-sized RMSA / RWA / DeepRMSA, 3 waves/SIMD
+// (168 VGPRs, no spills) for the heavier RMCSA and Germany50 steps (cfg4 5.0e8 vs 4.6e8, cfg5 3.4e8 vs 3.2e8).
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_PERSIST_WAVES, ORL_PERSIST_WAVES)))
+k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
+  persist_body<ENV, W>(P, pol, target, wg_step, n_unfinished);
+}
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_persist3(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
+  persist_body<ENV, W>(P, pol, target, wg_step, n_unfinished);
+}
+
+// serial tail, one small workgroup per launch: the envs whose releases of this step did not fit the item form (about
+// one env-step in 10^7; the control phase appends them to q_def) release them in place, 8 lanes per env.  A launch of its
+// own because inlined into the row phase this code cost it half its occupancy.  DeepRMSA: the observation the persistent
+// kernel wrote for such an env predates these releases and is written again.
+template <int ENV, int W>
+__global__ void __launch_bounds__(256) k_rel_tail(DevParams P, int buffer) {
+  u32* dq = P.q_def + (size_t)buffer * P.q_def_stride;
+  const u32 nd = dq[0];
+  for (u32 d = threadIdx.x >> 3; d < nd; d += 32u) {
+    const i64 env = (i64)dq[16 + d];
+    sp::rel_serial<ENV, W>(P, env, lane_id());
+    if (ENV == ENV_DEEPRMSA && P.obs_dim) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      obs8_env<W>(P, env, lane_id(), 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) dq[0] = 0u;  // a following launch of any form starts from an empty list
+}
+
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) k_obs(DevParams P, int with_terminal) {
+  const i64 env = blockIdx.x;
+  const int lane = lane_id();
+  Env e;
+  env_load(P, e, env, lane);
+  stage_in(P, e, (u64*)orl_lds_raw, lane);
+  // after a step: an env that just finished its episode also gets the observation as `terminal_observation` (the soft
+  // reset keeps the pending service, so the values are the same; SB3 VecEnv convention)
+  if (ENV == ENV_DEEPRMSA)
+    deep_observation<W>(P, e, lane, P.obs + env * P.obs_dim, (with_terminal && P.done[env]) ? P.term_obs + env * P.obs_dim : nullptr);
+}
+
+// DeepRMSAEnv.observation (deeprmsa_env.py:60-121) with 8 lanes per env, lane = path (k <= 8), 8 envs per wavefront: rows
+// are read straight from global memory (the form of the slot scan), every lane writes its own path block.  The
+// one-wavefront-per-env k_obs above staged the whole slot map in LDS and took 26.7 us per 32 768-env launch (cfg3).
+template <int W>
+__device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, int with_terminal) {
+  const int gl = lane & 7;
+  const u64* s = P.scal + env * ORL_SCAL_WORDS;
+  u64 t = s[SC_SRC_DST];
+  const int src = (int)(u32)t, dst = (int)(t >> 32);
+  t = s[SC_BR_IDX];
+  const int bit_rate = (int)(u32)t, br_idx = (int)(t >> 32);
+  const int N = P.N, J = P.J, S = P.S, WD = 2 * J + 3;
+  double* o = P.obs + env * P.obs_dim;
+  double* o2 = (with_terminal && P.done[env]) ? P.term_obs + env * P.obs_dim : nullptr;
+  const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
+  for (int i = gl; i < 1 + 2 * N; i += 8) {
+    const double v = (i == 0) ? (double)bit_rate / 100 : ((i == 1 + mn || i == 1 + N + mx) ? 1.0 : 0.0);
+    o[i] = v;
+    if (o2) o2[i] = v;
+  }
+  if (gl < P.K) {
+    double f[19];  // 2 * J + 3 <= 19
+#pragma unroll
+    for (int i = 0; i < 19; i++) f[i] = -1.0;
+    if (gl < P.n_paths[src * N + dst]) {
+      const int pidx = (src * N + dst) * P.K + gl;
+      const Row<W> m = path_and_rec<W>(path_rec_load(P, pidx), P.bitmap + env * P.bm_words, P.E, S, 0);
+      const int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
+      Row<W> r = row_runs_ge<W>(m, n);
+      const Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        if (b < J && row_any<W>(r)) {
+          const int st = row_ctz<W>(r);
+          const Row<W> z = row_andn<W>(zeros, row_mask_lo<W>(st));
+          const int end = row_any<W>(z) ? row_ctz<W>(z) : S;
+          f[2 * b] = 2 * ((double)st - 0.5 * (double)S) / (double)S;
+          f[2 * b + 1] = (double)(end - st - 8) / 8;
+          r = row_andn<W>(r, row_mask_lo<W>(end));
+        }
+      }
+      const double fn = ((double)n - 5.5) / 3.5;
+      const int tot = row_popc<W>(m);
+      const double ft = 2 * ((double)tot - 0.5 * (double)S) / (double)S;
+      const int nruns = row_popc<W>(row_starts<W>(m));
+      const double fr = (nruns > 0) ? ((double)tot / (double)nruns - 4) / 4 : -1.0;
+      // f[2J], f[2J+1], f[2J+2] with a run-time J: written below by position
+#pragma unroll
+      for (int i = 0; i < 19; i++) f[i] = (i == 2 * J) ? fn : (i == 2 * J + 1) ? ft : (i == 2 * J + 2) ? fr : f[i];
+    }
+    double* sp = o + 1 + 2 * N + gl * WD;
+#pragma unroll
+    for (int i = 0; i < 19; i++)
+      if (i < WD) { sp[i] = f[i]; if (o2) o2[1 + 2 * N + gl * WD + i] = f[i]; }
+  }
+}
+template <int W>
+__global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
+  const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (env >= P.B) return;
+  obs8_env<W>(P, env, lane_id(), with_terminal);
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+#define ORL_FOR_ENV(B_, MACRO)                              \
+  switch ((B_)->P.env_type) {                               \
+    case ENV_RMSA: { MACRO(ENV_RMSA) } break;               \
+    case ENV_DEEPRMSA: { MACRO(ENV_DEEPRMSA) } break;       \
+    case ENV_RWA: { MACRO(ENV_RWA) } break;                 \
+    default: { MACRO(ENV_RMCSA) } break;                    \
+  }
+
+namespace orl_launch {
+
+template <int W> void reset(orl_batch* b, int full, const unsigned char* dmask) {
+  const DevParams& VP = b->P;
+  dim3 g((unsigned)VP.B), blk(64);
+  size_t lds = VP.lds_bytes;
+#define PER_ENV(E_) hipLaunchKernelGGL((k_reset<E_, W>), g, blk, lds, b->stream, VP, full, dmask);
+  ORL_FOR_ENV(b, PER_ENV)
+#undef PER_ENV
+}
+
+template <int W> void policy(orl_batch* b, int pol) {
+  const DevParams& VP = b->P;
+  // RMCSA scans (path, core) pairs: one env per wavefront.  The other families put 8 envs on a wavefront when k <= 8.
+  const bool wide = (VP.env_type == ENV_RMCSA) || VP.K > 8;
+  const i64 per_wg = ORL_POLICY_WAVES * (wide ? 1 : 8);
+  dim3 g((unsigned)((VP.B + per_wg - 1) / per_wg)), blk(64 * ORL_POLICY_WAVES);
+#define PER_ENV(E_)                                                                             \
+  if (wide) hipLaunchKernelGGL((k_policy<E_, W, 64>), g, blk, 0, b->stream, VP, pol);           \
+  else hipLaunchKernelGGL((k_policy<E_, W, 8>), g, blk, 0, b->stream, VP, pol);
+  ORL_FOR_ENV(b, PER_ENV)
+#undef PER_ENV
+  ORL_TK(b, "k_policy");
+}
+
+template <int W> void step64(orl_batch* b, int auto_reset, int want_info, int fused_policy) {
+  const DevParams& VP = b->P;
+  dim3 g((unsigned)VP.B), blk(64);
+  // stage the pending release times through LDS when the per-env window stays small enough for 5 waves/SIMD
+  const size_t ev_bytes = (size_t)VP.ev_cap * 8;
+  const bool evl = (VP.lds_bytes + ev_bytes) <= 8 * 1024;
+  size_t lds = VP.lds_bytes + (evl ? ev_bytes : 0);
+#define PER_ENV(E_)                                                                                                          \
+  if (evl) hipLaunchKernelGGL((k_step<E_, W, true>), g, blk, lds, b->stream, VP, auto_reset, want_info, fused_policy);       \
+  else hipLaunchKernelGGL((k_step<E_, W, false>), g, blk, lds, b->stream, VP, auto_reset, want_info, fused_policy);
+  ORL_FOR_ENV(b, PER_ENV)
+#undef PER_ENV
+  ORL_TK(b, "k_step");
+}
+
+template <int W> void obs(orl_batch* b, int with_terminal) {
+  const DevParams& VP = b->P;
+  if (VP.K <= 8 && VP.J <= 8) {
+    hipLaunchKernelGGL((k_obs8<W>), dim3((unsigned)((VP.B + 31) / 32)), dim3(256), 0, b->stream, VP, with_terminal);
+  } else {
+    hipLaunchKernelGGL((k_obs<ENV_DEEPRMSA, W>), dim3((unsigned)VP.B), dim3(64), (size_t)VP.lds_bytes, b->stream, VP, with_terminal);
+  }
+  ORL_TK(b, "k_obs");
+}
+
+template <int W> void persist(orl_batch* b, int pol, int target) {
+  const DevParams& VP = b->P;
+  dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64), blk_tail(256);
+  const size_t lds_a = (size_t)8 * VP.E * sizeof(sp::SinkEntry);
+  const bool roomy = VP.env_type == ENV_RMCSA || VP.E >= 64;  // 3 waves/SIMD without spills (see k_persist3)
+#define PER_ENV(E_)                                                                                                          \
+  if (roomy) hipLaunchKernelGGL((k_persist3<E_, W>), gc, blk, lds_a, b->stream, VP, pol, target, b->d_wg_step, b->d_unfinished); \
+  else hipLaunchKernelGGL((k_persist<E_, W>), gc, blk, lds_a, b->stream, VP, pol, target, b->d_wg_step, b->d_unfinished);    \
+  hipLaunchKernelGGL((k_rel_tail<E_, W>), dim3(1), blk_tail, 0, b->stream, VP, 0);
+  ORL_FOR_ENV(b, PER_ENV)
+#undef PER_ENV
+}
+
+template <int W> void step2(orl_batch* b, int pol) {
+#ifdef ORL_ALT_IMPLS
+  const DevParams& VP = b->P;
+  const bool wide = VP.K > 8;
+  if (wide) policy<W>(b, pol);  // k > 8: the one-env-per-wavefront slot scan stays a launch of its own
+  dim3 gc((unsigned)((VP.B + 31) / 32)), blk(256), blk_r(ORL_ROWS2_THREADS);
+  const size_t lds_a = (size_t)32 * VP.E * sizeof(sp::SinkEntry);
+  int& par = b->parity;
+#define PER_ENV(E_)                                                                                                          \
+  if (wide) {                                                                                                                \
+    if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_step_a2<E_, W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
+    hipLaunchKernelGGL((k_step_a2<E_, W, false>), gc, blk, lds_a, b->stream, VP, pol, par);                                  \
+  } else {                                                                                                                   \
+    if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_step_a2<E_, W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
+    hipLaunchKernelGGL((k_step_a2<E_, W, true>), gc, blk, lds_a, b->stream, VP, pol, par);                                   \
+  }                                                                                                                          \
+  ORL_TK(b, "k_step_a2");                                                                                                    \
+  hipLaunchKernelGGL((k_rows2<E_, W>), gc, blk_r, 0, b->stream, VP, par);                                                    \
+  ORL_TK(b, "k_rows2");                                                                                                      \
+  hipLaunchKernelGGL((k_rel_tail<E_, W>), dim3(1), blk, 0, b->stream, VP, par);                                              \
+  ORL_TK(b, "k_rel_tail");
+  ORL_FOR_ENV(b, PER_ENV)
+#undef PER_ENV
+  par ^= 1;
+  if (VP.obs_dim) obs<W>(b, 1);
+#else
+  (void)b; (void)pol;
+#endif
+}
+
+template void reset<ORL_W>(orl_batch*, int, const unsigned char*);
+template void policy<ORL_W>(orl_batch*, int);
+template void step64<ORL_W>(orl_batch*, int, int, int);
+template void obs<ORL_W>(orl_batch*, int);
+template void persist<ORL_W>(orl_batch*, int, int);
+template void step2<ORL_W>(orl_batch*, int);
+
+}  // namespace orl_launch

@@ -17,7 +17,8 @@ import numpy as np
 from . import _lib
 from .topology import Topology
 
-POLICIES = {"SP_FF": 0, "SAP_FF": 1, "KSP_FF": 1, "LLP_FF": 2, "SAP_LF": 3, "SP": 0, "SAP": 1, "SAP_BM_FC_FF": 1}
+POLICIES = {"SP_FF": 0, "SAP_FF": 1, "KSP_FF": 1, "LLP_FF": 2, "SAP_LF": 3, "SP": 0, "SAP": 1, "SAP_BM_FC_FF": 1,
+            "PATH_FF": 4}
 
 RMSA_INFO_KEYS = ["service_blocking_rate", "episode_service_blocking_rate", "bit_rate_blocking_rate",
                   "episode_bit_rate_blocking_rate", "network_compactness", "network_compactness_difference",
@@ -64,8 +65,9 @@ class BatchedOpticalEnv:
                num_spectrum_resources, allow_rejection, node_request_probabilities, channel_width,
                bit_rate_selection="continuous", bit_rates=(10, 40, 100), bit_rate_probabilities=None,
                bit_rate_lower_bound=25, bit_rate_higher_bound=100, j=1, num_spatial_resources=1,
-               modulations=None, worst_xt=None, event_capacity=0):
-        self.lib = _lib.lib()
+               modulations=None, worst_xt=None, event_capacity=0, action_histograms=False):
+        self.lib = _lib.lib()  # ORL_LIB_VARIANT=alt selects the -DORL_ALT_IMPLS build (cross-implementation tests)
+        self.action_histograms = bool(action_histograms)
         self.topology = Topology.load(topology) if isinstance(topology, str) else topology
         t = self.topology
         self.num_envs = int(num_envs)
@@ -171,9 +173,10 @@ class BatchedOpticalEnv:
                                  _ptr(keep["path_hops"]), _ptr(keep["path_links"]), _ptr(keep["path_length"]),
                                  _ptr(keep["path_mod"]), _ptr(keep["edge_iter_order"]))
         self._topo_h = C.c_void_p()
-        _lib.check(self.lib.orl_topology_create(C.byref(desc), device_id, C.byref(self._topo_h)))
+        self._ck(self.lib.orl_topology_create(C.byref(desc), device_id, C.byref(self._topo_h)))
         cfg = _lib.EnvConfig(self.ENV_TYPE, num_spectrum_resources, num_spatial_resources, episode_length,
-                             int(self.allow_rejection), j, mode, lo, hi, len(table_rates), event_capacity, 0,
+                             int(self.allow_rejection), j, mode, lo, hi, len(table_rates), event_capacity,
+                             int(self.action_histograms),
                              lambda_a, lambda_h, _ptr(cum_src), _ptr(keep["cum_dst"]), _ptr(keep["bit_rates"]),
                              _ptr(cum_br), _ptr(keep["n_slots"]), _ptr(lmax_snr), _ptr(lmax_xt))
         self._h = C.c_void_p()
@@ -181,11 +184,11 @@ class BatchedOpticalEnv:
         if all(-2**63 < s_ < 2**63 for s_ in int_seeds):
             # device-side random.Random(seed): no 2.5 KB/env upload, no Python loop over envs
             sd = np.array(int_seeds, np.int64)
-            _lib.check(self.lib.orl_batch_create_seeded(C.byref(cfg), self._topo_h, self.num_envs, sd.ctypes.data,
+            self._ck(self.lib.orl_batch_create_seeded(C.byref(cfg), self._topo_h, self.num_envs, sd.ctypes.data,
                                                         C.byref(self._h)))
         else:  # seeds beyond 64 bits: let CPython expand them
             st = mt_states(self.seeds)
-            _lib.check(self.lib.orl_batch_create(C.byref(cfg), self._topo_h, self.num_envs, st.ctypes.data,
+            self._ck(self.lib.orl_batch_create(C.byref(cfg), self._topo_h, self.num_envs, st.ctypes.data,
                                                  C.byref(self._h)))
         self.n_info = self.lib.orl_batch_info_dim(self._h)
         self.obs_dim = self.lib.orl_batch_obs_dim(self._h)
@@ -198,10 +201,13 @@ class BatchedOpticalEnv:
         self._info = self._host_array((n, self.n_info), np.float64)
         self._obs = self._host_array((n, self.obs_dim), np.float64) if self.obs_dim else None
 
+    def _ck(self, rc):
+        _lib.check(rc, self.lib)
+
     def _host_array(self, shape, dtype):
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = C.c_void_p()
-        _lib.check(self.lib.orl_host_alloc(max(nbytes, 1), C.byref(ptr)))
+        self._ck(self.lib.orl_host_alloc(max(nbytes, 1), C.byref(ptr)))
         buf = (C.c_ubyte * max(nbytes, 1)).from_address(ptr.value)
         buf._block = _PinnedBlock(self.lib, ptr)  # freed when the last numpy view of it is gone, not at close()
         return np.frombuffer(buf, dtype=np.uint8, count=nbytes).view(dtype).reshape(shape)
@@ -224,14 +230,23 @@ class BatchedOpticalEnv:
     def reset(self, full=False, mask=None):
         """reset(only_episode_counters = not full) for the envs selected by `mask` (default: all)."""
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
-        _lib.check(self.lib.orl_batch_reset(self._h, int(full), _ptr(m)))
+        self._ck(self.lib.orl_batch_reset(self._h, int(full), _ptr(m)))
         return self.observation() if self.obs_dim else None
 
-    def policy(self, policy, fetch=True):
+    def set_paths(self, paths):
+        """The path each env's agent chose (PathOnlyFirstFitAction's Discrete(k + reject) action) for policy "PATH_FF"."""
+        p = np.ascontiguousarray(np.asarray(paths).reshape(self.num_envs), np.int32)
+        self._ck(self.lib.orl_batch_set_paths(self._h, p.ctypes.data))
+
+    def policy(self, policy, fetch=True, paths=None):
         """On-device heuristic; returns [num_envs, 4] int32 actions (or None with fetch=False: they stay on
-        the GPU for the next step(None))."""
+        the GPU for the next step(None)).  policy "PATH_FF" (PathOnlyFirstFitAction, rmsa_env.py:840-874 /
+        rwa_env.py:505-536) takes the agents' path choices in `paths` (or from a previous set_paths / the "paths"
+        device array)."""
         pid = POLICIES[policy] if isinstance(policy, str) else int(policy)
-        _lib.check(self.lib.orl_batch_policy(self._h, pid, self._act.ctypes.data if fetch else None))
+        if paths is not None:
+            self.set_paths(paths)
+        self._ck(self.lib.orl_batch_policy(self._h, pid, self._act.ctypes.data if fetch else None))
         return self._act if fetch else None
 
     def step(self, actions, auto_reset=False, fetch=True):
@@ -245,25 +260,43 @@ class BatchedOpticalEnv:
             a = self._act_in  # columns beyond the family's action width stay zero from allocation
             a[:, : actions.shape[1]] = actions
         if fetch:
-            _lib.check(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), _ptr(self._obs), self._reward.ctypes.data,
+            self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), _ptr(self._obs), self._reward.ctypes.data,
                                                self._done.ctypes.data, self._info.ctypes.data))
             return self._obs, self._reward, self._done, self._info
-        _lib.check(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), None, None, None, None))
+        self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), None, None, None, None))
         return None
 
     def run(self, policy, n_steps, time_kernels=False):
         """n_steps x (policy; step with auto reset) without leaving the device; returns RunStats."""
         pid = POLICIES[policy] if isinstance(policy, str) else int(policy)
         st = _lib.RunStats()
-        _lib.check(self.lib.orl_batch_run(self._h, pid, int(n_steps), int(time_kernels), C.byref(st)))
+        self._ck(self.lib.orl_batch_run(self._h, pid, int(n_steps), int(time_kernels), C.byref(st)))
         return st
 
     def sync(self):
-        _lib.check(self.lib.orl_batch_sync(self._h))
+        self._ck(self.lib.orl_batch_sync(self._h))
+
+    def check(self):
+        """Synchronise and raise what the kernels flagged since the last report: IndexError for a device-resident action
+        outside the action space (rmsa_env.py:167), OverflowError when an env ran out of pending-release slots."""
+        self._ck(self.lib.orl_batch_check(self._h))
+
+    def seed(self, seeds, mask=None):
+        """seed(seed) of the selected envs (optical_network_env.py:205-210): env i continues with the stream of
+        random.Random(seeds[i]); a scalar means seed + i.  Nothing else of the state changes."""
+        if np.isscalar(seeds):
+            seeds = [int(seeds) + i for i in range(self.num_envs)]
+        sd = np.array([41 if x is None else int(x) for x in seeds], np.int64)
+        assert sd.shape == (self.num_envs,)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self._ck(self.lib.orl_batch_reseed(self._h, sd.ctypes.data, _ptr(m)))
+        for i in range(self.num_envs):
+            if m is None or m[i]:
+                self.seeds[i] = int(sd[i])
 
     # ---- zero-copy device views (an agent on the same GPU: no PCIe in the loop) -------------------------
     _BUFFERS = {"actions": (0, "<i4", 4), "reward": (1, "<f8", 0), "done": (2, "|u1", 0), "info": (3, "<f8", -1),
-                "obs": (4, "<f8", -2), "terminal_obs": (5, "<f8", -2)}
+                "obs": (4, "<f8", -2), "terminal_obs": (5, "<f8", -2), "paths": (6, "<i4", 0)}
 
     def device_array(self, name):
         """The batch's device-resident I/O array `name` as an object with `__cuda_array_interface__` (what
@@ -271,7 +304,7 @@ class BatchedOpticalEnv:
         `step(None, fetch=False)`, `sync()`, read "reward" / "done" / "info" / "obs" in place."""
         which, typestr, cols = self._BUFFERS[name]
         ptr, n = C.c_void_p(), C.c_int64()
-        _lib.check(self.lib.orl_batch_device_buffer(self._h, which, C.byref(ptr), C.byref(n)))
+        self._ck(self.lib.orl_batch_device_buffer(self._h, which, C.byref(ptr), C.byref(n)))
         cols = {-1: self.n_info, -2: self.obs_dim}.get(cols, cols)
         if n.value == 0 or not ptr.value:
             raise _lib.OrlError("this env family has no '%s' array" % name)
@@ -293,38 +326,38 @@ class BatchedOpticalEnv:
     def observation(self):
         if not self.obs_dim:
             return None
-        _lib.check(self.lib.orl_batch_observation(self._h, self._obs.ctypes.data))
+        self._ck(self.lib.orl_batch_observation(self._h, self._obs.ctypes.data))
         return self._obs
 
     # ---- state read-back -------------------------------------------------------------------------
     def services(self):
         out = np.zeros((self.num_envs, 6))
-        _lib.check(self.lib.orl_batch_get_services(self._h, out.ctypes.data))
+        self._ck(self.lib.orl_batch_get_services(self._h, out.ctypes.data))
         return out
 
     def counters(self):
         out = np.zeros((self.num_envs, 8), np.int64)
-        _lib.check(self.lib.orl_batch_get_counters(self._h, out.ctypes.data))
+        self._ck(self.lib.orl_batch_get_counters(self._h, out.ctypes.data))
         return out
 
     def slots(self, env=0):
         out = np.zeros((self.num_spatial_resources, self.topology.n_links, self.num_spectrum_resources), np.uint8)
-        _lib.check(self.lib.orl_batch_get_slots(self._h, env, out.ctypes.data))
+        self._ck(self.lib.orl_batch_get_slots(self._h, env, out.ctypes.data))
         return out
 
     def link_stats(self, env=0):
         out = np.zeros((4, self.topology.n_links))
-        _lib.check(self.lib.orl_batch_get_link_stats(self._h, env, out.ctypes.data))
+        self._ck(self.lib.orl_batch_get_link_stats(self._h, env, out.ctypes.data))
         return out
 
     def net_stats(self, env=0):
         out = np.zeros(4)
-        _lib.check(self.lib.orl_batch_get_net_stats(self._h, env, out.ctypes.data))
+        self._ck(self.lib.orl_batch_get_net_stats(self._h, env, out.ctypes.data))
         return out
 
     def active(self):
         out = np.zeros(self.num_envs, np.int32)
-        _lib.check(self.lib.orl_batch_get_active(self._h, out.ctypes.data))
+        self._ck(self.lib.orl_batch_get_active(self._h, out.ctypes.data))
         return out
 
     def n_active(self, env=0):
@@ -332,30 +365,51 @@ class BatchedOpticalEnv:
 
     def flags(self):
         out = np.zeros(self.num_envs, np.int32)
-        _lib.check(self.lib.orl_batch_get_flags(self._h, out.ctypes.data))
+        self._ck(self.lib.orl_batch_get_flags(self._h, out.ctypes.data))
         return out
+
+    def action_histograms_of(self, env=0):
+        """(actions_output, actions_taken) of env `env` as [k_paths+1, slots+1] int arrays (rmsa_env.py:126-137; RWA's
+        arrays are the top-left [k+reject, slots+reject] corner, rwa_env.py:52-58).  Needs action_histograms=True."""
+        K1, S1 = self.k_paths + 1, self.num_spectrum_resources + 1
+        out = np.zeros((2, K1, S1), np.int32)
+        self._ck(self.lib.orl_batch_get_action_histograms(self._h, env, out.ctypes.data))
+        return out[0].astype(np.int64), out[1].astype(np.int64)
+
+    def pending(self, env=0):
+        """The pending releases of env `env` (the reference's `_events` heap, unordered): (release_time[n],
+        records[n, 6] = (src*N+dst, path index, initial slot, number of slots, core, bit rate))."""
+        n = self.lib.orl_batch_get_pending(self._h, env, 0, None, None)
+        if n < 0:
+            self._ck(n)
+        t = np.zeros(max(n, 1), np.float64)
+        rec = np.zeros((max(n, 1), 6), np.int32)
+        n2 = self.lib.orl_batch_get_pending(self._h, env, n, t.ctypes.data, rec.ctypes.data)
+        if n2 < 0:
+            self._ck(n2)
+        return t[:n], rec[:n]
 
     def matrix_observation(self):
         """SimpleMatrixObservation of every env, built on the device: uint8 [num_envs, 2N + C*E*S]."""
         dim = self.lib.orl_batch_matrix_obs_dim(self._h)
         out = np.zeros((self.num_envs, dim), np.uint8)
-        _lib.check(self.lib.orl_batch_matrix_observation(self._h, out.ctypes.data))
+        self._ck(self.lib.orl_batch_matrix_observation(self._h, out.ctypes.data))
         return out
 
     def get_state(self):
         """Opaque snapshot of the whole batch (bytes); restore with set_state()."""
         buf = np.zeros(self.lib.orl_batch_state_bytes(self._h), np.uint8)
-        _lib.check(self.lib.orl_batch_get_state(self._h, buf.ctypes.data))
+        self._ck(self.lib.orl_batch_get_state(self._h, buf.ctypes.data))
         return buf
 
     def set_state(self, buf):
         buf = np.ascontiguousarray(buf, np.uint8)
         assert buf.size == self.lib.orl_batch_state_bytes(self._h)
-        _lib.check(self.lib.orl_batch_set_state(self._h, buf.ctypes.data))
+        self._ck(self.lib.orl_batch_set_state(self._h, buf.ctypes.data))
 
     def totals(self):
         p, a = C.c_int64(), C.c_int64()
-        _lib.check(self.lib.orl_batch_totals(self._h, C.byref(p), C.byref(a)))
+        self._ck(self.lib.orl_batch_totals(self._h, C.byref(p), C.byref(a)))
         return p.value, a.value
 
 
@@ -368,7 +422,7 @@ class BatchedRMSAEnv(BatchedOpticalEnv):
                  mean_service_holding_time=10800.0, num_spectrum_resources=100, bit_rate_selection="continuous",
                  bit_rates=(10, 40, 100), bit_rate_probabilities=None, node_request_probabilities=None,
                  bit_rate_lower_bound=25.0, bit_rate_higher_bound=100.0, seed=None, allow_rejection=False,
-                 reset=True, channel_width=12.5, event_capacity=0):
+                 reset=True, channel_width=12.5, event_capacity=0, action_histograms=False):
         if seeds is None and seed is not None:
             seeds = seed
         self._setup(topology, num_envs, seeds, device_id, episode_length=episode_length, load=load,
@@ -377,7 +431,8 @@ class BatchedRMSAEnv(BatchedOpticalEnv):
                     node_request_probabilities=node_request_probabilities, channel_width=channel_width,
                     bit_rate_selection=bit_rate_selection, bit_rates=bit_rates,
                     bit_rate_probabilities=bit_rate_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
-                    bit_rate_higher_bound=bit_rate_higher_bound, event_capacity=event_capacity)
+                    bit_rate_higher_bound=bit_rate_higher_bound, event_capacity=event_capacity,
+                    action_histograms=action_histograms)
         self.info_keys = list(RMSA_INFO_KEYS)
         if bit_rate_selection == "discrete":
             self.info_keys += ["bit_rate_blocking_%s" % b for b in bit_rates] + ["fairness"]
@@ -391,7 +446,8 @@ class BatchedDeepRMSAEnv(BatchedOpticalEnv):
 
     def __init__(self, topology=None, num_envs=1, seeds=None, device_id=0, j=1, episode_length=1000,
                  mean_service_holding_time=25.0, mean_service_inter_arrival_time=0.1, num_spectrum_resources=100,
-                 node_request_probabilities=None, seed=None, allow_rejection=False, event_capacity=0):
+                 node_request_probabilities=None, seed=None, allow_rejection=False, event_capacity=0,
+                 action_histograms=False):
         if seeds is None and seed is not None:
             seeds = seed
         self._setup(topology, num_envs, seeds, device_id, episode_length=episode_length,
@@ -399,7 +455,7 @@ class BatchedDeepRMSAEnv(BatchedOpticalEnv):
                     mean_service_holding_time=mean_service_holding_time,
                     num_spectrum_resources=num_spectrum_resources, allow_rejection=allow_rejection,
                     node_request_probabilities=node_request_probabilities, channel_width=12.5, j=j,
-                    event_capacity=event_capacity)
+                    event_capacity=event_capacity, action_histograms=action_histograms)
         self.info_keys = list(RMSA_INFO_KEYS)
 
 
@@ -410,14 +466,15 @@ class BatchedRWAEnv(BatchedOpticalEnv):
 
     def __init__(self, topology=None, num_envs=1, seeds=None, device_id=0, episode_length=1000, load=10,
                  mean_service_holding_time=10800.0, num_spectrum_resources=80, node_request_probabilities=None,
-                 allow_rejection=True, seed=None, reset=True, channel_width=50.0, event_capacity=0):
+                 allow_rejection=True, seed=None, reset=True, channel_width=50.0, event_capacity=0,
+                 action_histograms=False):
         if seeds is None and seed is not None:
             seeds = seed
         self._setup(topology, num_envs, seeds, device_id, episode_length=episode_length, load=load,
                     mean_service_holding_time=mean_service_holding_time,
                     num_spectrum_resources=num_spectrum_resources, allow_rejection=allow_rejection,
                     node_request_probabilities=node_request_probabilities, channel_width=channel_width,
-                    event_capacity=event_capacity)
+                    event_capacity=event_capacity, action_histograms=action_histograms)
         rej = self.reject_action
         self.info_keys = (["service_blocking_rate", "episode_service_blocking_rate"]
                           + ["path_action_probability[%d]" % i for i in range(self.k_paths + rej)]

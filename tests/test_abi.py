@@ -48,3 +48,36 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "from oracle" not in src and "import oracle" not in src and "orl_oracle" not in src, f
+
+
+def test_staleness_hash_covers_every_included_source():
+    """A stale .so must never ship with a matching stamp: every file a translation unit #includes (transitively, quoted
+    form) is part of the content hash, and so are the flags and the compiler version."""
+    from optical_rl_gym_amd import _build
+
+    hashed = {os.path.realpath(p) for p in _build.sources()}
+    seen, todo = set(), [os.path.join(_build.CSRC, f) for f in ("orl_api.hip", "orl_kernels.hip")]
+    while todo:
+        path = os.path.realpath(todo.pop())
+        if path in seen:
+            continue
+        seen.add(path)
+        assert path in hashed, "%s is compiled into liborlgpu.so but not hashed" % path
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(path).read()):
+            todo.append(os.path.join(os.path.dirname(path), inc))
+    assert len(seen) >= 8
+    h0 = _build.source_hash()
+    os.environ["ORL_HIPCC_EXTRA"] = "-DORL_SOMETHING"
+    try:
+        assert _build.source_hash() != h0
+    finally:
+        del os.environ["ORL_HIPCC_EXTRA"]
+    assert _build.source_hash("alt") != h0
+    assert len(h0.split()) == 2  # sources+flags, compiler version
+
+
+def test_alt_library_exports_the_same_abi():
+    from optical_rl_gym_amd import _lib
+
+    assert _lib.lib("default").orl_build_has_alt() == 0
+    assert _lib.lib("alt").orl_build_has_alt() == 1

@@ -8,16 +8,24 @@ from tests.helpers import golden_names, load_golden, replay
 
 pytestmark = pytest.mark.gpu
 
-# The library picks the step implementation by batch size and env family (two-kernel pipeline for large batches, one
-# wavefront per env below); the small parity cases run against all of them by forcing it (the variable is read when a
-# batch is created).
-IMPLS = ["wave64", "split", "split2", "persist"]
+# Device-resident runs go through the persistent kernel (k_persist) wherever it applies, host-driven step() through the
+# one-wavefront-per-env kernel (k_step).  The small parity cases run against every implementation by forcing it (the
+# variables are read when a batch is created): "wave64" = k_step for everything, "persist" = the default, "split2" = the
+# phases of the persistent kernel as two separate launches (liborlgpu_alt.so, the -DORL_ALT_IMPLS build).
+IMPLS = ["wave64", "split2", "persist"]
+IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default"),
+            "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt"),
+            "persist": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default")}
+
+
+def force_impl(monkeypatch, name):
+    for k, v in IMPL_ENV[name].items():
+        monkeypatch.setenv(k, v)
 
 
 @pytest.fixture(params=IMPLS)
 def impl(request, monkeypatch):
-    monkeypatch.setenv("ORL_STEP_IMPL", {"wave64": "64", "split": "1", "split2": "2", "persist": "2"}[request.param])
-    monkeypatch.setenv("ORL_PERSIST", "1" if request.param == "persist" else "0")
+    force_impl(monkeypatch, request.param)
     return request.param
 
 
@@ -195,11 +203,10 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
     kw = dict(kw, episode_length=90)
     seeds = [77 + 3 * i for i in range(batch)]
     out = {}
-    for name, v in (("wave64", "64"), ("split", "1"), ("split2", "2"), ("persist", "2")):
-        monkeypatch.setenv("ORL_STEP_IMPL", v)
-        monkeypatch.setenv("ORL_PERSIST", "1" if name == "persist" else "0")
+    for name in IMPLS:
+        force_impl(monkeypatch, name)
         env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
-        env.run(policy, steps // 2)  # two calls: the two-kernel pipeline finishes its pending update between them
+        env.run(policy, steps // 2)  # two calls: the pipeline finishes its pending update between them
         env.run(policy, steps - steps // 2)
         pick = [0, 1, batch // 3, batch - 1]
         if env.obs_dim:  # the observation the run left in the device buffer is the one a fresh evaluation gives
@@ -213,7 +220,7 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
         env.close()
     a = out["wave64"]
     chk = _exact(workload)
-    for other in ("split", "split2", "persist"):
+    for other in ("split2", "persist"):
         b = out[other]
         for key in ("counters", "services", "active", "flags"):
             chk(0, other + " " + key, b[key], a[key])
@@ -234,10 +241,9 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         fam, topo, kw, policy = WORKLOADS[workload]
         kw = dict(kw, episode_length=70)
         seeds = [5 + 11 * i for i in range(batch)]
-        for name, v, masks in (("wave64", "64", None), ("split", "1", "1"), ("split2", "1", "2"), ("two", "2", "1"), ("two2", "2", "2"),
-                               ("persist", "2", "1"), ("persist2", "2", "2")):
-            monkeypatch.setenv("ORL_STEP_IMPL", v)
-            monkeypatch.setenv("ORL_PERSIST", "1" if name.startswith("persist") else "0")
+        for name, v, masks in (("wave64", "wave64", None), ("two", "split2", "1"), ("two2", "split2", "2"),
+                               ("persist", "persist", "1"), ("persist2", "persist", "2")):
+            force_impl(monkeypatch, v)
             if masks:
                 monkeypatch.setenv("ORL_ITEM_MASKS", masks)
             else:
@@ -250,10 +256,10 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
             assert not env.flags().any()
             env.close()
         chk = _exact(workload)
-        for name in ("split", "split2", "two", "two2", "persist", "persist2"):
+        for name in ("two", "two2", "persist", "persist2"):
             for key in ("counters", "services", "active", "slots", "link", "net"):
                 chk(0, name + " " + key, out[name][key], out["wave64"][key])
-        assert out["split"]["serial"] > 100 and out["split2"]["serial"] > 0 and out["two"]["serial"] > 100
+        assert out["two"]["serial"] > 100 and out["two2"]["serial"] > 0 and out["persist"]["serial"] > 100
 
 
 CORNERS = [
@@ -278,9 +284,8 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
 
     seeds = [int(x) for x in np.random.RandomState(len(topo) + batch).randint(0, 2**31 - 1, batch)]
     out = {}
-    for v in ("64", "1", "2", "p"):
-        monkeypatch.setenv("ORL_STEP_IMPL", "2" if v == "p" else v)
-        monkeypatch.setenv("ORL_PERSIST", "1" if v == "p" else "0")
+    for v in IMPLS:
+        force_impl(monkeypatch, v)
         env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
         env.run(policy, 130)
         env.run(policy, 170)
@@ -289,15 +294,15 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
                  [env.slots(i).copy() for i in pick] + [env.link_stats(i).copy() for i in pick] + [env.net_stats(i).copy() for i in pick]
         env.close()
     chk = _exact(fam + "/" + topo)
-    for v in ("1", "2", "p"):
-        for k, (x, y) in enumerate(zip(out[v], out["64"])):
+    for v in ("split2", "persist"):
+        for k, (x, y) in enumerate(zip(out[v], out["wave64"])):
             chk(k, "impl " + v, x, y)
     # ... and that state is the reference's: the first envs against the oracle
     from oracle.oracle import OracleBatch
 
     ora = OracleBatch(fam, topo, seeds[:5], **kw)
     ora.run(policy, 300)
-    ref = out["64"]
+    ref = out["wave64"]
     chk(0, "oracle counters", ref[0][:5], ora.counters())
     chk(0, "oracle services", ref[1][:5], ora.services())
     chk(0, "oracle slots", ref[4], ora.slots(0))
@@ -310,11 +315,8 @@ def test_run_reports_every_kernel_of_the_step(monkeypatch):
     from bench import WORKLOADS
 
     fam, topo, kw, policy = WORKLOADS["cfg2"]
-    monkeypatch.setenv("ORL_PERSIST", "0")
-    for v, names in (("64", ["k_step"]),
-                     ("1", ["k_policy_ctrl_a", "k_rows(provision)", "k_ctrl_b2", "k_rows(release)", "k_rel_tail"]),
-                     ("2", ["k_step_a2", "k_rows2", "k_rel_tail"])):
-        monkeypatch.setenv("ORL_STEP_IMPL", v)
+    for v, names in (("wave64", ["k_step"]), ("split2", ["k_step_a2", "k_rows2", "k_rel_tail"])):
+        force_impl(monkeypatch, v)
         env = orl.make(fam, topology=topo, num_envs=2048, seeds=list(range(2048)), **kw)
         st = env.run(policy, 20, time_kernels=1)
         assert [n for n, _ in st.kernels()] == names
@@ -322,8 +324,7 @@ def test_run_reports_every_kernel_of_the_step(monkeypatch):
         st2 = env.run(policy, 20, time_kernels=2)
         assert st2.ms_policy > 0 and st2.ms_step > 0
         env.close()
-    monkeypatch.setenv("ORL_PERSIST", "1")  # the default: the production run is one launch of the persistent kernel
-    monkeypatch.setenv("ORL_STEP_IMPL", "2")
+    force_impl(monkeypatch, "persist")  # the default: the production run is launches of the persistent kernel
     env = orl.make(fam, topology=topo, num_envs=2048, seeds=list(range(2048)), **kw)
     st = env.run(policy, 20)
     assert [n for n, _ in st.kernels()] == ["k_persist"] and st.kernels()[0][1] > 0
@@ -473,8 +474,8 @@ def test_snapshot_moves_between_step_implementations(monkeypatch):
     kw = dict(load=300, mean_service_holding_time=25, episode_length=50, num_spectrum_resources=320)
     seeds = list(range(200, 296))
     envs = {}
-    for name, v in (("wave64", "64"), ("two", "2")):
-        monkeypatch.setenv("ORL_STEP_IMPL", v)
+    for name, v in (("wave64", "wave64"), ("two", "persist")):
+        force_impl(monkeypatch, v)
         envs[name] = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=96, seeds=seeds, **kw)
     envs["two"].run("SAP_FF", 300)
     envs["wave64"].set_state(envs["two"].get_state())

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv files: mean counter value per kernel over the last N dispatches."""
+"""Summarise rocprofv3 --pmc counter_collection.csv files: mean counter value per kernel over the last N dispatches
+(default 10 = the measured launches of tools/pmc_traffic.py; 20 for the stand-alone k_policy launches)."""
 import csv
 import glob
 import sys
 from collections import defaultdict
 
 
-def main(paths, last=20):
+def main(paths, last=10):
     for path in paths:
         for f in sorted(glob.glob(path + "/**/*counter_collection.csv", recursive=True)):
             rows = list(csv.DictReader(open(f)))

@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
-"""Run under `rocprofv3 --pmc FETCH_SIZE` (and again with WRITE_SIZE): one calibration stream over the slot maps with
-8-B and with 16-B loads (known byte count), then 1200 warm-up steps and 20 measured steps of the cfg2 bench loop.
-tools/pmc_summary.py + the calibration factors turn the counters into HBM bytes per launch (profiles/*traffic*)."""
+"""Workload driver for the rocprofv3 counter passes (tools/run_profiles.sh): state preparation to the steady state, one
+calibration stream over the slot maps with 8-B and with 16-B loads (known byte count), then MEASURED launches of the
+persistent kernel — 10 x run(policy, 64), i.e. ten single 64-step launches, the production chunk length — and 20 launches
+of the stand-alone slot-scan kernel on the same steady-state slot maps.  tools/collect_profiles.py turns the counters of the
+LAST 10 k_persist dispatches into per-launch / per-step figures (profiles/traffic_<workload>.json).
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out -- python3 tools/pmc_traffic.py cfg2 65536
+"""
+import json
+import math
 import os
 import sys
 
-os.environ["ORL_STREAMS"] = "1"  # whole-batch launches on one stream: the configuration the roofline pass of bench.py times
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import optical_rl_gym_amd as orl  # noqa: E402
-from bench import WORKLOADS  # noqa: E402
+from bench import WORKLOADS, workload_load  # noqa: E402
 
-fam, topo, kw, policy = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
-B = 65536
+STEPS_PER_LAUNCH = 64
+MEASURED_LAUNCHES = 10
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+fam, topo, kw, policy = WORKLOADS[name]
 env = orl.make(fam, topology=topo, num_envs=B, seeds=[10 + i for i in range(B)], **kw)
-env.run(policy, 1200)
+env.run(policy, max(1500, int(math.ceil(5 * workload_load(kw)))))
 for w in (0, 1, 0, 1):
     n = env.lib.orl_batch_debug_stream_read(env._h, w)
-print("calibration bytes", n)
-for _ in range(6):  # six launches of the persistent kernel, 20 steps each (tools/collect_profiles.py: STEPS)
-    env.run(policy, 20)
-for _ in range(20):  # the stand-alone slot-scan kernel (orl_batch_policy), on the same steady-state slot maps
-    env.policy(policy)
+for _ in range(MEASURED_LAUNCHES):
+    env.run(policy, STEPS_PER_LAUNCH)
+for _ in range(20):
+    env.policy(policy, fetch=False)
+env.sync()
+print(json.dumps(dict(workload=name, batch=B, calibration_bytes=int(n), steps_per_launch=STEPS_PER_LAUNCH,
+                      measured_launches=MEASURED_LAUNCHES, mean_active_services=float(env.active().mean()))))
 env.close()
