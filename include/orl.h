@@ -233,6 +233,9 @@ int orl_batch_set_state(orl_batch* b, const void* in);
 int64_t orl_batch_debug_stream_read(orl_batch* b, int width16);
 /* Statistics: env-steps whose releases took the serial tail (more than 8 of one step meeting on one link). */
 int64_t orl_batch_debug_serial_count(orl_batch* b);
+/* Diagnostic builds with -DORL_TIMING only (zeros otherwise): shader-clock cycles per phase of the persistent kernel, 48
+ * slots summed over wavefronts (0-15 control phase, 16-31 release detection, 32-47 row phase). */
+int orl_batch_debug_prof(orl_batch* b, uint64_t* out48, int reset);
 /* 1 when the library was built with -DORL_ALT_IMPLS (the two-kernel form of the persistent kernel's phases, used by
  * the cross-implementation tests), else 0. */
 int orl_build_has_alt(void);

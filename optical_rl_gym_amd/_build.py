@@ -19,7 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include", "orl.h")
 ROW_WIDTHS = (1, 2, 5, 8)
-VARIANTS = {"default": ("liborlgpu.so", []), "alt": ("liborlgpu_alt.so", ["-DORL_ALT_IMPLS"])}
+VARIANTS = {"default": ("liborlgpu.so", []), "alt": ("liborlgpu_alt.so", ["-DORL_ALT_IMPLS"]),
+            "timing": ("liborlgpu_timing.so", ["-DORL_TIMING=1"])}  # diagnostic: per-phase shader-clock profile (tools/phase_prof.py)
 LIB = os.path.join(HERE, VARIANTS["default"][0])
 
 # -ffp-contract=off: float64 statistics and the log restatement must round exactly like the reference

@@ -1037,6 +1037,17 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
   return ORL_OK;
 }
 
+/* diagnostic builds (-DORL_TIMING): shader-clock cycles per phase of the persistent kernel, summed over wavefronts */
+extern "C" int orl_batch_debug_prof(orl_batch* b, uint64_t* out48, int reset) {
+  if (!b || !out48) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  int rc = 0;
+#define CALL(WW) rc = orl_launch::prof_read<WW>((unsigned long long*)out48, reset)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+  return rc ? fail(ORL_E_HIP, "reading the profile failed") : ORL_OK;
+}
 extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
   if (!b) return -1;
   if (hipSetDevice(b->device) != hipSuccess) return -1;

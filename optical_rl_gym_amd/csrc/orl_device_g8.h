@@ -89,8 +89,11 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
   e.mt = P.mt + env * 624;
 }
 
-__device__ __forceinline__ void env_store(const DevParams& P, const EnvG& e, int gl) {
-  if (gl != 0) return;
+// returns the service descriptor of the pending service (what the slot scan reads); stored only when write_desc
+__device__ __forceinline__ u64 env_store(const DevParams& P, const EnvG& e, int gl, bool write_desc = true) {
+  const u64 np_ = (u64)(u32)P.n_paths[e.src * P.N + e.dst];
+  const u64 desc = (u64)(u32)((e.src * P.N + e.dst) * P.K) | ((u64)(u32)e.br_idx << 32) | (np_ << 48);
+  if (gl != 0) return desc;
   u64* s = e.scal;
 #define PF(slot, x) s[slot] = (u64)__double_as_longlong(x);
   PF(SC_NOW, e.now) PF(SC_AT, e.at) PF(SC_HT, e.ht) PF(SC_GTHR, e.g_thr) PF(SC_GCOMP, e.g_comp) PF(SC_GLAST, e.g_last)
@@ -102,8 +105,8 @@ __device__ __forceinline__ void env_store(const DevParams& P, const EnvG& e, int
   s[SC_SRC_DST] = pack2(e.src, e.dst); s[SC_BR_IDX] = pack2(e.bit_rate, e.br_idx);
   s[SC_ID_MTPOS] = pack2(e.id, e.mt_pos); s[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
   s[SC_FLAGS] = pack2(e.new_service, e.flags); s[SC_HINT] = pack2(e.nfree, 0);
-  u64 np_ = (u64)(u32)P.n_paths[e.src * P.N + e.dst];
-  P.svc_desc[e.env] = (u64)(u32)((e.src * P.N + e.dst) * P.K) | ((u64)(u32)e.br_idx << 32) | (np_ << 48);
+  if (write_desc) P.svc_desc[e.env] = desc;
+  return desc;
 }
 
 // ---- MT19937, 16-word window per refill (lane w holds window words w and w+8) ----------------------
@@ -239,12 +242,7 @@ __device__ __forceinline__ void free_push(EnvG& e, int gl, int slot) {
   }
 }
 
-#if defined(ORL_TIMING) && ORL_TIMING == 3
-__device__ unsigned long long g_dbg[64];  // event counts of ev_push (orl_batch_debug_prof, slots 0..15)
-#define ORL_DBG(k, v) do { if ((lane & 7) == 0) atomicAdd(&::orl::g8::g_dbg[k], (unsigned long long)(v)); } while (0)
-#else
 #define ORL_DBG(k, v) do { } while (0)
-#endif
 // ---- pending releases: slot i belongs to lane i % 8 -------------------------------------------------
 __device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
   const int gl = lane & 7;

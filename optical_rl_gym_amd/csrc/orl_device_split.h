@@ -31,48 +31,36 @@
 namespace orl {
 namespace sp {
 
-// -DORL_TIMING=1 (control kernel B2) / =2 (merged slot-scan + control kernel A): shader-clock cycles per phase, per
-// wavefront, summed on the host (orl_batch_debug_prof, tools/phase_prof.py)
-#define ORL_PROF_SLOTS 32
+// -DORL_TIMING (diagnostic builds only): shader-clock cycles per phase of the persistent kernel, accumulated per wavefront
+// over a launch and added into g_prof at its end; orl_batch_debug_prof sums them over the wavefronts.  Slots: 0..15 control
+// phase (ORL_PROFA), 16..31 release detection inside it (ORL_PROF), 32..47 row phase (ORL_PROFR; the clock of lane 0's item).
+#define ORL_PROF_SLOTS 48
 #define ORL_PROF_WAVES 16384
-struct Prof { long long t; unsigned long long acc[16]; };
 #ifdef ORL_TIMING
-__device__ unsigned long long g_prof[ORL_PROF_WAVES * ORL_PROF_SLOTS];
-#define ORL_PROF_BEGIN_() for (int k_ = 0; k_ < 16; k_++) prof.acc[k_] = 0; prof.t = clock64()
+struct Prof { long long t; unsigned long long acc[ORL_PROF_SLOTS]; };
+static __device__ unsigned long long g_prof[ORL_PROF_WAVES * ORL_PROF_SLOTS];
+#define ORL_PROF_BEGIN_() do { for (int k_ = 0; k_ < ORL_PROF_SLOTS; k_++) prof.acc[k_] = 0; prof.t = clock64(); } while (0)
 #define ORL_PROF_(k) do { long long n_ = clock64(); prof.acc[k] += (unsigned long long)(n_ - prof.t); prof.t = n_; } while (0)
 #define ORL_PROF_END_() do { if ((threadIdx.x & 63) == 0) { const size_t w_ = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % ORL_PROF_WAVES; \
     unsigned long long* g_ = ::orl::sp::g_prof + w_ * ORL_PROF_SLOTS; \
-    unsigned long long tot_ = 0; for (int k_ = 0; k_ < 14; k_++) { g_[k_] += prof.acc[k_]; tot_ += prof.acc[k_]; } \
-    if (tot_ > g_[15]) g_[15] = tot_;  /* slowest launch of this wavefront */ \
-    if (tot_ > 60000) { g_[14] += 1; for (int k_ = 0; k_ < 14; k_++) g_[16 + k_] += prof.acc[k_]; } } } while (0)
-#endif
-#if defined(ORL_TIMING) && ORL_TIMING == 1
+    for (int k_ = 0; k_ < ORL_PROF_SLOTS; k_++) g_[k_] += prof.acc[k_]; } } while (0)
 #define ORL_PROF_BEGIN() ORL_PROF_BEGIN_()
-#define ORL_PROF(k) ORL_PROF_(k)
 #define ORL_PROF_END() ORL_PROF_END_()
-#else
-#define ORL_PROF_BEGIN() do { } while (0)
-#define ORL_PROF(k) do { } while (0)
-#define ORL_PROF_END() do { } while (0)
-#endif
-#if defined(ORL_TIMING) && ORL_TIMING == 4
-#define ORL_PROFR_BEGIN() ORL_PROF_BEGIN_()
-#define ORL_PROFR(k) ORL_PROF_(k)
-#define ORL_PROFR_END() ORL_PROF_END_()
-#else
-#define ORL_PROFR_BEGIN() do { } while (0)
-#define ORL_PROFR(k) do { } while (0)
-#define ORL_PROFR_END() do { } while (0)
-#endif
-#if defined(ORL_TIMING) && ORL_TIMING == 2
-#define ORL_PROFA_BEGIN() ORL_PROF_BEGIN_()
 #define ORL_PROFA(k) ORL_PROF_(k)
-#define ORL_PROFA_END() ORL_PROF_END_()
+#define ORL_PROF(k) ORL_PROF_(16 + (k))
+#define ORL_PROFR(k) ORL_PROF_(32 + (k))
 #else
-#define ORL_PROFA_BEGIN() do { } while (0)
+struct Prof { long long t; };
+#define ORL_PROF_BEGIN() do { } while (0)
+#define ORL_PROF_END() do { } while (0)
 #define ORL_PROFA(k) do { } while (0)
-#define ORL_PROFA_END() do { } while (0)
+#define ORL_PROF(k) do { } while (0)
+#define ORL_PROFR(k) do { } while (0)
 #endif
+#define ORL_PROFA_BEGIN() do { } while (0)
+#define ORL_PROFA_END() do { } while (0)
+#define ORL_PROFR_BEGIN() do { } while (0)
+#define ORL_PROFR_END() do { } while (0)
 
 using g8::EnvG;
 using g8::gballot;
@@ -170,12 +158,40 @@ __device__ __forceinline__ void emit_items(const DevParams& P, i64 env, const Si
 // control kernel A: everything of step() up to (and excluding) the effects of the provision on the link rows
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
-__device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             Prof& prof);
+__device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
+                                             bool write_io, Prof& prof);
 #ifndef ORL_SCAN_BATCH
 #define ORL_SCAN_BATCH 8  // release times a lane requests per round of the rebuild scan
 #endif
 struct SoonRegs { double t[ORL_SOON_PER_LANE]; int i[ORL_SOON_PER_LANE]; int dirty; };  // dirty: bit k = entry k of this lane changed
+
+// Where the slot maps, link statistics and per-core sums of the envs a wavefront works on live: the global arrays
+// (env0 = 0), or — persistent kernel, small topologies — the wavefront's own LDS window holding its 8 envs for the whole
+// launch (env0 = its first env).  Indexed by (env - env0) either way; the compiler infers the address space per kernel.
+struct Wmem {
+  u64* bm0;      // [..][bm_words]
+  double* ls0;   // [..][E][4]
+  int* cs0;      // [..][cs_words]
+  i64 env0;
+  double* clk;   // LDS [8][2] {provision clock, step clock} of the wavefront's envs, or nullptr (row phase reads SC_NOWA / SC_NOW)
+  i64 clk_env0;  // first env of the wavefront (index base of clk)
+  bool in_lds;   // wavefront-private state: plain accesses; else the sums are read through L2 where the row phase's atomics land
+};
+__device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
+  Wmem m;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.clk = nullptr; m.clk_env0 = 0; m.in_lds = false;
+  return m;
+}
+__device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
+__device__ __forceinline__ double* wm_ls(const DevParams& P, const Wmem& m, i64 env) { return m.ls0 + (env - m.env0) * 4 * P.E; }
+__device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.env0) * P.cs_words; }
+
+struct CtrlOpts {
+  bool persistent;  // inside k_persist: no kernel boundary between the row phase's L2 atomics and this phase's reads
+  bool write_io;    // store the action / reward / done / service descriptor of this step (device-resident runs: last step only)
+  bool trusted;     // the action comes from the in-kernel slot scan on the same slot map: is_path_free holds by construction
+  bool emit_queue;  // two-kernel form: copy the items into the global queue for the row kernel
+};
 template <int ENV, int W>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
                                              int extra = 0, int pushed_idx = -1, u64 pushed_info = 0ull);
@@ -184,12 +200,15 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 // release masks) and one row phase applies them.  The network-compactness average, which needs the sums between the
 // provision and the releases, is finished by the NEXT step from totals - (what the releases added): the row phase keeps
 // the latter in rel_sums.
+// Returns the service descriptor of the NEW pending service (what the next slot scan needs: pair base, bit-rate index,
+// number of paths), and through *n_items_out the number of items this env's step left in its sink table.
 template <int ENV, int W>
-__device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, int lane, Prof& prof,
-                                       const int4* given, u32* s_tally, SinkEntry* s_tab, int parity = 0,
-                                       int* s_deferred = nullptr) {
+__device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
+                                      const int4* given, u32* s_tally, SinkEntry* s_tab, int parity, int* s_deferred,
+                                      int* done_out) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
-  if (blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
+  if (!O.persistent && blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
+  u64 desc_out = 0ull;
   int cnt = 0, core = 0, slot = 0, n = 1;
   PathRec rec;
   rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
@@ -207,6 +226,9 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
   if (valid) {
     EnvG e;
     g8::env_load(P, e, env);
+    e.bm = wm_bm(P, M, env);
+    e.ls = wm_ls(P, M, env);
+    e.cs = wm_cs(P, M, env);
     int* rs = e.cs + 2 * P.C;
     {
       const u64 acc0 = e.scal[SC_ACC];
@@ -218,7 +240,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         // (the sums are updated by L2 atomics: in the persistent kernel, where no kernel boundary invalidates the L1 in
         // between, they are read through L2 as well)
         int occ, fb;
-        if (s_deferred) {
+        if (O.persistent && !M.in_lds) {
           occ = atomicAdd(e.cs + 2 * c0, 0) - atomicAdd(rs + 2 * c0, 0);
           fb = atomicAdd(e.cs + 2 * c0 + 1, 0) - atomicAdd(rs + 2 * c0 + 1, 0);
         } else {
@@ -231,7 +253,7 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
         e.g_comp = (a0 + (cmp * td)) / now_a;
       }
       for (int i = gl; i < 2 * P.C; i += 8) {  // this step's releases start from zero
-        if (s_deferred) atomicExch(rs + i, 0);
+        if (O.persistent && !M.in_lds) atomicExch(rs + i, 0);
         else rs[i] = 0;
       }
     }
@@ -277,8 +299,8 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
       if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
       else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
       rec = path_rec_load(P, pidx);
-      bool ok = false;
-      if (slot + n <= S) {  // is_path_free: lane w checks word w of every link row of the path
+      bool ok = O.trusted && ENV != ENV_DEEPRMSA;
+      if (!ok && slot + n <= S) {  // is_path_free: lane w checks word w of every link row of the path
         const int hops = path_rec_byte(rec, 0);
         bool busy = false;
         if (gl < W) {
@@ -339,17 +361,23 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
       }
     }
     if (gl == 0) {
-      P.reward[env] = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
+      if (O.write_io) {
+        P.reward[env] = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
+        if (given) *(int4*)(P.actions + env * 4) = av;
+      }
       e.scal[SC_ACC] = pack2(accepted ? 1 : 0, core);
       e.scal[SC_NOWA] = (u64)__double_as_longlong(e.now);
+      if (M.clk) M.clk[2 * (env - M.clk_env0)] = e.now;
     }
     ORL_PROFA(5);
     // the word service_part leaves in SC_ACC (recomputed here so that the deferral below need not read it back)
     const u64 acc_after = (accepted && ENV != ENV_RWA && e.now > 0)
                               ? (3ull | ((u64)(u32)core << 32) | ((u64)e.s_nh << 37))
                               : pack2(accepted ? 1 : 0, core);
-    service_part<ENV, W>(P, e, env, lane, 1, accepted, core, prof);
-    g8::env_store(P, e, gl);
+    const bool done = service_part<ENV, W>(P, e, env, lane, 1, accepted, core, O.write_io, prof);
+    if (done_out) *done_out = done ? 1 : 0;
+    desc_out = g8::env_store(P, e, gl, O.write_io);
+    if (M.clk && gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
     ORL_PROFA(8);
     {
       // due releases of the step (rmsa_env.py:590-597) -> masks behind the provision's in the same table.  The env record
@@ -387,16 +415,49 @@ __device__ __forceinline__ void ctrl_a(const DevParams& P, i64 env, bool valid, 
     }
   }
   ORL_PROFA(11);
-  emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a);
+  if (O.emit_queue) emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a);
   ORL_PROFA(9);
+  return desc_out;
+}
+
+// persistent kernel: the wavefront's items of this step = the sink-table entries that hold masks, as a dense list of
+// (local env << 8 | link) in LDS; returns their number.  All 64 lanes call.
+__device__ __forceinline__ int list_items(const DevParams& P, const SinkEntry* tab /*this env's*/, bool valid, int lane, unsigned short* list) {
+  const int gl = lane & 7, grp = lane >> 3, E = P.E;
+  int mine = 0;  // entries of this env (uniform within the group)
+  for (int l0 = 0; l0 < E; l0 += 8) {
+    const int l = l0 + gl;
+    const bool has = valid && l < E && ((tab[l].crn >> 40) & 15) != 0;
+    mine += __popc(gballot(has, lane));
+  }
+  int pre = 0, tot = 0;
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const int c = __builtin_amdgcn_readlane(mine, 8 * g);
+    pre += (g < grp) ? c : 0;
+    tot += c;
+  }
+  int at = pre;
+  for (int l0 = 0; l0 < E; l0 += 8) {
+    const int l = l0 + gl;
+    const bool has = valid && l < E && ((tab[l].crn >> 40) & 15) != 0;
+    const u32 fb = gballot(has, lane);
+    if (has) list[at + __popc(fb & ((1u << gl) - 1u))] = (unsigned short)((grp << 8) | l);
+    at += __popc(fb);
+  }
+  return tot;
+}
+__device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntry& t) {
+  const int nm = (int)((t.crn >> 40) & 15);
+  return make_item(env, (u32)link, nm, t.mk0, nm > 4 ? t.mk1 : 0ull, t.crn & 0xffffffffffull, 1 | (int)((t.crn >> 44) & 1) << 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // what step() does after the provision, except the link rows: network statistics, next service, done / auto reset
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
-__device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             Prof& prof) {
+__device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
+                                             bool write_io, Prof& prof) {
   const int gl = lane & 7;
   g8::RngG rng;
   g8::rng_fill(e, rng, gl);
@@ -424,7 +485,8 @@ __device__ __forceinline__ void service_part(const DevParams& P, EnvG& e, i64 en
     e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
     if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
   }
-  if (gl == 0) P.done[env] = done ? 1 : 0;
+  if (gl == 0 && write_io) P.done[env] = done ? 1 : 0;
+  return done;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -513,20 +575,6 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       const u32 qn = kb[NS] >> 8;
       const double T_lane = (qn >= 8388607u) ? INF : (qn < 2u ? -INF : e.now + ((double)qn - 524290.0) * (1.0 / 4096.0));
       const double T = g8::g8_min(T_lane);
-#if defined(ORL_TIMING) && ORL_TIMING == 3
-      if (!(e.now < T) && g8_sum(nd) > 0) {
-        unsigned long long was = 0;
-        if (gl == 0) was = atomicAdd(&g8::g_dbg[12], 1ull);
-        was = gget(was, 0, lane);
-        if (was == 0) {  // first occurrence: dump
-          if (gl == 0) { g8::g_dbg[16] = (u64)__double_as_longlong(e.now); g8::g_dbg[17] = (u64)__double_as_longlong(T); g8::g_dbg[18] = (u64)hwm; g8::g_dbg[19] = (u64)nd; }
-          g8::g_dbg[20 + gl] = ((u64)kb[NS] << 32) | kb[0];
-          g8::g_dbg[28 + gl] = (u64)__double_as_longlong(T_lane);
-          g8::g_dbg[36 + gl] = ((u64)kb[1] << 32) | kb[2];
-          g8::g_dbg[44 + gl] = (u64)__double_as_longlong(bt[0]);
-        }
-      }
-#endif
 #pragma unroll
       for (int k = 0; k < NS; k++) { st[k] = bt[k] < T ? bt[k] : INF; si[k] = bi[k]; }
       e.t_soon = T;
@@ -745,7 +793,7 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
 // provision clock (SC_NOWA) — followed by the step's releases at the new clock (SC_NOW); what the releases add to
 // the per-core sums is also accumulated in rel_sums (the next step needs the sums as they were in between).
 template <int ENV, int W>
-__device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it, Prof& prof) {
+__device__ __forceinline__ void row_item_lane(const DevParams& P, const Wmem& M, const Item it, Prof& prof) {
   constexpr bool MIXED = true;
   const int E = P.E, S = P.S;
   const i64 env = (i64)(u32)it.a.x;
@@ -753,18 +801,15 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Item it,
   const bool release = ((it.a.x >> 44) & 1) != 0;
   const bool prov_first = MIXED && ((it.a.x >> 45) & 1) != 0;
   const u64 cores = it.b.y;
-  u64* bm = P.bitmap + env * P.bm_words;
-  int* cs = P.core_sums + env * P.cs_words;
+  u64* bm = wm_bm(P, M, env);
+  int* cs = wm_cs(P, M, env);
   int* rs = MIXED ? cs + 2 * P.C : nullptr;
-  double* ls = P.lstat + env * 4 * E;
-  const double now = __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
-  const double now_prov = MIXED ? __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOWA]) : 0.0;
+  double* ls = wm_ls(P, M, env);
+  const double now = M.clk ? M.clk[2 * (env - M.clk_env0) + 1] : __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
+  const double now_prov = M.clk ? M.clk[2 * (env - M.clk_env0)] : __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOWA]);
   const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
   double last_update = ls23.y;
   double util = ls01.x, frag = ls01.y, comp = ls23.x;
-#if defined(ORL_TIMING) && ORL_TIMING == 4
-  if (last_update == -7.5 && util == 0.123) return;  // (keeps the loads ahead of the timing mark)
-#endif
   ORL_PROFR(3);
   u64 a[W];
   int pk = 0, prev_core = -1;

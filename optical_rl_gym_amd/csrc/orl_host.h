@@ -61,6 +61,8 @@ template <int W> void policy(orl_batch* b, int pol);                       // st
 template <int W> void step64(orl_batch* b, int auto_reset, int want_info, int fused_policy);  // one wavefront per env
 template <int W> void obs(orl_batch* b, int with_terminal);                // DeepRMSA observation
 template <int W> void persist(orl_batch* b, int pol, int target);          // k_persist up to step `target` of this run, then k_rel_tail
+template <int W> int persist_uses_lds(orl_batch* b);                       // 1: the persistent kernel keeps slot maps / link statistics in LDS
+template <int W> int prof_read(unsigned long long* out48, int reset);      // -DORL_TIMING builds: per-phase cycle sums
 template <int W> void step2(orl_batch* b, int pol);                        // ORL_ALT_IMPLS: k_step_a2 ; k_rows2 ; k_rel_tail
 }  // namespace orl_launch
 

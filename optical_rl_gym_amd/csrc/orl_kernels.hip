@@ -11,6 +11,8 @@
 // Launchers (orl_launch::*<W>) are explicitly instantiated at the end; orl_api.hip dispatches on the batch's W.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 #include "orl_host.h"
 #include "orl_device_g8.h"
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
 }
 
 template <int W>
-__device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, int with_terminal);
+__device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, i64 env, int lane, int terminal);
 
 #ifdef ORL_ALT_IMPLS
 // ---- two-kernel form of the persistent kernel's phases (cross-checks, per-kernel timing): k_step_a2 ; k_rows2 ------------
@@ -154,6 +156,9 @@ __global__ void __launch_bounds__(256) k_step_a2(DevParams P, int pol, int parit
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   const bool valid = env < P.B;
   sp::Prof prof;
+  const sp::Wmem M = sp::wmem_global(P);
+  sp::CtrlOpts O;
+  O.persistent = false; O.write_io = true; O.trusted = false; O.emit_queue = true;
   ORL_PROFA_BEGIN();
   if (FUSED_POLICY) {
     const i64 env0 = env - ((lane >> 3));  // first env of this wavefront
@@ -162,11 +167,11 @@ __global__ void __launch_bounds__(256) k_step_a2(DevParams P, int pol, int parit
     policy_g<ENV, W, 8>(P, P.bitmap + env0 * P.bm_words + (size_t)(lane >> 3) * P.bm_words, valid, (int)(u32)d,
                         (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane, pol, valid ? P.path_col[env] : 0, a);
     const int4 av = make_int4(a[0], a[1], a[2], a[3]);
-    if (valid && (lane & 7) == 0) *(int4*)(P.actions + env * 4) = av;
     ORL_PROFA(1);
-    sp::ctrl_a<ENV, W>(P, env, valid, lane, prof, &av, s_tally, (sp::SinkEntry*)orl_lds_raw, parity);
+    O.trusted = true;
+    sp::ctrl_a<ENV, W>(P, M, O, env, valid, lane, prof, &av, s_tally, (sp::SinkEntry*)orl_lds_raw, parity, nullptr, nullptr);
   } else {
-    sp::ctrl_a<ENV, W>(P, env, valid, lane, prof, nullptr, s_tally, (sp::SinkEntry*)orl_lds_raw, parity);
+    sp::ctrl_a<ENV, W>(P, M, O, env, valid, lane, prof, nullptr, s_tally, (sp::SinkEntry*)orl_lds_raw, parity, nullptr, nullptr);
   }
   ORL_PROFA_END();
 }
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
     it.a = q[2 * at];
     it.b = q[2 * at + 1];
     ORL_PROFR(2);
-    sp::row_item_lane<ENV, W>(P, it, prof);
+    sp::row_item_lane<ENV, W>(P, sp::wmem_global(P), it, prof);
   }
   ORL_PROFR(8);
   ORL_PROFR_END();
@@ -205,79 +210,146 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 #endif  // ORL_ALT_IMPLS
 
 // ---- persistent kernel -------------------------------------------------------------------------------------------------
-// Envs never interact, so a wavefront can own its 8 envs for a whole run: control phase -> row phase over the items the
-// wavefront itself just emitted (one lane per item) -> next step, with no kernel boundary and no grid-wide tail between the
-// phases; the wavefronts of a launch drift out of phase and keep the memory system uniformly busy.  What one phase writes and
-// the next reads stays within the wavefront's CU (same L1).  A wavefront in which an env's releases did not fit the item form
-// (one env-step in 10^7) leaves the loop after that step's row phase; k_rel_tail follows every launch, and the wavefront
-// resumes from its own step count in the next launch.
-#ifndef ORL_PERSIST_WAVES
-#define ORL_PERSIST_WAVES 4   // waves per SIMD the register allocator must leave room for
-#endif
-template <int ENV, int W>
+// Envs never interact, so a wavefront can own its 8 envs for a whole launch (64 steps): control phase -> row phase over the
+// items the wavefront itself just collected (one lane per touched link) -> next step, with no kernel boundary and no
+// grid-wide tail between the phases; the wavefronts of a launch drift out of phase and keep the memory system uniformly busy.
+// LDS = true (small topologies: 8 envs' slot maps + link statistics + per-core sums fit the wavefront's LDS budget): that
+// state is loaded once per launch, every scan / validation / row update of the 64 steps works on LDS, and it is written
+// back at the end — the slot map is read ~14 times and rewritten ~5 times per env-step, none of which reaches memory any
+// more.  Work items never leave LDS either (the sink table is read in place through a dense index list).
+// A wavefront in which an env's releases did not fit the item form (one env-step in 10^7) leaves the loop after that step's
+// row phase; k_rel_tail follows every launch, and the wavefront resumes from its own step count in the next launch.
+struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (all multiples of 16)
+  int tab, tally, list, clk, misc, bm, ls, cs, total;
+};
+__host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, int cs_words, bool state) {
+  PersistLds L;
+  int o = 0;
+  L.tab = o; o += 8 * E * (int)sizeof(sp::SinkEntry);
+  L.tally = o; o += 8 * 32 * 4;
+  L.list = o; o += ((8 * E * 2) + 15) & ~15;
+  L.clk = o; o += 8 * 2 * 8;
+  L.misc = o; o += 16;
+  L.bm = o; if (state) o += 8 * bm_words * 8;
+  L.ls = o; if (state) o += 8 * E * 32;
+  L.cs = o; if (state) o += (8 * cs_words * 4 + 15) & ~15;
+  L.total = o;
+  return L;
+}
+template <int ENV, int W, bool LDS>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
-  __shared__ u32 s_tally[32 * 8];
-  __shared__ int s_deferred[2];  // alternating by step
+  const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.cs_words, LDS);
+  sp::SinkEntry* s_tab = (sp::SinkEntry*)(orl_lds_raw + L.tab);
+  u32* s_tally = (u32*)(orl_lds_raw + L.tally);
+  unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
+  int* s_deferred = (int*)(orl_lds_raw + L.misc);  // [2], alternating by step
   const int lane = lane_id();
-  const i64 env = (i64)blockIdx.x * 8 + (threadIdx.x >> 3);
+  const i64 env0 = (i64)blockIdx.x * 8;
+  const i64 env = env0 + (threadIdx.x >> 3);
+  const int nenv = (int)(P.B - env0 < 8 ? P.B - env0 : 8);
   int step = wg_step[blockIdx.x];
   sp::Prof prof;
+  sp::Wmem M = sp::wmem_global(P);
+  M.clk = (double*)(orl_lds_raw + L.clk);
+  M.clk_env0 = env0;
+  if (LDS) {
+    M.bm0 = (u64*)(orl_lds_raw + L.bm);
+    M.ls0 = (double*)(orl_lds_raw + L.ls);
+    M.cs0 = (int*)(orl_lds_raw + L.cs);
+    M.env0 = env0;
+    M.in_lds = true;
+    if (step < target) {  // the wavefront's envs are contiguous in every array: coalesced 16-byte loads
+      const ulonglong2* g = (const ulonglong2*)(P.bitmap + env0 * P.bm_words);
+      ulonglong2* l = (ulonglong2*)M.bm0;
+      for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) l[i] = g[i];
+      const double2* gs = (const double2*)(P.lstat + env0 * 4 * P.E);
+      double2* ls = (double2*)M.ls0;
+      for (int i = lane; i < nenv * 2 * P.E; i += 64) ls[i] = gs[i];
+      const int4* gc = (const int4*)(P.core_sums + env0 * P.cs_words);
+      int4* lc = (int4*)M.cs0;
+      for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) lc[i] = gc[i];
+    }
+  }
   if (threadIdx.x == 0) s_deferred[0] = s_deferred[1] = 0;
+  const bool valid = env < P.B;
+  u64 desc = valid ? P.svc_desc[env] : 0ull;  // carried from step to step in registers
+  const int first_step = step;
+  ORL_PROF_BEGIN();
   while (step < target) {
-    __syncthreads();  // (one wavefront: a compiler-level ordering point) the previous row phase's writes are done
+    __syncthreads();  // (one wavefront: an ordering point) the previous row phase's writes are done
     if (threadIdx.x == 0) s_deferred[(step + 1) & 1] = 0;
     // per-iteration opaque copies: without them the compiler hoists every per-lane address out of the loop and keeps
-    // them all live across both phases (199 VGPRs instead of ~128)
+    // them all live across both phases
     int env_lo = (int)env, lane_i = lane;
     asm volatile("" : "+v"(env_lo), "+v"(lane_i));
     const i64 env_i = (i64)env_lo;
     const bool valid_i = env_i < P.B;
-    const i64 env0_i = env_i - (lane_i >> 3);
+    ORL_PROFA(0);
+    sp::CtrlOpts O;
+    O.persistent = true;
+    O.write_io = (step + 1 == target);  // what the host can see after the run: the last step's action / reward / done
+    O.trusted = true;
+    O.emit_queue = false;
+    int done_i = 0;
     {
-      u64 d = valid_i ? P.svc_desc[env_i] : 0ull;
       int a[4];
-      policy_g<ENV, W, 8>(P, P.bitmap + env0_i * P.bm_words + (size_t)(lane_i >> 3) * P.bm_words, valid_i, (int)(u32)d,
-                          (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu), lane_i, pol, valid_i ? P.path_col[env_i] : 0, a);
+      policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
+                          (int)((desc >> 48) & 0xffu), lane_i, pol, valid_i ? P.path_col[env_i] : 0, a);
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
-      if (valid_i && (lane_i & 7) == 0) *(int4*)(P.actions + env_i * 4) = av;
-      sp::ctrl_a<ENV, W>(P, env_i, valid_i, lane_i, prof, &av, s_tally, (sp::SinkEntry*)orl_lds_raw, 0, &s_deferred[step & 1]);
+      ORL_PROFA(1);
+      desc = sp::ctrl_a<ENV, W>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i);
     }
-    __syncthreads();  // items, fill counts, env records
+    __syncthreads();  // sink table, clocks, env records
     {
-      u32 r0 = blockIdx.x, tid = threadIdx.x;
-      asm volatile("" : "+s"(r0), "+v"(tid));
-      const u32 n_items = P.q_cnt_a[r0];
-      const ulonglong2* q = P.q_a + (size_t)r0 * P.q_wave * 2;
-      for (u32 idx = tid; idx < n_items; idx += 64) {
-        sp::Item it;
-        it.a = q[2 * idx];
-        it.b = q[2 * idx + 1];
-        sp::row_item_lane<ENV, W>(P, it, prof);
-      }
-    }
-    if (ENV == ENV_DEEPRMSA) {  // the observation of the new pending service, from the rows as they are now
+      const int n_items = sp::list_items(P, s_tab + P.E * (lane_i >> 3), valid_i, lane_i, s_list);
       __syncthreads();
-      if (valid_i) obs8_env<W>(P, env_i, lane_i, 1);
+      ORL_PROFA(12);
+      for (int idx = lane_i; idx < n_items; idx += 64) {
+        const int code = (int)s_list[idx];
+        const int el = code >> 8, link = code & 0xff;
+        const sp::Item it = sp::item_from_sink(env0 + el, link, s_tab[P.E * el + link]);
+        sp::row_item_lane<ENV, W>(P, M, it, prof);
+      }
+      ORL_PROFA(13);
+    }
+    const bool deferred = s_deferred[step & 1] != 0;  // set before the barrier in front of the row phase
+    if (ENV == ENV_DEEPRMSA && (O.write_io || deferred)) {  // the observation of the new pending service, from the rows as they are now
+      __syncthreads();
+      if (valid_i) obs8_env<W>(P, sp::wm_bm(P, M, env_i), env_i, lane_i, done_i);
     }
     step++;
-    if (s_deferred[(step - 1) & 1]) break;  // set before the barrier in front of the row phase
+    if (deferred) break;
+  }
+  ORL_PROF_END();
+  if (LDS && step > first_step) {
+    __syncthreads();
+    ulonglong2* g = (ulonglong2*)(P.bitmap + env0 * P.bm_words);
+    const ulonglong2* l = (const ulonglong2*)M.bm0;
+    for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) g[i] = l[i];
+    double2* gs = (double2*)(P.lstat + env0 * 4 * P.E);
+    const double2* ls = (const double2*)M.ls0;
+    for (int i = lane; i < nenv * 2 * P.E; i += 64) gs[i] = ls[i];
+    int4* gc = (int4*)(P.core_sums + env0 * P.cs_words);
+    const int4* lc = (const int4*)M.cs0;
+    for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) gc[i] = lc[i];
+  }
+  if (step > first_step && step < target && valid) {
+    // leaving early (deferred releases): the descriptor the next launch / the stand-alone scan reads; action, reward and done
+    // of an unfinished run are not host-visible
+    if ((lane & 7) == 0) P.svc_desc[env] = desc;
   }
   if (threadIdx.x == 0) {
     wg_step[blockIdx.x] = step;
     if (step < target) atomicAdd(n_unfinished, 1u);
   }
 }
-// Two register budgets of the same body: 4 waves/SIMD (128 VGPRs) for NSFNET-sized RMSA / RWA / DeepRMSA, 3 waves/SIMD
-// (168 VGPRs, no spills) for the heavier RMCSA and Germany50 steps (cfg4 5.0e8 vs 4.6e8, cfg5 3.4e8 vs 3.2e8).
-template <int ENV, int W>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_PERSIST_WAVES, ORL_PERSIST_WAVES)))
+// Register budgets: WAVES waves/SIMD -> 512 / WAVES VGPRs.  Global state: 4 (128 VGPRs) for NSFNET-sized RMSA / RWA /
+// DeepRMSA, 3 (168, no spills) for the heavier RMCSA and Germany50 steps.  LDS state: the LDS window decides the residency
+// (orl_launch::persist), the kernel is built for 2 or 3.
+template <int ENV, int W, bool LDS, int WAVES>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
-  persist_body<ENV, W>(P, pol, target, wg_step, n_unfinished);
-}
-template <int ENV, int W>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_persist3(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
-  persist_body<ENV, W>(P, pol, target, wg_step, n_unfinished);
+  persist_body<ENV, W, LDS>(P, pol, target, wg_step, n_unfinished);
 }
 
 // serial tail, one small workgroup per launch: the envs whose releases of this step did not fit the item form (about
@@ -293,7 +365,7 @@ __global__ void __launch_bounds__(256) k_rel_tail(DevParams P, int buffer) {
     sp::rel_serial<ENV, W>(P, env, lane_id());
     if (ENV == ENV_DEEPRMSA && P.obs_dim) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      obs8_env<W>(P, env, lane_id(), 1);
+      obs8_env<W>(P, P.bitmap + env * P.bm_words, env, lane_id(), P.done[env]);
     }
   }
   __syncthreads();
@@ -316,8 +388,10 @@ __global__ void __launch_bounds__(64) k_obs(DevParams P, int with_terminal) {
 // DeepRMSAEnv.observation (deeprmsa_env.py:60-121) with 8 lanes per env, lane = path (k <= 8), 8 envs per wavefront: rows
 // are read straight from global memory (the form of the slot scan), every lane writes its own path block.  The
 // one-wavefront-per-env k_obs above staged the whole slot map in LDS and took 26.7 us per 32 768-env launch (cfg3).
+// bm: the env's slot map (global or LDS); terminal: also write the observation as `terminal_observation` (the env just
+// finished its episode: the soft reset keeps the pending service, so the values are the same; SB3 VecEnv convention)
 template <int W>
-__device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, int with_terminal) {
+__device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, i64 env, int lane, int terminal) {
   const int gl = lane & 7;
   const u64* s = P.scal + env * ORL_SCAL_WORDS;
   u64 t = s[SC_SRC_DST];
@@ -326,7 +400,7 @@ __device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, 
   const int bit_rate = (int)(u32)t, br_idx = (int)(t >> 32);
   const int N = P.N, J = P.J, S = P.S, WD = 2 * J + 3;
   double* o = P.obs + env * P.obs_dim;
-  double* o2 = (with_terminal && P.done[env]) ? P.term_obs + env * P.obs_dim : nullptr;
+  double* o2 = terminal ? P.term_obs + env * P.obs_dim : nullptr;
   const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
   for (int i = gl; i < 1 + 2 * N; i += 8) {
     const double v = (i == 0) ? (double)bit_rate / 100 : ((i == 1 + mn || i == 1 + N + mx) ? 1.0 : 0.0);
@@ -339,7 +413,7 @@ __device__ __forceinline__ void obs8_env(const DevParams& P, i64 env, int lane, 
     for (int i = 0; i < 19; i++) f[i] = -1.0;
     if (gl < P.n_paths[src * N + dst]) {
       const int pidx = (src * N + dst) * P.K + gl;
-      const Row<W> m = path_and_rec<W>(path_rec_load(P, pidx), P.bitmap + env * P.bm_words, P.E, S, 0);
+      const Row<W> m = path_and_rec<W>(path_rec_load(P, pidx), bm, P.E, S, 0);
       const int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
       Row<W> r = row_runs_ge<W>(m, n);
       const Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
@@ -373,7 +447,7 @@ template <int W>
 __global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   if (env >= P.B) return;
-  obs8_env<W>(P, env, lane_id(), with_terminal);
+  obs8_env<W>(P, P.bitmap + env * P.bm_words, env, lane_id(), with_terminal && P.done[env]);
 }
 
 // =============================================================================================
@@ -437,17 +511,46 @@ template <int W> void obs(orl_batch* b, int with_terminal) {
   ORL_TK(b, "k_obs");
 }
 
+// LDS budget per wavefront for 2 / 3 resident waves per SIMD (8 / 12 workgroups per CU of 160 KiB)
+static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
+  const PersistLds with = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, true);
+  const PersistLds without = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, false);
+  int v;  // 0: global state, 4 waves; 1: global state, 3 waves; 2: LDS state, 2 waves; 3: LDS state, 3 waves
+  if (with.total <= (160 * 1024) / 12) v = 3;
+  else if (with.total <= (160 * 1024) / 8) v = 2;
+  else v = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0;
+  if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
+    const int f = atoi(e);
+    if (f == 0 || f == 1 || ((f == 2 || f == 3) && with.total <= 64 * 1024)) v = f;
+  }
+  *lds_bytes = (size_t)(v >= 2 ? with.total : without.total);
+  return v;
+}
+template <int W> int persist_uses_lds(orl_batch* b) {
+  size_t lds;
+  return persist_variant(b->P, &lds) >= 2 ? 1 : 0;
+}
 template <int W> void persist(orl_batch* b, int pol, int target) {
   const DevParams& VP = b->P;
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64), blk_tail(256);
-  const size_t lds_a = (size_t)8 * VP.E * sizeof(sp::SinkEntry);
-  const bool roomy = VP.env_type == ENV_RMCSA || VP.E >= 64;  // 3 waves/SIMD without spills (see k_persist3)
+  size_t lds_a = 0;
+  const int v = persist_variant(VP, &lds_a);
+#define LAUNCH(E_, LDS_, WV_)                                                                                                 \
+  do {                                                                                                                       \
+    if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<E_, W, LDS_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
+    hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_>), gc, blk, lds_a, b->stream, VP, pol, target, b->d_wg_step, b->d_unfinished); \
+  } while (0)
 #define PER_ENV(E_)                                                                                                          \
-  if (roomy) hipLaunchKernelGGL((k_persist3<E_, W>), gc, blk, lds_a, b->stream, VP, pol, target, b->d_wg_step, b->d_unfinished); \
-  else hipLaunchKernelGGL((k_persist<E_, W>), gc, blk, lds_a, b->stream, VP, pol, target, b->d_wg_step, b->d_unfinished);    \
+  switch (v) {                                                                                                               \
+    case 0: LAUNCH(E_, false, 4); break;                                                                                     \
+    case 1: LAUNCH(E_, false, 3); break;                                                                                     \
+    case 2: LAUNCH(E_, true, 2); break;                                                                                      \
+    default: LAUNCH(E_, true, 3); break;                                                                                     \
+  }                                                                                                                          \
   hipLaunchKernelGGL((k_rel_tail<E_, W>), dim3(1), blk_tail, 0, b->stream, VP, 0);
   ORL_FOR_ENV(b, PER_ENV)
 #undef PER_ENV
+#undef LAUNCH
 }
 
 template <int W> void step2(orl_batch* b, int pol) {
@@ -480,11 +583,31 @@ template <int W> void step2(orl_batch* b, int pol) {
 #endif
 }
 
+// diagnostic builds (-DORL_TIMING): per-phase cycle sums of this unit's persistent kernels; zeros otherwise
+template <int W> int prof_read(unsigned long long* out48, int reset) {
+  for (int k = 0; k < ORL_PROF_SLOTS; k++) out48[k] = 0;
+#ifdef ORL_TIMING
+  std::vector<unsigned long long> h((size_t)ORL_PROF_WAVES * ORL_PROF_SLOTS);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(sp::g_prof), h.size() * 8) != hipSuccess) return -1;
+  for (size_t w = 0; w < ORL_PROF_WAVES; w++)
+    for (int k = 0; k < ORL_PROF_SLOTS; k++) out48[k] += h[w * ORL_PROF_SLOTS + k];
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sp::g_prof), h.data(), h.size() * 8) != hipSuccess) return -1;
+  }
+#else
+  (void)reset;
+#endif
+  return 0;
+}
+
 template void reset<ORL_W>(orl_batch*, int, const unsigned char*);
+template int prof_read<ORL_W>(unsigned long long*, int);
 template void policy<ORL_W>(orl_batch*, int);
 template void step64<ORL_W>(orl_batch*, int, int, int);
 template void obs<ORL_W>(orl_batch*, int);
 template void persist<ORL_W>(orl_batch*, int, int);
+template int persist_uses_lds<ORL_W>(orl_batch*);
 template void step2<ORL_W>(orl_batch*, int);
 
 }  // namespace orl_launch
