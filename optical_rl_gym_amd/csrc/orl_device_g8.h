@@ -390,9 +390,15 @@ template <int ENV, int W>
 __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int lane, RngG& r) {
   if (e.new_service) return;
   const int gl = lane & 7;
-  double at = e.now + rng_expovariate(e, r, lane, P.lambda_a);
+  // at = now + expovariate(1/miat); ht = expovariate(1/mht) (rmsa_env.py:548-553): the two random() draws come first, in
+  // the reference's order, then lanes 0-3 of the group evaluate -log(1 - u1) / lambda_a and lanes 4-7 -log(1 - u2) / lambda_h
+  // in one pass (same operations on the same operands as two calls one after the other)
+  const double u1 = rng_random(e, r, lane), u2 = rng_random(e, r, lane);
+  const bool second = gl >= 4;
+  const double q = -orl_log(1.0 - (second ? u2 : u1)) / (second ? P.lambda_h : P.lambda_a);
+  double at = e.now + gget(q, 0, lane);
   e.now = at;
-  double ht = rng_expovariate(e, r, lane, P.lambda_h);
+  double ht = gget(q, 4, lane);
   int src = rng_choice(e, r, lane, P.cum_src, P.N);
   int dst = rng_choice(e, r, lane, P.cum_dst + src * P.N, P.N);
   int bit_rate = 0, br_idx = 0;

@@ -112,6 +112,8 @@ struct SinkEntry {
   u64 crn;  // the core of each mask, 5 bits each (40 bits) | number of masks << 40 | mask 0 is a provision << 44
 };
 struct Sink {
+  unsigned short* list;  // LDS (persistent kernel, else nullptr): the wavefront's open table entries, (local env << 8) | link ...
+  u32* list_n;           // ... and their number, zeroed at the start of the step
   SinkEntry* tab;  // LDS, E entries of this env, crn zeroed
   u32* tally;      // LDS, 32 words per env, zeroed: per-link touch counters (4 x 8 bit per word) for the capacity check
   bool active;     // item mode decided: the releases of this step fit the item form
@@ -130,6 +132,10 @@ __device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, 
     else t->mk1 = (j == 4 ? 0ull : t->mk1) | (m << (16 * (j - 4)));
     t->crn = (crn & ((1ull << 44) | 0xffffffffffull)) | ((u64)(u32)core << (5 * j)) | ((u64)(u32)(j + 1) << 40);
     s.cnt += (j == 0) ? 1 : 0;
+    // a new item: the row phase finds it through the list (any order: items are independent).  A link that carries the
+    // step's provision AND a release gets a second entry (bit 15): two lanes share its row work (row_item_lane1)
+    if (s.list && (j == 0 || (j == 1 && ((crn >> 44) & 1))))
+      s.list[atomicAdd(s.list_n, 1u)] = (unsigned short)((j << 15) | (((lane >> 3) & 7) << 8) | path_rec_byte(rec, 2 + h));
   }
 }
 
@@ -172,19 +178,20 @@ struct Wmem {
   u64* bm0;      // [..][bm_words]
   double* ls0;   // [..][E][4]
   int* cs0;      // [..][cs_words]
-  i64 env0;
+  i64 env0;      // index base of bm0
+  i64 senv0;     // index base of ls0 / cs0
   double* clk;   // LDS [8][2] {provision clock, step clock} of the wavefront's envs, or nullptr (row phase reads SC_NOWA / SC_NOW)
   i64 clk_env0;  // first env of the wavefront (index base of clk)
   bool in_lds;   // wavefront-private state: plain accesses; else the sums are read through L2 where the row phase's atomics land
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.clk = nullptr; m.clk_env0 = 0; m.in_lds = false;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.clk = nullptr; m.clk_env0 = 0; m.in_lds = false;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
-__device__ __forceinline__ double* wm_ls(const DevParams& P, const Wmem& m, i64 env) { return m.ls0 + (env - m.env0) * 4 * P.E; }
-__device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.env0) * P.cs_words; }
+__device__ __forceinline__ double* wm_ls(const DevParams& P, const Wmem& m, i64 env) { return m.ls0 + (env - m.senv0) * 4 * P.E; }
+__device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.senv0) * P.cs_words; }
 
 struct CtrlOpts {
   bool persistent;  // inside k_persist: no kernel boundary between the row phase's L2 atomics and this phase's reads
@@ -205,7 +212,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 template <int ENV, int W>
 __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
                                       const int4* given, u32* s_tally, SinkEntry* s_tab, int parity, int* s_deferred,
-                                      int* done_out) {
+                                      int* done_out, unsigned short* s_list = nullptr, u32* s_list_n = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   if (!O.persistent && blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
   u64 desc_out = 0ull;
@@ -214,6 +221,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
   rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
   Sink sink;
   sink.tab = nullptr; sink.tally = nullptr; sink.active = false; sink.deferred = false; sink.cnt = 0;
+  sink.list = s_list; sink.list_n = s_list_n;
+  if (s_list_n && lane == 0) *s_list_n = 0u;
   {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
     u32* ty = s_tally + 32 * 8 * (int)(threadIdx.x >> 6);
     SinkEntry* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
@@ -420,33 +429,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
   return desc_out;
 }
 
-// persistent kernel: the wavefront's items of this step = the sink-table entries that hold masks, as a dense list of
-// (local env << 8 | link) in LDS; returns their number.  All 64 lanes call.
-__device__ __forceinline__ int list_items(const DevParams& P, const SinkEntry* tab /*this env's*/, bool valid, int lane, unsigned short* list) {
-  const int gl = lane & 7, grp = lane >> 3, E = P.E;
-  int mine = 0;  // entries of this env (uniform within the group)
-  for (int l0 = 0; l0 < E; l0 += 8) {
-    const int l = l0 + gl;
-    const bool has = valid && l < E && ((tab[l].crn >> 40) & 15) != 0;
-    mine += __popc(gballot(has, lane));
-  }
-  int pre = 0, tot = 0;
-#pragma unroll
-  for (int g = 0; g < 8; g++) {
-    const int c = __builtin_amdgcn_readlane(mine, 8 * g);
-    pre += (g < grp) ? c : 0;
-    tot += c;
-  }
-  int at = pre;
-  for (int l0 = 0; l0 < E; l0 += 8) {
-    const int l = l0 + gl;
-    const bool has = valid && l < E && ((tab[l].crn >> 40) & 15) != 0;
-    const u32 fb = gballot(has, lane);
-    if (has) list[at + __popc(fb & ((1u << gl) - 1u))] = (unsigned short)((grp << 8) | l);
-    at += __popc(fb);
-  }
-  return tot;
-}
+// persistent kernel: an item of the row phase read from the sink table in place
 __device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntry& t) {
   const int nm = (int)((t.crn >> 40) & 15);
   return make_item(env, (u32)link, nm, t.mk0, nm > 4 ? t.mk1 : 0ull, t.crn & 0xffffffffffull, 1 | (int)((t.crn >> 44) & 1) << 1);
@@ -771,15 +754,11 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
       c = (int)__builtin_clzll(~a[w]);
     }
   }
+  // free blocks strictly inside [lambda_min, lambda_max): that range starts and ends with a used block and blocks alternate,
+  // so there is exactly one free block between consecutive used blocks (what rmsa_env.py:733-741 counts by run-length
+  // encoding the slice)
   const bool two = nu > 1;
-  int fb = 0;
-#pragma unroll
-  for (int w = 0; w < W; w++) {  // free blocks strictly inside [lambda_min, lambda_max)
-    const u64 in = two ? (a[w] & word_range(lo - 64 * w, hi - 64 * w)) : 0ull;
-    const bool prev_top = (w > 0) && ((a[w > 0 ? w - 1 : 0] >> 63) != 0ull);
-    const u64 carry_i = (prev_top && (64 * w - 1 >= lo) && (64 * w - 1 < hi)) ? 1ull : 0ull;
-    fb += __popcll(in & ~((in << 1) | carry_i));
-  }
+  const int fb = two ? nu - 1 : 0;
   st.nu = nu; st.lo = lo; st.hi = hi; st.occ = two ? hi - lo : 0; st.fb = fb; st.free_ = free_; st.nf = nf;
   max_empty = best;
   const int tw = (S - 1) >> 6, tb = (S - 1) & 63;
@@ -787,6 +766,155 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
 #pragma unroll
   for (int w = 0; w < W; w++) top_bit = (w == tw) ? (int)((a[w] >> tb) & 1ull) : top_bit;
   edge = (int)(a[0] & 1ull) + top_bit;
+}
+
+// the part of the row summary the compactness sums need: used blocks, lambda_min, lambda_max
+template <int W>
+__device__ __forceinline__ void row_occ_fb(const u64 (&a)[W], int S, int& occ, int& fb) {
+  int nu = 0, lo = 1 << 20, hi = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) {
+    const u64 used = ~a[w] & word_mask_lo(S - 64 * w);
+    const u64 carry_u = (w == 0) ? 0ull : ((a[w > 0 ? w - 1 : 0] >> 63) ^ 1ull);
+    nu += __popcll(used & ~((used << 1) | carry_u));
+    if (used) {
+      const int l = 64 * w + (int)__builtin_ctzll(used);
+      lo = l < lo ? l : lo;
+      hi = 64 * w + 64 - (int)__builtin_clzll(used);
+    }
+  }
+  const bool two = nu > 1;
+  occ = two ? hi - lo : 0;
+  fb = two ? nu - 1 : 0;
+}
+
+// Single-core families (RMSA, DeepRMSA, RWA): every mask of an item works on the same row, and only the first touch of
+// the link at a clock value needs the row's statistics — the provision at the provision clock and the first release at the
+// step clock (_update_link_stats, rmsa_env.py:464-543); further releases of the step see time_diff == 0, i.e.
+// new = ((old * now) + (cur * 0.0)) / now with a finite cur, whatever the row looks like.  So an item costs at most two
+// full row summaries and two float64 updates, however many releases meet on the link.  Few links carry both in one step
+// (two per wavefront-step), and a lane that looped twice would hold the other 63 back: such an item is worked on by TWO
+// lanes at once (role): lane A summarises the row after the provision and updates the statistics at the provision clock;
+// lane B applies the provision and the releases, summarises the row after the first release, and — once A's statistics are
+// stored — does the update at the step clock, the further releases and the row store.  Everything else (`whole`) is one lane.
+// The compactness sums change by (summary after the provision - before) and (final - after the provision), the latter
+// also into rel_sums.
+template <int ENV, int W>
+__device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M, const Item it, int second, Prof& prof) {
+  const int E = P.E, S = P.S;
+  const i64 env = (i64)(u32)it.a.x;
+  const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
+  const bool prov_first = ((it.a.x >> 45) & 1) != 0;
+  const bool shared = prov_first && nmask >= 2;   // two lanes work on this item
+  const bool role_b = shared && second;           // ... this one on the releases
+  const bool role_a = shared && !second;          // ... this one on the provision
+  u64* row = wm_bm(P, M, env) + (size_t)link * W;
+  int* cs = wm_cs(P, M, env);
+  int* rs = cs + 2;
+  double* ls = wm_ls(P, M, env) + 4 * link;
+  const double now = M.clk ? M.clk[2 * (env - M.clk_env0) + 1] : __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
+  const double now_prov = M.clk ? M.clk[2 * (env - M.clk_env0)] : __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOWA]);
+  u64 a[W];
+#pragma unroll
+  for (int w = 0; w < W; w++) a[w] = row[w];
+  ORL_PROFR(3);
+  // the mask whose statistics this lane evaluates: B the first release (mask 1, after applying the provision), else mask 0
+  const int kf = role_b ? 1 : 0;
+  if (role_b) {
+    const int s0 = (int)(it.a.y & 0x1ff), n = (int)((it.a.y >> 9) & 0x7f);
+#pragma unroll
+    for (int w = 0; w < W; w++) a[w] &= ~word_range(s0 - 64 * w, s0 + n - 64 * w);
+  }
+  int occ0 = 0, fb0 = 0;  // B: the summary after the provision
+  if (ENV != ENV_RWA) row_occ_fb<W>(a, S, occ0, fb0);
+  const bool rel_f = !(kf == 0 && prov_first);  // the evaluated mask is a release
+  {
+    const u64 mw = it.a.y >> (16 * kf);
+    const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+      const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
+      a[w] = rel_f ? (a[w] | m) : (a[w] & ~m);
+    }
+  }
+  ORL_PROFR(4);
+  RowStat after;
+  int max_empty = 0, edge = 0;
+  if (ENV != ENV_RWA) {
+    row_stat_lane<W>(a, S, after, max_empty, edge);
+  } else {
+    int f = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) f += __popcll(a[w]);
+    after.free_ = f;
+  }
+  ORL_PROFR(5);
+  // the values _update_link_stats derives from the row (rmsa_env.py:464-543)
+  const int free_ = after.free_;
+  const double cur_util = (double)(S - free_) / (double)S;
+  double cur_frag = 0.0, cur_comp = 0.0;
+  if (ENV != ENV_RWA && free_ > 0) {
+    int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
+    cur_frag = 1.0 - ((double)me / (double)free_);
+    if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
+    else cur_comp = 1.0;
+  }
+  const double clock = rel_f ? now : now_prov;
+  // the running averages: round 0 every lane but the B lanes, round 1 the B lanes (their link's record has been updated and
+  // stored by the A lane of the same wavefront in round 0)
+  const u64 any_b = __ballot(role_b);
+  for (int round = 0; round < 2; round++) {
+    if (round == 1 && !any_b) break;
+    if ((round == 1) == role_b) {
+      const double2 ls01 = *(const double2*)ls, ls23 = *(const double2*)(ls + 2);  // one 32-byte record
+      double last_update = ls23.y;
+      double util = ls01.x, frag = ls01.y, comp = ls23.x;
+      if (clock > 0) {  // the first touch of the link at this clock value
+        const double time_diff = clock - last_update;
+        util = ((util * last_update) + (cur_util * time_diff)) / clock;
+        if (ENV != ENV_RWA) {
+          frag = ((frag * last_update) + (cur_frag * time_diff)) / clock;
+          comp = ((comp * last_update) + (cur_comp * time_diff)) / clock;
+        }
+      }
+      last_update = clock;
+      // further releases of the step on this link: the time_diff == 0 form of the update (never for an A lane)
+      if (!role_a && now > 0)
+        for (int k = kf + 1; k < nmask; k++) {
+          util = ((util * now) + 0.0) / now;
+          if (ENV != ENV_RWA) { frag = ((frag * now) + 0.0) / now; comp = ((comp * now) + 0.0) / now; }
+        }
+      *(double2*)ls = make_double2(util, frag);
+      *(double2*)(ls + 2) = make_double2(comp, last_update);
+    }
+    wave_fence();
+  }
+  ORL_PROFR(6);
+  int occL = after.occ, fbL = after.fb;
+  if (!role_a && nmask > kf + 1) {  // the masks of the further releases, then what the row contributes in the end
+    for (int k = kf + 1; k < nmask; k++) {
+      const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
+      const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
+#pragma unroll
+      for (int w = 0; w < W; w++) a[w] |= word_range(s0 - 64 * w, s0 + n - 64 * w);
+    }
+    if (ENV != ENV_RWA) row_occ_fb<W>(a, S, occL, fbL);
+  }
+  if (ENV != ENV_RWA) {
+    // this lane's part of the row's contribution to the compactness sums; releases also go into rel_sums
+    const int d_occ = occL - occ0, d_fb = fbL - fb0;
+    if (d_occ) atomicAdd(cs, d_occ);
+    if (d_fb) atomicAdd(cs + 1, d_fb);
+    if (rel_f) {
+      if (d_occ) atomicAdd(rs, d_occ);
+      if (d_fb) atomicAdd(rs + 1, d_fb);
+    }
+  }
+  if (!role_a) {
+#pragma unroll
+    for (int w = 0; w < W; w++) row[w] = a[w];
+  }
+  ORL_PROFR(7);
 }
 
 // MIXED (two-kernel pipeline): mask 0 of an item may be this step's provision — slots cleared, statistics at the

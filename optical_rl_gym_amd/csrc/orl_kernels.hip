@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
     it.a = q[2 * at];
     it.b = q[2 * at + 1];
     ORL_PROFR(2);
-    sp::row_item_lane<ENV, W>(P, sp::wmem_global(P), it, prof);
+    sp::row_item_lane<ENV, W>(P, sp::wmem_global(P), it, prof);  // (the general form: one lane walks all masks of the item)
   }
   ORL_PROFR(8);
   ORL_PROFR_END();
@@ -222,27 +222,29 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (all multiples of 16)
   int tab, tally, list, clk, misc, bm, ls, cs, total;
 };
-__host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, int cs_words, bool state) {
+__host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, int cs_words, int state) {
   PersistLds L;
   int o = 0;
   L.tab = o; o += 8 * E * (int)sizeof(sp::SinkEntry);
   L.tally = o; o += 8 * 32 * 4;
-  L.list = o; o += ((8 * E * 2) + 15) & ~15;
+  L.list = o; o += ((2 * 8 * E * 2) + 15) & ~15;  // an item may have two entries
   L.clk = o; o += 8 * 2 * 8;
   L.misc = o; o += 16;
-  L.bm = o; if (state) o += 8 * bm_words * 8;
-  L.ls = o; if (state) o += 8 * E * 32;
-  L.cs = o; if (state) o += (8 * cs_words * 4 + 15) & ~15;
+  L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
+  L.ls = o; if (state >= 2) o += 8 * E * 32;
+  L.cs = o; if (state >= 2) o += (8 * cs_words * 4 + 15) & ~15;
   L.total = o;
   return L;
 }
-template <int ENV, int W, bool LDS>
+// LDS: 0 = the state stays in global memory, 1 = slot maps in LDS, 2 = slot maps + link statistics + per-core sums in LDS
+template <int ENV, int W, int LDS>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.cs_words, LDS);
   sp::SinkEntry* s_tab = (sp::SinkEntry*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
   int* s_deferred = (int*)(orl_lds_raw + L.misc);  // [2], alternating by step
+  u32* s_list_n = (u32*)(orl_lds_raw + L.misc + 8);
   const int lane = lane_id();
   const i64 env0 = (i64)blockIdx.x * 8;
   const i64 env = env0 + (threadIdx.x >> 3);
@@ -252,16 +254,21 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   sp::Wmem M = sp::wmem_global(P);
   M.clk = (double*)(orl_lds_raw + L.clk);
   M.clk_env0 = env0;
-  if (LDS) {
+  if (LDS >= 1) {  // the wavefront's envs are contiguous in every array: coalesced 16-byte loads
     M.bm0 = (u64*)(orl_lds_raw + L.bm);
-    M.ls0 = (double*)(orl_lds_raw + L.ls);
-    M.cs0 = (int*)(orl_lds_raw + L.cs);
     M.env0 = env0;
-    M.in_lds = true;
-    if (step < target) {  // the wavefront's envs are contiguous in every array: coalesced 16-byte loads
+    if (step < target) {
       const ulonglong2* g = (const ulonglong2*)(P.bitmap + env0 * P.bm_words);
       ulonglong2* l = (ulonglong2*)M.bm0;
       for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) l[i] = g[i];
+    }
+  }
+  if (LDS >= 2) {
+    M.ls0 = (double*)(orl_lds_raw + L.ls);
+    M.cs0 = (int*)(orl_lds_raw + L.cs);
+    M.senv0 = env0;
+    M.in_lds = true;
+    if (step < target) {
       const double2* gs = (const double2*)(P.lstat + env0 * 4 * P.E);
       double2* ls = (double2*)M.ls0;
       for (int i = lane; i < nenv * 2 * P.E; i += 64) ls[i] = gs[i];
@@ -297,18 +304,19 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
                           (int)((desc >> 48) & 0xffu), lane_i, pol, valid_i ? P.path_col[env_i] : 0, a);
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
-      desc = sp::ctrl_a<ENV, W>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i);
+      desc = sp::ctrl_a<ENV, W>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
+                                s_list, s_list_n);
     }
-    __syncthreads();  // sink table, clocks, env records
+    __syncthreads();  // sink table + item list, clocks, env records
     {
-      const int n_items = sp::list_items(P, s_tab + P.E * (lane_i >> 3), valid_i, lane_i, s_list);
-      __syncthreads();
+      const int n_items = (int)*s_list_n;
       ORL_PROFA(12);
       for (int idx = lane_i; idx < n_items; idx += 64) {
         const int code = (int)s_list[idx];
-        const int el = code >> 8, link = code & 0xff;
+        const int el = (code >> 8) & 7, link = code & 0xff, second = code >> 15;
         const sp::Item it = sp::item_from_sink(env0 + el, link, s_tab[P.E * el + link]);
-        sp::row_item_lane<ENV, W>(P, M, it, prof);
+        if (ENV == ENV_RMCSA) { if (!second) sp::row_item_lane<ENV, W>(P, M, it, prof); }
+        else sp::row_item_lane1<ENV, W>(P, M, it, second, prof);
       }
       ORL_PROFA(13);
     }
@@ -321,11 +329,13 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if (deferred) break;
   }
   ORL_PROF_END();
-  if (LDS && step > first_step) {
+  if (LDS >= 1 && step > first_step) {
     __syncthreads();
     ulonglong2* g = (ulonglong2*)(P.bitmap + env0 * P.bm_words);
     const ulonglong2* l = (const ulonglong2*)M.bm0;
     for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) g[i] = l[i];
+  }
+  if (LDS >= 2 && step > first_step) {
     double2* gs = (double2*)(P.lstat + env0 * 4 * P.E);
     const double2* ls = (const double2*)M.ls0;
     for (int i = lane; i < nenv * 2 * P.E; i += 64) gs[i] = ls[i];
@@ -346,7 +356,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 // Register budgets: WAVES waves/SIMD -> 512 / WAVES VGPRs.  Global state: 4 (128 VGPRs) for NSFNET-sized RMSA / RWA /
 // DeepRMSA, 3 (168, no spills) for the heavier RMCSA and Germany50 steps.  LDS state: the LDS window decides the residency
 // (orl_launch::persist), the kernel is built for 2 or 3.
-template <int ENV, int W, bool LDS, int WAVES>
+template <int ENV, int W, int LDS, int WAVES>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
   persist_body<ENV, W, LDS>(P, pol, target, wg_step, n_unfinished);
@@ -511,24 +521,30 @@ template <int W> void obs(orl_batch* b, int with_terminal) {
   ORL_TK(b, "k_obs");
 }
 
-// LDS budget per wavefront for 2 / 3 resident waves per SIMD (8 / 12 workgroups per CU of 160 KiB)
+// Forms of the persistent kernel: (what lives in LDS, waves per SIMD the registers are budgeted for).  The LDS window decides
+// how many wavefronts a CU holds (160 KiB / window, 4 SIMDs).  Measured on MI355X (cfg2, 65 536 envs): see DESIGN.md 4.3.
+struct PersistForm { int lds, waves; };
+static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}};
 static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
-  const PersistLds with = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, true);
-  const PersistLds without = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, false);
-  int v;  // 0: global state, 4 waves; 1: global state, 3 waves; 2: LDS state, 2 waves; 3: LDS state, 3 waves
-  if (with.total <= (160 * 1024) / 12) v = 3;
-  else if (with.total <= (160 * 1024) / 8) v = 2;
+  const int full = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, 2).total;
+  const int maps = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, 1).total;
+  const int lim4 = (160 * 1024) / 16, lim3 = (160 * 1024) / 12, lim2 = (160 * 1024) / 8;
+  int v;
+  if (full <= lim3) v = 3;
+  else if (maps <= lim3) v = 4;
+  else if (full <= lim2) v = 2;
   else v = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0;
+  (void)lim4;
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
-    if (f == 0 || f == 1 || ((f == 2 || f == 3) && with.total <= 64 * 1024)) v = f;
+    if (f >= 0 && f < 6 && persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[f].lds).total <= 64 * 1024) v = f;
   }
-  *lds_bytes = (size_t)(v >= 2 ? with.total : without.total);
+  *lds_bytes = (size_t)persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[v].lds).total;
   return v;
 }
 template <int W> int persist_uses_lds(orl_batch* b) {
   size_t lds;
-  return persist_variant(b->P, &lds) >= 2 ? 1 : 0;
+  return kPersistForms[persist_variant(b->P, &lds)].lds;
 }
 template <int W> void persist(orl_batch* b, int pol, int target) {
   const DevParams& VP = b->P;
@@ -542,10 +558,12 @@ template <int W> void persist(orl_batch* b, int pol, int target) {
   } while (0)
 #define PER_ENV(E_)                                                                                                          \
   switch (v) {                                                                                                               \
-    case 0: LAUNCH(E_, false, 4); break;                                                                                     \
-    case 1: LAUNCH(E_, false, 3); break;                                                                                     \
-    case 2: LAUNCH(E_, true, 2); break;                                                                                      \
-    default: LAUNCH(E_, true, 3); break;                                                                                     \
+    case 0: LAUNCH(E_, 0, 4); break;                                                                                         \
+    case 1: LAUNCH(E_, 0, 3); break;                                                                                         \
+    case 2: LAUNCH(E_, 2, 2); break;                                                                                         \
+    case 3: LAUNCH(E_, 2, 3); break;                                                                                         \
+    case 4: LAUNCH(E_, 1, 3); break;                                                                                         \
+    default: LAUNCH(E_, 1, 4); break;                                                                                        \
   }                                                                                                                          \
   hipLaunchKernelGGL((k_rel_tail<E_, W>), dim3(1), blk_tail, 0, b->stream, VP, 0);
   ORL_FOR_ENV(b, PER_ENV)
