@@ -48,15 +48,27 @@ __global__ void __launch_bounds__(64) k_init_mt(DevParams P, const u32* raw, con
     wave_fence();
   }
   u32* dst = P.mt + env * 624;
-  for (int i = lane; i < 624; i += 64) dst[i] = m[i];
   const int pos = p0 >= 624 ? 0 : p0;
   if (keep_record) {
+    u64* rec = P.scal + env * ORL_SCAL_WORDS;
+    const u64 fl = rec[SC_FLAGS], idp = rec[SC_ID_MTPOS];
+    const bool first = P.mt2 && !((fl >> 32) & ORL_FLAG_MT2) && P.env_type != ENV_RWA;
+    if (first) {  // the stream the env was constructed with lives on as its bit-rate stream (see DevParams::mt2)
+      u32* d2 = P.mt2 + env * 624;
+      for (int i = lane; i < 624; i += 64) d2[i] = dst[i];
+    }
+    wave_fence();
+    for (int i = lane; i < 624; i += 64) dst[i] = m[i];
     if (lane == 0) {
-      u64* w = P.scal + env * ORL_SCAL_WORDS + SC_ID_MTPOS;
-      *w = (*w & 0xffffffffull) | ((u64)(u32)pos << 32);
+      rec[SC_ID_MTPOS] = (idp & 0xffffffffull) | ((u64)(u32)pos << 32);
+      if (first) {
+        rec[SC_FLAGS] = fl | ((u64)ORL_FLAG_MT2 << 32);
+        rec[SC_HINT] = (rec[SC_HINT] & 0xffffffffull) | ((idp >> 32) << 32);
+      }
     }
     return;
   }
+  for (int i = lane; i < 624; i += 64) dst[i] = m[i];
   u64 v = 0;
   if (lane == SC_ID_MTPOS) v = pack2(0, pos);
   if (lane < ORL_SCAL_WORDS) P.scal[env * ORL_SCAL_WORDS + lane] = v;
@@ -574,6 +586,17 @@ extern "C" int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_
   const size_t B = (size_t)b->P.B;
   DevMask m;
   if (m.upload(b, env_mask)) return ORL_E_HIP;
+  if (!b->P.mt2 && b->P.env_type != ENV_RWA) {
+    // from now on a reseeded env draws its bit rates from the stream it was constructed with (rmsa_env.py:85-87); the
+    // persistent kernel does not carry that second stream: device-resident runs of this batch use the per-env kernel
+    u32* p = nullptr;
+    HIPCHK(hipMalloc((void**)&p, B * 624 * sizeof(u32) + 64));
+    b->allocs.push_back(p);
+    b->P.mt2 = p;
+    b->persist = 0;
+    b->two_kernel = 0;
+    b->P.pipeline2 = 0;
+  }
   u32* raw = nullptr;
   long long* dseeds = nullptr;
   HIPCHK(hipMalloc((void**)&raw, B * 625 * sizeof(u32)));
@@ -1010,6 +1033,7 @@ static std::vector<Section> state_sections(orl_batch* b) {
   if (P.br_hist) v.push_back({P.br_hist, B * 2 * P.n_br * 8});
   if (P.act_hist) v.push_back({P.act_hist, B * ((P.K + 1) + (P.S + 1)) * 8});
   if (P.act2d) v.push_back({P.act2d, B * (size_t)P.act2d_words * 4});
+  if (P.mt2) v.push_back({P.mt2, B * 624 * 4});
   return v;
 }
 extern "C" int64_t orl_batch_state_bytes(orl_batch* b) {

@@ -61,6 +61,7 @@ enum {
 #define ORL_IMASKS 8  // masks one work item can carry = releases of one step that may meet on one link (orl_device_split.h)
 #define ORL_FLAG_EV_OVERFLOW 1
 #define ORL_FLAG_BAD_ACTION 2
+#define ORL_FLAG_MT2 4  // the env was reseeded: its bit rates keep coming from the stream it was constructed with (mt2)
 
 // soon list (split pipeline): the earliest pending releases of an env, ORL_SOON_PER_LANE per lane of its 8-lane group
 #ifndef ORL_SOON_PER_LANE
@@ -93,6 +94,9 @@ struct DevParams {
   double* ev_time;  // [B][ev_cap]        +inf = empty slot
   u64* ev_info;     // [B][ev_cap]        packed {pair_path:24 | slot:12 | n:8 | core:5 | bit_rate:15}
   u32* mt;          // [B][624]           update-behind MT19937 state
+  u32* mt2;         // [B][624] or null   after seed(): the stream the env was constructed with, which the reference keeps drawing
+                    //                    bit rates from (functools.partial bound in __init__, rmsa_env.py:85-87, 97-99); position in
+                    //                    the high half of SC_HINT
   double* lstat;    // [B][E][4]          utilization, external_fragmentation, compactness, last_update
   u64* scal;        // [B][32]
   u64* svc_desc;    // [B]  pending service for the slot-scan kernel: pair_base:32 | br_idx:16 | n_paths:8
@@ -342,6 +346,7 @@ struct Env {
   double now, at, ht, g_thr, g_comp, g_last;
   i64 sp, sa, esp, esa, brq, brp, ebrq, ebrp, s_br, s_nh;
   int src, dst, bit_rate, br_idx, id, mt_pos, ev_hwm, ev_cnt, new_service, flags;
+  int mt2_pos;  // position in the construction-time stream (ORL_FLAG_MT2)
   // freshly pushed release event of this kernel invocation (kept in registers: the store to
   // ev_time is not guaranteed visible to the other lanes' loads within the same kernel)
   double push_t;
@@ -377,6 +382,7 @@ __device__ __forceinline__ void env_unpack(const DevParams& P, Env& e, i64 env, 
   t = rdlane64(v, SC_ID_MTPOS); e.id = (int)(u32)t; e.mt_pos = (int)(t >> 32);
   t = rdlane64(v, SC_EV); e.ev_hwm = (int)(u32)t; e.ev_cnt = (int)(t >> 32);
   t = rdlane64(v, SC_FLAGS); e.new_service = (int)(u32)t; e.flags = (int)(t >> 32);
+  t = rdlane64(v, SC_HINT); e.mt2_pos = (int)(t >> 32);
 #undef F64
 #undef I64
   e.push_idx = -1;
@@ -403,7 +409,7 @@ __device__ __forceinline__ void env_store(const DevParams& P, const Env& e, int 
   PUTI(SC_SBR, e.s_br) PUTI(SC_SNH, e.s_nh)
   PUTI(SC_SRC_DST, pack2(e.src, e.dst)) PUTI(SC_BR_IDX, pack2(e.bit_rate, e.br_idx))
   PUTI(SC_ID_MTPOS, pack2(e.id, e.mt_pos)) PUTI(SC_EV, pack2(e.ev_hwm, e.ev_cnt)) PUTI(SC_FLAGS, pack2(e.new_service, e.flags))
-  PUTF(SC_NEXTREL, -__builtin_inf()) PUTI(SC_HINT, 0ull) PUTF(SC_TSOON, -__builtin_inf())  // caches of the 8-lane kernels: unknown
+  PUTF(SC_NEXTREL, -__builtin_inf()) PUTI(SC_HINT, pack2(0, e.mt2_pos)) PUTF(SC_TSOON, -__builtin_inf())  // caches of the 8-lane kernels: unknown
 #undef PUTF
 #undef PUTI
   if (lane < SC_COUNT) P.scal[e.env * ORL_SCAL_WORDS + lane] = v;
@@ -836,14 +842,35 @@ __device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lan
   int dst = rng_choice(e, r, lane, P.cum_dst + src * P.N, P.N);
   int bit_rate = 0, br_idx = 0;
   if (ENV != ENV_RWA) {
+    // After seed() the reference draws the bit rate from the Random object it bound at construction (functools.partial,
+    // rmsa_env.py:85-87 / 97-99) while everything else uses the new one: a second stream for envs that were reseeded.
+    const bool second = P.mt2 && (e.flags & ORL_FLAG_MT2);
+    u32* mt_main = e.mt;
+    int pos_main = 0;
+    Rng r2;
+    if (second) {
+      rng_commit(e, r, lane);
+      pos_main = e.mt_pos;
+      e.mt = P.mt2 + e.env * 624;
+      e.mt_pos = e.mt2_pos;
+      rng_fill(e, r2, lane);
+    }
+    Rng& rb = second ? r2 : r;
     if (P.bit_rate_mode == 0) {  // randint(lo, hi) = lo + _randbelow(hi + 1 - lo)
-      u32 v = rng_u32(e, r, lane) >> (32 - P.rand_bits);
-      while ((int)v >= P.rand_n) v = rng_u32(e, r, lane) >> (32 - P.rand_bits);
+      u32 v = rng_u32(e, rb, lane) >> (32 - P.rand_bits);
+      while ((int)v >= P.rand_n) v = rng_u32(e, rb, lane) >> (32 - P.rand_bits);
       br_idx = (int)v;
       bit_rate = P.br_lo + br_idx;
     } else {
-      br_idx = rng_choice(e, r, lane, P.cum_br, P.n_br);
+      br_idx = rng_choice(e, rb, lane, P.cum_br, P.n_br);
       bit_rate = P.bit_rates[br_idx];
+    }
+    if (second) {
+      rng_commit(e, r2, lane);
+      e.mt2_pos = e.mt_pos;
+      e.mt = mt_main;
+      e.mt_pos = pos_main;
+      r.used = 0;  // (already committed)
     }
   }
   rng_commit(e, r, lane);

@@ -56,12 +56,13 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
   for (int i = lane; i < P.ev_cap; i += 64) e.ev_time[i] = __builtin_inf();
   if (P.br_hist) for (int i = lane; i < 2 * P.n_br; i += 64) P.br_hist[env * 2 * P.n_br + i] = 0;
   if (P.act_hist) for (int i = lane; i < (P.K + 1) + (P.S + 1); i += 64) P.act_hist[env * ((P.K + 1) + (P.S + 1)) + i] = 0;
-  if (P.act2d) for (int i = lane; i < P.act2d_words; i += 64) P.act2d[env * P.act2d_words + i] = 0;
+  // RWAEnv.reset clears actions_output / actions_taken (rwa_env.py:194-203); RMSAEnv.reset never does (rmsa_env.py:284-359)
+  if (P.act2d && ENV == ENV_RWA) for (int i = lane; i < P.act2d_words; i += 64) P.act2d[env * P.act2d_words + i] = 0;
   wave_fence();
   e.now = 0; e.at = 0; e.ht = 0; e.g_thr = 0; e.g_comp = 0; e.g_last = 0;
   e.sp = e.sa = e.esp = e.esa = e.brq = e.brp = e.ebrq = e.ebrp = e.s_br = e.s_nh = 0;
   e.src = e.dst = e.bit_rate = e.br_idx = e.id = 0;
-  e.ev_hwm = 0; e.ev_cnt = 0; e.new_service = 0; e.flags = 0;
+  e.ev_hwm = 0; e.ev_cnt = 0; e.new_service = 0; e.flags &= ORL_FLAG_MT2;  // (a full reset keeps the Random objects)
   next_service<ENV, W, false>(P, e, lane, nullptr);
   stage_out(P, e, lane);
   env_store(P, e, lane);
@@ -526,15 +527,17 @@ template <int W> void obs(orl_batch* b, int with_terminal) {
 struct PersistForm { int lds, waves; };
 static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}};
 static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
-  const int full = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, 2).total;
   const int maps = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, 1).total;
-  const int lim4 = (160 * 1024) / 16, lim3 = (160 * 1024) / 12, lim2 = (160 * 1024) / 8;
+  const int lim4 = (160 * 1024) / 16, lim3 = (160 * 1024) / 12;
+  // Measured on MI355X, env-steps/s (form 0 / 2 / 3 / 4 / 5 = global 4 waves / full LDS 2 / full LDS 3 / maps 3 / maps 4):
+  //   cfg2 65 536 envs: 8.0e8 / 6.5e8 / - / 7.8e8 / - (does not fit); HBM traffic per batched step 206 MB / - / - / 114 MB,
+  //   L2<->fabric requests 2.63 M / - / - / 1.61 M.  cfg1 32 768: 8.8e8 / - / 7.7e8 / - / 9.5e8;  cfg3 32 768: 8.5e8 / - / 8.2e8 / - / 9.9e8.
+  // The kernel is bound by instruction issue, so residency (waves per SIMD) beats keeping more state in LDS; the slot maps
+  // are the state every phase reads, and keeping them in LDS halves what reaches memory at the same speed.
   int v;
-  if (full <= lim3) v = 3;
+  if (maps <= lim4) v = 5;
   else if (maps <= lim3) v = 4;
-  else if (full <= lim2) v = 2;
   else v = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0;
-  (void)lim4;
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
     if (f >= 0 && f < 6 && persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[f].lds).total <= 64 * 1024) v = f;

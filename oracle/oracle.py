@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ENV_TYPES = {"RMSA": 0, "DeepRMSA": 1, "RWA": 2, "RMCSA": 3}
-POLICIES = {"SP_FF": 0, "SAP_FF": 1, "LLP_FF": 2, "SAP_LF": 3, "SP": 0, "SAP": 1, "SAP_BM_FC_FF": 1}
+POLICIES = {"SP_FF": 0, "SAP_FF": 1, "LLP_FF": 2, "SAP_LF": 3, "SP": 0, "SAP": 1, "SAP_BM_FC_FF": 1, "PATH_FF": 4}
 
 
 class _Config(C.Structure):
@@ -64,6 +64,9 @@ def _lib(omp=False):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
         for name in ("orc_get_slots", "orc_get_link_stats", "orc_get_net_stats"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        lib.orc_set_paths.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_reseed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.orc_get_action_histograms.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         lib.orc_get_active.restype = C.c_int32
         lib.orc_get_active.argtypes = [C.c_void_p, C.c_int64]
         _LIBS[key] = lib
@@ -167,7 +170,38 @@ class OracleBatch:
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         self.lib.orc_reset(self.h, int(full), None if m is None else m.ctypes.data)
 
-    def policy(self, policy):
+    def set_paths(self, paths):
+        p = np.ascontiguousarray(np.asarray(paths).reshape(self.n), np.int32)
+        self.lib.orc_set_paths(self.h, p.ctypes.data)
+
+    def seed(self, seeds, mask=None):
+        """env.seed(seed) of the selected envs (optical_network_env.py:205-210)."""
+        if np.isscalar(seeds):
+            seeds = [int(seeds) + i for i in range(self.n)]
+        st = mt_states(seeds)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.lib.orc_reseed(self.h, st.ctypes.data, None if m is None else m.ctypes.data)
+
+    def action_histograms_of(self, env=0):
+        out = np.zeros((2, self.k + 1, self.S + 1), np.int64)
+        self.lib.orc_get_action_histograms(self.h, env, out.ctypes.data)
+        return out[0], out[1]
+
+    def matrix_observation(self):
+        """SimpleMatrixObservation (rmsa_env.py:806-837, rmcsa_env.py:914-947) from the read-back state."""
+        N = len(self.tables["node_names"])
+        svc = self.services()
+        out = np.zeros((self.n, 2 * N + self.C * self.E * self.S), np.uint8)
+        for i in range(self.n):
+            src, dst = int(svc[i, 2]), int(svc[i, 3])
+            out[i, min(src, dst)] = 1
+            out[i, N + max(src, dst)] = 1
+            out[i, 2 * N:] = self.slots(i).reshape(-1)
+        return out
+
+    def policy(self, policy, paths=None):
+        if paths is not None:
+            self.set_paths(paths)
         a = np.zeros((self.n, 4), np.int32)
         self.lib.orc_policy(self.h, POLICIES[policy] if isinstance(policy, str) else policy, a.ctypes.data)
         return a

@@ -40,6 +40,7 @@
 #define POLICY_SAP_FF 1
 #define POLICY_LLP_FF 2
 #define POLICY_SAP_LF 3
+#define POLICY_PATH_FF 4
 
 typedef struct {
   int32_t env_type, n_nodes, n_links, k_paths, max_hops, n_mods;
@@ -82,6 +83,10 @@ typedef struct {
 typedef struct {
   uint32_t mt[624];
   int32_t mti;
+  /* seed() replaces self.rng, but bit_rate_function stays bound to the Random object of __init__ (functools.partial,
+     rmsa_env.py:85-87, 97-99): after a reseed the bit rates keep coming from the construction-time stream */
+  uint32_t mt_init[624];
+  int32_t mti_init, reseeded;
   double current_time;
   int64_t services_processed, services_accepted, episode_services_processed, episode_services_accepted;
   int64_t bit_rate_requested, bit_rate_provisioned, episode_bit_rate_requested, episode_bit_rate_provisioned;
@@ -101,6 +106,8 @@ typedef struct {
   int64_t *br_req_hist, *br_prov_hist; /* discrete mode, per bit-rate index */
   int64_t *act_path, *act_slot;        /* RWA: marginals of actions_output */
   int64_t act_total;
+  int64_t *actions_output, *actions_taken; /* [(k+1)][(S+1)] (rmsa_env.py:126-137; RWA uses the top-left corner, rwa_env.py:52-58) */
+  int32_t path_choice;                     /* PathOnlyFirstFitAction: the agent's Discrete(k + reject) action */
   int32_t error;
 } orc_env;
 
@@ -486,8 +493,18 @@ static void next_service(const orc_batch* b, orc_env* e) {
   ht = py_expovariate(e, 1 / b->cfg.mean_ht);
   get_node_pair(b, e, &src, &dst);
   if (t != ENV_RWA) {
+    uint32_t keep[624];
+    int32_t keep_i = 0;
+    if (e->reseeded) { /* draw from the construction-time stream */
+      memcpy(keep, e->mt, sizeof keep); keep_i = e->mti;
+      memcpy(e->mt, e->mt_init, sizeof keep); e->mti = e->mti_init;
+    }
     if (b->cfg.bit_rate_mode == 0) bit_rate = b->cfg.br_lo + (int)py_randbelow(e, b->cfg.br_hi + 1 - b->cfg.br_lo);
     else bit_rate = b->bit_rates[py_choices(e, b->bit_rate_probs, b->cfg.n_bit_rates)];
+    if (e->reseeded) {
+      memcpy(e->mt_init, e->mt, sizeof keep); e->mti_init = e->mti;
+      memcpy(e->mt, keep, sizeof keep); e->mti = keep_i;
+    }
   }
   if (t == ENV_RWA || t == ENV_RMCSA) release_due(b, e); /* these two release BEFORE creating the service */
   memset(&e->cur, 0, sizeof(e->cur));
@@ -540,6 +557,9 @@ static void env_reset(const orc_batch* b, orc_env* e, int full) {
     for (i = 0; i < b->cfg.k_paths + rej; i++) e->act_path[i] = 0;
     for (i = 0; i < b->cfg.num_slots + rej; i++) e->act_slot[i] = 0;
     e->act_total = 0;
+    /* rwa_env.py:194-203; RMSAEnv.reset never clears actions_output / actions_taken (rmsa_env.py:284-359) */
+    memset(e->actions_output, 0, sizeof(int64_t) * (size_t)(b->cfg.k_paths + 1) * (b->cfg.num_slots + 1));
+    memset(e->actions_taken, 0, sizeof(int64_t) * (size_t)(b->cfg.k_paths + 1) * (b->cfg.num_slots + 1));
   }
   e->new_service = 0;
   next_service(b, e);
@@ -595,6 +615,7 @@ static int env_step(const orc_batch* b, orc_env* e, const int32_t* action, doubl
   } else {
     if (path < 0 || path > k || slot < 0 || slot > S) return -2;
   }
+  if (t != ENV_RMCSA) e->actions_output[(size_t)path * (S + 1) + slot] += 1; /* rmsa_env.py:167, rwa_env.py:103 */
   if (t == ENV_RMSA || t == ENV_DEEPRMSA) prev_compactness = network_compactness(b, e, 0);
   e->cur.accepted = 0;
   if (t == ENV_RMCSA) {
@@ -631,6 +652,10 @@ static int env_step(const orc_batch* b, orc_env* e, const int32_t* action, doubl
     }
   }
   if (t == ENV_RWA) { e->services_processed += 1; e->episode_services_processed += 1; }
+  if (t != ENV_RMCSA) { /* actions_taken: rmsa_env.py:201, 211-212; rwa_env.py:125, 132-133 */
+    if (e->cur.accepted) e->actions_taken[(size_t)path * (S + 1) + slot] += 1;
+    else e->actions_taken[(size_t)k * (S + 1) + S] += 1;
+  }
   if (t == ENV_RMSA || t == ENV_DEEPRMSA) cur_compactness = network_compactness(b, e, 0);
 
   *reward = e->cur.accepted ? 1.0 : ((t == ENV_DEEPRMSA) ? -1.0 : 0.0);
@@ -691,6 +716,21 @@ static void env_policy(const orc_batch* b, orc_env* e, int policy, int32_t* acti
   int t = c->env_type, k = c->k_paths, S = c->num_slots, src = e->cur.src, dst = e->cur.dst;
   int np_ = b->n_paths[src * c->n_nodes + dst], idp, s0;
   action[0] = action[1] = action[2] = action[3] = 0;
+  if (policy == POLICY_PATH_FF) { /* PathOnlyFirstFitAction.action: rmsa_env.py:848-871, rwa_env.py:513-533 */
+    int a = e->path_choice;
+    action[0] = k; action[1] = S;
+    if (a >= 0 && a < k && a < np_) {
+      if (t == ENV_RWA) {
+        for (s0 = 0; s0 < S; s0++)
+          if (is_path_free(b, e, src, dst, a, 0, s0, 1)) { action[0] = a; action[1] = s0; return; }
+      } else {
+        int n = number_slots(b, e->cur.bit_rate, b->path_best_mod[PIDX(b, src, dst, a)]);
+        for (s0 = 0; s0 < S - n; s0++)
+          if (is_path_free(b, e, src, dst, a, 0, s0, n)) { action[0] = a; action[1] = s0; return; }
+      }
+    }
+    return;
+  }
   if (t == ENV_RMSA) {
     action[0] = k; action[1] = S;
     if (policy == POLICY_SP_FF) { /* rmsa_env.py:747-764 */
@@ -868,6 +908,8 @@ orc_batch* orc_create(const orc_config* cfg, const orc_tables* tb, int64_t n_env
       e->br_req_hist = (int64_t*)calloc(cfg->n_bit_rates, 8);
       e->br_prov_hist = (int64_t*)calloc(cfg->n_bit_rates, 8);
     }
+    e->actions_output = (int64_t*)calloc((size_t)(cfg->k_paths + 1) * (cfg->num_slots + 1), 8);
+    e->actions_taken = (int64_t*)calloc((size_t)(cfg->k_paths + 1) * (cfg->num_slots + 1), 8);
     if (cfg->env_type == ENV_RWA) {
       e->act_path = (int64_t*)calloc(cfg->k_paths + rej, 8);
       e->act_slot = (int64_t*)calloc(cfg->num_slots + rej, 8);
@@ -885,6 +927,7 @@ void orc_destroy(orc_batch* b) {
     free(e->heap); free(e->pool); free(e->free_list); free(e->running); free(e->avail);
     free(e->l_util); free(e->l_frag); free(e->l_comp); free(e->l_last);
     free(e->br_req_hist); free(e->br_prov_hist); free(e->act_path); free(e->act_slot);
+    free(e->actions_output); free(e->actions_taken);
   }
   free(b->envs);
   free(b->n_paths); free(b->path_hops); free(b->path_links); free(b->path_length); free(b->path_best_mod);
@@ -955,6 +998,32 @@ int64_t orc_run(orc_batch* b, int policy, int64_t n_steps) {
     free(info);
   }
   return acc;
+}
+
+/* PathOnlyFirstFitAction: the agents' path choices for POLICY_PATH_FF */
+void orc_set_paths(orc_batch* b, const int32_t* paths /*[n]*/) {
+  int64_t i;
+  for (i = 0; i < b->n_envs; i++) b->envs[i].path_choice = paths[i];
+}
+/* seed(seed) (optical_network_env.py:205-210): self.rng = random.Random(seed); nothing else changes */
+void orc_reseed(orc_batch* b, const uint32_t* mt_state /*[n][625]*/, const uint8_t* mask) {
+  int64_t i;
+  for (i = 0; i < b->n_envs; i++)
+    if (!mask || mask[i]) {
+      orc_env* e = &b->envs[i];
+      if (!e->reseeded && b->cfg.env_type != ENV_RWA) {
+        memcpy(e->mt_init, e->mt, 624 * 4);
+        e->mti_init = e->mti;
+        e->reseeded = 1;
+      }
+      memcpy(e->mt, mt_state + i * 625, 624 * 4);
+      e->mti = (int32_t)mt_state[i * 625 + 624];
+    }
+}
+void orc_get_action_histograms(orc_batch* b, int64_t env, int64_t* out /*[2][(k+1)][(S+1)]*/) {
+  size_t n = (size_t)(b->cfg.k_paths + 1) * (b->cfg.num_slots + 1);
+  memcpy(out, b->envs[env].actions_output, n * 8);
+  memcpy(out + n, b->envs[env].actions_taken, n * 8);
 }
 
 /* state read-back for the parity tests */

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def golden_names(prefix=""):
+def golden_names(prefix="g"):
+    """g* = step traces (gen_golden.py), w* = wrappers / seed / full reset (gen_golden_wrappers.py)."""
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
 
 
@@ -69,3 +70,58 @@ def replay(env, g, check, n_steps=None):
                 check(t, "wavelength_action_probability", info[0, 2 + len(pa) : 2 + len(pa) + len(wa)], wa)
     if T == meta["n_steps"]:
         check(T, "svc", env.services()[0], g["svc"][T])
+
+
+def replay_w(env, g, check):
+    """Replay a w* fixture (oracle/gen_golden_wrappers.py) on a 1-env batch object `env` (oracle or product):
+    PathOnlyFirstFitAction through policy "PATH_FF", SimpleMatrixObservation through matrix_observation(), seed() and
+    full resets at the recorded steps, the 2-D action histograms at the end."""
+    meta = g["meta"]
+    events = {int(k): v for k, v in meta.get("events", {}).items()}
+    wrapper = meta.get("wrapper")
+    done = True
+    for t in range(meta["n_steps"]):
+        for kind, arg in events.get(t, []):
+            if kind == "seed":
+                env.seed([arg])
+            else:
+                env.reset(full=True)
+                done = False
+        if done:
+            env.reset(full=False)
+        check(t, "svc", env.services()[0], g["svc"][t])
+        if "obs_bits" in g:
+            obs = np.asarray(env.matrix_observation()[0], np.uint8)
+            check(t, "matrix_obs", np.packbits(obs, bitorder="little"), g["obs_bits"][t])
+            assert obs.size == int(g["obs_dim"])
+        if wrapper == "PathOnlyFirstFitAction":
+            a = env.policy("PATH_FF", paths=[int(g["choice"][t][0])])
+        else:
+            a = env.policy(meta["policy"])
+        width = g["actions"].shape[1]
+        check(t, "action", np.asarray(a[0, :width], np.int64), g["actions"][t])
+        _, reward, done_a, info = env.step(a)
+        done = bool(done_a[0])
+        check(t, "reward", reward[0], g["reward"][t])
+        check(t, "done", int(done), int(g["done"][t]))
+        check(t, "info", info[0, : g["info"].shape[1]], g["info"][t])
+        check(t, "counters", env.counters()[0], g["counters"][t])
+        sl = env.slots(0)
+        if sl.shape[0] == 1:
+            sl = sl[0]
+        check(t, "crc", crc_slots(sl), int(g["crc"][t]))
+        check(t, "n_active", env.n_active(0), int(g["n_active"][t]))
+    T = meta["n_steps"]
+    check(T, "svc", env.services()[0], g["svc"][T])
+    sl = env.slots(0)
+    if sl.shape[0] == 1:
+        sl = sl[0]
+    check(T, "final_slots", np.packbits(sl, axis=-1, bitorder="little"), g["final_slots"])
+    check(T, "final_link_stats", env.link_stats(0), g["final_link_stats"])
+    check(T, "final_net_stats", env.net_stats(0), g["final_net_stats"])
+    if "actions_output" in g:
+        out, taken = env.action_histograms_of(0)
+        ro, rt = g["actions_output"], g["actions_taken"]
+        check(T, "actions_output", out[: ro.shape[0], : ro.shape[1]], ro)
+        check(T, "actions_taken", taken[: rt.shape[0], : rt.shape[1]], rt)
+        assert out.sum() == ro.sum() and taken.sum() == rt.sum()

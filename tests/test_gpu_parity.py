@@ -4,7 +4,7 @@ too (the device evaluates the reference's expressions in the same order and its 
 import numpy as np
 import pytest
 
-from tests.helpers import golden_names, load_golden, replay
+from tests.helpers import golden_names, load_golden, replay, replay_w
 
 pytestmark = pytest.mark.gpu
 
@@ -12,15 +12,22 @@ pytestmark = pytest.mark.gpu
 # one-wavefront-per-env kernel (k_step).  The small parity cases run against every implementation by forcing it (the
 # variables are read when a batch is created): "wave64" = k_step for everything, "persist" = the default, "split2" = the
 # phases of the persistent kernel as two separate launches (liborlgpu_alt.so, the -DORL_ALT_IMPLS build).
-IMPLS = ["wave64", "split2", "persist"]
-IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default"),
-            "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt"),
-            "persist": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default")}
+IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds"]
+IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None),
+            "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT=None),
+            # the persistent kernel in the form the library picks, with all state in global memory, and with slot maps +
+            # link statistics + per-core sums resident in LDS (falls back to the default form where that does not fit)
+            "persist": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None),
+            "persist_global": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="0"),
+            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="2")}
 
 
 def force_impl(monkeypatch, name):
     for k, v in IMPL_ENV[name].items():
-        monkeypatch.setenv(k, v)
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, v)
 
 
 @pytest.fixture(params=IMPLS)
@@ -29,11 +36,12 @@ def impl(request, monkeypatch):
     return request.param
 
 
-def _product(meta, num_envs=1, seeds=None):
+def _product(meta, num_envs=1, seeds=None, **extra):
     import optical_rl_gym_amd as orl
 
     kw = dict(meta["kwargs"])
     seed = kw.pop("seed")
+    kw.update(extra)
     return orl.make(meta["env"], topology=meta["topology"], num_envs=num_envs,
                     seeds=[seed] if seeds is None else seeds, **kw)
 
@@ -151,11 +159,13 @@ def test_gym_front_end_reproduces_reference_script_numbers():
     env.close()
 
 
-@pytest.mark.parametrize("workload,batch", [("cfg2", 65536), ("cfg5", 32768)])
+@pytest.mark.parametrize("workload,batch", [("cfg2", 65536), ("cfg5", 32768), ("cfg1", 4096), ("cfg3", 4096), ("cfg4", 16384),
+                                            ("cfg2", 4096)])
 def test_full_size_batch_sampled_envs_match_oracle(workload, batch):
-    """BASELINE.json sizes.  Envs are independent, so env i of the big batch must equal a 1-env oracle run with
-    seed_i; 24 sampled envs are compared in full (slot map, link statistics, counters, pending service), and
-    cheap invariants are checked on every env."""
+    """Every BASELINE.json configuration at its size, with the bench's own kwargs (cfg4: COST239, 7 cores x 320 slots, load
+    1500; cfg5: the per-GPU shard of the 8-GPU batch).  Envs are independent, so env i of the big batch must equal a 1-env
+    oracle run with seed_i; 24 sampled envs are compared in full (slot map, link statistics, counters, pending service,
+    DeepRMSA observation), and cheap invariants are checked on every env."""
     import optical_rl_gym_amd as orl
     from bench import WORKLOADS
     from oracle.oracle import OracleBatch
@@ -178,8 +188,11 @@ def test_full_size_batch_sampled_envs_match_oracle(workload, batch):
         chk(i, "link_stats", dev.link_stats(i), ora.link_stats(j))
         chk(i, "net_stats", dev.net_stats(i), ora.net_stats(j))
         chk(i, "n_active", int(ad[i]), ora.n_active(j))
+    if dev.obs_dim:
+        chk(0, "observation", dev.observation()[sample], ora.observation())
     assert not dev.flags().any()
-    assert (cd[:, 0] == steps + 1).all() and (cd[:, 1] <= cd[:, 0]).all() and (cd[:, 5] <= cd[:, 4]).all()
+    first = 0 if fam == "RWA" else (0 if fam == "RMCSA" else 1)  # RMSA / DeepRMSA count a service when it is created
+    assert (cd[:, 0] == steps + first).all() and (cd[:, 1] <= cd[:, 0]).all() and (cd[:, 5] <= cd[:, 4]).all()
     assert (ad >= 0).all() and (ad <= cd[:, 1]).all()
     p, a = dev.totals()
     assert p == int(cd[:, 0].sum()) and a == int(cd[:, 1].sum())
@@ -220,7 +233,7 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
         env.close()
     a = out["wave64"]
     chk = _exact(workload)
-    for other in ("split2", "persist"):
+    for other in IMPLS[1:]:
         b = out[other]
         for key in ("counters", "services", "active", "flags"):
             chk(0, other + " " + key, b[key], a[key])
@@ -242,7 +255,8 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         kw = dict(kw, episode_length=70)
         seeds = [5 + 11 * i for i in range(batch)]
         for name, v, masks in (("wave64", "wave64", None), ("two", "split2", "1"), ("two2", "split2", "2"),
-                               ("persist", "persist", "1"), ("persist2", "persist", "2")):
+                               ("persist", "persist", "1"), ("persist2", "persist", "2"), ("persist_g", "persist_global", "1"),
+                               ("persist_l", "persist_lds", "1")):
             force_impl(monkeypatch, v)
             if masks:
                 monkeypatch.setenv("ORL_ITEM_MASKS", masks)
@@ -256,7 +270,7 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
             assert not env.flags().any()
             env.close()
         chk = _exact(workload)
-        for name in ("two", "two2", "persist", "persist2"):
+        for name in ("two", "two2", "persist", "persist2", "persist_g", "persist_l"):
             for key in ("counters", "services", "active", "slots", "link", "net"):
                 chk(0, name + " " + key, out[name][key], out["wave64"][key])
         assert out["two"]["serial"] > 100 and out["two2"]["serial"] > 0 and out["persist"]["serial"] > 100
@@ -294,7 +308,7 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
                  [env.slots(i).copy() for i in pick] + [env.link_stats(i).copy() for i in pick] + [env.net_stats(i).copy() for i in pick]
         env.close()
     chk = _exact(fam + "/" + topo)
-    for v in ("split2", "persist"):
+    for v in IMPLS[1:]:
         for k, (x, y) in enumerate(zip(out[v], out["wave64"])):
             chk(k, "impl " + v, x, y)
     # ... and that state is the reference's: the first envs against the oracle
@@ -539,3 +553,189 @@ def test_vecenv_adapter_on_hip_batch():
             assert infos[i]["episode"]["l"] == 49 and np.array_equal(infos[i]["terminal_observation"], obs[i])
     assert [r["r"] for r in venv.episode_log][0::3][:2] == g["meta"]["episode_rewards"][:2]
     venv.close()
+
+
+@pytest.mark.parametrize("name", golden_names("w"))
+def test_hip_reproduces_wrapper_and_event_fixtures(name):
+    """PathOnlyFirstFitAction on the device (policy PATH_FF), SimpleMatrixObservation (k_matrix_obs), the 2-D action
+    histograms, seed() and reset(full) in the middle of a run — against fixtures captured from the reference
+    (oracle/gen_golden_wrappers.py)."""
+    g = load_golden(name)
+    extra = dict(action_histograms=True) if "actions_output" in g else {}
+    env = _product(g["meta"], **extra)
+    replay_w(env, g, _exact(name))
+    assert not env.flags().any() or name.startswith("w3_rmsa")  # (w3_rmsa carries the "reseeded" flag)
+    env.close()
+
+
+@pytest.mark.parametrize("gname,policy", [("g2_rmsa_cfg2_sapff", "SAP_FF"), ("g5_rwa_testcfg_sapff", "SAP_FF"),
+                                          ("g4_deeprmsa_j2_sap", "SAP"), ("g6_rmcsa_7x320_sapff", "SAP_BM_FC_FF")])
+def test_full_and_masked_resets_match_oracle(gname, policy):
+    """reset(only_episode_counters=False) after stepping, for all envs and for a mask of envs, and masked soft resets
+    (rmsa_env.py:284-359, rwa_env.py:164-208, rmcsa_env.py:386-483): the batch keeps equal to the oracle."""
+    from oracle.oracle import OracleBatch
+
+    meta = load_golden(gname)["meta"]
+    kw = dict(meta["kwargs"])
+    kw.pop("seed")
+    kw["episode_length"] = 55
+    n = 80
+    seeds = [4000 + 3 * i for i in range(n)]
+    ora = OracleBatch(meta["env"], meta["topology"], seeds, **kw)
+    dev = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=n, seeds=seeds)
+    chk = _exact(gname)
+    rs = np.random.RandomState(11)
+
+    def compare(tag):
+        chk(tag, "counters", dev.counters(), ora.counters())
+        chk(tag, "services", dev.services(), ora.services())
+        chk(tag, "active", dev.active(), np.array([ora.n_active(i) for i in range(n)]))
+        for e in (0, 17, n - 1):
+            chk(tag, "slots", dev.slots(e), ora.slots(e))
+            chk(tag, "link_stats", dev.link_stats(e), ora.link_stats(e))
+            chk(tag, "net_stats", dev.net_stats(e), ora.net_stats(e))
+        if dev.obs_dim:
+            chk(tag, "obs", dev.observation(), ora.observation())
+
+    dev.run(policy, 130); ora.run(policy, 130)
+    mask = (rs.random_sample(n) < 0.4).astype(np.uint8)
+    dev.reset(full=True, mask=mask); ora.reset(full=True, mask=mask)
+    compare(1)
+    dev.run(policy, 90); ora.run(policy, 90)
+    compare(2)
+    for t in range(40):  # host-driven steps after a masked full reset
+        a_o, a_d = ora.policy(policy), dev.policy(policy)
+        chk(t, "actions", a_d, a_o)
+        _, r_o, d_o, i_o = ora.step(a_o, auto_reset=True)
+        _, r_d, d_d, i_d = dev.step(a_d, auto_reset=True)
+        chk(t, "reward", r_d, r_o); chk(t, "done", d_d, d_o); chk(t, "info", i_d, i_o)
+    dev.reset(full=True); ora.reset(full=True)
+    compare(3)
+    dev.run(policy, 70); ora.run(policy, 70)
+    mask = (rs.random_sample(n) < 0.5).astype(np.uint8)
+    dev.reset(full=False, mask=mask); ora.reset(full=False, mask=mask)
+    compare(4)
+    dev.run(policy, 60); ora.run(policy, 60)
+    compare(5)
+    assert not dev.flags().any()
+    dev.close()
+
+
+def test_pending_release_overflow_is_reported():
+    """A batch whose event_capacity is too small for its load must say so (ORL_E_OVERFLOW -> OverflowError) instead of
+    silently dropping the release (the reference's heap is unbounded), in run() and in step()."""
+    import optical_rl_gym_amd as orl
+
+    kw = dict(load=300, mean_service_holding_time=25, episode_length=1000, num_spectrum_resources=320)
+    for impl in ("persist", "wave64"):
+        env = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=64, seeds=list(range(64)), event_capacity=32, **kw)
+        with pytest.raises(OverflowError):
+            if impl == "persist":
+                env.run("SAP_FF", 400)
+            else:
+                for _ in range(400):
+                    env.step(env.policy("SAP_FF"), auto_reset=True)
+        assert (env.flags() & 1).any()
+        with pytest.raises(OverflowError):
+            env.check()  # sticky: those envs have lost a release for good
+        env.close()
+    ok = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=64, seeds=list(range(64)), **kw)  # the default capacity never overflows
+    ok.run("SAP_FF", 1500)
+    ok.check()
+    ok.close()
+
+
+def test_out_of_range_actions_raise_like_the_reference():
+    """rmsa_env.py:167 / rwa_env.py:103 / rmcsa_env.py:219 raise IndexError on actions_output[...] before anything is
+    modified; so does a host-driven step().  Device-resident actions cannot be checked beforehand: the kernel treats them
+    as a rejection and the next synchronous call reports them."""
+    import torch
+
+    import optical_rl_gym_amd as orl
+
+    kw = dict(load=300, mean_service_holding_time=25, episode_length=100, num_spectrum_resources=320)
+    env = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=8, seeds=list(range(8)), **kw)
+    env.run("SAP_FF", 30)
+    before = (env.counters().copy(), env.services().copy(), env.slots(3).copy())
+    good = env.policy("SAP_FF").copy()
+    for bad_row in ([6, 0, 0, 0], [0, 321, 0, 0], [-1, 0, 0, 0], [0, -5, 0, 0]):
+        a = good.copy()
+        a[3] = bad_row
+        with pytest.raises(IndexError):
+            env.step(a)
+        assert np.array_equal(env.counters(), before[0]) and np.array_equal(env.services(), before[1])
+        assert np.array_equal(env.slots(3), before[2])
+    env.step(good)  # the batch is still usable
+    assert (env.counters()[:, 0] == before[0][:, 0] + 1).all()
+    # device-resident actions
+    act = env.device_tensor("actions")
+    a = torch.from_numpy(env.policy("SAP_FF").copy())
+    a[5, 0] = 17
+    act.copy_(a)
+    torch.cuda.synchronize()
+    env.step(None, fetch=False)
+    with pytest.raises(IndexError):
+        env.check()
+    env.check()  # reported once
+    assert env.counters()[5, 0] == before[0][5, 0] + 2  # it was treated as a rejection: the env moved on
+    env.close()
+    rwa = orl.BatchedRWAEnv("nsfnet_chen", num_envs=4, seeds=[1, 2, 3, 4], load=100, mean_service_holding_time=10,
+                            allow_rejection=False)
+    with pytest.raises(IndexError):  # without the reject action the arrays are [k][S] (rwa_env.py:52-58)
+        rwa.step(np.array([[5, 0]] * 4))
+    rwa.close()
+
+
+def test_path_only_first_fit_in_the_device_loop(monkeypatch):
+    """run("PATH_FF") with a fixed path column: the persistent kernel (all forms) against the one-wavefront-per-env kernel
+    and the oracle."""
+    import optical_rl_gym_amd as orl
+    from oracle.oracle import OracleBatch
+
+    kw = dict(load=320, mean_service_holding_time=25, episode_length=60, num_spectrum_resources=320, allow_rejection=True)
+    n = 512
+    seeds = [9000 + i for i in range(n)]
+    paths = np.random.RandomState(2).randint(0, 6, n)
+    out = {}
+    for name in ("wave64", "persist", "persist_global", "persist_lds", "split2"):
+        force_impl(monkeypatch, name)
+        env = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=n, seeds=seeds, **kw)
+        env.set_paths(paths)
+        env.run("PATH_FF", 220)
+        out[name] = (env.counters().copy(), env.services().copy(), env.slots(7).copy(), env.link_stats(7).copy())
+        env.close()
+    ora = OracleBatch("RMSA", "nsfnet_chen", seeds[:16], **kw)
+    ora.set_paths(paths[:16])
+    ora.run("PATH_FF", 220)
+    chk = _exact("path_ff")
+    chk(0, "oracle counters", out["wave64"][0][:16], ora.counters())
+    chk(0, "oracle slots", out["wave64"][2], ora.slots(7))
+    for name in ("persist", "persist_global", "persist_lds", "split2"):
+        for k, (x, y) in enumerate(zip(out[name], out["wave64"])):
+            chk(k, name, x, y)
+
+
+def test_two_shards_on_one_gpu_equal_the_unsharded_batch():
+    """Multi-GPU is one process per GPU over contiguous env ranges with seeds base + index and no collective
+    (optical_rl_gym_amd/sharding.py): two shards, here as two batches on the same GPU, reproduce the unsharded batch."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+    from optical_rl_gym_amd.sharding import shard_range, shard_seeds
+
+    fam, topo, kw, policy = WORKLOADS["cfg2"]
+    kw = dict(kw, episode_length=80)
+    total = 3000  # not a multiple of 8 per shard: ragged last wavefront
+    whole = orl.make(fam, topology=topo, num_envs=total, seeds=shard_seeds(10, total, 0, 1), **kw)
+    whole.run(policy, 200)
+    for rank in (0, 1):
+        lo, hi = shard_range(total, rank, 2)
+        part = orl.make(fam, topology=topo, num_envs=hi - lo, seeds=shard_seeds(10, total, rank, 2), **kw)
+        part.run(policy, 200)
+        assert np.array_equal(part.counters(), whole.counters()[lo:hi])
+        assert np.array_equal(part.services(), whole.services()[lo:hi])
+        assert np.array_equal(part.active(), whole.active()[lo:hi])
+        for e in (0, (hi - lo) // 2, hi - lo - 1):
+            assert np.array_equal(part.slots(e), whole.slots(lo + e))
+            assert np.array_equal(part.link_stats(e), whole.link_stats(lo + e))
+        part.close()
+    whole.close()

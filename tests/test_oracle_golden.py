@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import OracleBatch
-from tests.helpers import golden_names, load_golden, replay
+from tests.helpers import golden_names, load_golden, replay, replay_w
 
 
 def _make(meta):
@@ -32,3 +32,12 @@ def test_oracle_reproduces_reference_trace(name):
     g = load_golden(name)
     env = _make(g["meta"])
     replay(env, g, _exact(name))
+
+
+@pytest.mark.parametrize("name", golden_names("w"))
+def test_oracle_reproduces_wrapper_and_event_fixtures(name):
+    """PathOnlyFirstFitAction, SimpleMatrixObservation, the 2-D action histograms, seed() and reset(full) mid-run, as
+    captured from the reference by oracle/gen_golden_wrappers.py."""
+    g = load_golden(name)
+    env = _make(g["meta"])
+    replay_w(env, g, _exact(name))

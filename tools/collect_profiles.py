@@ -1,56 +1,66 @@
 #!/usr/bin/env python3
-"""Copy the judged summaries of tools/run_profiles.sh from gpurun_out/final into profiles/<tag>_* (newest files win)."""
+"""Copy the judged summaries of tools/run_profiles.sh from gpurun_out/<tag> into profiles/<tag>_* and derive
+profiles/traffic_<workload>.json (HBM bytes and L2<->fabric requests per launch / per step of the persistent kernel and of
+the stand-alone slot scan) from the counter passes.  The JSON carries the source hash of the build it was measured on:
+bench.py reports `roofline.traffic` only when that matches the library it runs.
+
+    python3 tools/collect_profiles.py <tag> [workload]
+"""
 import csv
 import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
-O = "gpurun_out/final"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from optical_rl_gym_amd import _build  # noqa: E402
+
 tag = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+O = os.path.join(ROOT, "gpurun_out", tag)
 
 
 def newest(pattern):
     return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
 
 
-def mean_last(d, kern, n=20):
+def mean_last(d, kern, counter, n):
     f = newest("%s/%s/**/*counter_collection.csv" % (O, d))
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]][-n:]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"] and r["Counter_Name"] == counter][-n:]
     return sum(v) / len(v)
 
 
-known = 65536 * 110 * 8
-factor = known / (mean_last("tr_f", "k_calib", 4) * 1024)
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.py), cfg2 B=65536, mean of the last 20 "
-               "steady-state launches of each kernel; FETCH_SIZE x the factor measured on k_calib_read (known byte count; 8-B and 16-B per-lane "
-               "loads both give 2.0, as MI355X_MICROARCH.md states); WRITE_SIZE as is",
-       "workload": "cfg2", "batch": 65536, "fetch_calibration_factor": round(factor, 4), "kernels": {}}
-# bench.py looks kernels up by these names
-STEPS = {"k_persist": 20}  # tools/pmc_traffic.py measures launches of env.run(policy, 20)
-for name, kern in (("k_persist", "k_persist<"), ("k_policy", "void k_policy<")):
-    last = 5 if name in STEPS else 20  # (the run before the measured launches is one long launch of the same kernel)
-    f = mean_last("tr_f", kern, last) * 1024 * factor
-    w = mean_last("tr_w", kern, last) * 1024
-    out["kernels"][name] = {"fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w)}
-    if name in STEPS:
-        out["kernels"][name]["steps_per_launch"] = STEPS[name]
-    try:  # L2 <-> fabric requests (TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum), the quantity the random-access roofline counts
-        fe = newest("%s/ea/**/*counter_collection.csv" % O)
-        rows = [r for r in csv.DictReader(open(fe)) if kern in r["Kernel_Name"]]
-        rd = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "TCC_EA0_RDREQ_sum"][-last:]
-        wr = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "TCC_EA0_WRREQ_sum"][-last:]
-        out["kernels"][name]["dram_requests_per_launch"] = int(sum(rd) / len(rd) + sum(wr) / len(wr))
+run = json.loads([l for l in open(os.path.join(O, "tr_f.log")) if l.startswith("{")][-1])  # what tools/pmc_traffic.py printed
+factor = run["calibration_bytes"] / (mean_last("tr_f", "k_calib", "FETCH_SIZE", 4) * 1024)
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum (separate passes over tools/pmc_traffic.py): "
+               "mean of the measured launches; FETCH_SIZE (KiB) x the factor measured on k_calib_read's known byte count "
+               "(MI355X_MICROARCH.md: 2.0 for wide coalesced reads); WRITE_SIZE as is",
+       "workload": run["workload"], "batch": run["batch"], "mean_active_services": run["mean_active_services"],
+       "source_hash": _build.source_hash(with_compiler=False), "tag": tag, "fetch_calibration_factor": round(factor, 4), "kernels": {}}
+for name, kern, last, spl in (("k_persist", "k_persist<", run["measured_launches"], run["steps_per_launch"]), ("k_policy", "void k_policy<", 20, None)):
+    f = mean_last("tr_f", kern, "FETCH_SIZE", last) * 1024 * factor
+    w = mean_last("tr_w", kern, "WRITE_SIZE", last) * 1024
+    rec = {"fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w)}
+    if spl:
+        rec["steps_per_launch"] = spl
+        rec["hbm_bytes_per_step"] = int((f + w) / spl)
+    try:
+        rq = mean_last("ea", kern, "TCC_EA0_RDREQ_sum", last) + mean_last("ea", kern, "TCC_EA0_WRREQ_sum", last)
+        rec["dram_requests_per_launch"] = int(rq)
+        if spl:
+            rec["dram_requests_per_step"] = int(rq / spl)
     except Exception as exc:  # noqa: BLE001
         print("no request counters for", name, exc)
-json.dump(out, open("profiles/traffic_cfg2.json", "w"), indent=1)
-shutil.copy(newest(O + "/stats/**/*kernel_stats.csv"), "profiles/%s_bench_cfg2_kernel_stats.csv" % tag)
-shutil.copy(newest(O + "/stats1/**/*kernel_stats.csv"), "profiles/%s_bench_cfg2_single_stream_kernel_stats.csv" % tag)
-for f in glob.glob(O + "/bench_*.json"):
-    shutil.copy(f, "profiles/%s_%s" % (tag, os.path.basename(f)))
+    out["kernels"][name] = rec
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % workload), "w"), indent=1)
 print(json.dumps(out["kernels"]))
-# counter summaries (SQ issue/wait counters of the bench run, L2<->fabric request counts) as one text file
-import subprocess
-txt = subprocess.run([sys.executable, "tools/pmc_summary.py", O + "/sq", O + "/ea", O + "/tr_f", O + "/tr_w"], capture_output=True, text=True).stdout
-open("profiles/%s_pmc_summary.txt" % tag, "w").write(txt.replace(os.getcwd() + "/", ""))
+shutil.copy(newest(O + "/stats/**/*kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_cfg2_kernel_stats.csv" % tag))
+for f in glob.glob(O + "/bench_*.json") + glob.glob(O + "/phase_*.txt"):
+    shutil.copy(f, os.path.join(ROOT, "profiles", "%s_%s" % (tag, os.path.basename(f))))
+passes = [os.path.join(O, d) for d in ("sq1", "sq2", "sq3", "hit", "ea", "tr_f", "tr_w") if os.path.isdir(os.path.join(O, d))]
+txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + passes, capture_output=True, text=True).stdout
+open(os.path.join(ROOT, "profiles", "%s_pmc_summary.txt" % tag), "w").write(txt.replace(ROOT + "/", ""))
