@@ -496,6 +496,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   HIPCHK_B(hipMemsetAsync(P.q_def, 0, 2 * (size_t)P.q_def_stride * sizeof(u32), b->stream));
   HIPCHK_B(hipMemsetAsync(P.q_stat, 0, 16 * sizeof(u32), b->stream));
   HIPCHK_B(hipMemsetAsync(P.path_col, 0, B * sizeof(int), b->stream));
+  if (P.act2d) HIPCHK_B(hipMemsetAsync(P.act2d, 0, B * (size_t)P.act2d_words * sizeof(int), b->stream));  // (RMSAEnv.reset never clears them)
   HIPCHK_B(hipMemsetAsync(P.actions, 0, B * 4 * sizeof(int), b->stream));
   // MT state upload + conversion, then the constructor's full reset
   u32* raw = nullptr;
