@@ -141,6 +141,14 @@ int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask);
  * envs are ignored). */
 int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_t* env_mask);
 
+/* evaluate_heuristic on the device (utils.py:103-141: reset, loop until done, sum the rewards, n episodes).  Arm a per-env
+ * log of `capacity` episodes (0 = disarm); from then on every env that finishes an episode appends its
+ * episode_services_accepted — the episode's reward sum for RMSA / RWA / RMCSA (reward 1 per accepted service), and
+ * 2 * accepted - steps for DeepRMSA (reward +1 / -1) — before the auto (soft) reset.  Read it back with
+ * orl_batch_get_episode_log: counts[n_envs], accepted[n_envs][capacity]. */
+int orl_batch_episode_log(orl_batch* b, int32_t capacity);
+int orl_batch_get_episode_log(orl_batch* b, int32_t* counts, int32_t* accepted);
+
 /* ORL_POLICY_PATH_FF: the path index chosen for every env, [n_envs] int32 (>= k_paths = reject). */
 int orl_batch_set_paths(orl_batch* b, const int32_t* paths);
 

@@ -9,3 +9,5 @@ from .gym_api import (DeepRMSAEnv, PathOnlyFirstFitAction, RMCSAEnv, RMSAEnv, RW
                       SimpleMatrixObservation, evaluate_heuristic, least_loaded_path_first_fit, random_policy,
                       shortest_available_path_best_modulation_first_core_first_fit,
                       shortest_available_path_first_fit, shortest_available_path_last_fit, shortest_path_first_fit)
+from .sharding import MultiDeviceBatch, shard_range, shard_seeds  # noqa: F401,E402
+from .vec_env import OpticalVecEnv  # noqa: F401,E402

@@ -69,6 +69,8 @@ EXPORTS = {
     "orl_batch_debug_prof": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "orl_batch_reseed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orl_batch_set_paths": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_episode_log": (C.c_int, [C.c_void_p, C.c_int32]),
+    "orl_batch_get_episode_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orl_batch_check": (C.c_int, [C.c_void_p]),
     "orl_batch_get_action_histograms": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "orl_batch_get_pending": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -615,6 +615,34 @@ extern "C" int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_
   return ORL_OK;
 }
 
+extern "C" int orl_batch_episode_log(orl_batch* b, int32_t capacity) {
+  if (!b || capacity < 0) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const size_t B = (size_t)b->P.B;
+  if (capacity > b->P.ep_cap) {  // (the previous, smaller log stays allocated until the batch is destroyed)
+    int *lg = nullptr, *ct = b->P.ep_count;
+    HIPCHK(hipMalloc((void**)&lg, B * (size_t)capacity * sizeof(int) + 64));
+    b->allocs.push_back(lg);
+    if (!ct) { HIPCHK(hipMalloc((void**)&ct, B * sizeof(int) + 64)); b->allocs.push_back(ct); }
+    b->P.ep_log = lg; b->P.ep_count = ct; b->P.ep_cap = capacity;
+  }
+  if (capacity == 0) { b->P.ep_log = nullptr; b->P.ep_cap = 0; return ORL_OK; }
+  HIPCHK(hipMemsetAsync(b->P.ep_count, 0, B * sizeof(int), b->stream));
+  HIPCHK(hipMemsetAsync(b->P.ep_log, 0, B * (size_t)b->P.ep_cap * sizeof(int), b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_episode_log(orl_batch* b, int32_t* counts, int32_t* accepted) {
+  if (!b || !counts || !accepted) return fail(ORL_E_INVALID, "null argument");
+  if (!b->P.ep_log) return fail(ORL_E_INVALID, "the episode log is not armed (orl_batch_episode_log)");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(counts, b->P.ep_count, (size_t)b->P.B * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(accepted, b->P.ep_log, (size_t)b->P.B * b->P.ep_cap * sizeof(int), hipMemcpyDeviceToHost));
+  return ORL_OK;
+}
+
 extern "C" int orl_batch_set_paths(orl_batch* b, const int32_t* paths) {
   if (!b || !paths) return fail(ORL_E_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));

@@ -120,6 +120,9 @@ struct DevParams {
   int* act2d;       // [B][2][(K+1)*(S+1)] opt-in: actions_output, actions_taken (rmsa_env.py:126-137, rwa_env.py:52-58); else null
   int act2d_words;  // 2*(K+1)*(S+1)
   int* path_col;    // [B] POL_PATH_FF: the path index each env's agent chose (Discrete(k + reject) action)
+  int* ep_log;      // [B][ep_cap] or null: episode_services_accepted of every finished episode (evaluate_heuristic on the device)
+  int* ep_count;    // [B] episodes finished since the log was armed
+  int ep_cap;
   // I/O (device resident; the C-ABI copies to/from host buffers)
   int* actions;            // [B][4]
   double* reward;          // [B]
@@ -978,6 +981,13 @@ __device__ __forceinline__ double link_mean(const DevParams& P, const double* va
   return res / (double)E;
 }
 
+// evaluate_heuristic on the device (utils.py:103-141): what an episode's reward sum derives from, logged when it ends
+__device__ __forceinline__ void episode_log(const DevParams& P, i64 env, i64 accepted) {
+  const int idx = P.ep_count[env];
+  if (idx < P.ep_cap) P.ep_log[env * P.ep_cap + idx] = (int)accepted;
+  P.ep_count[env] = idx + 1;
+}
+
 // opt-in 2-D action histograms (rmsa_env.py:126-137, 167, 201, 211-212; rwa_env.py:52-58, 103, 125, 132-133):
 // actions_output[path, slot] counts every action, actions_taken[path, slot] the accepted ones and [k, S] the rejections
 __device__ __forceinline__ void act2d_count(const DevParams& P, i64 env, int path, int slot, bool accepted) {
@@ -1244,6 +1254,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
   e.new_service = 0;
   next_service<ENV, W, EVL>(P, e, lane, prefilled, pf);
   bool done = (e.esp == (i64)P.episode_length);
+  if (done && P.ep_log && lane == 0) episode_log(P, e.env, e.esa);
   if (ENV == ENV_DEEPRMSA && obs_out) {
     deep_observation<W>(P, e, lane, obs_out, (done && term_obs_out) ? term_obs_out : nullptr);
   }

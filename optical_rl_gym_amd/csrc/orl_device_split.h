@@ -464,6 +464,7 @@ __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 en
   g8::next_service<ENV, W>(P, e, lane, rng);  // the due releases are release_soon's job
   ORL_PROFA(7);
   bool done = (e.esp == (i64)P.episode_length);
+  if (done && P.ep_log && gl == 0) episode_log(P, env, e.esa);
   if (done && auto_reset) {
     e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
     if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }

@@ -276,6 +276,37 @@ class BatchedOpticalEnv:
     def sync(self):
         self._ck(self.lib.orl_batch_sync(self._h))
 
+    # ---- evaluate_heuristic on the device (utils.py:103-141) ---------------------------------------------------
+    def steps_per_episode(self):
+        """RMSA / DeepRMSA / RMCSA episodes last episode_length - 1 steps (the soft reset counts the pending service again,
+        rmsa_env.py:310-315), RWA episodes episode_length steps (rwa_env.py:135-136, 160)."""
+        return self.episode_length if self.ENV_TYPE == 2 else self.episode_length - 1
+
+    def evaluate(self, policy, n_eval_episodes=10):
+        """n_eval_episodes episodes of every env under the on-device heuristic `policy`, with the reference harness's
+        accounting (reset -> loop until done -> sum of rewards): returns (episode_rewards [num_envs, n_eval_episodes],
+        episode_lengths).  One device-resident run; the kernels log each finished episode."""
+        n = int(n_eval_episodes)
+        self._ck(self.lib.orl_batch_reset(self._h, 0, None))  # the harness's reset() before the first episode (soft)
+        self._ck(self.lib.orl_batch_episode_log(self._h, n))
+        L = self.steps_per_episode()
+        # the harness stops at the last done without resetting: all steps but the last in one device-resident run (auto
+        # reset between episodes = the harness's reset() at the start of the next one), the last one without auto reset
+        if n * L > 1:
+            self.run(policy, n * L - 1)
+        self.policy(policy, fetch=False)
+        self.step(None, auto_reset=False, fetch=False)
+        self.check()
+        counts = np.zeros(self.num_envs, np.int32)
+        acc = np.zeros((self.num_envs, n), np.int32)
+        self._ck(self.lib.orl_batch_get_episode_log(self._h, counts.ctypes.data, acc.ctypes.data))
+        self._ck(self.lib.orl_batch_episode_log(self._h, 0))
+        assert (counts == n).all(), "every env finishes exactly n episodes in n * steps_per_episode steps"
+        rewards = acc.astype(np.float64)
+        if self.ENV_TYPE == 1:  # DeepRMSA: +1 accepted, -1 otherwise (deeprmsa_env.py:123-124)
+            rewards = 2.0 * rewards - L
+        return rewards, np.full((self.num_envs, n), L, np.int64)
+
     def check(self):
         """Synchronise and raise what the kernels flagged since the last report: IndexError for a device-resident action
         outside the action space (rmsa_env.py:167), OverflowError when an env ran out of pending-release slots."""
@@ -310,10 +341,27 @@ class BatchedOpticalEnv:
             raise _lib.OrlError("this env family has no '%s' array" % name)
         shape = (self.num_envs, cols) if cols else (self.num_envs,)
 
+        cai = {"shape": shape, "typestr": typestr, "data": (int(ptr.value), False), "version": 2, "strides": None}
+        device_id, owner = self.device_id, self
+
+        class _Raw:  # what torch.as_tensor consumes
+            __cuda_array_interface__ = cai
+
         class _DeviceArray:
-            __cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr.value), False), "version": 2,
-                                        "strides": None}
-            owner = self  # keeps the batch alive
+            """Device-resident array of the batch: `__cuda_array_interface__` (torch.as_tensor, CuPy) and DLPack
+            (`torch.from_dlpack`, `cupy.from_dlpack`, jax): no copy either way; the batch owns the memory."""
+            __cuda_array_interface__ = cai
+            _owner = owner  # keeps the batch alive
+
+            def __dlpack_device__(self):
+                return (10, device_id)  # kDLROCM
+
+            def __dlpack__(self, stream=None, **kw):
+                import torch
+
+                t = torch.as_tensor(_Raw(), device="cuda:%d" % device_id)
+                t._orl_owner = owner
+                return t.__dlpack__() if stream is None else t.__dlpack__(stream=stream)
 
         return _DeviceArray()
 
@@ -520,6 +568,14 @@ ENV_CLASSES = {"RMSA": BatchedRMSAEnv, "DeepRMSA": BatchedDeepRMSAEnv, "RWA": Ba
                "RMCSA-v0": BatchedRMCSAEnv}
 
 
-def make(env_id, **kwargs):
-    """gym.make analogue for the registry ids of optical_rl_gym/__init__.py:3-26."""
+def make(env_id, device_ids=None, **kwargs):
+    """Batch constructor by registry id (optical_rl_gym/__init__.py:3-26).  `device_ids=[0, 1, ...]` spreads the envs over
+    several GPUs of the node behind one object (sharding.MultiDeviceBatch); default: one batch on `device_id`."""
+    if device_ids is not None and len(device_ids) > 1:
+        from .sharding import MultiDeviceBatch
+
+        kwargs.pop("device_id", None)
+        return MultiDeviceBatch(env_id, kwargs.pop("num_envs"), seeds=kwargs.pop("seeds", None), device_ids=device_ids, **kwargs)
+    if device_ids is not None and len(device_ids) == 1:
+        kwargs["device_id"] = int(device_ids[0])
     return ENV_CLASSES[env_id](**kwargs)

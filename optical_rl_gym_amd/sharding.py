@@ -1,8 +1,19 @@
-"""Multi-GPU = one process per GPU, each owning a contiguous block of env indices.
+"""Multi-GPU: contiguous blocks of env indices per device, no data-path collective.
 
-Envs are independent, so there is no data-path collective: rank r of `world` simply builds the batch for
-global env indices [lo, hi) with seeds base_seed + index.  A given env's trajectory therefore does not depend
-on the number of GPUs — tests/test_sharding.py checks exactly that with 2 gloo ranks."""
+Envs are independent, so env i's trajectory depends only on seeds[i] and its action stream: the number of GPUs (and how
+the batch is cut) never changes a result.  Two ways to use several GPUs of a node:
+
+  * one process per GPU (bench.py --gpus N under torchrun): rank r builds the batch for global env indices
+    [lo, hi) = shard_range(total, r, world) with seeds base + index;
+  * one process, `MultiDeviceBatch(..., device_ids=[0, 1, ...])`: one batch per device behind the interface of a single
+    batch — actions are scattered and rewards / dones / infos / observations gathered per shard, each shard driven by its
+    own host thread on its own stream (the library calls release the GIL), so one VecEnv / one agent process can drive all
+    GPUs.  The SURVEY's `n_devices, device_ids` arguments of the batch constructor live here, above the C ABI, because a
+    handle of the ABI is bound to one device.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
 
 
 def shard_range(n_envs_total, rank, world):
@@ -16,3 +27,145 @@ def shard_range(n_envs_total, rank, world):
 def shard_seeds(base_seed, n_envs_total, rank, world):
     lo, hi = shard_range(n_envs_total, rank, world)
     return [base_seed + i for i in range(lo, hi)]
+
+
+class MultiDeviceBatch:
+    """`num_envs` envs spread over `device_ids` (contiguous shards), with the methods of `BatchedOpticalEnv`."""
+
+    def __init__(self, env_id, num_envs, seeds=None, device_ids=(0,), **kwargs):
+        from .envs import ENV_CLASSES
+
+        if seeds is None:
+            seeds = [None] * num_envs
+        elif np.isscalar(seeds):
+            seeds = [int(seeds) + i for i in range(num_envs)]
+        shards = []
+        for r, dev in enumerate(device_ids):
+            lo, hi = shard_range(num_envs, r, len(device_ids))
+            shards.append(ENV_CLASSES[env_id](num_envs=hi - lo, seeds=list(seeds[lo:hi]), device_id=int(dev), **kwargs))
+        self._init_from(shards)
+
+    @classmethod
+    def from_shards(cls, shards):
+        """Wrap existing batches (any objects with the batch interface), in env-index order."""
+        self = cls.__new__(cls)
+        self._init_from(list(shards))
+        return self
+
+    def _init_from(self, shards):
+        self.shards = shards
+        self.bounds = np.cumsum([0] + [s.num_envs for s in shards])
+        self.num_envs = int(self.bounds[-1])
+        self._pool = ThreadPoolExecutor(max_workers=len(shards))
+        first = shards[0]
+        for name in ("topology", "info_keys", "obs_dim", "n_info", "ENV_TYPE", "N_ACTION", "episode_length", "allow_rejection",
+                     "k_paths", "num_spectrum_resources", "num_spatial_resources", "j", "modulation_formats", "reject_action"):
+            if hasattr(first, name):
+                setattr(self, name, getattr(first, name))
+
+    # ---- helpers ----
+    def _map(self, fn):
+        return list(self._pool.map(fn, range(len(self.shards))))
+
+    def _cut(self, arr, r):
+        return None if arr is None else np.asarray(arr)[self.bounds[r]:self.bounds[r + 1]]
+
+    def _owner(self, env):
+        r = int(np.searchsorted(self.bounds, env, side="right") - 1)
+        return self.shards[r], int(env - self.bounds[r])
+
+    @staticmethod
+    def _cat(parts):
+        return None if parts[0] is None else np.concatenate(parts, axis=0)
+
+    # ---- the batch interface ----
+    def reset(self, full=False, mask=None):
+        return self._cat(self._map(lambda r: self.shards[r].reset(full=full, mask=self._cut(mask, r))))
+
+    def seed(self, seeds, mask=None):
+        if np.isscalar(seeds):
+            seeds = [int(seeds) + i for i in range(self.num_envs)]
+        self._map(lambda r: self.shards[r].seed(list(seeds[self.bounds[r]:self.bounds[r + 1]]), mask=self._cut(mask, r)))
+
+    def set_paths(self, paths):
+        self._map(lambda r: self.shards[r].set_paths(self._cut(paths, r)))
+
+    def policy(self, policy, fetch=True, paths=None):
+        out = self._map(lambda r: self.shards[r].policy(policy, fetch=fetch, paths=self._cut(paths, r)))
+        return self._cat(out) if fetch else None
+
+    def step(self, actions, auto_reset=False, fetch=True):
+        out = self._map(lambda r: self.shards[r].step(self._cut(actions, r), auto_reset=auto_reset, fetch=fetch))
+        if not fetch:
+            return None
+        self._info = self._cat([o[3] for o in out])
+        return self._cat([o[0] for o in out]), self._cat([o[1] for o in out]), self._cat([o[2] for o in out]), self._info
+
+    def run(self, policy, n_steps, time_kernels=False):
+        """Every shard runs its own device-resident loop concurrently; returns the shards' RunStats."""
+        return self._map(lambda r: self.shards[r].run(policy, n_steps, time_kernels))
+
+    def evaluate(self, policy, n_eval_episodes=10):
+        out = self._map(lambda r: self.shards[r].evaluate(policy, n_eval_episodes))
+        return self._cat([o[0] for o in out]), self._cat([o[1] for o in out])
+
+    def observation(self):
+        return self._cat(self._map(lambda r: self.shards[r].observation()))
+
+    def matrix_observation(self):
+        return self._cat(self._map(lambda r: self.shards[r].matrix_observation()))
+
+    def sync(self):
+        self._map(lambda r: self.shards[r].sync())
+
+    def check(self):
+        self._map(lambda r: self.shards[r].check())
+
+    def counters(self):
+        return self._cat(self._map(lambda r: self.shards[r].counters()))
+
+    def services(self):
+        return self._cat(self._map(lambda r: self.shards[r].services()))
+
+    def active(self):
+        return self._cat(self._map(lambda r: self.shards[r].active()))
+
+    def flags(self):
+        return self._cat(self._map(lambda r: self.shards[r].flags()))
+
+    def totals(self):
+        t = self._map(lambda r: self.shards[r].totals())
+        return sum(x[0] for x in t), sum(x[1] for x in t)
+
+    def slots(self, env=0):
+        s, i = self._owner(env)
+        return s.slots(i)
+
+    def link_stats(self, env=0):
+        s, i = self._owner(env)
+        return s.link_stats(i)
+
+    def net_stats(self, env=0):
+        s, i = self._owner(env)
+        return s.net_stats(i)
+
+    def n_active(self, env=0):
+        s, i = self._owner(env)
+        return s.n_active(i)
+
+    def action_histograms_of(self, env=0):
+        s, i = self._owner(env)
+        return s.action_histograms_of(i)
+
+    def pending(self, env=0):
+        s, i = self._owner(env)
+        return s.pending(i)
+
+    def device_tensor(self, name):
+        """Per-shard zero-copy device tensors (one per GPU), in env-index order."""
+        return [s.device_tensor(name) for s in self.shards]
+
+    def close(self):
+        for s in self.shards:
+            s.close()
+        self._pool.shutdown(wait=False)

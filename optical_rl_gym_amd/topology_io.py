@@ -150,6 +150,72 @@ def save_topology(t, path):
         mod_inband_xt=np.array([m.inband_xt for m in t.modulations], np.float64))
 
 
+# ---- compatibility loader for the reference's pickled topologies -------------------------------------------------------
+def load_reference_pickle(path):
+    """A topology file written by the reference's examples/create_topology.py:184-185 (a pickled networkx graph whose
+    graph["ksp"] holds `optical_rl_gym.utils.Path` objects and graph["modulations"] `optical_rl_gym.utils.Modulation`s)
+    -> flattened `Topology`.  The reference package need not be importable: the two classes are resolved to stand-ins that
+    just take the pickled attributes.  Needs networkx (the graph class inside the pickle)."""
+    import pickle
+
+    class _Attrs:
+        def __setstate__(self, state):
+            self.__dict__.update(state if isinstance(state, dict) else state[0] or {})
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.startswith("optical_rl_gym"):
+                return type(name, (_Attrs,), {})
+            return super().find_class(module, name)
+
+    with open(path, "rb") as f:
+        g = _Unpickler(f).load()
+    return topology_from_reference_graph(g)
+
+
+def topology_from_reference_graph(g):
+    """networkx graph in the reference's layout (graph["ksp"], ["k_paths"], ["modulations"], ["node_indices"], ["name"];
+    edge attrs index / id / length: create_topology.py:138-147, graph_utils.py:77-84, 106-113) -> `Topology`."""
+    nodes = list(g.graph["node_indices"])
+    pos = {n: i for i, n in enumerate(nodes)}
+    e, k = g.number_of_edges(), int(g.graph["k_paths"])
+    mods = [Modulation(str(m.name), float(m.maximum_length), int(m.spectral_efficiency),
+                       None if getattr(m, "minimum_osnr", None) is None else float(m.minimum_osnr),
+                       None if getattr(m, "inband_xt", None) is None else float(m.inband_xt)) for m in g.graph["modulations"]]
+    mod_index = {m.name: i for i, m in enumerate(mods)}
+    link_nodes, link_length = np.zeros((e, 2), np.int32), np.zeros(e, np.float64)
+    link_ids, order = [None] * e, np.zeros(e, np.int32)
+    for it, (a, b) in enumerate(g.edges()):
+        idx = g[a][b]["index"]
+        order[it] = idx
+        link_nodes[idx] = (pos[a], pos[b])
+        link_length[idx] = g[a][b]["length"]
+        link_ids[idx] = str(g[a][b].get("id", idx))
+    n = len(nodes)
+    hmax = max(p.hops for paths in g.graph["ksp"].values() for p in paths)
+    n_paths = np.zeros((n, n), np.int32)
+    hops = np.zeros((n, n, k), np.int32)
+    links = np.full((n, n, k, hmax), -1, np.int32)
+    pnodes = np.full((n, n, k, hmax + 1), -1, np.int32)
+    length = np.zeros((n, n, k), np.float64)
+    pid = np.full((n, n, k), -1, np.int32)
+    best = np.full((n, n, k), -1, np.int32)
+    for (s, d), paths in g.graph["ksp"].items():
+        si, di = pos[s], pos[d]
+        n_paths[si, di] = len(paths)
+        for ip, p in enumerate(paths):
+            hops[si, di, ip] = p.hops
+            length[si, di, ip] = p.length
+            pid[si, di, ip] = p.path_id
+            best[si, di, ip] = mod_index[p.best_modulation.name]
+            for h in range(p.hops):
+                links[si, di, ip, h] = g[p.node_list[h]][p.node_list[h + 1]]["index"]
+            for h, nd in enumerate(p.node_list):
+                pnodes[si, di, ip, h] = pos[nd]
+    return Topology(str(g.graph["name"]), [str(x) for x in nodes], k, link_nodes, link_length, link_ids, order, n_paths, hops,
+                    links, pnodes, length, pid, best, mods)
+
+
 if __name__ == "__main__":
     import sys
 

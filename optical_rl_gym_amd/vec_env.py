@@ -1,22 +1,74 @@
-"""stable-baselines3 `VecEnv`-shaped adapter over a batched env.
+"""stable-baselines3 `VecEnv` over a batched env.
 
-SB3 drives N env copies through `reset()`, `step_async(actions)`, `step_wait()` and expects a soft reset
-right after an env reports done, with the pre-reset observation under infos[i]["terminal_observation"]
-(DummyVecEnv behaviour; reference usage: examples/stable_baselines3/DeepRMSA.ipynb cells 224-302, where the
-env sits behind `Monitor(..., info_keywords=("episode_service_blocking_rate", "episode_bit_rate_blocking_rate"))`).
-Here the N copies are one HIP batch; the soft reset happens inside the step kernel (auto_reset), and the
-Monitor's per-episode bookkeeping (r, l, t + info keywords) is done on the host from the returned arrays.
+SB3 drives N env copies through `reset()`, `step_async(actions)`, `step_wait()` and expects a soft reset right after an
+env reports done, with the pre-reset observation under infos[i]["terminal_observation"] (DummyVecEnv behaviour;
+reference usage: examples/stable_baselines3/DeepRMSA.ipynb cells 224-302, where the env sits behind
+`Monitor(..., info_keywords=("episode_service_blocking_rate", "episode_bit_rate_blocking_rate"))`).
+Here the N copies are one HIP batch: the soft reset happens inside the step kernel (auto_reset), and the Monitor's
+per-episode bookkeeping (r, l, t + info keywords) is done on the host from the returned arrays.
+
+The class implements every abstract method of `stable_baselines3.common.vec_env.VecEnv` (reset, step_async, step_wait,
+close, get_attr, set_attr, env_method, env_is_wrapped, seed — plus get_images / render) and carries `num_envs`,
+`observation_space`, `action_space`, so `PPO("MlpPolicy", OpticalVecEnv(batch))` can be constructed.  The spaces are
+gymnasium / gym spaces when one of them is importable (SB3 checks their types), else the descriptions of spaces.py.
 stable-baselines3 itself is not a dependency: if it is importable the class registers as a virtual subclass.
+For an agent on the same GPU, `device_obs()` / `device_tensors()` hand out zero-copy views (DLPack) of the batch's
+device-resident arrays; `obs_dtype=np.float32` casts observations for float32 policies.
 """
 import time
 
 import numpy as np
 
+from . import spaces as _own_spaces
+
+
+def _space_module():
+    for name in ("gymnasium.spaces", "gym.spaces"):
+        try:
+            import importlib
+
+            return importlib.import_module(name)
+        except Exception:  # not installed in the build image
+            continue
+    return _own_spaces
+
+
+def make_spaces(batch, obs_dtype=np.float64, mod=None):
+    """(observation_space, action_space) of one env of `batch`, as the reference defines them: rmsa_env.py:138-151,
+    deeprmsa_env.py:38-45, rwa_env.py:72-85, rmcsa_env.py:181-196."""
+    sp = mod or _space_module()
+    rej = 1 if batch.allow_rejection else 0
+    k, S = batch.k_paths, batch.num_spectrum_resources
+    fam = batch.ENV_TYPE
+    if fam == 1:
+        obs = sp.Box(low=-2**30, high=2**30, shape=(batch.obs_dim,), dtype=obs_dtype)
+        act = sp.Discrete(k * batch.j + rej)
+    else:
+        obs = sp.Dict({"topology": sp.Discrete(10), "current_service": sp.Discrete(10)})
+        if fam == 3:
+            act = sp.MultiDiscrete((k + rej, len(batch.modulation_formats), batch.num_spatial_resources + rej, S + rej))
+        else:
+            act = sp.MultiDiscrete((k + rej, S + rej))
+    return obs, act
+
 
 class OpticalVecEnv:
-    def __init__(self, batch, info_keywords=("episode_service_blocking_rate", "episode_bit_rate_blocking_rate")):
+    metadata = {"render_modes": []}
+    render_mode = None
+
+    def __init__(self, batch, info_keywords=("episode_service_blocking_rate", "episode_bit_rate_blocking_rate"),
+                 obs_dtype=np.float64, observation="default"):
+        """observation: "default" (DeepRMSA: its 1-D vector; other families: None, as their Dict observation holds live
+        objects) or "matrix" (SimpleMatrixObservation built on the device: uint8 [2N + C*E*S])."""
         self.batch = batch
         self.num_envs = batch.num_envs
+        self.obs_dtype = np.dtype(obs_dtype)
+        self.observation_mode = observation
+        self.observation_space, self.action_space = make_spaces(batch, obs_dtype)
+        if observation == "matrix":
+            t = batch.topology
+            dim = 2 * t.n_nodes + batch.num_spatial_resources * t.n_links * batch.num_spectrum_resources
+            self.observation_space = _space_module().Box(low=0, high=1, shape=(dim,), dtype=np.uint8)
         self.info_keywords = tuple(k for k in info_keywords if k in batch.info_keys)
         self._kw_idx = [batch.info_keys.index(k) for k in self.info_keywords]
         self._actions = None
@@ -38,6 +90,7 @@ class OpticalVecEnv:
         obs, reward, done, info = self.batch.step(self._actions, auto_reset=True)
         self._ep_ret += reward
         self._ep_len += 1
+        obs = self._obs(obs)
         infos = [{} for _ in range(self.num_envs)]
         for i in np.flatnonzero(done):
             row = dict(r=float(self._ep_ret[i]), l=int(self._ep_len[i]), t=round(time.time() - self._t0, 6))
@@ -49,12 +102,97 @@ class OpticalVecEnv:
             self.episode_log.append(row)
             self._ep_ret[i] = 0
             self._ep_len[i] = 0
-        return self._obs(obs), np.array(reward), np.array(done, dtype=bool), infos
+        return obs, np.array(reward), np.array(done, dtype=bool), infos
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
 
+    def close(self):
+        self.batch.close()
+
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        if isinstance(indices, int):
+            return [indices]
+        return list(indices)
+
+    def get_attr(self, attr_name, indices=None):
+        """Per-env value of a public attribute of the reference env: counters, current_time, current_service fields,
+        or any attribute the whole batch shares (k_paths, episode_length, ...)."""
+        from .envs import COUNTER_NAMES
+
+        idx = self._indices(indices)
+        if attr_name in COUNTER_NAMES:
+            c = self.batch.counters()[:, COUNTER_NAMES.index(attr_name)]
+            return [int(c[i]) for i in idx]
+        if attr_name == "current_time":
+            return [float(self.batch.net_stats(i)[3]) for i in idx]
+        if attr_name == "current_service":
+            svc = self.batch.services()
+            keys = ("arrival_time", "holding_time", "source_id", "destination_id", "bit_rate", "service_id")
+            return [dict(zip(keys, svc[i])) for i in idx]
+        if attr_name in ("render_mode",):
+            return [None for _ in idx]
+        if hasattr(self, "_extra_attrs") and attr_name in self._extra_attrs:
+            return [self._extra_attrs[attr_name][i] for i in idx]
+        return [getattr(self.batch, attr_name) for _ in idx]
+
+    def set_attr(self, attr_name, value, indices=None):
+        """Attributes set through the VecEnv live beside the batch (one value per env): the simulation parameters of a batch
+        are fixed at construction, like a reference env's after __init__."""
+        if not hasattr(self, "_extra_attrs"):
+            self._extra_attrs = {}
+        col = self._extra_attrs.setdefault(attr_name, [None] * self.num_envs)
+        for i in self._indices(indices):
+            col[i] = value
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        """Call a method of the reference env on the selected envs: reset / seed / observation / render are mapped onto the
+        batch (masked where the method changes state); anything else is looked up on the batch and called once."""
+        idx = self._indices(indices)
+        mask = np.zeros(self.num_envs, np.uint8)
+        mask[idx] = 1
+        if method_name == "reset":
+            only = method_kwargs.get("only_episode_counters", method_kwargs.get("only_counters", method_args[0] if method_args else True))
+            obs = self.batch.reset(full=not only, mask=mask)
+            return [None if obs is None else np.array(obs[i]) for i in idx]
+        if method_name == "seed":
+            s = method_args[0] if method_args else method_kwargs.get("seed")
+            return self.seed(s, indices=idx)
+        if method_name == "observation":
+            obs = self._obs(self.batch.observation() if self.batch.obs_dim else None)
+            return [None if obs is None else np.array(obs[i]) for i in idx]
+        if method_name == "render":
+            return [None for _ in idx]
+        out = getattr(self.batch, method_name)(*method_args, **method_kwargs)
+        return [out for _ in idx]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * len(self._indices(indices))
+
+    def seed(self, seed=None, indices=None):
+        """VecEnv.seed: env i gets seed + i (optical_network_env.py:205-210 per env)."""
+        idx = self._indices(indices)
+        base = 41 if seed is None else int(seed)
+        seeds = [base + i for i in range(self.num_envs)]
+        mask = np.zeros(self.num_envs, np.uint8)
+        mask[idx] = 1
+        self.batch.seed(seeds, mask=mask)
+        return [seeds[i] for i in idx]
+
+    def get_images(self):
+        return [None] * self.num_envs  # the reference's render() is a no-op (rmsa_env.py:361-362)
+
+    def render(self, mode=None):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    # ---- Monitor file ----
     def save_monitor_csv(self, path, env_id=None):
         """The episode log in stable-baselines3's Monitor file format — a JSON header line, then `r,l,t` plus the info
         keywords (cf. the reference's examples/heuristics/bkp/rmsa-heu/sap_ff.monitor.csv) — so that SB3's
@@ -72,28 +210,19 @@ class OpticalVecEnv:
         """Last step's info as [num_envs, len(info_keys)] (cheaper than per-env dicts for large batches)."""
         return self.batch._info
 
-    def close(self):
-        self.batch.close()
-
-    def get_attr(self, name, indices=None):
-        idx = range(self.num_envs) if indices is None else indices
-        if name in ("services_processed", "services_accepted", "episode_services_processed",
-                    "episode_services_accepted", "bit_rate_requested", "bit_rate_provisioned",
-                    "episode_bit_rate_requested", "episode_bit_rate_provisioned"):
-            from .envs import COUNTER_NAMES
-
-            c = self.batch.counters()[:, COUNTER_NAMES.index(name)]
-            return [int(c[i]) for i in idx]
-        return [getattr(self.batch, name) for _ in idx]
-
-    def env_is_wrapped(self, wrapper_class, indices=None):
-        return [False] * (self.num_envs if indices is None else len(indices))
-
-    def seed(self, seed=None):
-        return [None] * self.num_envs  # seeds are fixed at construction
+    # ---- zero-copy views for an agent on the same GPU ----
+    def device_tensors(self):
+        """{"actions", "reward", "done", "info"[, "obs", "terminal_obs"]}: torch views of the batch's device arrays (DLPack /
+        __cuda_array_interface__, no copy).  Write actions, `batch.step(None, auto_reset=True, fetch=False)`, `batch.sync()`."""
+        names = ["actions", "reward", "done", "info"] + (["obs", "terminal_obs"] if self.batch.obs_dim else [])
+        return {n: self.batch.device_tensor(n) for n in names}
 
     def _obs(self, obs):
-        return None if obs is None else np.array(obs)
+        if self.observation_mode == "matrix":
+            return self.batch.matrix_observation()
+        if obs is None:
+            return None
+        return np.array(obs, dtype=self.obs_dtype)
 
 
 try:  # optional: make isinstance(x, VecEnv) true without inheriting SB3's constructor requirements

@@ -739,3 +739,135 @@ def test_two_shards_on_one_gpu_equal_the_unsharded_batch():
             assert np.array_equal(part.link_stats(e), whole.link_stats(lo + e))
         part.close()
     whole.close()
+
+
+def test_batched_evaluate_heuristic_on_device():
+    """evaluate_heuristic over a whole batch in one device-resident run (the kernels log every finished episode): per-env
+    episode returns equal the oracle's host loop, and env 0 reproduces the reference script's numbers."""
+    import optical_rl_gym_amd as orl
+    from tests.oracle_backend import OracleBackend
+
+    kw = dict(allow_rejection=True, load=50, mean_service_holding_time=25, episode_length=100,
+              num_spectrum_resources=64, bit_rate_selection="discrete")
+    seeds = [10 + i for i in range(24)]
+    for heur, name, mean, std in ((orl.shortest_available_path_first_fit, "SAP_FF", 95.0, 3.2558),
+                                  (orl.least_loaded_path_first_fit, "LLP_FF", 95.1, 3.3897)):
+        dev = orl.BatchedRMSAEnv("nsfnet_chen", num_envs=24, seeds=seeds, **kw)
+        ora = OracleBackend("RMSA", "nsfnet_chen", seeds, **kw)
+        rew_d, len_d = orl.evaluate_heuristic(dev, heur, n_eval_episodes=10, return_episode_rewards=True)
+        rew_o, len_o = ora.evaluate(name, 10)
+        assert np.array_equal(np.array(rew_d), rew_o) and np.array_equal(np.array(len_d), len_o)
+        assert (round(float(np.mean(rew_d[0])), 4), round(float(np.std(rew_d[0])), 4)) == (mean, std)
+        assert np.array_equal(dev.counters(), ora.counters())  # the last episode is left un-reset, like the harness does
+        dev.close()
+    g = load_golden("g4_deeprmsa_j1_sap")
+    dkw = dict(g["meta"]["kwargs"])
+    dkw.pop("seed")
+    dev = orl.BatchedDeepRMSAEnv("nsfnet_chen", num_envs=5, seeds=[10, 11, 12, 13, 14], **dkw)
+    mean, std = orl.evaluate_heuristic(dev, "SAP", n_eval_episodes=10)
+    assert (round(float(mean[0]), 4), round(float(std[0]), 4)) == (43.2, 4.6)
+    dev.close()
+
+
+def test_vecenv_on_hip_dlpack_and_monitor_file(tmp_path):
+    """The SB3-shaped VecEnv over a HIP batch: 2 000 random-policy steps driven through zero-copy DLPack tensors, float32
+    observations, and a Monitor file in the format of the reference's examples/heuristics/bkp/rmsa-heu/sap_ff.monitor.csv
+    (`#{"t_start": ..., "env_id": ...}` / `r,l,t,<info keywords>` / one row per episode)."""
+    import csv
+    import json
+
+    import torch
+
+    import optical_rl_gym_amd as orl
+
+    kw = dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=1.0 / 12.0, j=1, episode_length=50)
+    batch = orl.BatchedDeepRMSAEnv("nsfnet_chen", num_envs=16, seeds=list(range(16)), **kw)
+    venv = orl.OpticalVecEnv(batch, obs_dtype=np.float32)
+    assert venv.observation_space.shape == (54,) and venv.action_space.n == 5
+    obs = venv.reset()
+    assert obs.dtype == np.float32 and obs.shape == (16, 54)
+    rs = np.random.RandomState(0)
+    total_done = 0
+    for t in range(2000 // 16):
+        obs, rew, done, infos = venv.step(rs.randint(0, 5, 16))
+        total_done += int(done.sum())
+        for i in np.flatnonzero(done):
+            assert infos[i]["episode"]["l"] == 49 and infos[i]["terminal_observation"].dtype == np.float32
+    assert total_done == len(venv.episode_log) == 16 * ((2000 // 16) // 49)
+    path = tmp_path / "rnd.monitor.csv"
+    venv.save_monitor_csv(str(path), env_id="DeepRMSA-v0")
+    lines = path.read_text().splitlines()
+    head = json.loads(lines[0][1:])
+    assert lines[0][0] == "#" and set(head) == {"t_start", "env_id"}
+    assert lines[1] == "r,l,t,episode_service_blocking_rate,episode_bit_rate_blocking_rate"
+    rows = list(csv.reader(lines[2:]))
+    assert len(rows) == total_done and all(len(r) == 5 and int(r[1]) == 49 for r in rows)
+    # the same arrays through DLPack, no copy: an agent on the GPU writes actions and reads results in place
+    act = torch.from_dlpack(batch.device_array("actions"))
+    rew_t = torch.from_dlpack(batch.device_array("reward"))
+    obs_t = torch.from_dlpack(batch.device_array("obs"))
+    assert act.is_cuda and act.shape == (16, 4) and rew_t.dtype == torch.float64 and obs_t.shape == (16, 54)
+    assert act.data_ptr() == batch.device_tensor("actions").data_ptr()
+    a = torch.zeros(16, 4, dtype=torch.int32, device="cuda")
+    act.copy_(a)
+    torch.cuda.synchronize()
+    batch.step(None, auto_reset=True, fetch=False)
+    batch.sync()
+    assert np.array_equal(obs_t.cpu().numpy(), batch.observation())
+    assert venv.get_attr("services_processed") == [int(x) for x in batch.counters()[:, 0]]
+    assert venv.env_method("seed", 9, indices=[1, 2]) == [10, 11]
+    venv.close()
+
+
+def test_multi_device_wrapper_on_one_gpu():
+    """make(..., device_ids=[0, 0]): two shards behind one batch object (here both on the only GPU of the box), each driven
+    by its own host thread and stream — same results as the single batch."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    fam, topo, kw, policy = WORKLOADS["cfg2"]
+    kw = dict(kw, episode_length=70)
+    n = 1000
+    seeds = [10 + i for i in range(n)]
+    one = orl.make(fam, topology=topo, num_envs=n, seeds=seeds, **kw)
+    two = orl.make(fam, topology=topo, num_envs=n, seeds=seeds, device_ids=[0, 0], **kw)
+    assert isinstance(two, orl.MultiDeviceBatch) and two.num_envs == n and [s.num_envs for s in two.shards] == [500, 500]
+    one.run(policy, 150)
+    two.run(policy, 150)
+    for t in range(20):
+        a = one.policy(policy).copy()
+        assert np.array_equal(two.policy(policy), a)
+        _, r1, d1, i1 = one.step(a, auto_reset=True)
+        _, r2, d2, i2 = two.step(a, auto_reset=True)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(i1, i2)
+    assert np.array_equal(one.counters(), two.counters()) and np.array_equal(one.services(), two.services())
+    for e in (0, 499, 500, 999):
+        assert np.array_equal(one.slots(e), two.slots(e)) and np.array_equal(one.link_stats(e), two.link_stats(e))
+    assert one.totals() == two.totals()
+    one.close()
+    two.close()
+
+
+def test_facade_queries_and_wrappers_on_hip():
+    import optical_rl_gym_amd as orl
+
+    env = orl.RMSAEnv(topology="nsfnet_chen", seed=10, load=300, mean_service_holding_time=25, episode_length=1000,
+                      num_spectrum_resources=320, allow_rejection=True)
+    for _ in range(400):
+        env.step(orl.shortest_available_path_first_fit(env))
+    svc = env.current_service
+    po, mo = orl.PathOnlyFirstFitAction(env), orl.SimpleMatrixObservation(env)
+    avail = np.asarray(env.topology.graph["available_slots"])
+    for p, path in enumerate(env.k_shortest_paths[svc.source, svc.destination]):
+        n = env.get_number_slots(path)
+        both = env.get_available_slots(path)
+        fit = [s0 for s0 in range(0, 320 - n) if both[s0:s0 + n].all()]
+        assert po.action(p) == ((p, fit[0]) if fit else (5, 320))
+        assert env.is_path_free(path, fit[0], n) if fit else True
+    assert po.action(5) == (5, 320)
+    obs = mo.observation()
+    assert obs.dtype == np.float64 and obs.shape == (28 + 22 * 320,) and np.array_equal(obs[28:], avail.reshape(-1))
+    assert env.actions_output.sum() == 400 and env.actions_taken.sum() == 400
+    with pytest.raises(IndexError):
+        env.step((0, 400))
+    env.close()

@@ -100,3 +100,190 @@ def test_vecenv_auto_reset_and_monitor_rows():
         rows = list(csv.DictReader(lines[1:]))
         assert len(rows) == 6 and list(rows[0])[:3] == ["r", "l", "t"] and int(rows[0]["l"]) == 49
         assert "episode_service_blocking_rate" in rows[0]
+
+
+def test_query_methods_of_the_facade_match_their_reference_definitions():
+    """is_path_free / get_available_slots / rle / get_available_blocks (rmsa_env.py:623-697), get_path_capacity
+    (rwa_env.py:403-422), seed(), the 2-D action histograms — on a live env, against direct evaluations of the slot map."""
+    env = _env(orl.RMSAEnv, "RMSA", **RMSA_KW)
+    for _ in range(60):
+        env.step(orl.shortest_available_path_first_fit(env))
+    svc = env.current_service
+    avail = np.asarray(env.topology.graph["available_slots"])
+    assert avail.shape == (22, 64) and set(np.unique(avail)) <= {0, 1}
+    for p, path in enumerate(env.k_shortest_paths[svc.source, svc.destination]):
+        links = [int(x) for x in env.topo.path_links[svc.source_id, svc.destination_id, p][: path.hops]]
+        assert env._links(path) == links
+        both = avail[links].min(axis=0)
+        assert np.array_equal(env.get_available_slots(path), both)
+        n = env.get_number_slots(path)
+        for s0 in (0, 5, 30, 64 - n, 64 - n + 1):
+            assert env.is_path_free(path, s0, n) == (s0 + n <= 64 and bool(both[s0:s0 + n].all()))
+        starts, values, lengths = env.rle(both)
+        assert starts[0] == 0 and lengths.sum() == 64 and np.array_equal(np.repeat(values, lengths), both)
+    a = orl.shortest_available_path_first_fit(env)
+    path = env.k_shortest_paths[svc.source, svc.destination][a[0]]
+    assert env.is_path_free(path, a[1], env.get_number_slots(path))
+    out, taken = env.actions_output, env.actions_taken
+    assert out.shape == (6, 65) and out.sum() == 60 and taken.sum() == 60
+    assert env.episode_actions_output.shape == (6, 65) and env.episode_actions_output.sum() == 0  # rmsa_env.py:289-302
+    with pytest.raises(IndexError):
+        env.step((7, 0))
+    assert env.seed(123) == [123] and env.rand_seed == 123
+    # DeepRMSA: get_available_blocks of the facade == what the observation encodes
+    g = load_golden("g4_deeprmsa_j2_sap")
+    kw = dict(g["meta"]["kwargs"])
+    kw.pop("seed")
+    d = _env(orl.DeepRMSAEnv, "DeepRMSA", **kw)
+    for _ in range(40):
+        d.step(orl.shortest_available_path_first_fit(d))
+    obs = d.observation()
+    for p in range(5):
+        starts, lengths = d.get_available_blocks(p)
+        blk = obs[1 + 28 + p * 7: 1 + 28 + p * 7 + 4].reshape(2, 2)
+        for b in range(len(starts)):
+            assert blk[b, 0] == 2 * (starts[b] - 0.5 * 100) / 100 and blk[b, 1] == (lengths[b] - 8) / 8
+    assert d._get_route_block_id(7) == (3, 1)
+    # RWA
+    r = _env(orl.RWAEnv, "RWA", allow_rejection=True, load=450, mean_service_holding_time=25, episode_length=1000)
+    r.reset()
+    for _ in range(50):
+        r.step(orl.shortest_available_path_first_fit(r))
+    svc = r.current_service
+    avail = np.asarray(r.topology.graph["available_wavelengths"])
+    for p, path in enumerate(r.k_shortest_paths[svc.source, svc.destination]):
+        both = avail[r._links(path)].min(axis=0)
+        assert r.get_path_capacity(path) == int(both.sum())
+        assert r.is_path_free(path, 3) == bool(both[3])
+    assert r.actions_output.shape == (6, 81) and r.actions_output.sum() == 50 and r.episode_actions_output.sum() == 50
+    r.reset()
+    assert r.episode_actions_output.sum() == 0 and r.actions_output.sum() == 50
+
+
+def test_batched_evaluate_heuristic_and_registry():
+    from optical_rl_gym_amd import registration
+
+    batch = OracleBackend("RMSA", "nsfnet_chen", [10, 11, 12], **RMSA_KW)
+    mean, std = orl.evaluate_heuristic(batch, orl.shortest_available_path_first_fit, n_eval_episodes=10)
+    assert mean.shape == (3,) and (round(float(mean[0]), 4), round(float(std[0]), 4)) == (95.0, 3.2558)
+    with pytest.raises(TypeError):
+        orl.evaluate_heuristic(batch, lambda e: (0, 0))
+    env = _env(orl.RMSAEnv, "RMSA", **RMSA_KW)
+    m, s = orl.evaluate_heuristic(env, lambda e: orl.shortest_path_first_fit(e), n_eval_episodes=10)  # host loop: any callable
+    assert (round(float(m), 4), round(float(s), 4)) == (88.7, 7.1281)
+    assert set(registration.SINGLE) == {"RMSA-v0", "DeepRMSA-v0", "RWA-v0", "RMCSA-v0"}
+    assert registration.make.__doc__ and isinstance(registration.REGISTERED_WITH, list)
+
+
+def test_vecenv_implements_the_sb3_interface():
+    """Every abstract method of stable_baselines3.common.vec_env.VecEnv (listed here: SB3 is not installed in the build
+    image) plus the attributes BaseAlgorithm reads at construction."""
+    abstract = ["reset", "step_async", "step_wait", "close", "get_attr", "set_attr", "env_method", "env_is_wrapped"]
+    concrete_used = ["step", "seed", "render", "get_images", "unwrapped"]
+    g = load_golden("g4_deeprmsa_j1_sap")
+    kw = dict(g["meta"]["kwargs"])
+    kw.pop("seed")
+    batch = OracleBackend("DeepRMSA", "nsfnet_chen", [10, 11, 12, 13], **kw)
+    venv = OpticalVecEnv(batch, obs_dtype=np.float32)
+    for name in abstract + concrete_used:
+        assert hasattr(venv, name), name
+    assert venv.num_envs == 4 and venv.observation_space.shape == (54,) and venv.action_space.n == 5
+    obs = venv.reset()
+    assert obs.dtype == np.float32 and obs.shape == (4, 54)
+    assert venv.get_attr("services_processed") == [1, 1, 1, 1] and venv.get_attr("episode_length", indices=[2]) == [50]
+    venv.set_attr("tag", "x", indices=[1])
+    assert venv.get_attr("tag") == [None, "x", None, None]
+    assert venv.env_is_wrapped(object) == [False] * 4 and venv.get_images() == [None] * 4
+    first = batch.services().copy()
+    assert venv.env_method("seed", 5, indices=[0, 3]) == [5, 8]
+    venv.step(batch.policy("SAP")[:, 0])
+    assert venv.env_method("reset", only_episode_counters=False, indices=[1])[0].shape == (54,)
+    assert venv.get_attr("services_processed") == [2, 1, 2, 2]
+    assert not np.array_equal(batch.services()[1], first[1])
+
+
+def test_multi_device_wrapper_equals_one_batch():
+    """sharding.MultiDeviceBatch over two shards == the unsharded batch, step by step (scatter / gather) and in run()."""
+    seeds = list(range(40, 47))
+    whole = OracleBackend("RMSA", "nsfnet_chen", seeds, **RMSA_KW)
+    multi = orl.MultiDeviceBatch.from_shards([OracleBackend("RMSA", "nsfnet_chen", seeds[:4], **RMSA_KW),
+                                              OracleBackend("RMSA", "nsfnet_chen", seeds[4:], **RMSA_KW)])
+    assert multi.num_envs == 7
+    for t in range(150):
+        a = whole.policy("SAP_FF")
+        assert np.array_equal(multi.policy("SAP_FF"), a)
+        o1, r1, d1, i1 = whole.step(a, auto_reset=True)
+        o2, r2, d2, i2 = multi.step(a, auto_reset=True)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(i1, i2)
+    whole.run("LLP_FF", 80)
+    multi.run("LLP_FF", 80)
+    assert np.array_equal(whole.counters(), multi.counters()) and np.array_equal(whole.services(), multi.services())
+    for e in (0, 3, 4, 6):
+        assert np.array_equal(whole.slots(e), multi.slots(e)) and np.array_equal(whole.link_stats(e), multi.link_stats(e))
+    mask = np.array([1, 0, 0, 1, 1, 0, 1], np.uint8)
+    whole.reset(full=True, mask=mask)
+    multi.reset(full=True, mask=mask)
+    assert np.array_equal(whole.counters(), multi.counters())
+    multi.close()
+
+
+def test_reference_pickle_loader(tmp_path):
+    """examples/create_topology.py:184-185 pickles a networkx graph holding optical_rl_gym.utils.Path / Modulation objects;
+    the loader reads such a file without the reference package and gives the committed table."""
+    import pickle
+    import sys
+    import types
+
+    nx = pytest.importorskip("networkx")
+    from optical_rl_gym_amd import topology_io
+    from optical_rl_gym_amd.topology import Topology
+
+    t = Topology.load("nsfnet_chen")
+    # write a file the way the reference does, with classes that pickle under the reference's module path
+    mod = types.ModuleType("optical_rl_gym.utils")
+    pkg = types.ModuleType("optical_rl_gym")
+
+    class Modulation:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class Path:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    for c in (Modulation, Path):
+        c.__module__, c.__qualname__ = "optical_rl_gym.utils", c.__name__
+        setattr(mod, c.__name__, c)
+    sys.modules["optical_rl_gym"], sys.modules["optical_rl_gym.utils"] = pkg, mod
+    try:
+        g = nx.Graph()
+        for n in t.node_names:
+            g.add_node(n)
+        for it in t.edge_iter_order:
+            a, b = t.link_nodes[it]
+            g.add_edge(t.node_names[a], t.node_names[b], index=int(it), id=int(t.link_ids[it]), length=float(t.link_length[it]), weight=1)
+        mods = [Modulation(name=m.name, maximum_length=m.maximum_length, spectral_efficiency=m.spectral_efficiency,
+                           minimum_osnr=m.minimum_osnr, inband_xt=m.inband_xt) for m in t.modulations]
+        ksp = {}
+        for s in range(t.n_nodes):
+            for d in range(t.n_nodes):
+                if s != d:
+                    ksp[t.node_names[s], t.node_names[d]] = [
+                        Path(path_id=p.path_id, node_list=p.node_list, hops=p.hops, length=p.length,
+                             best_modulation=mods[int(t.path_best_mod[s, d, i])], current_modulation=None)
+                        for i, p in enumerate(t.ksp(s, d))]
+        g.graph.update(name=t.name, ksp=ksp, modulations=mods, k_paths=t.k_paths, node_indices=list(t.node_names))
+        path = tmp_path / "topo.h5"
+        with open(path, "wb") as f:
+            pickle.dump(g, f)
+    finally:
+        del sys.modules["optical_rl_gym"], sys.modules["optical_rl_gym.utils"]
+    got = topology_io.load_reference_pickle(str(path))
+    for name in ("n_paths", "path_hops", "path_links", "path_length", "path_best_mod", "edge_iter_order", "link_length", "link_nodes"):
+        assert np.array_equal(getattr(got, name), getattr(t, name)), name
+    assert got.node_names == t.node_names and [m.name for m in got.modulations] == [m.name for m in t.modulations]
+    ref = "/root/reference/examples/topologies/nsfnet_chen_5-paths_6-modulations.h5"
+    import os
+    if os.path.exists(ref):  # build container only: the reference's own file
+        real = topology_io.load_reference_pickle(ref)
+        assert np.array_equal(real.path_links, t.path_links) and np.array_equal(real.path_length, t.path_length)
