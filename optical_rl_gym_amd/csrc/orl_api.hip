@@ -303,10 +303,36 @@ static void launch_obs(orl_batch* b, int with_terminal) {
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
-static void launch_persist(orl_batch* b, int pol, int target) {
-#define CALL(WW) orl_launch::persist<WW>(b, pol, target)
+static void launch_persist(orl_batch* b, const DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished) {
+#define CALL(WW) orl_launch::persist<WW>(b, VP, st, pol, target, wg_step, unfinished)
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
+}
+static int persist_resident(orl_batch* b) {
+  int r = 0;
+#define CALL(WW) r = orl_launch::persist_resident<WW>(b, b->n_cu)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+  return r;
+}
+// the per-env arrays of envs [lo, lo + cnt) as a batch of their own (lo a multiple of 8: wavefronts own 8 consecutive envs)
+static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
+  DevParams q = P;
+  q.B = cnt;
+  q.bitmap += lo * P.bm_words; q.ev_time += lo * P.ev_cap; q.ev_info += lo * P.ev_cap; q.mt += lo * 624;
+  if (q.mt2) q.mt2 += lo * 624;
+  q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
+  q.soon_t += lo * ORL_SOON; q.soon_i += lo * ORL_SOON;
+  if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
+  if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (P.S + 1));
+  if (q.act2d) q.act2d += lo * P.act2d_words;
+  if (q.ep_log) { q.ep_log += lo * P.ep_cap; q.ep_count += lo; }
+  q.path_col += lo;
+  q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
+  if (q.obs) { q.obs += lo * P.obs_dim; q.term_obs += lo * P.obs_dim; }
+  q.q_a += (lo / 8) * P.q_wave * 2; q.q_cnt_a += lo / 8;
+  q.q_def = P.q_def + (size_t)part * P.q_def_stride;  // each part has its own list of deferred envs (indices relative to lo)
+  return q;
 }
 static void launch_step2(orl_batch* b, int pol) {
 #define CALL(WW) orl_launch::step2<WW>(b, pol)
@@ -490,6 +516,12 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   rc |= dalloc(b, &b->d_totals, 2);
   if (rc) { orl_batch_destroy(b); return ORL_E_HIP; }
   HIPCHK_B(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  HIPCHK_B(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+  HIPCHK_B(hipEventCreateWithFlags(&b->ev_half, hipEventDisableTiming));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) b->n_cu = prop.multiProcessorCount;
+  }
   HIPCHK_B(hipEventCreate(&b->ev0));
   HIPCHK_B(hipEventCreate(&b->ev1));
   // everything below is ordered on the batch's own stream
@@ -540,6 +572,8 @@ extern "C" void orl_batch_destroy(orl_batch* b) {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
+  if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); }
+  if (b->ev_half) hipEventDestroy(b->ev_half);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   for (void* p : b->allocs) hipFree(p);
@@ -800,18 +834,48 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     HIPCHK(hipMemsetAsync(b->d_wg_step, 0, n_wg * sizeof(int), b->stream));
     int chunk = 64;
     if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
+    // A launch occupies the GPU in rounds of `resident` wavefronts, and a last round that is not full leaves CUs idle until
+    // the launch ends (cfg2: 8 192 wavefronts over 3 072 resident = 2.67 rounds, 11 % of the machine-time lost).  When the
+    // rounds do not come out even, the batch runs as two halves on two streams: the tail of one half's launch overlaps the
+    // other half's next one.  (ORL_PERSIST_PARTS=1|2 forces either.)
+    int parts = 1;
+    {
+      const int resident = persist_resident(b);
+      const double rounds = (double)n_wg / (double)(resident > 0 ? resident : 1);
+      // (a run of a single chunk has no next launch to overlap with: one part)
+      if (n_steps > chunk && n_wg >= 2048 && rounds > 1.0) parts = 2;
+      if (const char* pv = getenv("ORL_PERSIST_PARTS")) { int v = atoi(pv); if (v == 1 || (v == 2 && n_wg >= 2)) parts = v; }
+    }
+    const i64 half = parts == 2 ? (i64)((n_wg + 1) / 2) * 8 : b->P.B;
+    DevParams view[2] = {env_view(b->P, 0, parts == 2 ? half : b->P.B, 0), env_view(b->P, parts == 2 ? half : 0, parts == 2 ? b->P.B - half : 0, 1)};
+    hipStream_t strm[2] = {b->stream, b->stream2};
+    int* wg_step[2] = {b->d_wg_step, b->d_wg_step + half / 8};
+    if (parts == 2) {
+      HIPCHK(hipEventRecord(b->ev_half, b->stream));
+      HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_half, 0));
+    }
     b->persist_launches = 0;
     for (int64_t tgt = 0; tgt < n_steps;) {
       tgt = (tgt + chunk < n_steps) ? tgt + chunk : n_steps;
       for (;;) {
-        HIPCHK(hipMemsetAsync(b->d_unfinished, 0, 2 * sizeof(unsigned int), b->stream));
         b->persist_launches++;
-        launch_persist(b, policy_id, (int)tgt);
+        for (int p = 0; p < parts; p++) {
+          HIPCHK(hipMemsetAsync(b->d_unfinished + 4 * p, 0, 2 * sizeof(unsigned int), strm[p]));
+          launch_persist(b, view[p], strm[p], policy_id, (int)tgt, wg_step[p], b->d_unfinished + 4 * p);
+        }
         if (tgt < n_steps) break;  // stragglers catch up in the next chunk's launch
-        launch_finish2(b, 1);  // (harmless for a straggler: it does what that env's next control phase would do first)
+        for (int p = 0; p < parts; p++)  // (harmless for a straggler: it does what that env's next control phase would do first)
+          hipLaunchKernelGGL(k_finish2, dim3((unsigned)((view[p].B + 255) / 256)), dim3(256), 0, strm[p], view[p], 1, b->d_unfinished + 4 * p + 1);
+        if (parts == 2) {
+          HIPCHK(hipEventRecord(b->ev_half, b->stream2));
+          HIPCHK(hipStreamWaitEvent(b->stream, b->ev_half, 0));
+        }
         HIPCHK(hipEventRecord(b->ev1, b->stream));
-        HIPCHK(hipMemcpyAsync(tail, b->d_unfinished, sizeof tail, hipMemcpyDeviceToHost, b->stream));
+        unsigned int both[8] = {0};
+        HIPCHK(hipMemcpyAsync(both, b->d_unfinished, sizeof both, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
+        tail[0] = both[0] + (parts == 2 ? both[4] : 0);
+        tail[1] = both[1] | (parts == 2 ? both[5] : 0);
         if (!tail[0]) break;
       }
     }

@@ -38,6 +38,9 @@ struct orl_batch {
   unsigned int* d_unfinished = nullptr;  // [0] straggler workgroups of the last persistent launch, [1] OR of the env flag words (k_finish2)
   int device = 0, wt = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // second half of the batch in device-resident runs (see orl_batch_run)
+  hipEvent_t ev_half = nullptr;
+  int n_cu = 256;
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_totals = nullptr;
@@ -60,7 +63,9 @@ template <int W> void reset(orl_batch* b, int full, const unsigned char* dmask);
 template <int W> void policy(orl_batch* b, int pol);                       // stand-alone slot scan -> P.actions
 template <int W> void step64(orl_batch* b, int auto_reset, int want_info, int fused_policy);  // one wavefront per env
 template <int W> void obs(orl_batch* b, int with_terminal);                // DeepRMSA observation
-template <int W> void persist(orl_batch* b, int pol, int target);          // k_persist up to step `target` of this run, then k_rel_tail
+// k_persist over the env range of view VP up to step `target` of this run, then k_rel_tail, on stream st
+template <int W> void persist(orl_batch* b, const orl::DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished);
+template <int W> int persist_resident(orl_batch* b, int n_cu);              // wavefronts of k_persist the GPU holds at once
 template <int W> int persist_uses_lds(orl_batch* b);                       // 1: the persistent kernel keeps slot maps / link statistics in LDS
 template <int W> int prof_read(unsigned long long* out48, int reset);      // -DORL_TIMING builds: per-phase cycle sums
 template <int W> void step2(orl_batch* b, int pol);                        // ORL_ALT_IMPLS: k_step_a2 ; k_rows2 ; k_rel_tail

@@ -549,15 +549,33 @@ template <int W> int persist_uses_lds(orl_batch* b) {
   size_t lds;
   return kPersistForms[persist_variant(b->P, &lds)].lds;
 }
-template <int W> void persist(orl_batch* b, int pol, int target) {
-  const DevParams& VP = b->P;
+// Workgroups per CU the form allows (LDS window, register budget).  ORL_PERSIST_WGS_PER_CU=r lowers the residency by padding
+// the LDS request (experiment: a launch runs in rounds of r x CUs wavefronts, and 8 192 wavefronts over 12 per CU are 2.67
+// rounds; r = 11 makes three nearly full rounds — measured SLOWER, 6.5e8 against 7.2e8 env-steps/s for 20-step runs of cfg2:
+// the kernel is not purely issue-bound, the twelfth wavefront still hides latency).
+static int persist_max_per_cu(int v, size_t lds) {
+  int per_cu = 4 * kPersistForms[v].waves;
+  if (lds > 0 && (int)((160 * 1024) / lds) < per_cu) per_cu = (int)((160 * 1024) / lds);
+  return per_cu < 1 ? 1 : per_cu;
+}
+static size_t persist_tuned_lds(int v, size_t lds) {
+  const int rmax = persist_max_per_cu(v, lds);
+  int want_r = rmax;
+  if (const char* e = getenv("ORL_PERSIST_WGS_PER_CU")) { int f = atoi(e); if (f >= 1 && f <= rmax) want_r = f; }
+  if (want_r == rmax) return lds;
+  size_t want = ((size_t)(160 * 1024) / (size_t)want_r) & ~(size_t)511;
+  while (want > lds && (int)((160 * 1024) / want) < want_r) want -= 512;
+  return want > lds ? want : lds;
+}
+template <int W> void persist(orl_batch* b, const DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished) {
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64), blk_tail(256);
   size_t lds_a = 0;
   const int v = persist_variant(VP, &lds_a);
+  lds_a = persist_tuned_lds(v, lds_a);
 #define LAUNCH(E_, LDS_, WV_)                                                                                                 \
   do {                                                                                                                       \
     if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<E_, W, LDS_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
-    hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_>), gc, blk, lds_a, b->stream, VP, pol, target, b->d_wg_step, b->d_unfinished); \
+    hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished);            \
   } while (0)
 #define PER_ENV(E_)                                                                                                          \
   switch (v) {                                                                                                               \
@@ -568,10 +586,16 @@ template <int W> void persist(orl_batch* b, int pol, int target) {
     case 4: LAUNCH(E_, 1, 3); break;                                                                                         \
     default: LAUNCH(E_, 1, 4); break;                                                                                        \
   }                                                                                                                          \
-  hipLaunchKernelGGL((k_rel_tail<E_, W>), dim3(1), blk_tail, 0, b->stream, VP, 0);
+  hipLaunchKernelGGL((k_rel_tail<E_, W>), dim3(1), blk_tail, 0, st, VP, 0);
   ORL_FOR_ENV(b, PER_ENV)
 #undef PER_ENV
 #undef LAUNCH
+}
+// wavefronts of the persistent kernel a GPU of `n_cu` CUs holds at once for this batch (LDS window and register budget)
+template <int W> int persist_resident(orl_batch* b, int n_cu) {
+  size_t lds = 0;
+  const int v = persist_variant(b->P, &lds);
+  return persist_max_per_cu(v, lds) * n_cu;
 }
 
 template <int W> void step2(orl_batch* b, int pol) {
@@ -627,7 +651,8 @@ template int prof_read<ORL_W>(unsigned long long*, int);
 template void policy<ORL_W>(orl_batch*, int);
 template void step64<ORL_W>(orl_batch*, int, int, int);
 template void obs<ORL_W>(orl_batch*, int);
-template void persist<ORL_W>(orl_batch*, int, int);
+template void persist<ORL_W>(orl_batch*, const DevParams&, hipStream_t, int, int, int*, unsigned int*);
+template int persist_resident<ORL_W>(orl_batch*, int);
 template int persist_uses_lds<ORL_W>(orl_batch*);
 template void step2<ORL_W>(orl_batch*, int);
 

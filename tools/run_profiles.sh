@@ -35,3 +35,4 @@ pass sq3 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_
 pass hit TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 fi
 ls $O
+python3 $R/tools/phase_prof.py cfg2 65536 256 > $O/phase_cfg2.txt 2>&1
