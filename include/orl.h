@@ -38,6 +38,10 @@ extern "C" {
 #define ORL_ENV_DEEPRMSA 1  /* "DeepRMSA-v0"  optical_rl_gym/envs/deeprmsa_env.py:9 */
 #define ORL_ENV_RWA 2       /* "RWA-v0"       optical_rl_gym/envs/rwa_env.py:15 */
 #define ORL_ENV_RMCSA 3     /* "RMCSA-v0"     optical_rl_gym/envs/rmcsa_env.py:18 */
+#define ORL_ENV_QOS 4       /* "QoSConstrainedRA-v0"  optical_rl_gym/envs/qos_constrained_ra.py:13 (its constructor raises
+                             * upstream, :32-41; semantics as the class is written, see oracle/gen_golden_qos.py).  Actions: the
+                             * path index (Discrete(k + reject)); policies SP_FF / SAP_FF / LLP_FF = shortest_path /
+                             * shortest_available_path / least_loaded_path (:408-450); info: the two service blocking rates. */
 
 /* on-device heuristics.  RMSA: rmsa_env.py:747-803; DeepRMSA: deeprmsa_env.py:135-155 (SP=0, SAP=1);
  * RWA: rwa_env.py:425-502; RMCSA: rmcsa_env.py:882-911 (id 1). */
@@ -86,6 +90,11 @@ typedef struct {
   const uint8_t* n_slots;      /* [n_bit_rates*n_modulations] get_number_slots (rmsa_env.py:610-621) */
   const double* lmax_snr;      /* [n_modulations*n_bit_rates] RMCSA reach limit, eq.(1) (rmcsa_env.py:366-375); may be NULL */
   const double* lmax_xt;       /* [n_modulations]             RMCSA reach limit, eq.(2) (rmcsa_env.py:377-379); may be NULL */
+  /* QoSConstrainedRA only (qos_constrained_ra.py:21-23); ignored (may be 0 / NULL) for the other families */
+  int32_t n_service_classes;   /* num_service_classes */
+  int32_t reserved;
+  const double* cum_class;     /* [n_service_classes] accumulate(classes_arrival_probabilities) */
+  const double* class_reward;  /* [n_service_classes] classes_reward */
 } orl_env_config;
 
 typedef struct orl_topology orl_topology;
@@ -211,6 +220,8 @@ int orl_batch_get_counters(orl_batch* b, int64_t* out /*[n_envs][ORL_N_COUNTERS]
 int orl_batch_get_services(orl_batch* b, double* out /*[n_envs][ORL_N_SERVICE]*/);
 int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out /*[cores][links][slots] 0/1*/);
 int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out /*[4][links]: utilization, external_fragmentation, compactness, last_update*/);
+/* QoSConstrainedRA: topology.graph["available_spectrum"] of one env (free units per link, optical_network_env.py:189-193) */
+int orl_batch_get_spectrum(orl_batch* b, int64_t env, int32_t* out /*[links]*/);
 int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out /*[4]: throughput, compactness, last_update, current_time*/);
 int orl_batch_get_active(orl_batch* b, int32_t* out /*[n_envs] pending releases*/);
 int orl_batch_get_flags(orl_batch* b, int32_t* out /*[n_envs] bit0 event overflow, bit1 bad action*/);

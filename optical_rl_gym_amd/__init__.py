@@ -1,7 +1,7 @@
 """optical_rl_gym_amd: batched RWA / RMSA / DeepRMSA / RMCSA optical-network environments whose
 reset()/step()/heuristic hot path runs as hand-written HIP kernels on AMD MI355X (gfx950)."""
-from .envs import (BatchedDeepRMSAEnv, BatchedOpticalEnv, BatchedRMCSAEnv, BatchedRMSAEnv, BatchedRWAEnv,  # noqa: F401
-                   make)
+from .envs import (BatchedDeepRMSAEnv, BatchedOpticalEnv, BatchedQoSConstrainedRA, BatchedRMCSAEnv,  # noqa: F401
+                   BatchedRMSAEnv, BatchedRWAEnv, make)
 from .topology import Modulation, Path, Topology, get_best_modulation_format  # noqa: F401
 
 __version__ = "0.1.0"
@@ -11,3 +11,4 @@ from .gym_api import (DeepRMSAEnv, PathOnlyFirstFitAction, RMCSAEnv, RMSAEnv, RW
                       shortest_available_path_first_fit, shortest_available_path_last_fit, shortest_path_first_fit)
 from .sharding import MultiDeviceBatch, shard_range, shard_seeds  # noqa: F401,E402
 from .vec_env import OpticalVecEnv  # noqa: F401,E402
+from .qos import QoSConstrainedRA  # noqa: F401,E402

@@ -18,7 +18,8 @@ class EnvConfig(C.Structure):
         "env_type", "num_spectrum_resources", "num_spatial_resources", "episode_length", "allow_rejection", "j",
         "bit_rate_mode", "bit_rate_lo", "bit_rate_hi", "n_bit_rates", "event_capacity", "action_histograms")] + [
         ("lambda_arrival", C.c_double), ("lambda_holding", C.c_double)] + [
-        (n, C.c_void_p) for n in ("cum_src", "cum_dst", "bit_rates", "cum_bit_rate", "n_slots", "lmax_snr", "lmax_xt")]
+        (n, C.c_void_p) for n in ("cum_src", "cum_dst", "bit_rates", "cum_bit_rate", "n_slots", "lmax_snr", "lmax_xt")] + [
+        ("n_service_classes", C.c_int32), ("reserved", C.c_int32), ("cum_class", C.c_void_p), ("class_reward", C.c_void_p)]
 
 
 class RunStats(C.Structure):
@@ -57,6 +58,7 @@ EXPORTS = {
     "orl_batch_get_services": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_slots": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "orl_batch_get_link_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "orl_batch_get_spectrum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "orl_batch_get_net_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "orl_batch_get_active": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_flags": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -354,6 +354,7 @@ template <typename T> static int dalloc(orl_batch* b, T** p, size_t n) {
 static int policy_ok(const orl_batch* b, int policy_id) {
   if (policy_id < 0 || policy_id > ORL_POLICY_PATH_FF) return 0;
   if (policy_id == ORL_POLICY_PATH_FF && b->P.env_type != ENV_RMSA && b->P.env_type != ENV_RWA) return 0;
+  if (b->P.env_type == ENV_QOS && policy_id > ORL_POLICY_LLP_FF) return 0;
   return 1;
 }
 
@@ -361,7 +362,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
                              const int64_t* seeds, orl_batch** out) {
   if (!c || !t || !out || (!mt_state && !seeds) || n_envs < 1) return fail(ORL_E_INVALID, "null/invalid argument");
   if (n_envs > (int64_t)1 << 30) return fail(ORL_E_INVALID, "n_envs must be <= 2^30");
-  if (c->env_type < 0 || c->env_type > 3) return fail(ORL_E_INVALID, "unknown env_type %d", c->env_type);
+  if (c->env_type < 0 || c->env_type > ORL_ENV_QOS) return fail(ORL_E_INVALID, "unknown env_type %d", c->env_type);
+  const bool qos = c->env_type == ORL_ENV_QOS;
+  if (qos && (c->n_service_classes < 1 || c->n_service_classes > 64 || !c->cum_class || !c->class_reward))
+    return fail(ORL_E_INVALID, "QoSConstrainedRA needs 1..64 service classes with their tables");
   const int S = c->num_spectrum_resources, C = c->num_spatial_resources;
   if (S < 2 || S > 512) return fail(ORL_E_INVALID, "num_spectrum_resources must be in [2, 512]");
   if (C < 1 || C > 31 || (c->env_type != ORL_ENV_RMCSA && C != 1)) return fail(ORL_E_INVALID, "bad num_spatial_resources");
@@ -369,20 +373,21 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   if (c->n_bit_rates < 1 || c->n_bit_rates > 4096) return fail(ORL_E_INVALID, "bad n_bit_rates");
   if (c->episode_length < 1) return fail(ORL_E_INVALID, "episode_length must be positive");
   if (!c->cum_src || !c->cum_dst) return fail(ORL_E_INVALID, "node probability tables missing");
-  if (c->env_type != ORL_ENV_RWA && (!c->n_slots || !c->bit_rates)) return fail(ORL_E_INVALID, "bit-rate tables missing");
+  const bool no_rates = c->env_type == ORL_ENV_RWA || qos;  // one unit per service, no bit rate
+  if (!no_rates && (!c->n_slots || !c->bit_rates)) return fail(ORL_E_INVALID, "bit-rate tables missing");
   if (c->env_type == ORL_ENV_RMCSA && (!c->lmax_snr || !c->lmax_xt)) return fail(ORL_E_INVALID, "RMCSA reach tables missing");
   if (c->bit_rate_mode == 1 && !c->cum_bit_rate) return fail(ORL_E_INVALID, "cum_bit_rate missing");
-  if (c->env_type != ORL_ENV_RWA) {
+  if (!no_rates) {
     for (int i = 0; i < c->n_bit_rates * t->M; i++)
       if (c->n_slots[i] < 1 || c->n_slots[i] > 64) return fail(ORL_E_INVALID, "n_slots entries must be in [1, 64]");
     for (int i = 0; i < c->n_bit_rates; i++)
       if (c->bit_rates[i] < 0 || c->bit_rates[i] > 32767) return fail(ORL_E_INVALID, "bit rates must be < 32768");
   }
   const int rand_n = c->bit_rate_hi + 1 - c->bit_rate_lo;
-  if (c->bit_rate_mode == 0 && c->env_type != ORL_ENV_RWA && (rand_n < 1 || rand_n != c->n_bit_rates))
+  if (c->bit_rate_mode == 0 && !no_rates && (rand_n < 1 || rand_n != c->n_bit_rates))
     return fail(ORL_E_INVALID, "continuous mode needs n_bit_rates == hi - lo + 1");
   if (!(c->lambda_arrival > 0) || !(c->lambda_holding > 0)) return fail(ORL_E_INVALID, "rates must be positive");
-  if (c->action_histograms && c->env_type == ORL_ENV_RMCSA) return fail(ORL_E_INVALID, "action histograms are not kept for RMCSA");
+  if (c->action_histograms && (c->env_type == ORL_ENV_RMCSA || qos)) return fail(ORL_E_INVALID, "action histograms are not kept for this env family");
   HIPCHK(hipSetDevice(t->device));
   // every early return below goes through orl_batch_destroy (frees what has been allocated so far)
   orl_batch* b = new orl_batch();
@@ -395,7 +400,9 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   P.N = t->N; P.E = t->E; P.K = t->K; P.H = t->H; P.M = t->M;
   P.S = S; P.C = C;
   b->wt = S <= 64 ? 1 : (S <= 128 ? 2 : (S <= 320 ? 5 : 8));
+  if (qos) b->wt = 1;  // one counter per link (available_spectrum) instead of a slot row
   P.W = b->wt;
+  P.n_classes = qos ? c->n_service_classes : 0;
   P.episode_length = c->episode_length;
   P.allow_rejection = c->allow_rejection ? 1 : 0;
   P.J = c->env_type == ORL_ENV_DEEPRMSA ? c->j : 1;
@@ -417,7 +424,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   int words = C * P.E * b->wt;
   P.bm_words = (words + 1) & ~1;
   int rej = P.allow_rejection;
-  if (c->env_type == ORL_ENV_RWA) P.n_info = 2 + (P.K + rej) + (S + rej);
+  if (qos) P.n_info = 2;
+  else if (c->env_type == ORL_ENV_RWA) P.n_info = 2 + (P.K + rej) + (S + rej);
   else if (c->env_type == ORL_ENV_RMCSA) P.n_info = 4;
   else P.n_info = 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
   P.obs_dim = c->env_type == ORL_ENV_DEEPRMSA ? 1 + 2 * P.N + (2 * P.J + 3) * P.K : 0;
@@ -431,7 +439,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     // 4 096: 1.6e8 vs 7.6e7; 32 768: 6.3e8 vs 4.0e8; RWA 4 096: 2.4e8 vs 8.3e7.  ORL_STEP_IMPL=64 forces the per-env kernel
     // (cross-checks); ORL_STEP_IMPL=2 with ORL_PERSIST=0 selects the two-kernel form in ORL_ALT_IMPLS builds.
     const char* impl = getenv("ORL_STEP_IMPL");
-    const bool pipeline_ok = t->K <= 8 && P.ev_cap <= 2048;
+    const bool pipeline_ok = t->K <= 8 && P.ev_cap <= 2048 && !qos;
     b->persist = pipeline_ok && !(impl && atoi(impl) == 64);
     if (const char* pv = getenv("ORL_PERSIST")) {
       if (atoi(pv) == 0 && b->persist) {
@@ -456,6 +464,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     if (c->n_slots) { rc |= upload_conv(&u, c->n_slots, (size_t)P.n_br * P.M, &b->allocs); P.nslots = u; }
     if (c->lmax_snr) { rc |= upload_conv(&p, c->lmax_snr, (size_t)P.n_br * P.M, &b->allocs); P.lmax_snr = p; }
     if (c->lmax_xt) { rc |= upload_conv(&p, c->lmax_xt, (size_t)P.M, &b->allocs); P.lmax_xt = p; }
+    if (qos) {
+      rc |= upload_conv(&p, c->cum_class, (size_t)P.n_classes, &b->allocs); P.cum_class = p;
+      rc |= upload_conv(&p, c->class_reward, (size_t)P.n_classes, &b->allocs); P.class_reward = p;
+    }
   }
   {
     // derived shared tables: 32-B path records and slots-per-path-per-bit-rate
@@ -709,6 +721,7 @@ static int64_t first_bad_action(const orl_batch* b, const int32_t* a) {
     if (P.env_type == ENV_RMSA) bad = r[0] < 0 || r[0] > P.K || r[1] < 0 || r[1] > P.S;
     else if (P.env_type == ENV_RWA) bad = r[0] < 0 || r[0] >= P.K + rej || r[1] < 0 || r[1] >= P.S + rej;
     else if (P.env_type == ENV_RMCSA) bad = r[0] < 0 || r[0] > P.K || r[1] < 0 || r[1] > P.M || r[2] < 0 || r[2] > P.C || r[3] < 0 || r[3] > P.S;
+    else if (P.env_type == ENV_QOS) bad = r[0] < 0 || r[0] >= P.K + rej;  // qos_constrained_ra.py:101
     if (bad) return i;
   }
   return -1;
@@ -1005,6 +1018,16 @@ extern "C" int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out) {
   const int W = b->wt, S = b->P.S, rows = b->P.C * b->P.E;
   for (int r = 0; r < rows; r++)
     for (int s = 0; s < S; s++) out[(size_t)r * S + s] = (uint8_t)((h[(size_t)r * W + (s >> 6)] >> (s & 63)) & 1ull);
+  return ORL_OK;
+}
+extern "C" int orl_batch_get_spectrum(orl_batch* b, int64_t env, int32_t* out) {
+  if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
+  if (b->P.env_type != ENV_QOS) return fail(ORL_E_INVALID, "available_spectrum counters exist for QoSConstrainedRA only");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  std::vector<u64> h((size_t)b->P.E);
+  HIPCHK(hipMemcpy(h.data(), b->P.bitmap + env * b->P.bm_words, h.size() * 8, hipMemcpyDeviceToHost));
+  for (int l = 0; l < b->P.E; l++) out[l] = (int32_t)h[(size_t)l];
   return ORL_OK;
 }
 extern "C" int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out) {

@@ -37,7 +37,8 @@ typedef unsigned long long u64;
 typedef long long i64;
 typedef unsigned int u32;
 
-enum { ENV_RMSA = 0, ENV_DEEPRMSA = 1, ENV_RWA = 2, ENV_RMCSA = 3 };
+enum { ENV_RMSA = 0, ENV_DEEPRMSA = 1, ENV_RWA = 2, ENV_RMCSA = 3,
+       ENV_QOS = 4 };  // QoSConstrainedRA (qos_constrained_ra.py): per-link spectrum counters instead of slot maps, service classes
 enum { POL_SP_FF = 0, POL_SAP_FF = 1, POL_LLP_FF = 2, POL_SAP_LF = 3,
        POL_PATH_FF = 4 };  // PathOnlyFirstFitAction (rmsa_env.py:840-874, rwa_env.py:505-536): first fit on the path the agent chose
 
@@ -89,6 +90,9 @@ struct DevParams {
   const double* lmax_xt;            // [M]
   const unsigned char* path_rec;    // [N*N*K][32]  {hops, modulation, link[30]}: one 32-B record per path
   const unsigned char* nslots_path; // [N*N*K][n_br] slots needed on that path (its best modulation) per bit rate
+  const double* cum_class;          // [n_classes]  QoSConstrainedRA: accumulate(classes_arrival_probabilities)
+  const double* class_reward;       // [n_classes]  classes_reward
+  int n_classes;
   // per-env state (struct-of-arrays over envs)
   u64* bitmap;      // [B][bm_words]      bm_words = C*E*W rounded up to a multiple of 2
   double* ev_time;  // [B][ev_cap]        +inf = empty slot
@@ -654,8 +658,36 @@ __device__ __forceinline__ int row_longest_run8(u64 a, int w) {
 // reference's per-link loop does (_provision_path rmsa_env.py:381-396, _release_path :417-436):
 // _update_link_stats (rmsa_env.py:464-543) per touched link, plus the integer sums behind
 // _get_network_compactness.  Returns the path's hop count.
+// QoSConstrainedRA: the env's "slot map" is one counter per link, topology.graph["available_spectrum"] (e.bm[link], free
+// units).  _provision_path / _release_path (qos_constrained_ra.py:296-338): every link of the path -/+ number_slots, then
+// _update_link_stats (:355-372, utilisation only).  Lane h owns hop h (the links of a path are distinct).
+__device__ __forceinline__ int qos_path_apply(const DevParams& P, Env& e, int lane, const PathRec rec, bool release) {
+  const int hops = path_rec_byte(rec, 0);
+  if (lane < hops) {
+    const int link = path_rec_byte(rec, 2 + lane);
+    const i64 avail = (i64)e.bm[link] + (release ? 1 : -1);
+    e.bm[link] = (u64)avail;
+    const double last_update = e.ls[4 * link + 3];
+    const double time_diff = e.now - last_update;
+    if (e.now > 0) {
+      const double cur_util = (double)((i64)P.S - avail) / (double)P.S;
+      e.ls[4 * link] = ((e.ls[4 * link] * last_update) + (cur_util * time_diff)) / e.now;
+    }
+    e.ls[4 * link + 3] = e.now;
+  }
+  wave_fence();
+  return hops;
+}
+// is_path_free (qos_constrained_ra.py:381-392) for number_slots = 1
+__device__ __forceinline__ bool qos_path_free(const DevParams& P, const Env& e, int lane, const PathRec rec) {
+  const int hops = path_rec_byte(rec, 0);
+  const bool busy = lane < hops && (i64)e.bm[path_rec_byte(rec, 2 + lane)] < 1;
+  return P.S >= 1 && __ballot(busy) == 0ull;
+}
+
 template <int ENV, int W>
 __device__ __forceinline__ int path_apply(const DevParams& P, Env& e, int lane, const PathRec rec, int core, int s0, int n, bool release) {
+  if (ENV == ENV_QOS) return qos_path_apply(P, e, lane, rec, release);
   const int hops = path_rec_byte(rec, 0);
   const int r = lane >> 3, w = lane & 7;
   const int E = P.E, S = P.S;
@@ -844,7 +876,11 @@ __device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lan
   int src = (pf && pf->have_cum) ? rng_choice_pre(e, r, lane, pf->cum_my, P.N) : rng_choice(e, r, lane, P.cum_src, P.N);
   int dst = rng_choice(e, r, lane, P.cum_dst + src * P.N, P.N);
   int bit_rate = 0, br_idx = 0;
-  if (ENV != ENV_RWA) {
+  if (ENV == ENV_QOS) {  // the service class (qos_constrained_ra.py:262-265) rides in the bit-rate fields
+    br_idx = rng_choice(e, r, lane, P.cum_class, P.n_classes);
+    bit_rate = br_idx;
+  }
+  if (ENV != ENV_RWA && ENV != ENV_QOS) {
     // After seed() the reference draws the bit rate from the Random object it bound at construction (functools.partial,
     // rmsa_env.py:85-87 / 97-99) while everything else uses the new one: a second stream for envs that were reseeded.
     const bool second = P.mt2 && (e.flags & ORL_FLAG_MT2);
@@ -877,12 +913,12 @@ __device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lan
     }
   }
   rng_commit(e, r, lane);
-  if (ENV == ENV_RWA || ENV == ENV_RMCSA) release_due<ENV, W, EVL>(P, e, lane);
+  if (ENV == ENV_RWA || ENV == ENV_RMCSA || ENV == ENV_QOS) release_due<ENV, W, EVL>(P, e, lane);
   e.id = (int)e.esp;
   e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
   e.new_service = 1;
   if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) { e.sp += 1; e.esp += 1; }
-  if (ENV != ENV_RWA) {
+  if (ENV != ENV_RWA && ENV != ENV_QOS) {
     e.brq += bit_rate;
     e.ebrq += bit_rate;
     if (P.bit_rate_mode == 1 && lane == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;
@@ -893,7 +929,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, Env& e, int lan
 // soft reset (reset(only_episode_counters=True)): the pending service is counted again
 template <int ENV> __device__ __forceinline__ void soft_reset(Env& e) {
   e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0;
-  if (ENV != ENV_RWA && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
+  if (ENV != ENV_RWA && ENV != ENV_QOS && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
 }
 
 // get_available_blocks: the first `want` free runs of m with length >= n; returns how many were found
@@ -1019,6 +1055,34 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
   const int K = P.K, S = P.S;
   const int p = lane & (GS - 1);
   a[0] = a[1] = a[2] = a[3] = 0;
+  if (ENV == ENV_QOS) {
+    // shortest_path / shortest_available_path / least_loaded_path (qos_constrained_ra.py:408-450); br_idx = service class.
+    // Lane = path: free on every link (>= 1 unit), hop count, capacity = min over the links.
+    bool free_ = false;
+    int hops = 0;
+    i64 cap = 0;
+    if (valid && p < np_) {
+      const PathRec rec = path_rec_load(P, pb + p);
+      hops = path_rec_byte(rec, 0);
+      cap = (i64)1 << 40;
+      for (int h = 0; h < hops; h++) { const i64 v = (i64)bm[path_rec_byte(rec, 2 + h)]; cap = v < cap ? v : cap; }
+      free_ = S >= 1 && cap >= 1;
+    }
+    if (pol == POL_SP_FF) {
+      a[0] = (group_ballot<GS>(free_, lane) & 1ull) ? 0 : K;
+    } else if (br_idx == 0) {
+      a[0] = 0;  // high-priority services only accept the shortest path
+    } else if (pol == POL_SAP_FF) {  // fewest hops among the free paths, the earlier one on ties (strict <)
+      const int mh = -group_max<GS>(free_ ? -hops : -(1 << 20));
+      const u64 bb = group_ballot<GS>(free_ && hops == mh, lane);
+      a[0] = bb ? (int)__builtin_ctzll(bb) : K;
+    } else {  // largest capacity, the earlier path on ties (strict >, starting from np.finfo(0.0).min: free or not)
+      const int mx = group_max<GS>((valid && p < np_) ? (int)cap : -1);
+      const u64 bb = group_ballot<GS>(valid && p < np_ && (int)cap == mx, lane);
+      a[0] = bb ? (int)__builtin_ctzll(bb) : K;
+    }
+    return;
+  }
   if (ENV == ENV_RMSA) {
     // KSP first-fit incl. the reference's off-by-one: start slots 0 .. S-n-1 only (rmsa_env.py:774-776)
     a[0] = K; a[1] = S;
@@ -1129,6 +1193,41 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
                                      double* reward_out, unsigned char* done_out, double* info_out, double* obs_out,
                                      double* term_obs_out, const Rng* prefilled, const Prefetch* pf = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0;
+  if (ENV == ENV_QOS) {  // QoSConstrainedRA.step (qos_constrained_ra.py:100-157)
+    int a = act[0];
+    const bool badq = a < 0 || a >= K + rej;  // actions_output[action] += 1 raises IndexError
+    if (badq) { e.flags |= ORL_FLAG_BAD_ACTION; a = K; }
+    const int clazz = e.bit_rate, np_ = P.n_paths[e.src * P.N + e.dst];
+    bool accepted = false;
+    if (!badq && ((clazz == 0 && a == 0) || (clazz != 0 && a < np_))) {
+      const int pidx = pair_base(P, e.src, e.dst) + a;
+      const PathRec prec = path_rec_load(P, pidx);
+      if (qos_path_free(P, e, lane, prec)) {
+        qos_path_apply(P, e, lane, prec, false);
+        e.sa += 1;
+        e.esa += 1;
+        accepted = true;
+        ev_push<EVL>(P, e, lane, e.at + e.ht, ev_pack(pidx, 0, 1, 0, 0));
+      }
+    }
+    e.sp += 1;
+    e.esp += 1;
+    const double rew = accepted ? P.class_reward[clazz] : 0.0;
+    if (info_out && lane == 0) {
+      info_out[0] = (double)(e.sp - e.sa) / (double)e.sp;
+      info_out[1] = (double)(e.esp - e.esa) / (double)e.esp;
+    }
+    e.new_service = 0;
+    next_service<ENV, W, EVL>(P, e, lane, prefilled, pf);
+    const bool doneq = (e.esp == (i64)P.episode_length);
+    if (doneq && P.ep_log && lane == 0) episode_log(P, e.env, e.esa);
+    if (doneq && auto_reset) soft_reset<ENV>(e);
+    if (lane == 0) {
+      if (reward_out) *reward_out = rew;
+      if (done_out) *done_out = doneq ? 1 : 0;
+    }
+    return;
+  }
   int path, slot, mod = 0, core = 0;
   bool bad = false;
   if (ENV == ENV_DEEPRMSA) {  // deeprmsa_env.py:48-58

@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
     int w = i % W;
     int c = P.S - 64 * w;
     u64 v = c >= 64 ? ~0ull : (c <= 0 ? 0ull : ((1ull << c) - 1ull));
+    if (ENV == ENV_QOS) v = (u64)P.S;  // available_spectrum = num_spectrum_resources per link (optical_network_env.py:189-193)
     lds[i] = (i < P.C * P.E * W) ? v : 0ull;
   }
   for (int i = lane; i < 4 * P.E; i += 64) e.ls[i] = 0.0;
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
   Rng pre;
   rng_fill(e, pre, lane);
   {
-    const int route = (ENV == ENV_DEEPRMSA) ? (av.x >= 0 ? av.x / P.J : P.K) : av.x;
+    const int route = (ENV == ENV_DEEPRMSA) ? (av.x >= 0 ? av.x / P.J : P.K) : av.x;  // (QoS: the action is the path)
     pf.have_rec = route >= 0 && route < P.K;
     pf.pidx = pair_base(P, e.src, e.dst) + (pf.have_rec ? route : 0);
     const PathRec r0 = path_rec_load(P, pf.pidx);
@@ -472,6 +473,11 @@ __global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
     default: { MACRO(ENV_RMCSA) } break;                    \
   }
 
+// the host-driven kernels also serve QoSConstrainedRA (one counter per link: row width 1 only)
+#define ORL_FOR_ENV_ALL(B_, MACRO)                                                  \
+  if ((B_)->P.env_type == ENV_QOS) { if constexpr (W == 1) { MACRO(ENV_QOS) } }     \
+  else ORL_FOR_ENV(B_, MACRO)
+
 namespace orl_launch {
 
 template <int W> void reset(orl_batch* b, int full, const unsigned char* dmask) {
@@ -479,7 +485,7 @@ template <int W> void reset(orl_batch* b, int full, const unsigned char* dmask) 
   dim3 g((unsigned)VP.B), blk(64);
   size_t lds = VP.lds_bytes;
 #define PER_ENV(E_) hipLaunchKernelGGL((k_reset<E_, W>), g, blk, lds, b->stream, VP, full, dmask);
-  ORL_FOR_ENV(b, PER_ENV)
+  ORL_FOR_ENV_ALL(b, PER_ENV)
 #undef PER_ENV
 }
 
@@ -492,7 +498,7 @@ template <int W> void policy(orl_batch* b, int pol) {
 #define PER_ENV(E_)                                                                             \
   if (wide) hipLaunchKernelGGL((k_policy<E_, W, 64>), g, blk, 0, b->stream, VP, pol);           \
   else hipLaunchKernelGGL((k_policy<E_, W, 8>), g, blk, 0, b->stream, VP, pol);
-  ORL_FOR_ENV(b, PER_ENV)
+  ORL_FOR_ENV_ALL(b, PER_ENV)
 #undef PER_ENV
   ORL_TK(b, "k_policy");
 }
@@ -507,7 +513,7 @@ template <int W> void step64(orl_batch* b, int auto_reset, int want_info, int fu
 #define PER_ENV(E_)                                                                                                          \
   if (evl) hipLaunchKernelGGL((k_step<E_, W, true>), g, blk, lds, b->stream, VP, auto_reset, want_info, fused_policy);       \
   else hipLaunchKernelGGL((k_step<E_, W, false>), g, blk, lds, b->stream, VP, auto_reset, want_info, fused_policy);
-  ORL_FOR_ENV(b, PER_ENV)
+  ORL_FOR_ENV_ALL(b, PER_ENV)
 #undef PER_ENV
   ORL_TK(b, "k_step");
 }
@@ -540,7 +546,11 @@ static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
   else v = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0;
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
-    if (f >= 0 && f < 6 && persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[f].lds).total <= 64 * 1024) v = f;
+    bool built = f >= 0 && f < 6;
+#ifndef ORL_ALT_IMPLS
+    built = built && f != 2 && f != 3;
+#endif
+    if (built && persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[f].lds).total <= 64 * 1024) v = f;
   }
   *lds_bytes = (size_t)persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[v].lds).total;
   return v;
@@ -567,6 +577,13 @@ static size_t persist_tuned_lds(int v, size_t lds) {
   while (want > lds && (int)((160 * 1024) / want) < want_r) want -= 512;
   return want > lds ? want : lds;
 }
+// forms 2 and 3 (link statistics and sums in LDS too) measured slower everywhere: they are built only into the
+// -DORL_ALT_IMPLS library, as one more independent form for the cross-implementation tests
+#ifdef ORL_ALT_IMPLS
+#define ORL_FULL_LDS_CASES(E_) case 2: LAUNCH(E_, 2, 2); break; case 3: LAUNCH(E_, 2, 3); break;
+#else
+#define ORL_FULL_LDS_CASES(E_)
+#endif
 template <int W> void persist(orl_batch* b, const DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished) {
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64), blk_tail(256);
   size_t lds_a = 0;
@@ -581,8 +598,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP, hipStream_t st,
   switch (v) {                                                                                                               \
     case 0: LAUNCH(E_, 0, 4); break;                                                                                         \
     case 1: LAUNCH(E_, 0, 3); break;                                                                                         \
-    case 2: LAUNCH(E_, 2, 2); break;                                                                                         \
-    case 3: LAUNCH(E_, 2, 3); break;                                                                                         \
+    ORL_FULL_LDS_CASES(E_)                                                                                                   \
     case 4: LAUNCH(E_, 1, 3); break;                                                                                         \
     default: LAUNCH(E_, 1, 4); break;                                                                                        \
   }                                                                                                                          \

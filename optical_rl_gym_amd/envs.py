@@ -65,7 +65,8 @@ class BatchedOpticalEnv:
                num_spectrum_resources, allow_rejection, node_request_probabilities, channel_width,
                bit_rate_selection="continuous", bit_rates=(10, 40, 100), bit_rate_probabilities=None,
                bit_rate_lower_bound=25, bit_rate_higher_bound=100, j=1, num_spatial_resources=1,
-               modulations=None, worst_xt=None, event_capacity=0, action_histograms=False):
+               modulations=None, worst_xt=None, event_capacity=0, action_histograms=False, num_service_classes=1,
+               classes_arrival_probabilities=(1.0,), classes_reward=(1.0,)):
         self.lib = _lib.lib()  # ORL_LIB_VARIANT=alt selects the -DORL_ALT_IMPLS build (cross-implementation tests)
         self.action_histograms = bool(action_histograms)
         self.topology = Topology.load(topology) if isinstance(topology, str) else topology
@@ -112,7 +113,7 @@ class BatchedOpticalEnv:
         mods = list(t.modulations if modulations is None else modulations)
         self.modulation_formats = mods
         M = len(mods)
-        if self.ENV_TYPE == 2:
+        if self.ENV_TYPE in (2, 4):
             table_rates, cum_br, mode = [0], None, 0
             lo = hi = 0
         elif bit_rate_selection == "continuous":
@@ -131,7 +132,7 @@ class BatchedOpticalEnv:
             mode, lo, hi = 1, 0, 0
         # get_number_slots (rmsa_env.py:610-621): ceil(bit_rate / (se * channel_width)) + 1
         n_slots = np.zeros((len(table_rates), M), np.uint8)
-        if self.ENV_TYPE != 2:
+        if self.ENV_TYPE not in (2, 4):
             for i, br in enumerate(table_rates):
                 for m, mod in enumerate(mods):
                     n_slots[i, m] = math.ceil(br / (mod.spectral_efficiency * channel_width)) + 1
@@ -158,6 +159,14 @@ class BatchedOpticalEnv:
                         SNR_min_calc * h * f_hz * amp_gain * nf * (br / mod.spectral_efficiency) * 1e9)
                     lmax_snr[m, i] = v / 1000
                 lmax_xt[m] = 10 ** ((mod.inband_xt - worst_xt - 4) / 10)
+        cum_class = class_reward = None
+        if self.ENV_TYPE == 4:  # qos_constrained_ra.py:43-47, 262-265
+            assert num_service_classes == len(classes_arrival_probabilities)
+            self.num_service_classes = int(num_service_classes)
+            self.classes_arrival_probabilities = list(classes_arrival_probabilities)
+            self.classes_reward = list(classes_reward)
+            cum_class = np.array(list(itertools.accumulate(classes_arrival_probabilities)), np.float64)
+            class_reward = np.array(classes_reward, np.float64)
         path_mod = t.path_best_mod if modulations is None else t.path_modulation_for(mods)
         # ---- hand everything to the C ABI ----
         keep = dict(
@@ -167,7 +176,8 @@ class BatchedOpticalEnv:
             path_mod=np.ascontiguousarray(path_mod, np.int32),
             edge_iter_order=np.ascontiguousarray(t.edge_iter_order, np.int32),
             cum_src=cum_src, cum_dst=np.ascontiguousarray(cum_dst), bit_rates=np.array(table_rates, np.int32),
-            cum_br=cum_br, n_slots=np.ascontiguousarray(n_slots), lmax_snr=lmax_snr, lmax_xt=lmax_xt)
+            cum_br=cum_br, n_slots=np.ascontiguousarray(n_slots), lmax_snr=lmax_snr, lmax_xt=lmax_xt,
+            cum_class=cum_class, class_reward=class_reward)
         self._keep = keep
         desc = _lib.TopologyDesc(t.n_nodes, t.n_links, t.k_paths, t.max_hops, M, _ptr(keep["n_paths"]),
                                  _ptr(keep["path_hops"]), _ptr(keep["path_links"]), _ptr(keep["path_length"]),
@@ -178,7 +188,8 @@ class BatchedOpticalEnv:
                              int(self.allow_rejection), j, mode, lo, hi, len(table_rates), event_capacity,
                              int(self.action_histograms),
                              lambda_a, lambda_h, _ptr(cum_src), _ptr(keep["cum_dst"]), _ptr(keep["bit_rates"]),
-                             _ptr(cum_br), _ptr(keep["n_slots"]), _ptr(lmax_snr), _ptr(lmax_xt))
+                             _ptr(cum_br), _ptr(keep["n_slots"]), _ptr(lmax_snr), _ptr(lmax_xt),
+                             int(num_service_classes) if self.ENV_TYPE == 4 else 0, 0, _ptr(cum_class), _ptr(class_reward))
         self._h = C.c_void_p()
         int_seeds = [41 if s_ is None else int(s_) for s_ in self.seeds]
         if all(-2**63 < s_ < 2**63 for s_ in int_seeds):
@@ -280,13 +291,15 @@ class BatchedOpticalEnv:
     def steps_per_episode(self):
         """RMSA / DeepRMSA / RMCSA episodes last episode_length - 1 steps (the soft reset counts the pending service again,
         rmsa_env.py:310-315), RWA episodes episode_length steps (rwa_env.py:135-136, 160)."""
-        return self.episode_length if self.ENV_TYPE == 2 else self.episode_length - 1
+        return self.episode_length if self.ENV_TYPE in (2, 4) else self.episode_length - 1
 
     def evaluate(self, policy, n_eval_episodes=10):
         """n_eval_episodes episodes of every env under the on-device heuristic `policy`, with the reference harness's
         accounting (reset -> loop until done -> sum of rewards): returns (episode_rewards [num_envs, n_eval_episodes],
         episode_lengths).  One device-resident run; the kernels log each finished episode."""
         n = int(n_eval_episodes)
+        if self.ENV_TYPE == 4:
+            raise NotImplementedError("QoSConstrainedRA rewards depend on the service class: evaluate it with the host loop")
         self._ck(self.lib.orl_batch_reset(self._h, 0, None))  # the harness's reset() before the first episode (soft)
         self._ck(self.lib.orl_batch_episode_log(self._h, n))
         L = self.steps_per_episode()
@@ -391,6 +404,12 @@ class BatchedOpticalEnv:
     def slots(self, env=0):
         out = np.zeros((self.num_spatial_resources, self.topology.n_links, self.num_spectrum_resources), np.uint8)
         self._ck(self.lib.orl_batch_get_slots(self._h, env, out.ctypes.data))
+        return out
+
+    def spectrum(self, env=0):
+        """QoSConstrainedRA: topology.graph["available_spectrum"] (free units per link)."""
+        out = np.zeros(self.topology.n_links, np.int32)
+        self._ck(self.lib.orl_batch_get_spectrum(self._h, env, out.ctypes.data))
         return out
 
     def link_stats(self, env=0):
@@ -563,9 +582,35 @@ class BatchedRMCSAEnv(BatchedOpticalEnv):
         self.info_keys = RMSA_INFO_KEYS[:4]
 
 
+class BatchedQoSConstrainedRA(BatchedOpticalEnv):
+    """reference: QoSConstrainedRA (qos_constrained_ra.py:13-398); gym id "QoSConstrainedRA-v0".  Upstream its constructor
+    raises (an unexpected `k_paths` keyword for the base class, :32-41, and a `service_class` field utils.Service lacks);
+    the semantics here are the class's as written, pinned by fixtures captured from the reference with those two things
+    repaired at import time (oracle/gen_golden_qos.py).  Actions: the path index; the service class of the pending service
+    is column 4 of services()."""
+
+    ENV_TYPE = 4
+    N_ACTION = 1
+
+    def __init__(self, topology=None, num_envs=1, seeds=None, device_id=0, episode_length=1000, load=10,
+                 mean_service_holding_time=10800.0, num_spectrum_resources=80, num_service_classes=1,
+                 classes_arrival_probabilities=(1.0,), classes_reward=(1.0,), node_request_probabilities=None,
+                 allow_rejection=True, k_paths=5, seed=None, reset=True, event_capacity=0):
+        if seeds is None and seed is not None:
+            seeds = seed
+        self._setup(topology, num_envs, seeds, device_id, episode_length=episode_length, load=load,
+                    mean_service_holding_time=mean_service_holding_time,
+                    num_spectrum_resources=num_spectrum_resources, allow_rejection=allow_rejection,
+                    node_request_probabilities=node_request_probabilities, channel_width=12.5,
+                    event_capacity=event_capacity, num_service_classes=num_service_classes,
+                    classes_arrival_probabilities=classes_arrival_probabilities, classes_reward=classes_reward)
+        self.info_keys = ["service_blocking_rate", "episode_service_blocking_rate"]
+
+
 ENV_CLASSES = {"RMSA": BatchedRMSAEnv, "DeepRMSA": BatchedDeepRMSAEnv, "RWA": BatchedRWAEnv, "RMCSA": BatchedRMCSAEnv,
                "RMSA-v0": BatchedRMSAEnv, "DeepRMSA-v0": BatchedDeepRMSAEnv, "RWA-v0": BatchedRWAEnv,
-               "RMCSA-v0": BatchedRMCSAEnv}
+               "RMCSA-v0": BatchedRMCSAEnv, "QoSConstrainedRA": BatchedQoSConstrainedRA,
+               "QoSConstrainedRA-v0": BatchedQoSConstrainedRA}
 
 
 def make(env_id, device_ids=None, **kwargs):

@@ -64,6 +64,8 @@ class _GraphView:
         e = self.env
         if key in ("available_slots", "available_wavelengths"):
             return e._slots()
+        if key == "available_spectrum":  # QoSConstrainedRA (optical_network_env.py:189-193)
+            return e.batch.spectrum(0).astype(int)
         if key == "throughput":
             return float(e.batch.net_stats(0)[0])
         if key == "compactness":
@@ -128,7 +130,7 @@ class _SingleEnv:
     def __init__(self, topology=None, seed=None, _backend=None, **kwargs):
         self.rand_seed = 41 if seed is None else seed
         if _backend is None:
-            extra = {} if self.BATCH_CLS is BatchedRMCSAEnv else dict(action_histograms=True)
+            extra = dict(action_histograms=True) if self.BATCH_CLS.ENV_TYPE in (0, 1, 2) else {}
             _backend = self.BATCH_CLS(topology=topology, num_envs=1, seeds=[seed], **extra, **kwargs)
             topo = _backend.topology
         else:

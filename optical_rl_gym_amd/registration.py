@@ -2,15 +2,16 @@
 
 `make(env_id, **kwargs)` works without gym.  When gymnasium or gym is importable, `register_envs()` (called on import of
 this module) also registers the ids there, so that `gym.make("RMSA-v0", topology=..., seed=..., **kwargs)` of a
-reference script returns this package's single-env front end.  QoSConstrainedRA-v0 is listed by the reference but its
-constructor is broken upstream (qos_constrained_ra.py:32-41); it is not registered here."""
-from . import gym_api
+reference script returns this package's single-env front end.  QoSConstrainedRA-v0 is registered too: upstream its
+constructor raises (qos_constrained_ra.py:32-41); here it works as the class is written (optical_rl_gym_amd/qos.py)."""
+from . import gym_api, qos
 from .envs import ENV_CLASSES
 
 SINGLE = {"RMSA-v0": gym_api.RMSAEnv, "DeepRMSA-v0": gym_api.DeepRMSAEnv, "RWA-v0": gym_api.RWAEnv,
-          "RMCSA-v0": gym_api.RMCSAEnv}
+          "RMCSA-v0": gym_api.RMCSAEnv, "QoSConstrainedRA-v0": qos.QoSConstrainedRA}
 ENTRY_POINTS = {"RMSA-v0": "optical_rl_gym_amd.gym_api:RMSAEnv", "DeepRMSA-v0": "optical_rl_gym_amd.gym_api:DeepRMSAEnv",
-                "RWA-v0": "optical_rl_gym_amd.gym_api:RWAEnv", "RMCSA-v0": "optical_rl_gym_amd.gym_api:RMCSAEnv"}
+                "RWA-v0": "optical_rl_gym_amd.gym_api:RWAEnv", "RMCSA-v0": "optical_rl_gym_amd.gym_api:RMCSAEnv",
+                "QoSConstrainedRA-v0": "optical_rl_gym_amd.qos:QoSConstrainedRA"}
 
 
 def make(env_id, num_envs=None, **kwargs):

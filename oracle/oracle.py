@@ -14,21 +14,22 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ENV_TYPES = {"RMSA": 0, "DeepRMSA": 1, "RWA": 2, "RMCSA": 3}
+ENV_TYPES = {"RMSA": 0, "DeepRMSA": 1, "RWA": 2, "RMCSA": 3, "QoSConstrainedRA": 4}
 POLICIES = {"SP_FF": 0, "SAP_FF": 1, "LLP_FF": 2, "SAP_LF": 3, "SP": 0, "SAP": 1, "SAP_BM_FC_FF": 1, "PATH_FF": 4}
 
 
 class _Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "env_type", "n_nodes", "n_links", "k_paths", "max_hops", "n_mods", "num_slots", "num_cores",
-        "episode_length", "allow_rejection", "j", "bit_rate_mode", "br_lo", "br_hi", "n_bit_rates", "reserved")] + [
+        "episode_length", "allow_rejection", "j", "bit_rate_mode", "br_lo", "br_hi", "n_bit_rates", "n_classes")] + [
         (n, C.c_double) for n in ("mean_iat", "mean_ht", "channel_width", "worst_xt")]
 
 
 class _Tables(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "n_paths", "path_hops", "path_links", "path_length", "path_best_mod", "mod_se", "mod_max_length",
-        "mod_min_osnr", "mod_inband_xt", "edge_iter_order", "node_probs", "bit_rates", "bit_rate_probs")]
+        "mod_min_osnr", "mod_inband_xt", "edge_iter_order", "node_probs", "bit_rates", "bit_rate_probs", "class_probs",
+        "class_reward")]
 
 
 def build(force=False):
@@ -64,6 +65,7 @@ def _lib(omp=False):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
         for name in ("orc_get_slots", "orc_get_link_stats", "orc_get_net_stats"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        lib.orc_get_spectrum.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         lib.orc_set_paths.argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_reseed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_get_action_histograms.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
@@ -109,8 +111,12 @@ class OracleBatch:
         else:
             load = kw.pop("load", 10)
         miat = 1 / float(load / float(mht))  # optical_network_env.py:92-94
-        S = kw.pop("num_spectrum_resources", 80 if et == 2 else 100)
-        allow_rejection = kw.pop("allow_rejection", True if et == 2 else False)
+        S = kw.pop("num_spectrum_resources", 80 if et in (2, 4) else 100)
+        allow_rejection = kw.pop("allow_rejection", True if et in (2, 4) else False)
+        n_classes = int(kw.pop("num_service_classes", 1))  # qos_constrained_ra.py:21-23
+        class_probs = np.asarray(kw.pop("classes_arrival_probabilities", [1.0]), np.float64)
+        class_reward = np.asarray(kw.pop("classes_reward", [1.0]), np.float64)
+        kw.pop("k_paths", None)
         probs = kw.pop("node_request_probabilities", None)
         probs = np.full(N, 1.0 / N) if probs is None else np.asarray(probs, np.float64)
         channel_width = kw.pop("channel_width", 50.0 if et == 2 else 12.5)
@@ -134,7 +140,7 @@ class OracleBatch:
         kw.pop("reset", None)
         assert not kw, "unknown kwargs %r" % kw
         cfg = _Config(et, N, E, k, H, M, S, cores, episode_length, int(bool(allow_rejection)), j,
-                      1 if mode == "discrete" else 0, lo, hi, len(bit_rates), 0,
+                      1 if mode == "discrete" else 0, lo, hi, len(bit_rates), n_classes,
                       miat, float(mht), channel_width, worst_xt)
         self.cfg = cfg
         keep = dict(
@@ -151,6 +157,7 @@ class OracleBatch:
             node_probs=np.ascontiguousarray(probs, np.float64),
             bit_rates=np.array(bit_rates, np.int32),
             bit_rate_probs=np.array(brp, np.float64),
+            class_probs=np.ascontiguousarray(class_probs), class_reward=np.ascontiguousarray(class_reward),
         )
         self._keep = keep
         tb = _Tables(*[keep[n].ctypes.data for n, _ in _Tables._fields_])
@@ -243,6 +250,12 @@ class OracleBatch:
     def slots(self, env=0):
         out = np.zeros((self.C, self.E, self.S), np.uint8)
         self.lib.orc_get_slots(self.h, env, out.ctypes.data)
+        return out
+
+    def spectrum(self, env=0):
+        """QoSConstrainedRA: topology.graph["available_spectrum"] (free units per link)."""
+        out = np.zeros(self.E, np.int32)
+        self.lib.orc_get_spectrum(self.h, env, out.ctypes.data)
         return out
 
     def link_stats(self, env=0):

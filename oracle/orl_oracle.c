@@ -35,6 +35,7 @@
 #define ENV_DEEPRMSA 1
 #define ENV_RWA 2
 #define ENV_RMCSA 3
+#define ENV_QOS 4 /* QoSConstrainedRA (qos_constrained_ra.py): per-link spectrum counters, service classes */
 
 #define POLICY_SP_FF 0
 #define POLICY_SAP_FF 1
@@ -47,7 +48,7 @@ typedef struct {
   int32_t num_slots, num_cores, episode_length, allow_rejection, j;
   int32_t bit_rate_mode; /* 0 continuous (randint lo..hi), 1 discrete (choices) */
   int32_t br_lo, br_hi, n_bit_rates;
-  int32_t reserved;
+  int32_t n_classes; /* QoSConstrainedRA: num_service_classes */
   double mean_iat, mean_ht; /* mean_service_inter_arrival_time, mean_service_holding_time */
   double channel_width;
   double worst_xt; /* RMCSA: value after the +4 dB of rmcsa_env.py:129 */
@@ -67,6 +68,8 @@ typedef struct {
   const double* node_probs;     /* [N] node_request_probabilities */
   const int32_t* bit_rates;     /* [n_bit_rates] */
   const double* bit_rate_probs; /* [n_bit_rates] */
+  const double* class_probs;    /* [n_classes] QoSConstrainedRA classes_arrival_probabilities */
+  const double* class_reward;   /* [n_classes] classes_reward */
 } orc_tables;
 
 typedef struct {
@@ -101,6 +104,7 @@ typedef struct {
   int32_t* running; /* pool indices of topology.graph["running_services"] */
   int32_t running_n;
   uint8_t* avail; /* [C][E][S] 1 = free */
+  int32_t* spectrum; /* QoSConstrainedRA: topology.graph["available_spectrum"], free units per link */
   double *l_util, *l_frag, *l_comp, *l_last; /* per link */
   double g_throughput, g_compactness, g_last_update;
   int64_t *br_req_hist, *br_prov_hist; /* discrete mode, per bit-rate index */
@@ -116,6 +120,7 @@ typedef struct {
   /* owned copies of the tables */
   int32_t *n_paths, *path_hops, *path_links, *path_best_mod, *mod_se, *edge_iter_order, *bit_rates;
   double *path_length, *mod_max_length, *mod_min_osnr, *mod_inband_xt, *node_probs, *bit_rate_probs;
+  double *class_probs, *class_reward;
   int64_t n_envs;
   orc_env* envs;
   int32_t n_info, obs_dim;
@@ -443,10 +448,19 @@ static void provision_path(const orc_batch* b, orc_env* e, int p, int core, int 
 }
 
 /* _release_path (rmsa_env.py:417-437, rmcsa_env.py:536-558, rwa_env.py:323-349) */
+static void qos_update_link_stats(const orc_batch* b, orc_env* e, int link);
 static void release_path(const orc_batch* b, orc_env* e, int sid) {
   service* s = &e->pool[sid];
   int h, i;
   const int32_t* links = path_links(b, s->src, s->dst, s->path_k);
+  if (b->cfg.env_type == ENV_QOS) { /* qos_constrained_ra.py:313-338 */
+    for (h = 0; h < s->hops; h++) {
+      e->spectrum[links[h]] += s->number_slots;
+      qos_update_link_stats(b, e, links[h]);
+    }
+    e->free_list[e->free_n++] = sid;
+    return;
+  }
   for (h = 0; h < s->hops; h++) {
     uint8_t* r = row(b, e, s->core, links[h]);
     for (i = s->initial_slot; i < s->initial_slot + s->number_slots; i++) r[i] = 1;
@@ -492,7 +506,8 @@ static void next_service(const orc_batch* b, orc_env* e) {
   e->current_time = at;
   ht = py_expovariate(e, 1 / b->cfg.mean_ht);
   get_node_pair(b, e, &src, &dst);
-  if (t != ENV_RWA) {
+  if (t == ENV_QOS) bit_rate = py_choices(e, b->class_probs, b->cfg.n_classes); /* the service class rides in `bit_rate` */
+  if (t != ENV_RWA && t != ENV_QOS) {
     uint32_t keep[624];
     int32_t keep_i = 0;
     if (e->reseeded) { /* draw from the construction-time stream */
@@ -506,22 +521,111 @@ static void next_service(const orc_batch* b, orc_env* e) {
       memcpy(e->mt, keep, sizeof keep); e->mti = keep_i;
     }
   }
-  if (t == ENV_RWA || t == ENV_RMCSA) release_due(b, e); /* these two release BEFORE creating the service */
+  if (t == ENV_RWA || t == ENV_RMCSA || t == ENV_QOS) release_due(b, e); /* these release BEFORE creating the service */
   memset(&e->cur, 0, sizeof(e->cur));
   e->cur.id = (int32_t)e->episode_services_processed;
   e->cur.src = src; e->cur.dst = dst; e->cur.at = at; e->cur.ht = ht; e->cur.bit_rate = bit_rate;
-  e->cur.number_slots = (t == ENV_RWA) ? 1 : 0;
+  e->cur.number_slots = (t == ENV_RWA || t == ENV_QOS) ? 1 : 0;
   e->new_service = 1;
   if (t == ENV_RMSA || t == ENV_DEEPRMSA) {
     e->services_processed += 1;
     e->episode_services_processed += 1;
   }
-  if (t != ENV_RWA) {
+  if (t != ENV_RWA && t != ENV_QOS) {
     e->bit_rate_requested += bit_rate;
     e->episode_bit_rate_requested += bit_rate;
     if (b->cfg.bit_rate_mode == 1) e->br_req_hist[bit_rate_index(b, bit_rate)] += 1;
   }
   if (t == ENV_RMSA || t == ENV_DEEPRMSA) release_due(b, e);
+}
+
+static double blocking(int64_t req, int64_t prov);
+/* ------------------------------------------------------------------------------------------
+ * QoSConstrainedRA (qos_constrained_ra.py).  Upstream its constructor raises (an unexpected k_paths keyword for the base
+ * class, :32-41, and a service_class field utils.Service does not have, :281-291); the fixtures come from the reference
+ * with exactly those two things patched at import time (oracle/gen_golden_qos.py).
+ * ---------------------------------------------------------------------------------------- */
+static void qos_update_link_stats(const orc_batch* b, orc_env* e, int link) { /* :355-372 */
+  double last_update = e->l_last[link];
+  double time_diff = e->current_time - e->l_last[link];
+  if (e->current_time > 0) {
+    double last_util = e->l_util[link];
+    double cur_util = (double)(b->cfg.num_slots - e->spectrum[link]) / (double)b->cfg.num_slots;
+    e->l_util[link] = ((last_util * last_update) + (cur_util * time_diff)) / e->current_time;
+  }
+  e->l_last[link] = e->current_time;
+}
+static int qos_is_path_free(const orc_batch* b, orc_env* e, int p, int number_slots) { /* :381-392 */
+  int h, hops = b->path_hops[PIDX(b, e->cur.src, e->cur.dst, p)];
+  const int32_t* links = path_links(b, e->cur.src, e->cur.dst, p);
+  if (number_slots > b->cfg.num_slots) return 0;
+  for (h = 0; h < hops; h++)
+    if (e->spectrum[links[h]] < number_slots) return 0;
+  return 1;
+}
+static int qos_step(const orc_batch* b, orc_env* e, const int32_t* action, double* reward, uint8_t* done, double* info) { /* :100-157 */
+  const orc_config* c = &b->cfg;
+  int k = c->k_paths, rej = c->allow_rejection ? 1 : 0, a = action[0], clazz = e->cur.bit_rate;
+  int np_ = b->n_paths[e->cur.src * c->n_nodes + e->cur.dst];
+  if (a < 0 || a >= k + rej) return -2; /* actions_output[action] += 1 */
+  e->cur.accepted = 0;
+  if ((clazz == 0 && a == 0) || (clazz != 0 && a < np_)) {
+    if (qos_is_path_free(b, e, a, e->cur.number_slots)) {
+      int h, hops = b->path_hops[PIDX(b, e->cur.src, e->cur.dst, a)], sid;
+      const int32_t* links = path_links(b, e->cur.src, e->cur.dst, a);
+      heap_item it;
+      for (h = 0; h < hops; h++) { /* _provision_path :296-311 */
+        e->spectrum[links[h]] -= e->cur.number_slots;
+        qos_update_link_stats(b, e, links[h]);
+      }
+      e->cur.path_k = a; e->cur.hops = hops;
+      sid = pool_alloc(e);
+      e->pool[sid] = e->cur;
+      e->cur.accepted = 1;
+      e->services_accepted += 1;
+      e->episode_services_accepted += 1;
+      it.sid = sid; it.time = e->cur.at + e->cur.ht;
+      heap_push(e, it);
+    }
+  }
+  e->services_processed += 1;
+  e->episode_services_processed += 1;
+  *reward = e->cur.accepted ? b->class_reward[clazz] : 0.0;
+  info[0] = blocking(e->services_processed, e->services_accepted);
+  info[1] = blocking(e->episode_services_processed, e->episode_services_accepted);
+  e->new_service = 0;
+  next_service(b, e);
+  *done = (uint8_t)(e->episode_services_processed == c->episode_length);
+  return 0;
+}
+/* the module-level heuristics :408-450 (policy ids: SP_FF = shortest_path, SAP_FF = shortest_available_path,
+   LLP_FF = least_loaded_path) */
+static void qos_policy(const orc_batch* b, orc_env* e, int policy, int32_t* action) {
+  const orc_config* c = &b->cfg;
+  int k = c->k_paths, np_ = b->n_paths[e->cur.src * c->n_nodes + e->cur.dst], idp, h;
+  action[0] = action[1] = action[2] = action[3] = 0;
+  if (policy == POLICY_SP_FF) {
+    action[0] = qos_is_path_free(b, e, 0, e->cur.number_slots) ? 0 : k;
+  } else if (policy == POLICY_SAP_FF) {
+    int best_hops = 1 << 30;
+    if (e->cur.bit_rate == 0) return; /* high-priority services only accept the shortest path */
+    action[0] = k;
+    for (idp = 0; idp < np_; idp++) {
+      int hops = b->path_hops[PIDX(b, e->cur.src, e->cur.dst, idp)];
+      if (hops < best_hops && qos_is_path_free(b, e, idp, e->cur.number_slots)) { best_hops = hops; action[0] = idp; }
+    }
+  } else {
+    double best_load = -1.7976931348623157e308; /* np.finfo(0.0).min */
+    if (e->cur.bit_rate == 0) return;
+    action[0] = k;
+    for (idp = 0; idp < np_; idp++) {
+      const int32_t* links = path_links(b, e->cur.src, e->cur.dst, idp);
+      int hops = b->path_hops[PIDX(b, e->cur.src, e->cur.dst, idp)];
+      double cap = 1.7976931348623157e308; /* np.finfo(0.0).max */
+      for (h = 0; h < hops; h++) if ((double)e->spectrum[links[h]] < cap) cap = (double)e->spectrum[links[h]];
+      if (cap > best_load) { best_load = cap; action[0] = idp; }
+    }
+  }
 }
 
 /* reset (rmsa_env.py:284-359, rwa_env.py:164-208, rmcsa_env.py:386-483, optical_network_env.py:181-203) */
@@ -532,7 +636,7 @@ static void env_reset(const orc_batch* b, orc_env* e, int full) {
   e->episode_services_processed = 0;
   e->episode_services_accepted = 0;
   if (!full) {
-    if (t != ENV_RWA && e->new_service) {
+    if (t != ENV_RWA && t != ENV_QOS && e->new_service) {
       e->episode_services_processed += 1;
       e->episode_bit_rate_requested += e->cur.bit_rate;
     }
@@ -549,7 +653,8 @@ static void env_reset(const orc_batch* b, orc_env* e, int full) {
   for (i = 0; i < E; i++) { e->l_util[i] = 0.0; e->l_last[i] = 0.0; e->l_frag[i] = 0.0; e->l_comp[i] = 0.0; }
   e->bit_rate_requested = 0;
   e->bit_rate_provisioned = 0;
-  memset(e->avail, 1, (size_t)b->cfg.num_cores * E * b->cfg.num_slots);
+  if (t == ENV_QOS) for (i = 0; i < E; i++) e->spectrum[i] = b->cfg.num_slots; /* optical_network_env.py:189-193 */
+  else memset(e->avail, 1, (size_t)b->cfg.num_cores * E * b->cfg.num_slots);
   if (b->cfg.bit_rate_mode == 1)
     for (i = 0; i < b->cfg.n_bit_rates; i++) { e->br_req_hist[i] = 0; e->br_prov_hist[i] = 0; }
   if (t == ENV_RWA) {
@@ -589,6 +694,7 @@ static double blocking(int64_t req, int64_t prov) { return (double)(req - prov) 
 
 /* step(): action[4]; RMSA/RWA use [0..1], DeepRMSA [0], RMCSA [0..3].  Returns 0 or a negative error. */
 static int env_step(const orc_batch* b, orc_env* e, const int32_t* action, double* reward, uint8_t* done, double* info) {
+  if (b->cfg.env_type == ENV_QOS) return qos_step(b, e, action, reward, done, info);
   const orc_config* c = &b->cfg;
   int t = c->env_type, k = c->k_paths, S = c->num_slots;
   int path, slot, mod = 0, core = 0, rej = c->allow_rejection ? 1 : 0, i;
@@ -716,6 +822,7 @@ static void env_policy(const orc_batch* b, orc_env* e, int policy, int32_t* acti
   int t = c->env_type, k = c->k_paths, S = c->num_slots, src = e->cur.src, dst = e->cur.dst;
   int np_ = b->n_paths[src * c->n_nodes + dst], idp, s0;
   action[0] = action[1] = action[2] = action[3] = 0;
+  if (t == ENV_QOS) { qos_policy(b, e, policy, action); return; }
   if (policy == POLICY_PATH_FF) { /* PathOnlyFirstFitAction.action: rmsa_env.py:848-871, rwa_env.py:513-533 */
     int a = e->path_choice;
     action[0] = k; action[1] = S;
@@ -861,6 +968,7 @@ static void* dup_mem(const void* p, size_t n) {
 
 int orc_info_dim(const orc_config* c) {
   int rej = c->allow_rejection ? 1 : 0;
+  if (c->env_type == ENV_QOS) return 2;
   if (c->env_type == ENV_RWA) return 2 + (c->k_paths + rej) + (c->num_slots + rej);
   if (c->env_type == ENV_RMCSA) return 4;
   return 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
@@ -888,6 +996,10 @@ orc_batch* orc_create(const orc_config* cfg, const orc_tables* tb, int64_t n_env
   b->node_probs = (double*)dup_mem(tb->node_probs, (size_t)cfg->n_nodes * 8);
   b->bit_rates = (int32_t*)dup_mem(tb->bit_rates, (size_t)cfg->n_bit_rates * 4);
   b->bit_rate_probs = (double*)dup_mem(tb->bit_rate_probs, (size_t)cfg->n_bit_rates * 8);
+  if (cfg->env_type == ENV_QOS) {
+    b->class_probs = (double*)dup_mem(tb->class_probs, (size_t)cfg->n_classes * 8);
+    b->class_reward = (double*)dup_mem(tb->class_reward, (size_t)cfg->n_classes * 8);
+  }
   b->n_envs = n_envs;
   b->n_info = orc_info_dim(cfg);
   b->obs_dim = orc_obs_dim(cfg);
@@ -902,6 +1014,7 @@ orc_batch* orc_create(const orc_config* cfg, const orc_tables* tb, int64_t n_env
     e->free_list = (int32_t*)malloc(sizeof(int32_t) * e->pool_cap);
     e->running = (int32_t*)malloc(sizeof(int32_t) * e->pool_cap);
     e->avail = (uint8_t*)malloc((size_t)cfg->num_cores * E * cfg->num_slots);
+    e->spectrum = (int32_t*)calloc(E, 4);
     e->l_util = (double*)calloc(E, 8); e->l_frag = (double*)calloc(E, 8);
     e->l_comp = (double*)calloc(E, 8); e->l_last = (double*)calloc(E, 8);
     if (cfg->bit_rate_mode == 1) {
@@ -924,7 +1037,7 @@ void orc_destroy(orc_batch* b) {
   if (!b) return;
   for (i = 0; i < b->n_envs; i++) {
     orc_env* e = &b->envs[i];
-    free(e->heap); free(e->pool); free(e->free_list); free(e->running); free(e->avail);
+    free(e->heap); free(e->pool); free(e->free_list); free(e->running); free(e->avail); free(e->spectrum);
     free(e->l_util); free(e->l_frag); free(e->l_comp); free(e->l_last);
     free(e->br_req_hist); free(e->br_prov_hist); free(e->act_path); free(e->act_slot);
     free(e->actions_output); free(e->actions_taken);
@@ -933,6 +1046,7 @@ void orc_destroy(orc_batch* b) {
   free(b->n_paths); free(b->path_hops); free(b->path_links); free(b->path_length); free(b->path_best_mod);
   free(b->mod_se); free(b->mod_max_length); free(b->mod_min_osnr); free(b->mod_inband_xt);
   free(b->edge_iter_order); free(b->node_probs); free(b->bit_rates); free(b->bit_rate_probs);
+  free(b->class_probs); free(b->class_reward);
   free(b);
 }
 
@@ -1048,6 +1162,9 @@ void orc_get_counters(orc_batch* b, int64_t* out /*[n][8]*/) {
 }
 void orc_get_slots(orc_batch* b, int64_t env, uint8_t* out /*[C][E][S]*/) {
   memcpy(out, b->envs[env].avail, (size_t)b->cfg.num_cores * b->cfg.n_links * b->cfg.num_slots);
+}
+void orc_get_spectrum(orc_batch* b, int64_t env, int32_t* out /*[E]*/) { /* QoSConstrainedRA: available_spectrum */
+  memcpy(out, b->envs[env].spectrum, (size_t)b->cfg.n_links * 4);
 }
 void orc_get_link_stats(orc_batch* b, int64_t env, double* out /*[4][E]*/) {
   const orc_env* e = &b->envs[env];

@@ -125,3 +125,31 @@ def replay_w(env, g, check):
         check(T, "actions_output", out[: ro.shape[0], : ro.shape[1]], ro)
         check(T, "actions_taken", taken[: rt.shape[0], : rt.shape[1]], rt)
         assert out.sum() == ro.sum() and taken.sum() == rt.sum()
+
+
+def replay_q(env, g, check):
+    """Replay a q* fixture (QoSConstrainedRA, oracle/gen_golden_qos.py) on a 1-env batch object `env`."""
+    meta = g["meta"]
+    use_policy = meta["policy"] != "ACTIONS"
+    for t in range(meta["n_steps"]):
+        if g["reset_before"][t]:
+            env.reset(full=False)
+        check(t, "svc", env.services()[0], g["svc"][t])
+        if use_policy:
+            a = env.policy(meta["policy"])
+            check(t, "action", np.asarray(a[0, :1], np.int64), g["actions"][t])
+        else:
+            a = g["actions"][t][None, :]
+        _, reward, done, info = env.step(a)
+        check(t, "reward", reward[0], g["reward"][t])
+        check(t, "done", int(done[0]), int(g["done"][t]))
+        check(t, "info", info[0, :2], g["info"][t])
+        check(t, "counters", env.counters()[0, :4], g["counters"][t][:4])
+        check(t, "spectrum", env.spectrum(0), g["spectrum"][t])
+        check(t, "n_active", env.n_active(0), int(g["n_active"][t]))
+        if (t + 1) in meta["snapshot_steps"]:
+            ls = env.link_stats(0)
+            ref = g["snap%d_link_stats" % (t + 1)]
+            check(t, "utilization", ls[0], ref[0])
+            check(t, "last_update", ls[3], ref[3])
+    check(meta["n_steps"], "svc", env.services()[0], g["svc"][meta["n_steps"]])

@@ -14,19 +14,21 @@ class OracleBackend(OracleBatch):
         self.num_envs = self.n
         self.num_spatial_resources = self.C
         self.num_spectrum_resources = self.S
-        rej = 1 if kw.get("allow_rejection", env_type == "RWA") else 0
+        rej = 1 if kw.get("allow_rejection", env_type in ("RWA", "QoSConstrainedRA")) else 0
         if env_type == "RWA":
             self.info_keys = (["service_blocking_rate", "episode_service_blocking_rate"]
                               + ["path_action_probability[%d]" % i for i in range(self.k + rej)]
                               + ["wavelength_action_probability[%d]" % i for i in range(self.S + rej)])
         elif env_type == "RMCSA":
             self.info_keys = RMSA_INFO_KEYS[:4]
+        elif env_type == "QoSConstrainedRA":
+            self.info_keys = RMSA_INFO_KEYS[:2]
         else:
             self.info_keys = list(RMSA_INFO_KEYS)
             if kw.get("bit_rate_selection") == "discrete":
                 self.info_keys += ["bit_rate_blocking_%s" % b for b in kw.get("bit_rates", (10, 40, 100))] + ["fairness"]
         self._info = np.zeros((self.n, self.n_info))
-        self.ENV_TYPE = {"RMSA": 0, "DeepRMSA": 1, "RWA": 2, "RMCSA": 3}[env_type]
+        self.ENV_TYPE = {"RMSA": 0, "DeepRMSA": 1, "RWA": 2, "RMCSA": 3, "QoSConstrainedRA": 4}[env_type]
         self.episode_length = kw.get("episode_length", 1000)
         self.k_paths = self.k
         self.allow_rejection = bool(rej)

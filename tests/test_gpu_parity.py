@@ -4,7 +4,7 @@ too (the device evaluates the reference's expressions in the same order and its 
 import numpy as np
 import pytest
 
-from tests.helpers import golden_names, load_golden, replay, replay_w
+from tests.helpers import golden_names, load_golden, replay, replay_q, replay_w
 
 pytestmark = pytest.mark.gpu
 
@@ -16,10 +16,11 @@ IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds"]
 IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None),
             "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT=None),
             # the persistent kernel in the form the library picks, with all state in global memory, and with slot maps +
-            # link statistics + per-core sums resident in LDS (falls back to the default form where that does not fit)
+            # link statistics + per-core sums resident in LDS (a form only liborlgpu_alt.so carries; where it does not fit
+            # the library's default form runs)
             "persist": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None),
             "persist_global": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="0"),
-            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="2")}
+            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT="2")}
 
 
 def force_impl(monkeypatch, name):
@@ -871,3 +872,50 @@ def test_facade_queries_and_wrappers_on_hip():
     with pytest.raises(IndexError):
         env.step((0, 400))
     env.close()
+
+
+@pytest.mark.parametrize("name", golden_names("q"))
+def test_hip_reproduces_qos_fixtures(name):
+    """QoSConstrainedRA (qos_constrained_ra.py) on the device against fixtures captured from the reference with its
+    constructor repaired at import time: three heuristics and a stored action stream, three service classes."""
+    g = load_golden(name)
+    env = _product(g["meta"])
+    replay_q(env, g, _exact(name))
+    assert not env.flags().any()
+    env.close()
+
+
+def test_qos_batches_match_oracle_and_run_equals_stepping():
+    import optical_rl_gym_amd as orl
+    from oracle.oracle import OracleBatch
+
+    kw = dict(load=900, mean_service_holding_time=25, episode_length=45, num_spectrum_resources=32, num_service_classes=4,
+              classes_arrival_probabilities=[0.1, 0.4, 0.3, 0.2], classes_reward=[8.0, 4.0, 2.0, 1.0], allow_rejection=True)
+    n = 96
+    seeds = [700 + 3 * i for i in range(n)]
+    chk = _exact("qos")
+    for policy in ("SP_FF", "SAP_FF", "LLP_FF"):
+        ora = OracleBatch("QoSConstrainedRA", "nsfnet_chen", seeds, **kw)
+        dev = orl.make("QoSConstrainedRA-v0", topology="nsfnet_chen", num_envs=n, seeds=seeds, **kw)
+        dev.run(policy, 160)
+        ora.run(policy, 160)
+        for t in range(120):
+            a_o, a_d = ora.policy(policy), dev.policy(policy)
+            chk(t, "actions", a_d, a_o)
+            _, r_o, d_o, i_o = ora.step(a_o, auto_reset=True)
+            _, r_d, d_d, i_d = dev.step(a_d, auto_reset=True)
+            chk(t, "reward", r_d, r_o); chk(t, "done", d_d, d_o); chk(t, "info", i_d, i_o)
+        chk(0, "counters", dev.counters(), ora.counters())
+        chk(0, "services", dev.services(), ora.services())
+        for e in (0, 50, n - 1):
+            chk(e, "spectrum", dev.spectrum(e), ora.spectrum(e))
+            chk(e, "link_stats", dev.link_stats(e)[[0, 3]], ora.link_stats(e)[[0, 3]])
+            chk(e, "n_active", dev.n_active(e), ora.n_active(e))
+        mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+        dev.reset(full=True, mask=mask); ora.reset(full=True, mask=mask)
+        dev.run(policy, 50); ora.run(policy, 50)
+        chk(1, "counters", dev.counters(), ora.counters())
+        chk(1, "spectrum", dev.spectrum(3), ora.spectrum(3))
+        with pytest.raises(IndexError):
+            dev.step(np.full((n, 1), 6))
+        dev.close()

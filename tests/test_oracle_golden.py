@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import OracleBatch
-from tests.helpers import golden_names, load_golden, replay, replay_w
+from tests.helpers import golden_names, load_golden, replay, replay_q, replay_w
 
 
 def _make(meta):
@@ -41,3 +41,12 @@ def test_oracle_reproduces_wrapper_and_event_fixtures(name):
     g = load_golden(name)
     env = _make(g["meta"])
     replay_w(env, g, _exact(name))
+
+
+@pytest.mark.parametrize("name", golden_names("q"))
+def test_oracle_reproduces_qos_fixtures(name):
+    """QoSConstrainedRA (qos_constrained_ra.py) as captured from the reference with its constructor repaired at import
+    time (oracle/gen_golden_qos.py): three heuristics and a stored action stream, three service classes."""
+    g = load_golden(name)
+    env = _make(g["meta"])
+    replay_q(env, g, _exact(name))
