@@ -179,19 +179,20 @@ struct Wmem {
   double* ls0;   // [..][E][4]
   int* cs0;      // [..][cs_words]
   i64 env0;      // index base of bm0
-  i64 senv0;     // index base of ls0 / cs0
+  i64 senv0;     // index base of ls0
+  i64 cenv0;     // index base of cs0
   double* clk;   // LDS [8][2] {provision clock, step clock} of the wavefront's envs, or nullptr (row phase reads SC_NOWA / SC_NOW)
   i64 clk_env0;  // first env of the wavefront (index base of clk)
-  bool in_lds;   // wavefront-private state: plain accesses; else the sums are read through L2 where the row phase's atomics land
+  bool cs_lds;   // the sums are in the wavefront's LDS window: plain reads; else they are read through L2 where the row phase's atomics land
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.clk = nullptr; m.clk_env0 = 0; m.in_lds = false;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
 __device__ __forceinline__ double* wm_ls(const DevParams& P, const Wmem& m, i64 env) { return m.ls0 + (env - m.senv0) * 4 * P.E; }
-__device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.senv0) * P.cs_words; }
+__device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.cenv0) * P.cs_words; }
 
 struct CtrlOpts {
   bool persistent;  // inside k_persist: no kernel boundary between the row phase's L2 atomics and this phase's reads
@@ -249,7 +250,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         // (the sums are updated by L2 atomics: in the persistent kernel, where no kernel boundary invalidates the L1 in
         // between, they are read through L2 as well)
         int occ, fb;
-        if (O.persistent && !M.in_lds) {
+        if (O.persistent && !M.cs_lds) {
           occ = atomicAdd(e.cs + 2 * c0, 0) - atomicAdd(rs + 2 * c0, 0);
           fb = atomicAdd(e.cs + 2 * c0 + 1, 0) - atomicAdd(rs + 2 * c0 + 1, 0);
         } else {
@@ -262,7 +263,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         e.g_comp = (a0 + (cmp * td)) / now_a;
       }
       for (int i = gl; i < 2 * P.C; i += 8) {  // this step's releases start from zero
-        if (O.persistent && !M.in_lds) atomicExch(rs + i, 0);
+        if (O.persistent && !M.cs_lds) atomicExch(rs + i, 0);
         else rs[i] = 0;
       }
     }

@@ -233,12 +233,12 @@ __host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, in
   L.clk = o; o += 8 * 2 * 8;
   L.misc = o; o += 16;
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
+  L.cs = o; if (state >= 1) o += (8 * cs_words * 4 + 15) & ~15;
   L.ls = o; if (state >= 2) o += 8 * E * 32;
-  L.cs = o; if (state >= 2) o += (8 * cs_words * 4 + 15) & ~15;
   L.total = o;
   return L;
 }
-// LDS: 0 = the state stays in global memory, 1 = slot maps in LDS, 2 = slot maps + link statistics + per-core sums in LDS
+// LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums in LDS, 2 = + link statistics
 template <int ENV, int W, int LDS>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.cs_words, LDS);
@@ -264,19 +264,22 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       ulonglong2* l = (ulonglong2*)M.bm0;
       for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) l[i] = g[i];
     }
+    M.cs0 = (int*)(orl_lds_raw + L.cs);
+    M.cenv0 = env0;
+    M.cs_lds = true;
+    if (step < target) {
+      const int4* gc = (const int4*)(P.core_sums + env0 * P.cs_words);
+      int4* lc = (int4*)M.cs0;
+      for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) lc[i] = gc[i];
+    }
   }
   if (LDS >= 2) {
     M.ls0 = (double*)(orl_lds_raw + L.ls);
-    M.cs0 = (int*)(orl_lds_raw + L.cs);
     M.senv0 = env0;
-    M.in_lds = true;
     if (step < target) {
       const double2* gs = (const double2*)(P.lstat + env0 * 4 * P.E);
       double2* ls = (double2*)M.ls0;
       for (int i = lane; i < nenv * 2 * P.E; i += 64) ls[i] = gs[i];
-      const int4* gc = (const int4*)(P.core_sums + env0 * P.cs_words);
-      int4* lc = (int4*)M.cs0;
-      for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) lc[i] = gc[i];
     }
   }
   if (threadIdx.x == 0) s_deferred[0] = s_deferred[1] = 0;
@@ -336,14 +339,14 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     ulonglong2* g = (ulonglong2*)(P.bitmap + env0 * P.bm_words);
     const ulonglong2* l = (const ulonglong2*)M.bm0;
     for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) g[i] = l[i];
+    int4* gc = (int4*)(P.core_sums + env0 * P.cs_words);
+    const int4* lc = (const int4*)M.cs0;
+    for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) gc[i] = lc[i];
   }
   if (LDS >= 2 && step > first_step) {
     double2* gs = (double2*)(P.lstat + env0 * 4 * P.E);
     const double2* ls = (const double2*)M.ls0;
     for (int i = lane; i < nenv * 2 * P.E; i += 64) gs[i] = ls[i];
-    int4* gc = (int4*)(P.core_sums + env0 * P.cs_words);
-    const int4* lc = (const int4*)M.cs0;
-    for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) gc[i] = lc[i];
   }
   if (step > first_step && step < target && valid) {
     // leaving early (deferred releases): the descriptor the next launch / the stand-alone scan reads; action, reward and done
