@@ -439,7 +439,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     // 4 096: 1.6e8 vs 7.6e7; 32 768: 6.3e8 vs 4.0e8; RWA 4 096: 2.4e8 vs 8.3e7.  ORL_STEP_IMPL=64 forces the per-env kernel
     // (cross-checks); ORL_STEP_IMPL=2 with ORL_PERSIST=0 selects the two-kernel form in ORL_ALT_IMPLS builds.
     const char* impl = getenv("ORL_STEP_IMPL");
-    const bool pipeline_ok = t->K <= 8 && P.ev_cap <= 2048 && !qos;
+    int max_n = 1;  // slots of the largest service: the row items of the persistent kernel carry (first slot: 9 bits | slots: 6 bits)
+    if (c->n_slots)
+      for (size_t i = 0; i < (size_t)P.n_br * P.M; i++) max_n = c->n_slots[i] > max_n ? c->n_slots[i] : max_n;
+    const bool pipeline_ok = t->K <= 8 && P.ev_cap <= 2048 && !qos && max_n <= 63 && S <= 512;
     b->persist = pipeline_ok && !(impl && atoi(impl) == 64);
     if (const char* pv = getenv("ORL_PERSIST")) {
       if (atoi(pv) == 0 && b->persist) {

@@ -52,9 +52,10 @@ struct EnvG {
   u64* scal;
 };
 
-__device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
-  const u64* s = P.scal + env * ORL_SCAL_WORDS;
-  e.scal = P.scal + env * ORL_SCAL_WORDS;
+// `rec`: where the env's record lives (the global array, or the persistent kernel's LDS copy)
+__device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env, u64* rec) {
+  const u64* s = rec;
+  e.scal = rec;
 #define F64(slot) __longlong_as_double((i64)s[slot])
   e.now = F64(SC_NOW); e.at = F64(SC_AT); e.ht = F64(SC_HT);
   e.g_thr = F64(SC_GTHR); e.g_comp = F64(SC_GCOMP); e.g_last = F64(SC_GLAST); e.next_rel = F64(SC_NEXTREL);
@@ -88,6 +89,7 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) {
   e.soon_i = P.soon_i + env * ORL_SOON;
   e.mt = P.mt + env * 624;
 }
+__device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) { env_load(P, e, env, P.scal + env * ORL_SCAL_WORDS); }
 
 // returns the service descriptor of the pending service (what the slot scan reads); stored only when write_desc
 __device__ __forceinline__ u64 env_store(const DevParams& P, const EnvG& e, int gl, bool write_desc = true) {

@@ -111,30 +111,60 @@ struct SinkEntry {
   u64 mk1;  // masks 4..7
   u64 crn;  // the core of each mask, 5 bits each (40 bits) | number of masks << 40 | mask 0 is a provision << 44
 };
-struct Sink {
+// compact form (single-core families in the persistent kernel's LDS window): no cores, 15-bit masks (s0:9 | n:6 — the
+// split pipeline is used for services of at most 63 slots, orl_api.hip)
+struct SinkEntryC {
+  u64 mk0;  // masks 0..3, 15 bits each | number of masks << 60
+  u64 mk1;  // masks 4..7, 15 bits each | mask 0 is a provision << 60
+};
+template <bool CP> struct SinkEntryOf { typedef SinkEntry type; };
+template <> struct SinkEntryOf<true> { typedef SinkEntryC type; };
+template <bool CP> struct SinkT {
+  typedef typename SinkEntryOf<CP>::type Entry;
   unsigned short* list;  // LDS (persistent kernel, else nullptr): the wavefront's open table entries, (local env << 8) | link ...
   u32* list_n;           // ... and their number, zeroed at the start of the step
-  SinkEntry* tab;  // LDS, E entries of this env, crn zeroed
-  u32* tally;      // LDS, 32 words per env, zeroed: per-link touch counters (4 x 8 bit per word) for the capacity check
+  Entry* tab;      // LDS, E entries of this env, mask count zeroed
+  u32* tally;      // LDS, `tw` words per env, zeroed: per-link touch counters (4 x 8 bit per word) for the capacity check
+  int tw;
   bool active;     // item mode decided: the releases of this step fit the item form
   bool deferred;   // they do not: nothing has been touched, k_rel_tail releases them in place
   int cnt;         // links this LANE has opened an item for
 };
+typedef SinkT<false> Sink;
+__device__ __forceinline__ void sink_entry_clear(SinkEntry& t) { t.crn = 0ull; }
+__device__ __forceinline__ void sink_entry_clear(SinkEntryC& t) { t.mk0 = 0ull; }
+// appends mask m to the entry; returns the number of masks it held, bit 8: the entry starts with the step's provision
+__device__ __forceinline__ int sink_entry_add(SinkEntry* t, u64 m, int core, bool prov) {
+  const u64 crn = t->crn | (prov ? (1ull << 44) : 0ull);  // (a provision is the first thing a step adds)
+  const int j = (int)((crn >> 40) & 15);
+  if (j < 4) t->mk0 = (j == 0 ? 0ull : t->mk0) | (m << (16 * j));
+  else t->mk1 = (j == 4 ? 0ull : t->mk1) | (m << (16 * (j - 4)));
+  t->crn = (crn & ((1ull << 44) | 0xffffffffffull)) | ((u64)(u32)core << (5 * j)) | ((u64)(u32)(j + 1) << 40);
+  return j | (int)((crn >> 44) & 1) << 8;
+}
+__device__ __forceinline__ int sink_entry_add(SinkEntryC* t, u64 m, int core, bool prov) {
+  u64 m0 = t->mk0;
+  const int j = (int)(m0 >> 60);
+  int pf = prov ? 1 : 0;
+  if (j == 0) t->mk1 = prov ? (1ull << 60) : 0ull;
+  else pf = (int)((t->mk1 >> 60) & 1);
+  if (j < 4) m0 |= m << (15 * j);
+  else t->mk1 |= m << (15 * (j - 4));
+  t->mk0 = (m0 & ~(15ull << 60)) | ((u64)(u32)(j + 1) << 60);
+  return j | pf << 8;
+}
 // lane h of the group appends the mask to the item of hop h's link (the links of one path are distinct)
-__device__ __forceinline__ void sink_add(Sink& s, const PathRec& rec, int core, int s0, int n, int lane, bool prov = false) {
+template <bool CP>
+__device__ __forceinline__ void sink_add(SinkT<CP>& s, const PathRec& rec, int core, int s0, int n, int lane, bool prov = false) {
   const int hops = path_rec_byte(rec, 0);
   const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
   for (int h = lane & 7; h < hops; h += 8) {
-    SinkEntry* t = s.tab + path_rec_byte(rec, 2 + h);
-    const u64 crn = t->crn | (prov ? (1ull << 44) : 0ull);  // (a provision is the first thing a step adds)
-    const int j = (int)((crn >> 40) & 15);
-    if (j < 4) t->mk0 = (j == 0 ? 0ull : t->mk0) | (m << (16 * j));
-    else t->mk1 = (j == 4 ? 0ull : t->mk1) | (m << (16 * (j - 4)));
-    t->crn = (crn & ((1ull << 44) | 0xffffffffffull)) | ((u64)(u32)core << (5 * j)) | ((u64)(u32)(j + 1) << 40);
+    const int r = sink_entry_add(s.tab + path_rec_byte(rec, 2 + h), m, core, prov);
+    const int j = r & 15;
     s.cnt += (j == 0) ? 1 : 0;
     // a new item: the row phase finds it through the list (any order: items are independent).  A link that carries the
     // step's provision AND a release gets a second entry (bit 15): two lanes share its row work (row_item_lane1)
-    if (s.list && (j == 0 || (j == 1 && ((crn >> 44) & 1))))
+    if (s.list && (j == 0 || (j == 1 && (r >> 8))))
       s.list[atomicAdd(s.list_n, 1u)] = (unsigned short)((j << 15) | (((lane >> 3) & 7) << 8) | path_rec_byte(rec, 2 + h));
   }
 }
@@ -181,17 +211,20 @@ struct Wmem {
   i64 env0;      // index base of bm0
   i64 senv0;     // index base of ls0
   i64 cenv0;     // index base of cs0
+  u64* sc0;      // [..][ORL_SCAL_WORDS] env records
+  i64 scenv0;    // index base of sc0
   double* clk;   // LDS [8][2] {provision clock, step clock} of the wavefront's envs, or nullptr (row phase reads SC_NOWA / SC_NOW)
   i64 clk_env0;  // first env of the wavefront (index base of clk)
   bool cs_lds;   // the sums are in the wavefront's LDS window: plain reads; else they are read through L2 where the row phase's atomics land
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
 __device__ __forceinline__ double* wm_ls(const DevParams& P, const Wmem& m, i64 env) { return m.ls0 + (env - m.senv0) * 4 * P.E; }
+__device__ __forceinline__ u64* wm_scal(const DevParams& P, const Wmem& m, i64 env) { return m.sc0 + (env - m.scenv0) * ORL_SCAL_WORDS; }
 __device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.cenv0) * P.cs_words; }
 
 struct CtrlOpts {
@@ -200,8 +233,8 @@ struct CtrlOpts {
   bool trusted;     // the action comes from the in-kernel slot scan on the same slot map: is_path_free holds by construction
   bool emit_queue;  // two-kernel form: copy the items into the global queue for the row kernel
 };
-template <int ENV, int W>
-__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
+template <int ENV, int W, bool CP>
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
                                              int extra = 0, int pushed_idx = -1, u64 pushed_info = 0ull);
 
 // The provision and the releases of the step go into ONE queue as mixed items (per link: the provision mask first, then the
@@ -210,32 +243,34 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 // the latter in rel_sums.
 // Returns the service descriptor of the NEW pending service (what the next slot scan needs: pair base, bit-rate index,
 // number of paths), and through *n_items_out the number of items this env's step left in its sink table.
-template <int ENV, int W>
+// CP: compact sink entries (SinkEntryC); tw: tally words per env (>= ceil(E / 4))
+template <int ENV, int W, bool CP = false>
 __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
-                                      const int4* given, u32* s_tally, SinkEntry* s_tab, int parity, int* s_deferred,
-                                      int* done_out, unsigned short* s_list = nullptr, u32* s_list_n = nullptr) {
+                                      const int4* given, u32* s_tally, typename SinkEntryOf<CP>::type* s_tab, int parity,
+                                      int* s_deferred, int* done_out, unsigned short* s_list = nullptr, u32* s_list_n = nullptr,
+                                      int tw = 32) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   if (!O.persistent && blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
   u64 desc_out = 0ull;
   int cnt = 0, core = 0, slot = 0, n = 1;
   PathRec rec;
   rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
-  Sink sink;
-  sink.tab = nullptr; sink.tally = nullptr; sink.active = false; sink.deferred = false; sink.cnt = 0;
+  SinkT<CP> sink;
+  sink.tab = nullptr; sink.tally = nullptr; sink.tw = tw; sink.active = false; sink.deferred = false; sink.cnt = 0;
   sink.list = s_list; sink.list_n = s_list_n;
   if (s_list_n && lane == 0) *s_list_n = 0u;
   {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
-    u32* ty = s_tally + 32 * 8 * (int)(threadIdx.x >> 6);
-    SinkEntry* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
-    for (int i = lane; i < 8 * 32; i += 64) ty[i] = 0u;
-    for (int i = lane; i < 8 * P.E; i += 64) tb[i].crn = 0ull;
+    u32* ty = s_tally + tw * 8 * (int)(threadIdx.x >> 6);
+    typename SinkEntryOf<CP>::type* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
+    for (int i = lane; i < 8 * tw; i += 64) ty[i] = 0u;
+    for (int i = lane; i < 8 * P.E; i += 64) sink_entry_clear(tb[i]);
     wave_fence();
     sink.tab = s_tab + P.E * (int)(threadIdx.x >> 3);
-    sink.tally = s_tally + 32 * (int)(threadIdx.x >> 3);
+    sink.tally = s_tally + tw * (int)(threadIdx.x >> 3);
   }
   if (valid) {
     EnvG e;
-    g8::env_load(P, e, env);
+    g8::env_load(P, e, env, wm_scal(P, M, env));
     e.bm = wm_bm(P, M, env);
     e.ls = wm_ls(P, M, env);
     e.cs = wm_cs(P, M, env);
@@ -394,7 +429,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       // has gone back already (so that only the handful of release-related fields stays in registers through the
       // detection); those fields are written again below when the detection changed them.
       SoonRegs soon;
-      release_soon<ENV, W>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info);
+      release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info);
       ORL_PROFA(10);
       if (sink.deferred) {
         // more releases meet on one link than an item holds masks for: the release state stays as stored and the
@@ -425,12 +460,19 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     }
   }
   ORL_PROFA(11);
-  if (O.emit_queue) emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a);
+  if constexpr (!CP) { if (O.emit_queue) emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a); }
   ORL_PROFA(9);
   return desc_out;
 }
 
 // persistent kernel: an item of the row phase read from the sink table in place
+__device__ __forceinline__ u64 masks15_to_16(u64 x) {
+  return (x & 0x7fffull) | (((x >> 15) & 0x7fffull) << 16) | (((x >> 30) & 0x7fffull) << 32) | (((x >> 45) & 0x7fffull) << 48);
+}
+__device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntryC& t) {
+  const int nm = (int)(t.mk0 >> 60);
+  return make_item(env, (u32)link, nm, masks15_to_16(t.mk0), nm > 4 ? masks15_to_16(t.mk1) : 0ull, 0ull, 1 | (int)((t.mk1 >> 60) & 1) << 1);
+}
 __device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntry& t) {
   const int nm = (int)((t.crn >> 40) & 15);
   return make_item(env, (u32)link, nm, t.mk0, nm > 4 ? t.mk1 : 0ull, t.crn & 0xffffffffffull, 1 | (int)((t.crn >> 44) & 1) << 1);
@@ -482,10 +524,10 @@ __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 en
 // only when the clock passes t_soon the list is rebuilt from a full scan.  Pushes keep the invariant (g8::ev_push).
 // ---------------------------------------------------------------------------------------------------------------
 // The list is returned in registers: the caller writes it back (when dirty) after everything that still loads.
-template <int ENV, int W>
+template <int ENV, int W, bool CP>
 // `extra`: masks this step already put on links (its provision, two-kernel pipeline); `pushed_idx / pushed_info`: the
 // release slot the same kernel has just written — its info word is taken from registers, not re-read through memory.
-__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, Sink& sink, SoonRegs& out, Prof& prof,
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
                                              int extra, int pushed_idx, u64 pushed_info) {
   constexpr int NS = ORL_SOON_PER_LANE;
   out.dirty = 0;
@@ -632,7 +674,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         }
         wave_fence();
         u32 mx = 0;
-        for (int wd = gl; wd < 32; wd += 8) {
+        for (int wd = gl; wd < sink.tw; wd += 8) {
           const u32 v = sink.tally[wd];
           const u32 a0 = v & 0xff, a1 = (v >> 8) & 0xff, a2 = (v >> 16) & 0xff, a3 = v >> 24;
           u32 m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3;
@@ -814,8 +856,8 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   int* cs = wm_cs(P, M, env);
   int* rs = cs + 2;
   double* ls = wm_ls(P, M, env) + 4 * link;
-  const double now = M.clk ? M.clk[2 * (env - M.clk_env0) + 1] : __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
-  const double now_prov = M.clk ? M.clk[2 * (env - M.clk_env0)] : __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOWA]);
+  const double now = M.clk ? M.clk[2 * (env - M.clk_env0) + 1] : __longlong_as_double((i64)wm_scal(P, M, env)[SC_NOW]);
+  const double now_prov = M.clk ? M.clk[2 * (env - M.clk_env0)] : __longlong_as_double((i64)wm_scal(P, M, env)[SC_NOWA]);
   u64 a[W];
 #pragma unroll
   for (int w = 0; w < W; w++) a[w] = row[w];
@@ -935,8 +977,8 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Wmem& M,
   int* cs = wm_cs(P, M, env);
   int* rs = MIXED ? cs + 2 * P.C : nullptr;
   double* ls = wm_ls(P, M, env);
-  const double now = M.clk ? M.clk[2 * (env - M.clk_env0) + 1] : __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOW]);
-  const double now_prov = M.clk ? M.clk[2 * (env - M.clk_env0)] : __longlong_as_double((i64)P.scal[env * ORL_SCAL_WORDS + SC_NOWA]);
+  const double now = M.clk ? M.clk[2 * (env - M.clk_env0) + 1] : __longlong_as_double((i64)wm_scal(P, M, env)[SC_NOW]);
+  const double now_prov = M.clk ? M.clk[2 * (env - M.clk_env0)] : __longlong_as_double((i64)wm_scal(P, M, env)[SC_NOWA]);
   const double2 ls01 = *(const double2*)(ls + 4 * link), ls23 = *(const double2*)(ls + 4 * link + 2);  // one 32-byte record
   double last_update = ls23.y;
   double util = ls01.x, frag = ls01.y, comp = ls23.x;

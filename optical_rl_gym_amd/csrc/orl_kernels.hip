@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
 }
 
 template <int W>
-__device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, i64 env, int lane, int terminal);
+__device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, const u64* rec, i64 env, int lane, int terminal);
 
 #ifdef ORL_ALT_IMPLS
 // ---- two-kernel form of the persistent kernel's phases (cross-checks, per-kernel timing): k_step_a2 ; k_rows2 ------------
@@ -222,27 +222,34 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 // A wavefront in which an env's releases did not fit the item form (one env-step in 10^7) leaves the loop after that step's
 // row phase; k_rel_tail follows every launch, and the wavefront resumes from its own step count in the next launch.
 struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (all multiples of 16)
-  int tab, tally, list, clk, misc, bm, ls, cs, total;
+  int tab, tally, tw, list, clk, misc, bm, ls, cs, sc, total;
 };
-__host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, int cs_words, int state) {
+// state: 0 = only the per-step tables, 1 = + slot maps, per-core sums and env records, 2 = + link statistics;
+// compact: 16-byte sink entries (single-core families, state >= 1)
+__host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, int cs_words, int state, bool compact) {
   PersistLds L;
   int o = 0;
-  L.tab = o; o += 8 * E * (int)sizeof(sp::SinkEntry);
-  L.tally = o; o += 8 * 32 * 4;
+  L.tab = o; o += 8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry));
+  L.tw = (E + 3) >> 2;
+  L.tally = o; o += 8 * L.tw * 4;
   L.list = o; o += ((2 * 8 * E * 2) + 15) & ~15;  // an item may have two entries
-  L.clk = o; o += 8 * 2 * 8;
+  L.clk = o; if (state == 0) o += 8 * 2 * 8;  // (state >= 1: the row phase reads the clocks from the record)
   L.misc = o; o += 16;
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
   L.cs = o; if (state >= 1) o += (8 * cs_words * 4 + 15) & ~15;
+  L.sc = o; if (state >= 1) o += 8 * ORL_SCAL_WORDS * 8;
   L.ls = o; if (state >= 2) o += 8 * E * 32;
   L.total = o;
   return L;
 }
-// LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums in LDS, 2 = + link statistics
+template <int ENV, int LDS> struct PersistCompact { static constexpr bool value = LDS >= 1 && ENV != ENV_RMCSA; };
+static inline bool persist_compact(int env_type, int state) { return state >= 1 && env_type != ENV_RMCSA; }
+// LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics
 template <int ENV, int W, int LDS>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
-  const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.cs_words, LDS);
-  sp::SinkEntry* s_tab = (sp::SinkEntry*)(orl_lds_raw + L.tab);
+  constexpr bool CP = PersistCompact<ENV, LDS>::value;
+  const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.cs_words, LDS, CP);
+  typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
   int* s_deferred = (int*)(orl_lds_raw + L.misc);  // [2], alternating by step
@@ -254,8 +261,10 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   int step = wg_step[blockIdx.x];
   sp::Prof prof;
   sp::Wmem M = sp::wmem_global(P);
-  M.clk = (double*)(orl_lds_raw + L.clk);
-  M.clk_env0 = env0;
+  if (LDS == 0) {
+    M.clk = (double*)(orl_lds_raw + L.clk);
+    M.clk_env0 = env0;
+  }
   if (LDS >= 1) {  // the wavefront's envs are contiguous in every array: coalesced 16-byte loads
     M.bm0 = (u64*)(orl_lds_raw + L.bm);
     M.env0 = env0;
@@ -271,6 +280,13 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       const int4* gc = (const int4*)(P.core_sums + env0 * P.cs_words);
       int4* lc = (int4*)M.cs0;
       for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) lc[i] = gc[i];
+    }
+    M.sc0 = (u64*)(orl_lds_raw + L.sc);
+    M.scenv0 = env0;
+    if (step < target) {
+      const ulonglong2* gr = (const ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
+      ulonglong2* lr = (ulonglong2*)M.sc0;
+      for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) lr[i] = gr[i];
     }
   }
   if (LDS >= 2) {
@@ -309,8 +325,8 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
                           (int)((desc >> 48) & 0xffu), lane_i, pol, valid_i ? P.path_col[env_i] : 0, a);
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
-      desc = sp::ctrl_a<ENV, W>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
-                                s_list, s_list_n);
+      desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
+                                    s_list, s_list_n, L.tw);
     }
     __syncthreads();  // sink table + item list, clocks, env records
     {
@@ -328,7 +344,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     const bool deferred = s_deferred[step & 1] != 0;  // set before the barrier in front of the row phase
     if (ENV == ENV_DEEPRMSA && (O.write_io || deferred)) {  // the observation of the new pending service, from the rows as they are now
       __syncthreads();
-      if (valid_i) obs8_env<W>(P, sp::wm_bm(P, M, env_i), env_i, lane_i, done_i);
+      if (valid_i) obs8_env<W>(P, sp::wm_bm(P, M, env_i), sp::wm_scal(P, M, env_i), env_i, lane_i, done_i);
     }
     step++;
     if (deferred) break;
@@ -342,6 +358,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     int4* gc = (int4*)(P.core_sums + env0 * P.cs_words);
     const int4* lc = (const int4*)M.cs0;
     for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) gc[i] = lc[i];
+    ulonglong2* gr = (ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
+    const ulonglong2* lr = (const ulonglong2*)M.sc0;
+    for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) gr[i] = lr[i];
   }
   if (LDS >= 2 && step > first_step) {
     double2* gs = (double2*)(P.lstat + env0 * 4 * P.E);
@@ -380,7 +399,7 @@ __global__ void __launch_bounds__(256) k_rel_tail(DevParams P, int buffer) {
     sp::rel_serial<ENV, W>(P, env, lane_id());
     if (ENV == ENV_DEEPRMSA && P.obs_dim) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      obs8_env<W>(P, P.bitmap + env * P.bm_words, env, lane_id(), P.done[env]);
+      obs8_env<W>(P, P.bitmap + env * P.bm_words, P.scal + env * ORL_SCAL_WORDS, env, lane_id(), P.done[env]);
     }
   }
   __syncthreads();
@@ -406,9 +425,9 @@ __global__ void __launch_bounds__(64) k_obs(DevParams P, int with_terminal) {
 // bm: the env's slot map (global or LDS); terminal: also write the observation as `terminal_observation` (the env just
 // finished its episode: the soft reset keeps the pending service, so the values are the same; SB3 VecEnv convention)
 template <int W>
-__device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, i64 env, int lane, int terminal) {
+__device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, const u64* rec, i64 env, int lane, int terminal) {
   const int gl = lane & 7;
-  const u64* s = P.scal + env * ORL_SCAL_WORDS;
+  const u64* s = rec;
   u64 t = s[SC_SRC_DST];
   const int src = (int)(u32)t, dst = (int)(t >> 32);
   t = s[SC_BR_IDX];
@@ -462,7 +481,7 @@ template <int W>
 __global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
   const i64 env = (i64)blockIdx.x * 32 + (threadIdx.x >> 3);
   if (env >= P.B) return;
-  obs8_env<W>(P, P.bitmap + env * P.bm_words, env, lane_id(), with_terminal && P.done[env]);
+  obs8_env<W>(P, P.bitmap + env * P.bm_words, P.scal + env * ORL_SCAL_WORDS, env, lane_id(), with_terminal && P.done[env]);
 }
 
 // =============================================================================================
@@ -536,7 +555,7 @@ template <int W> void obs(orl_batch* b, int with_terminal) {
 struct PersistForm { int lds, waves; };
 static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}};
 static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
-  const int maps = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, 1).total;
+  const int maps = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, 1, persist_compact(VP.env_type, 1)).total;
   const int lim4 = (160 * 1024) / 16, lim3 = (160 * 1024) / 12;
   // Measured on MI355X, env-steps/s (form 0 / 2 / 3 / 4 / 5 = global 4 waves / full LDS 2 / full LDS 3 / maps 3 / maps 4):
   //   cfg2 65 536 envs: 8.0e8 / 6.5e8 / - / 7.8e8 / - (does not fit); HBM traffic per batched step 206 MB / - / - / 114 MB,
@@ -553,9 +572,9 @@ static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
 #ifndef ORL_ALT_IMPLS
     built = built && f != 2 && f != 3;
 #endif
-    if (built && persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[f].lds).total <= 64 * 1024) v = f;
+    if (built && persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[f].lds, persist_compact(VP.env_type, kPersistForms[f].lds)).total <= 64 * 1024) v = f;
   }
-  *lds_bytes = (size_t)persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[v].lds).total;
+  *lds_bytes = (size_t)persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[v].lds, persist_compact(VP.env_type, kPersistForms[v].lds)).total;
   return v;
 }
 template <int W> int persist_uses_lds(orl_batch* b) {
