@@ -195,7 +195,7 @@ __device__ __forceinline__ void emit_items(const DevParams& P, i64 env, const Si
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
 __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             bool write_io, Prof& prof);
+                                             bool write_io, g8::RngG& rng, Prof& prof);
 #ifndef ORL_SCAN_BATCH
 #define ORL_SCAN_BATCH 8  // release times a lane requests per round of the rebuild scan
 #endif
@@ -213,25 +213,29 @@ struct Wmem {
   i64 cenv0;     // index base of cs0
   u64* sc0;      // [..][ORL_SCAL_WORDS] env records
   i64 scenv0;    // index base of sc0
+  int cs_stride; // ints per env in cs0
+  u32* ic0;      // LDS [8][E]: per link row, the longest free run strictly inside each 64-slot word (6 bits per word, 63 =
+                 // unknown), or nullptr; indexed with cenv0 (row_stat_lane)
   double* clk;   // LDS [8][2] {provision clock, step clock} of the wavefront's envs, or nullptr (row phase reads SC_NOWA / SC_NOW)
   i64 clk_env0;  // first env of the wavefront (index base of clk)
   bool cs_lds;   // the sums are in the wavefront's LDS window: plain reads; else they are read through L2 where the row phase's atomics land
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
 __device__ __forceinline__ double* wm_ls(const DevParams& P, const Wmem& m, i64 env) { return m.ls0 + (env - m.senv0) * 4 * P.E; }
 __device__ __forceinline__ u64* wm_scal(const DevParams& P, const Wmem& m, i64 env) { return m.sc0 + (env - m.scenv0) * ORL_SCAL_WORDS; }
-__device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.cenv0) * P.cs_words; }
+__device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.cenv0) * m.cs_stride; }
 
 struct CtrlOpts {
   bool persistent;  // inside k_persist: no kernel boundary between the row phase's L2 atomics and this phase's reads
   bool write_io;    // store the action / reward / done / service descriptor of this step (device-resident runs: last step only)
   bool trusted;     // the action comes from the in-kernel slot scan on the same slot map: is_path_free holds by construction
   bool emit_queue;  // two-kernel form: copy the items into the global queue for the row kernel
+  bool prefetch;    // request the Mersenne-Twister window at the start of the phase (costs registers: 3-wave forms only)
 };
 template <int ENV, int W, bool CP>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
@@ -271,6 +275,9 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
   if (valid) {
     EnvG e;
     g8::env_load(P, e, env, wm_scal(P, M, env));
+    // the Mersenne-Twister window the next service draws from: requested now, used after the provision
+    g8::RngG rng;
+    if (O.prefetch) g8::rng_fill(e, rng, gl);
     e.bm = wm_bm(P, M, env);
     e.ls = wm_ls(P, M, env);
     e.cs = wm_cs(P, M, env);
@@ -419,7 +426,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     const u64 acc_after = (accepted && ENV != ENV_RWA && e.now > 0)
                               ? (3ull | ((u64)(u32)core << 32) | ((u64)e.s_nh << 37))
                               : pack2(accepted ? 1 : 0, core);
-    const bool done = service_part<ENV, W>(P, e, env, lane, 1, accepted, core, O.write_io, prof);
+    if (!O.prefetch) g8::rng_fill(e, rng, gl);
+    const bool done = service_part<ENV, W>(P, e, env, lane, 1, accepted, core, O.write_io, rng, prof);
     if (done_out) *done_out = done ? 1 : 0;
     desc_out = g8::env_store(P, e, gl, O.write_io);
     if (M.clk && gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
@@ -483,10 +491,8 @@ __device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntr
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
 __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             bool write_io, Prof& prof) {
+                                             bool write_io, g8::RngG& rng, Prof& prof) {
   const int gl = lane & 7;
-  g8::RngG rng;
-  g8::rng_fill(e, rng, gl);
   if (accepted && ENV != ENV_RWA) {  // _update_network_stats (rmsa_env.py:439-462)
     double last_update = e.g_last, time_diff = e.now - last_update;
     if (e.now > 0) {
@@ -768,9 +774,13 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
 // the first touch of a link in a step, the time_diff == 0 form on later touches, and the integer sums behind
 // _get_network_compactness kept per core with each row's cached contribution.
 // ---------------------------------------------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat& st, int& max_empty, int& edge) {
+// CACHED: `cache` is this row's word of Wmem::ic0; `touched`: the 64-slot words that differ from the row the cache
+// describes; `update`: the row summarised is the one that stays (write the refreshed cache word back)
+template <int W, bool CACHED = false>
+__device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat& st, int& max_empty, int& edge, u32* cache = nullptr,
+                                              u32 touched = 0u, bool update = false) {
   int nu = 0, lo = 1 << 20, hi = 0, free_ = 0, nf = 0, best = 0, c = 0;
+  u64 inter[CACHED ? W : 1];
 #pragma unroll
   for (int w = 0; w < W; w++) {
     const u64 maskw = word_mask_lo(S - 64 * w);
@@ -790,13 +800,51 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
     if (a[w] == ~0ull) {
       c += 64;
       best = c > best ? c : best;
+      if (CACHED) inter[CACHED ? w : 0] = 0ull;
     } else {
       const int lead = (int)__builtin_ctzll(~a[w]);
-      const int inner = word_longest_run(a[w]);
-      const int cand = (c + lead) > inner ? (c + lead) : inner;
-      best = cand > best ? cand : best;
-      c = (int)__builtin_clzll(~a[w]);
+      if (CACHED) {
+        // the runs that touch a word boundary here; inter[w]: the word without its leading and trailing runs
+        const int trail = (int)__builtin_clzll(~a[w]);
+        best = (c + lead) > best ? (c + lead) : best;
+        c = trail;
+        inter[CACHED ? w : 0] = a[w] & ~word_range(0, lead) & ~word_range(64 - trail, 64);
+      } else {
+        const int inner = word_longest_run(a[w]);
+        const int cand = (c + lead) > inner ? (c + lead) : inner;
+        best = cand > best ? cand : best;
+        c = (int)__builtin_clzll(~a[w]);
+      }
     }
+  }
+  if (CACHED) {
+    best = c > best ? c : best;
+    // ... then the runs inside a word: a dozen dependent 64-bit shift-and-test steps per word (word_longest_run), 10 % of the
+    // persistent kernel's time when done for every word of every row (S = 320).  Only the words this step changed are
+    // searched; the result for the others comes from the row's cache word.
+    u32 cw = *cache;
+    u32 need = touched;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+      const int f = (int)((cw >> (6 * w)) & 63u);
+      if (!((touched >> w) & 1u)) {
+        if (f == 63) need |= 1u << w;
+        else best = f > best ? f : best;
+      }
+    }
+    while (need) {  // (per lane: one word, two when a mask straddles a word boundary)
+      const int w = (int)__builtin_ctz(need);
+      need &= need - 1u;
+      u64 x = inter[0];
+#pragma unroll
+      for (int k = 1; k < (CACHED ? W : 1); k++) x = (w == k) ? inter[k] : x;
+      // (searched whatever `best` is: an unknown entry would have to be searched in a later step, when the word has not
+      // changed, and the wavefront runs as many rounds as its lane with the most words to search)
+      const int f = word_longest_run(x);  // <= 62: x has neither its lowest nor its highest bit set
+      best = f > best ? f : best;
+      cw = (cw & ~(63u << (6 * w))) | ((u32)f << (6 * w));
+    }
+    if (update) *cache = cw;
   }
   // free blocks strictly inside [lambda_min, lambda_max): that range starts and ends with a used block and blocks alternate,
   // so there is exactly one free block between consecutive used blocks (what rmsa_env.py:733-741 counts by run-length
@@ -811,6 +859,25 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
   for (int w = 0; w < W; w++) top_bit = (w == tw) ? (int)((a[w] >> tb) & 1ull) : top_bit;
   edge = (int)(a[0] & 1ull) + top_bit;
 }
+
+// the cache word of a row, from scratch
+template <int W>
+__device__ __forceinline__ u32 row_inner_cache(const u64* row) {
+  u32 cw = 0u;
+#pragma unroll
+  for (int w = 0; w < (W <= 5 ? W : 0); w++) {
+    const u64 a = row[w];
+    int f = 0;
+    if (a != ~0ull) {
+      const int lead = (int)__builtin_ctzll(~a), trail = (int)__builtin_clzll(~a);
+      f = word_longest_run(a & ~word_range(0, lead) & ~word_range(64 - trail, 64));
+    }
+    cw |= (u32)f << (6 * w);
+  }
+  return cw;
+}
+// the 64-slot words the slots [s0, s0 + n) lie in
+__device__ __forceinline__ u32 mask_words(int s0, int n) { return (1u << (s0 >> 6)) | (1u << ((s0 + n - 1) >> 6)); }
 
 // the part of the row summary the compactness sums need: used blocks, lambda_min, lambda_max
 template <int W>
@@ -844,7 +911,7 @@ __device__ __forceinline__ void row_occ_fb(const u64 (&a)[W], int S, int& occ, i
 // The compactness sums change by (summary after the provision - before) and (final - after the provision), the latter
 // also into rel_sums.
 template <int ENV, int W>
-__device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M, const Item it, int second, Prof& prof) {
+__device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M, const Item it, int second, Prof& prof, bool early_ls = false) {
   const int E = P.E, S = P.S;
   const i64 env = (i64)(u32)it.a.x;
   const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
@@ -858,14 +925,20 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   double* ls = wm_ls(P, M, env) + 4 * link;
   const double now = M.clk ? M.clk[2 * (env - M.clk_env0) + 1] : __longlong_as_double((i64)wm_scal(P, M, env)[SC_NOW]);
   const double now_prov = M.clk ? M.clk[2 * (env - M.clk_env0)] : __longlong_as_double((i64)wm_scal(P, M, env)[SC_NOWA]);
+  // the link's 32-byte statistics record is requested before the row summary (a global round trip hidden behind it); a B
+  // lane reads it in round 1 below, after the A lane's store
+  double2 ls01 = make_double2(0.0, 0.0), ls23 = make_double2(0.0, 0.0);
+  if (early_ls && !role_b) { ls01 = *(const double2*)ls; ls23 = *(const double2*)(ls + 2); }
   u64 a[W];
 #pragma unroll
   for (int w = 0; w < W; w++) a[w] = row[w];
   ORL_PROFR(3);
   // the mask whose statistics this lane evaluates: B the first release (mask 1, after applying the provision), else mask 0
   const int kf = role_b ? 1 : 0;
+  u32 touched = 0u;  // words of the row this lane changes before it summarises it (row_stat_lane's cache)
   if (role_b) {
     const int s0 = (int)(it.a.y & 0x1ff), n = (int)((it.a.y >> 9) & 0x7f);
+    touched = mask_words(s0, n);
 #pragma unroll
     for (int w = 0; w < W; w++) a[w] &= ~word_range(s0 - 64 * w, s0 + n - 64 * w);
   }
@@ -875,6 +948,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   {
     const u64 mw = it.a.y >> (16 * kf);
     const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
+    touched |= mask_words(s0, n);
 #pragma unroll
     for (int w = 0; w < W; w++) {
       const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
@@ -884,8 +958,16 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   ORL_PROFR(4);
   RowStat after;
   int max_empty = 0, edge = 0;
+  u32* icw = (ENV != ENV_RWA && M.ic0) ? M.ic0 + (env - M.cenv0) * E + link : nullptr;
   if (ENV != ENV_RWA) {
-    row_stat_lane<W>(a, S, after, max_empty, edge);
+    if (W >= 3 && W <= 5 && icw) row_stat_lane<W, (W >= 3 && W <= 5)>(a, S, after, max_empty, edge, icw, touched, !role_a);
+    else row_stat_lane<W>(a, S, after, max_empty, edge);
+#if defined(ORL_DBL) && ORL_DBL == 1
+    { u64 a2[W];
+#pragma unroll
+      for (int w = 0; w < W; w++) { a2[w] = a[w]; asm volatile("" : "+v"(a2[w])); }
+      RowStat af2; int me2 = 0, ed2 = 0; row_stat_lane<W>(a2, S, af2, me2, ed2); if (me2 != max_empty) max_empty = -1; }
+#endif
   } else {
     int f = 0;
 #pragma unroll
@@ -910,7 +992,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   for (int round = 0; round < 2; round++) {
     if (round == 1 && !any_b) break;
     if ((round == 1) == role_b) {
-      const double2 ls01 = *(const double2*)ls, ls23 = *(const double2*)(ls + 2);  // one 32-byte record
+      if (role_b || !early_ls) { ls01 = *(const double2*)ls; ls23 = *(const double2*)(ls + 2); }
       double last_update = ls23.y;
       double util = ls01.x, frag = ls01.y, comp = ls23.x;
       if (clock > 0) {  // the first touch of the link at this clock value
@@ -936,13 +1018,21 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   ORL_PROFR(6);
   int occL = after.occ, fbL = after.fb;
   if (!role_a && nmask > kf + 1) {  // the masks of the further releases, then what the row contributes in the end
+    u32 later = 0u;
     for (int k = kf + 1; k < nmask; k++) {
       const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
       const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
+      later |= mask_words(s0, n);
 #pragma unroll
       for (int w = 0; w < W; w++) a[w] |= word_range(s0 - 64 * w, s0 + n - 64 * w);
     }
     if (ENV != ENV_RWA) row_occ_fb<W>(a, S, occL, fbL);
+    if (icw) {  // the cache word describes the row before these masks: their words become unknown
+      u32 cw = *icw;
+#pragma unroll
+      for (int w = 0; w < (W <= 5 ? W : 0); w++) cw |= ((later >> w) & 1u) ? (63u << (6 * w)) : 0u;
+      *icw = cw;
+    }
   }
   if (ENV != ENV_RWA) {
     // this lane's part of the row's contribution to the compactness sums; releases also go into rel_sums

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_step_a2(DevParams P, int pol, int parit
   sp::Prof prof;
   const sp::Wmem M = sp::wmem_global(P);
   sp::CtrlOpts O;
-  O.persistent = false; O.write_io = true; O.trusted = false; O.emit_queue = true;
+  O.persistent = false; O.write_io = true; O.trusted = false; O.emit_queue = true; O.prefetch = false;
   ORL_PROFA_BEGIN();
   if (FUSED_POLICY) {
     const i64 env0 = env - ((lane >> 3));  // first env of this wavefront
@@ -222,11 +222,11 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 // A wavefront in which an env's releases did not fit the item form (one env-step in 10^7) leaves the loop after that step's
 // row phase; k_rel_tail follows every launch, and the wavefront resumes from its own step count in the next launch.
 struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (all multiples of 16)
-  int tab, tally, tw, list, clk, misc, bm, ls, cs, sc, total;
+  int tab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, total;
 };
 // state: 0 = only the per-step tables, 1 = + slot maps, per-core sums and env records, 2 = + link statistics;
-// compact: 16-byte sink entries (single-core families, state >= 1)
-__host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, int cs_words, int state, bool compact) {
+// compact: 16-byte sink entries (single-core families, state >= 1); inner: the per-word longest-run cache of every row
+__host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, int C, int state, bool compact, bool inner) {
   PersistLds L;
   int o = 0;
   L.tab = o; o += 8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry));
@@ -236,19 +236,26 @@ __host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, in
   L.clk = o; if (state == 0) o += 8 * 2 * 8;  // (state >= 1: the row phase reads the clocks from the record)
   L.misc = o; o += 16;
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
-  L.cs = o; if (state >= 1) o += (8 * cs_words * 4 + 15) & ~15;
+  L.csw = (4 * C + 3) & ~3;  // sums + their release part, ints per env
+  L.cs = o; if (state >= 1) o += 8 * L.csw * 4;
   L.sc = o; if (state >= 1) o += 8 * ORL_SCAL_WORDS * 8;
+  L.ic = o; if (state >= 1 && inner) o += (8 * E * 4 + 15) & ~15;
   L.ls = o; if (state >= 2) o += 8 * E * 32;
   L.total = o;
   return L;
 }
 template <int ENV, int LDS> struct PersistCompact { static constexpr bool value = LDS >= 1 && ENV != ENV_RMCSA; };
 static inline bool persist_compact(int env_type, int state) { return state >= 1 && env_type != ENV_RMCSA; }
+// (rows of one or two words: searching both costs less than the bookkeeping — cfg3 measured 1.20e9 without, 1.01e9 with)
+template <int ENV, int W, int LDS> struct PersistInner { static constexpr bool value = LDS >= 1 && W >= 3 && W <= 5 && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA); };
+static inline bool persist_inner(int env_type, int W, int state) { return state >= 1 && W >= 3 && W <= 5 && (env_type == ENV_RMSA || env_type == ENV_DEEPRMSA); }
 // LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics
-template <int ENV, int W, int LDS>
+// PF: early requests of the Mersenne-Twister window and the link statistics (more live registers: the 3-wave forms)
+template <int ENV, int W, int LDS, bool PF>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
-  const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.cs_words, LDS, CP);
+  constexpr bool IC = PersistInner<ENV, W, LDS>::value;
+  const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.C, LDS, CP, IC);
   typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
@@ -276,10 +283,18 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     M.cs0 = (int*)(orl_lds_raw + L.cs);
     M.cenv0 = env0;
     M.cs_lds = true;
+    M.cs_stride = L.csw;
     if (step < target) {
-      const int4* gc = (const int4*)(P.core_sums + env0 * P.cs_words);
-      int4* lc = (int4*)M.cs0;
-      for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) lc[i] = gc[i];
+      const int q = L.csw / 4;  // 16-byte pieces per env
+      for (int i = lane; i < nenv * q; i += 64)
+        ((int4*)M.cs0)[i] = ((const int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q];
+    }
+    if (IC) {
+      M.ic0 = (u32*)(orl_lds_raw + L.ic);
+      if (step < target) {
+        __syncthreads();  // the rows are in LDS
+        for (int i = lane; i < nenv * P.E; i += 64) M.ic0[i] = sp::row_inner_cache<W>(M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W);
+      }
     }
     M.sc0 = (u64*)(orl_lds_raw + L.sc);
     M.scenv0 = env0;
@@ -318,11 +333,18 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     O.write_io = (step + 1 == target);  // what the host can see after the run: the last step's action / reward / done
     O.trusted = true;
     O.emit_queue = false;
+    O.prefetch = PF;
     int done_i = 0;
     {
       int a[4];
       policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
                           (int)((desc >> 48) & 0xffu), lane_i, pol, valid_i ? P.path_col[env_i] : 0, a);
+#if defined(ORL_DBL) && ORL_DBL == 3
+      { int a2[4]; int l2 = lane_i; asm volatile("" : "+v"(l2));
+        policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
+                            (int)((desc >> 48) & 0xffu), l2, pol, valid_i ? P.path_col[env_i] : 0, a2);
+        if (a2[1] != a[1]) a[0] = -1; }
+#endif
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
       desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
@@ -337,7 +359,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
         const int el = (code >> 8) & 7, link = code & 0xff, second = code >> 15;
         const sp::Item it = sp::item_from_sink(env0 + el, link, s_tab[P.E * el + link]);
         if (ENV == ENV_RMCSA) { if (!second) sp::row_item_lane<ENV, W>(P, M, it, prof); }
-        else sp::row_item_lane1<ENV, W>(P, M, it, second, prof);
+        else sp::row_item_lane1<ENV, W>(P, M, it, second, prof, PF);
       }
       ORL_PROFA(13);
     }
@@ -355,9 +377,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     ulonglong2* g = (ulonglong2*)(P.bitmap + env0 * P.bm_words);
     const ulonglong2* l = (const ulonglong2*)M.bm0;
     for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) g[i] = l[i];
-    int4* gc = (int4*)(P.core_sums + env0 * P.cs_words);
-    const int4* lc = (const int4*)M.cs0;
-    for (int i = lane; i < nenv * (P.cs_words / 4); i += 64) gc[i] = lc[i];
+    const int q = L.csw / 4;
+    for (int i = lane; i < nenv * q; i += 64)
+      ((int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q] = ((const int4*)M.cs0)[i];
     ulonglong2* gr = (ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
     const ulonglong2* lr = (const ulonglong2*)M.sc0;
     for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) gr[i] = lr[i];
@@ -383,7 +405,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 template <int ENV, int W, int LDS, int WAVES>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
-  persist_body<ENV, W, LDS>(P, pol, target, wg_step, n_unfinished);
+  persist_body<ENV, W, LDS, (WAVES <= 3)>(P, pol, target, wg_step, n_unfinished);
 }
 
 // serial tail, one small workgroup per launch: the envs whose releases of this step did not fit the item form (about
@@ -555,7 +577,7 @@ template <int W> void obs(orl_batch* b, int with_terminal) {
 struct PersistForm { int lds, waves; };
 static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}};
 static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
-  const int maps = persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, 1, persist_compact(VP.env_type, 1)).total;
+  const int maps = persist_lds_layout(VP.E, VP.bm_words, VP.C, 1, persist_compact(VP.env_type, 1), persist_inner(VP.env_type, ORL_W, 1)).total;
   const int lim4 = (160 * 1024) / 16, lim3 = (160 * 1024) / 12;
   // Measured on MI355X, env-steps/s (form 0 / 2 / 3 / 4 / 5 = global 4 waves / full LDS 2 / full LDS 3 / maps 3 / maps 4):
   //   cfg2 65 536 envs: 8.0e8 / 6.5e8 / - / 7.8e8 / - (does not fit); HBM traffic per batched step 206 MB / - / - / 114 MB,
@@ -572,9 +594,9 @@ static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
 #ifndef ORL_ALT_IMPLS
     built = built && f != 2 && f != 3;
 #endif
-    if (built && persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[f].lds, persist_compact(VP.env_type, kPersistForms[f].lds)).total <= 64 * 1024) v = f;
+    if (built && persist_lds_layout(VP.E, VP.bm_words, VP.C, kPersistForms[f].lds, persist_compact(VP.env_type, kPersistForms[f].lds), persist_inner(VP.env_type, ORL_W, kPersistForms[f].lds)).total <= 64 * 1024) v = f;
   }
-  *lds_bytes = (size_t)persist_lds_layout(VP.E, VP.bm_words, VP.cs_words, kPersistForms[v].lds, persist_compact(VP.env_type, kPersistForms[v].lds)).total;
+  *lds_bytes = (size_t)persist_lds_layout(VP.E, VP.bm_words, VP.C, kPersistForms[v].lds, persist_compact(VP.env_type, kPersistForms[v].lds), persist_inner(VP.env_type, ORL_W, kPersistForms[v].lds)).total;
   return v;
 }
 template <int W> int persist_uses_lds(orl_batch* b) {
