@@ -48,6 +48,10 @@ struct EnvG {
   u64* ev_info;
   double* soon_t;
   u32* soon_i;
+  // persistent kernel: this lane's soon-list entries (gl + 8k) live in registers for the whole launch
+  bool sr_on;
+  double sr_t[ORL_SOON_PER_LANE];
+  int sr_i[ORL_SOON_PER_LANE];
   u32* mt;
   u64* scal;
 };
@@ -87,6 +91,7 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env, u
   e.ev_info = P.ev_info + env * P.ev_cap;
   e.soon_t = P.soon_t + env * ORL_SOON;
   e.soon_i = P.soon_i + env * ORL_SOON;
+  e.sr_on = false;
   e.mt = P.mt + env * 624;
 }
 __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) { env_load(P, e, env, P.scal + env * ORL_SCAL_WORDS); }
@@ -245,6 +250,18 @@ __device__ __forceinline__ void free_push(EnvG& e, int gl, int slot) {
 }
 
 #define ORL_DBG(k, v) do { } while (0)
+// entry `slot` of the env's soon list (owned by lane slot % 8): registers or memory
+__device__ __forceinline__ void soon_set(EnvG& e, int gl, int slot, double t, int idx) {
+  if (gl != (slot & 7)) return;
+  if (e.sr_on) {
+#pragma unroll
+    for (int k = 0; k < ORL_SOON_PER_LANE; k++)
+      if ((slot >> 3) == k) { e.sr_t[k] = t; e.sr_i[k] = idx; }
+  } else {
+    e.soon_t[slot] = t;
+    e.soon_i[slot] = (u32)idx;
+  }
+}
 // ---- pending releases: slot i belongs to lane i % 8 -------------------------------------------------
 __device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
   const int gl = lane & 7;
@@ -284,7 +301,7 @@ __device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, do
     // invariant of the soon list: it holds EVERY pending release earlier than t_soon
     double a[ORL_SOON_PER_LANE];
 #pragma unroll
-    for (int k = 0; k < ORL_SOON_PER_LANE; k++) a[k] = e.soon_t[gl + 8 * k];
+    for (int k = 0; k < ORL_SOON_PER_LANE; k++) a[k] = e.sr_on ? e.sr_t[k] : e.soon_t[gl + 8 * k];
     int slot = -1;
 #pragma unroll
     for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
@@ -292,7 +309,7 @@ __device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, do
       if (f && slot < 0) slot = 8 * k + (int)__builtin_ctz(f);
     }
     if (slot >= 0) {
-      if (gl == (slot & 7)) { e.soon_t[slot] = t; e.soon_i[slot] = (u32)idx; }
+      soon_set(e, gl, slot, t, idx);
     } else {
       // full: keep the earliest ORL_SOON; the horizon moves down to the latest of what was there
       double m = a[0];
@@ -304,7 +321,7 @@ __device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, do
       ORL_MAX_STEP(ORL_DPP_XOR1) ORL_MAX_STEP(ORL_DPP_XOR2) ORL_MAX_STEP(ORL_DPP_HALF_MIRROR)
 #undef ORL_MAX_STEP
       if (t < m) {
-        if (gl == (ms & 7)) { e.soon_t[ms] = t; e.soon_i[ms] = (u32)idx; }
+        soon_set(e, gl, ms, t, idx);
         e.t_soon = m;
       } else {
         e.t_soon = t;

@@ -252,7 +252,7 @@ template <int ENV, int W, bool CP = false>
 __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
                                       const int4* given, u32* s_tally, typename SinkEntryOf<CP>::type* s_tab, int parity,
                                       int* s_deferred, int* done_out, unsigned short* s_list = nullptr, u32* s_list_n = nullptr,
-                                      int tw = 32) {
+                                      int tw = 32, SoonRegs* carried = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   if (!O.persistent && blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
   u64 desc_out = 0ull;
@@ -276,6 +276,11 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     EnvG e;
     g8::env_load(P, e, env, wm_scal(P, M, env));
     // the Mersenne-Twister window the next service draws from: requested now, used after the provision
+    if (carried) {  // persistent kernel: the soon list stays in registers from step to step
+      e.sr_on = true;
+#pragma unroll
+      for (int k = 0; k < ORL_SOON_PER_LANE; k++) { e.sr_t[k] = carried->t[k]; e.sr_i[k] = carried->i[k]; }
+    }
     g8::RngG rng;
     if (O.prefetch) g8::rng_fill(e, rng, gl);
     e.bm = wm_bm(P, M, env);
@@ -451,11 +456,14 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < ORL_SOON_PER_LANE; k++)
-          if ((soon.dirty >> k) & 1) {
+        for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+          if (e.sr_on) {
+            if (soon.dirty) { e.sr_t[k] = soon.t[k]; e.sr_i[k] = soon.i[k]; }  // (dirty == 0: returned untouched)
+          } else if ((soon.dirty >> k) & 1) {
             e.soon_t[gl + 8 * k] = soon.t[k];
             e.soon_i[gl + 8 * k] = (u32)soon.i[k];
           }
+        }
         if (gl == 0) {
           e.scal[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
           e.scal[SC_TSOON] = (u64)__double_as_longlong(e.t_soon);
@@ -465,6 +473,10 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
           e.scal[SC_HINT] = pack2(e.nfree, 0);
         }
       }
+    }
+    if (carried) {
+#pragma unroll
+      for (int k = 0; k < ORL_SOON_PER_LANE; k++) { carried->t[k] = e.sr_t[k]; carried->i[k] = e.sr_i[k]; }
     }
   }
   ORL_PROFA(11);
@@ -547,7 +559,10 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
   double st[NS];
   int si[NS];
 #pragma unroll
-  for (int k = 0; k < NS; k++) { st[k] = e.soon_t[gl + 8 * k]; si[k] = (int)e.soon_i[gl + 8 * k]; }
+  for (int k = 0; k < NS; k++) {
+    st[k] = e.sr_on ? e.sr_t[k] : e.soon_t[gl + 8 * k];
+    si[k] = e.sr_on ? e.sr_i[k] : (int)e.soon_i[gl + 8 * k];
+  }
   int dirty = 0;  // which of this lane's entries changed (only those go back to memory: a release touches one)
   ORL_PROF(4);
   for (int round = 0; round < 64; round++) {

@@ -255,6 +255,7 @@ template <int ENV, int W, int LDS, bool PF>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
   constexpr bool IC = PersistInner<ENV, W, LDS>::value;
+  constexpr bool SR = PF;  // soon list in registers: the forms with registers to spare
   const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.C, LDS, CP, IC);
   typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
@@ -316,6 +317,14 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   if (threadIdx.x == 0) s_deferred[0] = s_deferred[1] = 0;
   const bool valid = env < P.B;
   u64 desc = valid ? P.svc_desc[env] : 0ull;  // carried from step to step in registers
+  sp::SoonRegs soon_c;  // ... and so are this lane's entries of the env's soon list (LDS forms)
+  soon_c.dirty = 0;
+#pragma unroll
+  for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+    const bool ld = SR && valid && step < target;
+    soon_c.t[k] = ld ? P.soon_t[env * ORL_SOON + (lane & 7) + 8 * k] : __builtin_inf();
+    soon_c.i[k] = ld ? (int)P.soon_i[env * ORL_SOON + (lane & 7) + 8 * k] : 0;
+  }
   const int first_step = step;
   ORL_PROF_BEGIN();
   while (step < target) {
@@ -348,7 +357,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
       desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
-                                    s_list, s_list_n, L.tw);
+                                    s_list, s_list_n, L.tw, SR ? &soon_c : nullptr);
     }
     __syncthreads();  // sink table + item list, clocks, env records
     {
@@ -388,6 +397,13 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     double2* gs = (double2*)(P.lstat + env0 * 4 * P.E);
     const double2* ls = (const double2*)M.ls0;
     for (int i = lane; i < nenv * 2 * P.E; i += 64) gs[i] = ls[i];
+  }
+  if (SR && step > first_step && valid) {
+#pragma unroll
+    for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+      P.soon_t[env * ORL_SOON + (lane & 7) + 8 * k] = soon_c.t[k];
+      P.soon_i[env * ORL_SOON + (lane & 7) + 8 * k] = (u32)soon_c.i[k];
+    }
   }
   if (step > first_step && step < target && valid) {
     // leaving early (deferred releases): the descriptor the next launch / the stand-alone scan reads; action, reward and done
