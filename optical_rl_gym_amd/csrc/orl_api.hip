@@ -413,6 +413,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   P.rand_bits = 0;
   for (int v = P.rand_n; v > 0; v >>= 1) P.rand_bits++;
   P.lambda_a = c->lambda_arrival;
+  P.pf_window = 4.0 / c->lambda_arrival;
   P.lambda_h = c->lambda_holding;
   P.B = n_envs;
   int cap = c->event_capacity;

@@ -75,6 +75,7 @@ struct DevParams {
   int bit_rate_mode, br_lo, n_br, rand_n, rand_bits;
   int ev_cap, bm_words, n_info, obs_dim, lds_bytes, cs_words;
   double lambda_a, lambda_h;
+  double pf_window;  // releases due within this time of the clock are worth an early request of their info word (4 mean inter-arrival times)
   i64 B;
   // shared, read-only (L2-resident) topology / traffic tables
   const int* n_paths;               // [N*N]

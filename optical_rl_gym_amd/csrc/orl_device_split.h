@@ -239,7 +239,8 @@ struct CtrlOpts {
 };
 template <int ENV, int W, bool CP>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
-                                             int extra = 0, int pushed_idx = -1, u64 pushed_info = 0ull);
+                                             int extra = 0, int pushed_idx = -1, u64 pushed_info = 0ull, int pre_idx = -1,
+                                             u64 pre_info = 0ull);
 
 // The provision and the releases of the step go into ONE queue as mixed items (per link: the provision mask first, then the
 // release masks) and one row phase applies them.  The network-compactness average, which needs the sums between the
@@ -280,6 +281,19 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       e.sr_on = true;
 #pragma unroll
       for (int k = 0; k < ORL_SOON_PER_LANE; k++) { e.sr_t[k] = carried->t[k]; e.sr_i[k] = carried->i[k]; }
+    }
+    // the info word of this lane's earliest list entry, if it may come due in this step: requested now, the release
+    // detection at the end of the phase finds it in a register
+    int pre_idx = -1;
+    u64 pre_info = 0ull;
+    if (carried && O.prefetch) {
+      double pt = e.sr_t[0];
+      int pi = e.sr_i[0];
+#pragma unroll
+      for (int k = 1; k < ORL_SOON_PER_LANE; k++)
+        if (e.sr_t[k] < pt || (e.sr_t[k] == pt && e.sr_i[k] < pi)) { pt = e.sr_t[k]; pi = e.sr_i[k]; }
+      // (t_soon == -inf: the list is stale — after a reset or the serial tail — and its entries mean nothing)
+      if (pt <= e.now + P.pf_window && e.t_soon > -__builtin_inf() && (u32)pi < (u32)P.ev_cap) { pre_idx = pi; pre_info = e.ev_info[pi]; }
     }
     g8::RngG rng;
     if (O.prefetch) g8::rng_fill(e, rng, gl);
@@ -442,7 +456,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       // has gone back already (so that only the handful of release-related fields stays in registers through the
       // detection); those fields are written again below when the detection changed them.
       SoonRegs soon;
-      release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info);
+      release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
       ORL_PROFA(10);
       if (sink.deferred) {
         // more releases meet on one link than an item holds masks for: the release state stays as stored and the
@@ -543,10 +557,11 @@ __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 en
 // ---------------------------------------------------------------------------------------------------------------
 // The list is returned in registers: the caller writes it back (when dirty) after everything that still loads.
 template <int ENV, int W, bool CP>
+// `pre_idx / pre_info`: a release slot of this LANE's list whose info word the caller requested at the start of the step.
 // `extra`: masks this step already put on links (its provision, two-kernel pipeline); `pushed_idx / pushed_info`: the
 // release slot the same kernel has just written — its info word is taken from registers, not re-read through memory.
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
-                                             int extra, int pushed_idx, u64 pushed_info) {
+                                             int extra, int pushed_idx, u64 pushed_info, int pre_idx, u64 pre_info) {
   constexpr int NS = ORL_SOON_PER_LANE;
   out.dirty = 0;
   // The rebuild scan costs the wavefront the same whether one of its 8 envs runs it or all of them (the other lanes
@@ -713,7 +728,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
     // info word + path record of this lane's candidate, requested by all lanes together
     u64 inf0 = 0;
     PathRec rc0 = PathRec();
-    if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
+    if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : ((ci == pre_idx) ? pre_info : e.ev_info[ci]); rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
     ORL_PROF(6);
     for (;;) {
       double bt = ct;
@@ -739,7 +754,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
         }
         ck = nk;
-        if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : e.ev_info[ci]; rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
+        if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : ((ci == pre_idx) ? pre_info : e.ev_info[ci]); rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
       }
       const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
       const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
