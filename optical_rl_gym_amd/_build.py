@@ -20,10 +20,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include", "orl.h")
 ROW_WIDTHS = (1, 2, 5, 8)
 VARIANTS = {"default": ("liborlgpu.so", []), "alt": ("liborlgpu_alt.so", ["-DORL_ALT_IMPLS"]),
-            "timing": ("liborlgpu_timing.so", ["-DORL_TIMING=1"]),
-            "exp": ("liborlgpu_exp.so", []),
-            "dbl1": ("liborlgpu_dbl1.so", ["-DORL_DBL=1"]), "dbl2": ("liborlgpu_dbl2.so", ["-DORL_DBL=2"]),
-            "dbl3": ("liborlgpu_dbl3.so", ["-DORL_DBL=3"]), "dbl4": ("liborlgpu_dbl4.so", ["-DORL_DBL=4"])}  # A/B experiments: built with ORL_HIPCC_EXTRA="-D..." (same value when loading)  # diagnostic: per-phase shader-clock profile (tools/phase_prof.py)
+            "timing": ("liborlgpu_timing.so", ["-DORL_TIMING=1"]),  # diagnostic: per-phase shader-clock profile (tools/phase_prof.py)
+            "exp": ("liborlgpu_exp.so", [])}  # A/B experiments: built with ORL_HIPCC_EXTRA="-D..." (same value when loading)
 LIB = os.path.join(HERE, VARIANTS["default"][0])
 
 # -ffp-contract=off: float64 statistics and the log restatement must round exactly like the reference

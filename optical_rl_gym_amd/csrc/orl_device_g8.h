@@ -414,10 +414,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
   // in one pass (same operations on the same operands as two calls one after the other)
   const double u1 = rng_random(e, r, lane), u2 = rng_random(e, r, lane);
   const bool second = gl >= 4;
-  double q = -orl_log(1.0 - (second ? u2 : u1)) / (second ? P.lambda_h : P.lambda_a);
-#if defined(ORL_DBL) && ORL_DBL == 2
-  { double uu = second ? u2 : u1; asm volatile("" : "+v"(uu)); const double q2 = -orl_log(1.0 - uu) / (second ? P.lambda_h : P.lambda_a); if (q2 != q) q = 0.0; }
-#endif
+  const double q = -orl_log(1.0 - (second ? u2 : u1)) / (second ? P.lambda_h : P.lambda_a);
   double at = e.now + gget(q, 0, lane);
   e.now = at;
   double ht = gget(q, 4, lane);

@@ -992,12 +992,6 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   if (ENV != ENV_RWA) {
     if (W >= 3 && W <= 5 && icw) row_stat_lane<W, (W >= 3 && W <= 5)>(a, S, after, max_empty, edge, icw, touched, !role_a);
     else row_stat_lane<W>(a, S, after, max_empty, edge);
-#if defined(ORL_DBL) && ORL_DBL == 1
-    { u64 a2[W];
-#pragma unroll
-      for (int w = 0; w < W; w++) { a2[w] = a[w]; asm volatile("" : "+v"(a2[w])); }
-      RowStat af2; int me2 = 0, ed2 = 0; row_stat_lane<W>(a2, S, af2, me2, ed2); if (me2 != max_empty) max_empty = -1; }
-#endif
   } else {
     int f = 0;
 #pragma unroll

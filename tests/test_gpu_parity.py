@@ -325,6 +325,32 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
     chk(0, "oracle net_stats", ref[10], ora.net_stats(0))
 
 
+def test_services_wider_than_the_row_items_use_the_per_env_kernel():
+    """The row items of the persistent kernel carry a service as (first slot: 9 bits | slots: 6 bits); the library accepts
+    services of up to 64 slots: a configuration whose largest service needs exactly 64 runs on the per-env kernel
+    (orl_api.hip, pipeline_ok) — with the reference's results, checked against the oracle."""
+    import optical_rl_gym_amd as orl
+    from oracle.oracle import OracleBatch
+
+    kw = dict(load=60.0, mean_service_holding_time=10.0, episode_length=40, num_spectrum_resources=320,
+              bit_rate_selection="discrete", bit_rates=(100, 780), bit_rate_probabilities=(0.7, 0.3))  # 780 Gb/s on BPSK: 63 + 1 slots
+    seeds = [3 + 7 * i for i in range(64)]
+    env = orl.make("RMSA", topology="nsfnet_chen", num_envs=64, seeds=seeds, **kw)
+    st = env.run("SAP_FF", 300)
+    assert "k_persist" not in [n for n, _ in st.kernels()]
+    ora = OracleBatch("RMSA", "nsfnet_chen", seeds[:6], **kw)
+    ora.run("SAP_FF", 300)
+    chk = _exact("wide services")
+    chk(0, "counters", env.counters()[:6], ora.counters())
+    chk(0, "services", env.services()[:6], ora.services())
+    for i in range(6):
+        chk(i, "slots", env.slots(i), ora.slots(i))
+        chk(i, "link_stats", env.link_stats(i), ora.link_stats(i))
+        chk(i, "net_stats", env.net_stats(i), ora.net_stats(i))
+    assert env.counters()[:, 1].sum() > 0 and not env.flags().any()
+    env.close()
+
+
 def test_run_reports_every_kernel_of_the_step(monkeypatch):
     import optical_rl_gym_amd as orl
     from bench import WORKLOADS
