@@ -460,10 +460,13 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       ORL_PROFA(10);
       if (sink.deferred) {
         // more releases meet on one link than an item holds masks for: the release state stays as stored and the
-        // serial tail (k_rel_tail) releases them in place after this step's items
+        // serial path (rel_serial: k_rel_tail, or the start of the persistent kernel's next launch) releases them in
+        // place after this step's items
         if (gl == 0) {
-          u32* dq = P.q_def + (size_t)parity * P.q_def_stride;
-          dq[16 + atomicAdd(dq, 1u)] = (u32)env;
+          if (!O.persistent) {  // two-kernel form: the list k_rel_tail works through
+            u32* dq = P.q_def + (size_t)parity * P.q_def_stride;
+            dq[16 + atomicAdd(dq, 1u)] = (u32)env;
+          }
           if (s_deferred) *s_deferred = 1;  // persistent kernel: this workgroup stops after the row phase
           e.scal[SC_ACC] = acc_after | (1ull << 16);
           e.scal[SC_HINT] = pack2(e.nfree, 0);  // a rebuild may have rewritten the free-slot stack

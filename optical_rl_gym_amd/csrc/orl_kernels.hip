@@ -268,6 +268,25 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   const int nenv = (int)(P.B - env0 < 8 ? P.B - env0 : 8);
   int step = wg_step[blockIdx.x];
   sp::Prof prof;
+  {
+    // An env whose releases did not fit the item form in the last step of the previous launch (flag in its record; the
+    // wavefront left its loop right after that step's row phase): they are released in place now, by the wavefront that owns
+    // the env, before anything of this launch reads the state.  (A kernel of its own after every launch — round 1, and
+    // the two-kernel form still — had to wait for a free CU while the other half's launch filled the GPU: 0.5-1 ms on the
+    // stream between two 3 ms launches, rocprofv3 kernel trace r2n.)
+    const bool pend = (env < P.B) && ((P.scal[env * ORL_SCAL_WORDS + SC_ACC] >> 16) & 1ull) != 0ull;
+    if (__ballot(pend) != 0ull) {
+      if (pend) {
+        sp::rel_serial<ENV, W>(P, env, lane);
+        if (ENV == ENV_DEEPRMSA && P.obs_dim) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          obs8_env<W>(P, P.bitmap + env * P.bm_words, P.scal + env * ORL_SCAL_WORDS, env, lane, P.done[env]);
+        }
+      }
+      __threadfence();
+      __syncthreads();
+    }
+  }
   sp::Wmem M = sp::wmem_global(P);
   if (LDS == 0) {
     M.clk = (double*)(orl_lds_raw + L.clk);
@@ -326,6 +345,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     soon_c.i[k] = ld ? (int)P.soon_i[env * ORL_SOON + (lane & 7) + 8 * k] : 0;
   }
   const int first_step = step;
+  bool left_pending = false;  // the loop ended on a step whose releases are still to be done
   ORL_PROF_BEGIN();
   while (step < target) {
     __syncthreads();  // (one wavefront: an ordering point) the previous row phase's writes are done
@@ -372,7 +392,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       if (valid_i) obs8_env<W>(P, sp::wm_bm(P, M, env_i), sp::wm_scal(P, M, env_i), env_i, lane_i, done_i);
     }
     step++;
-    if (deferred) break;
+    if (deferred) { left_pending = true; break; }
   }
   ORL_PROF_END();
   if (LDS >= 1 && step > first_step) {
@@ -406,7 +426,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   }
   if (threadIdx.x == 0) {
     wg_step[blockIdx.x] = step;
-    if (step < target) atomicAdd(n_unfinished, 1u);
+    if (step < target || left_pending) atomicAdd(n_unfinished, 1u);  // (pending releases: the next launch starts with them)
   }
 }
 // Register budgets: WAVES waves/SIMD -> 512 / WAVES VGPRs.  Global state: 4 (128 VGPRs) for NSFNET-sized RMSA / RWA /
@@ -639,7 +659,7 @@ static size_t persist_tuned_lds(int v, size_t lds) {
 #define ORL_FULL_LDS_CASES(E_)
 #endif
 template <int W> void persist(orl_batch* b, const DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished) {
-  dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64), blk_tail(256);
+  dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64);
   size_t lds_a = 0;
   const int v = persist_variant(VP, &lds_a);
   lds_a = persist_tuned_lds(v, lds_a);
@@ -655,8 +675,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP, hipStream_t st,
     ORL_FULL_LDS_CASES(E_)                                                                                                   \
     case 4: LAUNCH(E_, 1, 3); break;                                                                                         \
     default: LAUNCH(E_, 1, 4); break;                                                                                        \
-  }                                                                                                                          \
-  hipLaunchKernelGGL((k_rel_tail<E_, W>), dim3(1), blk_tail, 0, st, VP, 0);
+  }
   ORL_FOR_ENV(b, PER_ENV)
 #undef PER_ENV
 #undef LAUNCH
