@@ -6,7 +6,8 @@
 //   k_step      host-driven step(): apply action, statistics, reward/info, next service, observation   one wavefront per env
 //   k_persist   device-resident loop: one wavefront owns 8 envs for a whole run and alternates a control phase (slot scan,
 //               validation, counters, next service, due releases -> work items) and a row phase (one lane per touched link)
-//   k_rel_tail  the rare envs whose releases of a step did not fit the item form release them in place
+//   k_rel_tail  two-kernel test form: the rare envs whose releases of a step did not fit the item form release them in place
+//               (k_persist does that itself at the start of the owning wavefront's next launch)
 //   k_obs8/k_obs DeepRMSA observation of the pending service
 // Launchers (orl_launch::*<W>) are explicitly instantiated at the end; orl_api.hip dispatches on the batch's W.
 #include <hip/hip_runtime.h>
@@ -215,12 +216,13 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 // Envs never interact, so a wavefront can own its 8 envs for a whole launch (64 steps): control phase -> row phase over the
 // items the wavefront itself just collected (one lane per touched link) -> next step, with no kernel boundary and no
 // grid-wide tail between the phases; the wavefronts of a launch drift out of phase and keep the memory system uniformly busy.
-// LDS = true (small topologies: 8 envs' slot maps + link statistics + per-core sums fit the wavefront's LDS budget): that
-// state is loaded once per launch, every scan / validation / row update of the 64 steps works on LDS, and it is written
-// back at the end — the slot map is read ~14 times and rewritten ~5 times per env-step, none of which reaches memory any
-// more.  Work items never leave LDS either (the sink table is read in place through a dense index list).
+// LDS forms (the 8 envs' slot maps, records and per-core sums fit the wavefront's share of the CU's LDS): that state is
+// loaded once per launch, every scan / validation / row update of the 64 steps works on LDS, and it is written back at the
+// end — the slot map is read ~14 times and rewritten ~5 times per env-step, none of which reaches memory any more.  Work
+// items never leave LDS either (the sink table is read in place through a dense index list).
 // A wavefront in which an env's releases did not fit the item form (one env-step in 10^7) leaves the loop after that step's
-// row phase; k_rel_tail follows every launch, and the wavefront resumes from its own step count in the next launch.
+// row phase and counts as unfinished; at the start of its next launch it releases them in place and resumes from its own
+// step count.
 struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (all multiples of 16)
   int tab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, total;
 };
@@ -609,11 +611,10 @@ static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 
 static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
   const int maps = persist_lds_layout(VP.E, VP.bm_words, VP.C, 1, persist_compact(VP.env_type, 1), persist_inner(VP.env_type, ORL_W, 1)).total;
   const int lim4 = (160 * 1024) / 16, lim3 = (160 * 1024) / 12;
-  // Measured on MI355X, env-steps/s (form 0 / 2 / 3 / 4 / 5 = global 4 waves / full LDS 2 / full LDS 3 / maps 3 / maps 4):
-  //   cfg2 65 536 envs: 8.0e8 / 6.5e8 / - / 7.8e8 / - (does not fit); HBM traffic per batched step 206 MB / - / - / 114 MB,
-  //   L2<->fabric requests 2.63 M / - / - / 1.61 M.  cfg1 32 768: 8.8e8 / - / 7.7e8 / - / 9.5e8;  cfg3 32 768: 8.5e8 / - / 8.2e8 / - / 9.9e8.
-  // The kernel is bound by instruction issue, so residency (waves per SIMD) beats keeping more state in LDS; the slot maps
-  // are the state every phase reads, and keeping them in LDS halves what reaches memory at the same speed.
+  // Measured on MI355X, env-steps/s: cfg2 65 536 envs: form 0 (global state, 4 waves) 8.3e8, form 4 (LDS
+  // state, 3 waves) 1.02e9 — 69 MB of HBM traffic and 0.85 M L2<->fabric requests per batched step against 206 MB / 2.63 M;
+  // cfg1 65 536: form 4 1.13e9, form 5 (LDS state, 4 waves) 1.18e9; cfg3: 1.25e9 / 1.27e9.  Residency is worth ~5 % per
+  // wavefront per CU, so a form is taken only if its window keeps 12 (16) wavefronts on a CU.
   int v;
   if (maps <= lim4) v = 5;
   else if (maps <= lim3) v = 4;
