@@ -277,6 +277,53 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         assert out["two"]["serial"] > 100 and out["two2"]["serial"] > 0 and out["persist"]["serial"] > 100
 
 
+def test_pending_releases_at_the_end_of_a_run(monkeypatch):
+    """A wavefront whose env could not put its releases into items leaves its loop, counts as unfinished, and releases them in
+    place at the start of its next launch — also when that happens on the LAST step of a run (the host relaunches until no
+    wavefront is left).  With one mask per item that is the common case: DeepRMSA runs of 1, 2, 3, 17, 64 and 65 steps leave
+    the state, the observation of the pending service (refreshed after those releases) and the rewards of the per-env
+    kernel, and the first envs equal the oracle."""
+    import optical_rl_gym_amd as orl
+    from oracle.oracle import OracleBatch
+
+    kw = dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=1.0 / 12.0, j=1, episode_length=50,
+              num_spectrum_resources=100)
+    seeds = [17 + 3 * i for i in range(1024)]
+    lengths = (1, 2, 3, 17, 64, 65, 1)
+    out = {}
+    for name, v, masks in (("wave64", "wave64", None), ("persist", "persist", "1"), ("persist_l", "persist_lds", "1"),
+                           ("persist_g", "persist_global", "1")):
+        force_impl(monkeypatch, v)
+        if masks:
+            monkeypatch.setenv("ORL_ITEM_MASKS", masks)
+        else:
+            monkeypatch.delenv("ORL_ITEM_MASKS", raising=False)
+        env = orl.make("DeepRMSA", topology="nsfnet_chen", num_envs=len(seeds), seeds=seeds, **kw)
+        env.run("SAP", 400)
+        rec = []
+        for n in lengths:
+            env.run("SAP", n)
+            stored = env.device_tensor("obs").cpu().numpy().copy()  # what the run's last step (or the release path) wrote
+            chk0 = _exact(name + " stored observation")
+            chk0(n, "obs", stored, env.observation())  # ... equals the observation computed from the state now
+            rec.append((stored, env.counters().copy(), env.services().copy(), env.active().copy(),
+                        env.slots(5).copy(), env.link_stats(5).copy(), env.net_stats(5).copy()))
+        out[name] = rec
+        if masks:
+            assert int(env.lib.orl_batch_debug_serial_count(env._h)) > 100
+        assert not env.flags().any()
+        env.close()
+    chk = _exact("pending releases")
+    for name in ("persist", "persist_l", "persist_g"):
+        for t, (a, b) in enumerate(zip(out[name], out["wave64"])):
+            for k, (x, y) in enumerate(zip(a, b)):
+                chk(t, "%s item %d" % (name, k), x, y)
+    ora = OracleBatch("DeepRMSA", "nsfnet_chen", seeds[:4], **kw)
+    ora.run("SAP", 400 + sum(lengths))
+    chk(0, "oracle observation", out["persist"][-1][0][:4], ora.observation())
+    chk(0, "oracle counters", out["persist"][-1][1][:4], ora.counters())
+
+
 CORNERS = [
     ("RWA", "cost239", "SAP_LF", 3000, dict(load=450.0, mean_service_holding_time=25.0, episode_length=7, num_spectrum_resources=17,
                                             allow_rejection=True)),

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r2m
-for s in 12 13 14 15 16 17; do ORL_LIB_VARIANT=alt timeout 1200 python3 tools/fuzz_cross.py $s 30 > gpurun_out/r2m/fuzz$s.txt 2>&1; tail -1 gpurun_out/r2m/fuzz$s.txt; grep -c "nsfnet_chen.*320" gpurun_out/r2m/fuzz$s.txt; grep -v OK gpurun_out/r2m/fuzz$s.txt | head -5; done
+timeout 900 python -m pytest tests -m gpu -x -q -k "pending_releases or terminal_observation" > gpurun_out/r2m/pytest.txt 2>&1; tail -c 2500 gpurun_out/r2m/pytest.txt
