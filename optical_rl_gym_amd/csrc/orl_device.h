@@ -111,6 +111,7 @@ struct DevParams {
   ulonglong2* q_a;  // [q_cap] mixed items of this step, one region of q_wave slots per control wavefront (8 envs)
   u32* q_cnt_a;     // [ceil(B/8)] items each control wavefront put into its region
   int q_wave;       // item slots per wavefront region
+  int persist_ic;   // persistent kernel: keep the per-row cache of inner free runs in LDS (set per launch by the host)
   int item_masks;   // releases of one step that may meet on one link before the env falls back to the serial tail (<= 8)
   int pipeline2;    // core_sums[2C..4C) accumulates what the current step's releases add to the sums (persistent kernel)
   i64 q_def_stride; // second q_def buffer (the steps of the two-kernel form alternate)

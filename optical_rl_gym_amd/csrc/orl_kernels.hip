@@ -228,13 +228,14 @@ struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (al
 };
 // state: 0 = only the per-step tables, 1 = + slot maps, per-core sums and env records, 2 = + link statistics;
 // compact: 16-byte sink entries (single-core families, state >= 1); inner: the per-word longest-run cache of every row
-__host__ __device__ inline PersistLds persist_lds_layout(int E, int bm_words, int C, int state, bool compact, bool inner) {
+__host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, bool inner) {
   PersistLds L;
   int o = 0;
   L.tab = o; o += 8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry));
   L.tw = (E + 3) >> 2;
   L.tally = o; o += 8 * L.tw * 4;
-  L.list = o; o += ((2 * 8 * E * 2) + 15) & ~15;  // an item may have two entries
+  // one entry per touched link and env, a second one where the step's provision meets a release (at most its hops)
+  L.list = o; o += ((8 * (E + (H < E ? H : E)) * 2) + 15) & ~15;
   L.clk = o; if (state == 0) o += 8 * 2 * 8;  // (state >= 1: the row phase reads the clocks from the record)
   L.misc = o; o += 16;
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
@@ -256,9 +257,9 @@ static inline bool persist_inner(int env_type, int W, int state) { return state 
 template <int ENV, int W, int LDS, bool PF>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
-  constexpr bool IC = PersistInner<ENV, W, LDS>::value;
+  const bool IC = PersistInner<ENV, W, LDS>::value && P.persist_ic != 0;  // (the host decides: only where it costs no wavefront)
   constexpr bool SR = PF;  // soon list in registers: the forms with registers to spare
-  const PersistLds L = persist_lds_layout(P.E, P.bm_words, P.C, LDS, CP, IC);
+  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, LDS, CP, IC);
   typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
@@ -605,42 +606,65 @@ template <int W> void obs(orl_batch* b, int with_terminal) {
 }
 
 // Forms of the persistent kernel: (what lives in LDS, waves per SIMD the registers are budgeted for).  The LDS window decides
-// how many wavefronts a CU holds (160 KiB / window, 4 SIMDs).  Measured on MI355X (cfg2, 65 536 envs): see DESIGN.md 4.3.
+// how many wavefronts a CU holds.  The hardware allocates LDS in pieces of 1 280 bytes (tools/probe/lds_resident.hip,
+// measured on MI355X: 12 workgroups share a CU's 160 KiB up to 12 800 B each, 11 up to 14 080, 16 up to 10 240 —
+// hipOccupancyMaxActiveBlocksPerMultiprocessor says 12 up to 13 648).
 struct PersistForm { int lds, waves; };
 static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}};
-static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
-  const int maps = persist_lds_layout(VP.E, VP.bm_words, VP.C, 1, persist_compact(VP.env_type, 1), persist_inner(VP.env_type, ORL_W, 1)).total;
-  const int lim4 = (160 * 1024) / 16, lim3 = (160 * 1024) / 12;
+static int lds_wgs_per_cu(size_t lds) {
+  if (lds == 0) return 1 << 20;
+  const size_t alloc = (lds + 1279) / 1280 * 1280;
+  return (int)((size_t)(160 * 1024) / alloc);
+}
+struct PersistChoice { int form; size_t lds; bool inner; };
+static size_t persist_window(const DevParams& VP, int state, bool inner) {
+  return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, state, persist_compact(VP.env_type, state), inner).total;
+}
+static PersistChoice persist_choose(const DevParams& VP) {
   // Measured on MI355X, env-steps/s: cfg2 65 536 envs: form 0 (global state, 4 waves) 8.3e8, form 4 (LDS
-  // state, 3 waves) 1.02e9 — 69 MB of HBM traffic and 0.85 M L2<->fabric requests per batched step against 206 MB / 2.63 M;
-  // cfg1 65 536: form 4 1.13e9, form 5 (LDS state, 4 waves) 1.18e9; cfg3: 1.25e9 / 1.27e9.  Residency is worth ~5 % per
-  // wavefront per CU, so a form is taken only if its window keeps 12 (16) wavefronts on a CU.
-  int v;
-  if (maps <= lim4) v = 5;
-  else if (maps <= lim3) v = 4;
-  else v = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0;
+  // state, 3 waves) 1.02e9 at 11 wavefronts per CU with the inner-run cache, 1.05e9 at 12 without it — 69 MB of HBM traffic
+  // and 0.85 M L2<->fabric requests per batched step against 206 MB / 2.63 M; cfg1 65 536: form 4 1.13e9, form 5 (LDS state,
+  // 4 waves) 1.18e9; cfg3: 1.25e9 / 1.27e9.  A wavefront more per CU is worth 3-5 %: the 4-wave form is taken if its
+  // window keeps 16 on a CU, the 3-wave form down to 10, and the inner-run cache (+2.5 %) only where it costs no wavefront.
+  const bool can_inner = persist_inner(VP.env_type, ORL_W, 1);
+  const size_t l0 = persist_window(VP, 1, false), l1 = can_inner ? persist_window(VP, 1, true) : l0;
+  const int r0 = lds_wgs_per_cu(l0), r1 = lds_wgs_per_cu(l1);
+  PersistChoice c;
+  if (r0 >= 16) { c.form = 5; c.inner = can_inner && r1 >= 16; }
+  else if (r0 >= 10) { c.form = 4; c.inner = can_inner && (r1 < 12 ? r1 : 12) == (r0 < 12 ? r0 : 12); }
+  else { c.form = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0; c.inner = false; }
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
     bool built = f >= 0 && f < 6;
 #ifndef ORL_ALT_IMPLS
     built = built && f != 2 && f != 3;
 #endif
-    if (built && persist_lds_layout(VP.E, VP.bm_words, VP.C, kPersistForms[f].lds, persist_compact(VP.env_type, kPersistForms[f].lds), persist_inner(VP.env_type, ORL_W, kPersistForms[f].lds)).total <= 64 * 1024) v = f;
+    if (built && persist_window(VP, kPersistForms[f].lds, persist_inner(VP.env_type, ORL_W, kPersistForms[f].lds)) <= 64 * 1024 && f != c.form) {
+      c.form = f;
+      const int st = kPersistForms[f].lds, cap = 4 * kPersistForms[f].waves;
+      const bool ci = persist_inner(VP.env_type, ORL_W, st);
+      const int a0 = lds_wgs_per_cu(persist_window(VP, st, false)), a1 = lds_wgs_per_cu(persist_window(VP, st, ci));
+      c.inner = ci && (a1 < cap ? a1 : cap) == (a0 < cap ? a0 : cap);
+    }
   }
-  *lds_bytes = (size_t)persist_lds_layout(VP.E, VP.bm_words, VP.C, kPersistForms[v].lds, persist_compact(VP.env_type, kPersistForms[v].lds), persist_inner(VP.env_type, ORL_W, kPersistForms[v].lds)).total;
-  return v;
+  if (const char* e = getenv("ORL_PERSIST_INNER")) c.inner = atoi(e) != 0 && persist_inner(VP.env_type, ORL_W, kPersistForms[c.form].lds);  // A/B
+  c.lds = persist_window(VP, kPersistForms[c.form].lds, c.inner);
+  return c;
+}
+static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
+  const PersistChoice c = persist_choose(VP);
+  *lds_bytes = c.lds;
+  return c.form;
 }
 template <int W> int persist_uses_lds(orl_batch* b) {
   size_t lds;
   return kPersistForms[persist_variant(b->P, &lds)].lds;
 }
 // Workgroups per CU the form allows (LDS window, register budget).  ORL_PERSIST_WGS_PER_CU=r lowers the residency by padding
-// the LDS request (experiment: a launch runs in rounds of r x CUs wavefronts, and 8 192 wavefronts over 12 per CU are 2.67
-// rounds; r = 11 makes three nearly full rounds — measured SLOWER, 6.5e8 against 7.2e8 env-steps/s for 20-step runs of cfg2:
-// the kernel is not purely issue-bound, the twelfth wavefront still hides latency).
+// the LDS request (experiments).
 static int persist_max_per_cu(int v, size_t lds) {
   int per_cu = 4 * kPersistForms[v].waves;
-  if (lds > 0 && (int)((160 * 1024) / lds) < per_cu) per_cu = (int)((160 * 1024) / lds);
+  if (lds_wgs_per_cu(lds) < per_cu) per_cu = lds_wgs_per_cu(lds);
   return per_cu < 1 ? 1 : per_cu;
 }
 static size_t persist_tuned_lds(int v, size_t lds) {
@@ -648,8 +672,7 @@ static size_t persist_tuned_lds(int v, size_t lds) {
   int want_r = rmax;
   if (const char* e = getenv("ORL_PERSIST_WGS_PER_CU")) { int f = atoi(e); if (f >= 1 && f <= rmax) want_r = f; }
   if (want_r == rmax) return lds;
-  size_t want = ((size_t)(160 * 1024) / (size_t)want_r) & ~(size_t)511;
-  while (want > lds && (int)((160 * 1024) / want) < want_r) want -= 512;
+  const size_t want = ((size_t)(160 * 1024) / (size_t)want_r) / 1280 * 1280;  // the largest window that still fits want_r times
   return want > lds ? want : lds;
 }
 // forms 2 and 3 (link statistics and sums in LDS too) measured slower everywhere: they are built only into the
@@ -659,11 +682,13 @@ static size_t persist_tuned_lds(int v, size_t lds) {
 #else
 #define ORL_FULL_LDS_CASES(E_)
 #endif
-template <int W> void persist(orl_batch* b, const DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished) {
+template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished) {
+  DevParams VP = VP0;
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64);
-  size_t lds_a = 0;
-  const int v = persist_variant(VP, &lds_a);
-  lds_a = persist_tuned_lds(v, lds_a);
+  const PersistChoice ch = persist_choose(VP);
+  const int v = ch.form;
+  VP.persist_ic = ch.inner ? 1 : 0;
+  size_t lds_a = persist_tuned_lds(v, ch.lds);
 #define LAUNCH(E_, LDS_, WV_)                                                                                                 \
   do {                                                                                                                       \
     if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<E_, W, LDS_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
