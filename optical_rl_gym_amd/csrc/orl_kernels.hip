@@ -227,7 +227,7 @@ struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (al
   int tab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, total;
 };
 // state: 0 = only the per-step tables, 1 = + slot maps, per-core sums and env records, 2 = + link statistics;
-// compact: 16-byte sink entries (single-core families, state >= 1); inner: the per-word longest-run cache of every row
+// compact: 16-byte sink entries (single-core families); inner: the per-word longest-run cache of every row
 __host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, bool inner) {
   PersistLds L;
   int o = 0;
@@ -247,8 +247,8 @@ __host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_wo
   L.total = o;
   return L;
 }
-template <int ENV, int LDS> struct PersistCompact { static constexpr bool value = LDS >= 1 && ENV != ENV_RMCSA; };
-static inline bool persist_compact(int env_type, int state) { return state >= 1 && env_type != ENV_RMCSA; }
+template <int ENV, int LDS> struct PersistCompact { static constexpr bool value = ENV != ENV_RMCSA; };
+static inline bool persist_compact(int env_type, int state) { return env_type != ENV_RMCSA; }
 // (rows of one or two words: searching both costs less than the bookkeeping — cfg3 measured 1.20e9 without, 1.01e9 with)
 template <int ENV, int W, int LDS> struct PersistInner { static constexpr bool value = LDS >= 1 && W >= 3 && W <= 5 && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA); };
 static inline bool persist_inner(int env_type, int W, int state) { return state >= 1 && W >= 3 && W <= 5 && (env_type == ENV_RMSA || env_type == ENV_DEEPRMSA); }
