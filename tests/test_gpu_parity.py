@@ -13,14 +13,15 @@ pytestmark = pytest.mark.gpu
 # variables are read when a batch is created): "wave64" = k_step for everything, "persist" = the default, "split2" = the
 # phases of the persistent kernel as two separate launches (liborlgpu_alt.so, the -DORL_ALT_IMPLS build).
 IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds"]
-IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None),
-            "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT=None),
+IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
+            "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             # the persistent kernel in the form the library picks, with all state in global memory, and with slot maps +
             # link statistics + per-core sums resident in LDS (a form only liborlgpu_alt.so carries; where it does not fit
-            # the library's default form runs)
-            "persist": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None),
-            "persist_global": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="0"),
-            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT="2")}
+            # the library's default form runs) and the per-row cache of inner free runs switched on (the library uses it only
+            # where it costs no wavefront per CU)
+            "persist": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
+            "persist_global": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="0", ORL_PERSIST_INNER=None),
+            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT="2", ORL_PERSIST_INNER="1")}
 
 
 def force_impl(monkeypatch, name):
