@@ -303,8 +303,9 @@ static void launch_obs(orl_batch* b, int with_terminal) {
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
-static void launch_persist(orl_batch* b, const DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished) {
-#define CALL(WW) orl_launch::persist<WW>(b, VP, st, pol, target, wg_step, unfinished)
+static void launch_persist(orl_batch* b, const DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished,
+                           unsigned int* clear_next) {
+#define CALL(WW) orl_launch::persist<WW>(b, VP, st, pol, target, wg_step, unfinished, clear_next)
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
@@ -339,9 +340,9 @@ static void launch_step2(orl_batch* b, int pol) {
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
-// d_unfinished[0] = straggler workgroups of the last persistent launch, d_unfinished[1] = OR of the env flag words
+// OR of the env flag words into d_unfinished[17] (the pair report_flags owns; the persistent launches have their own slots)
 static void launch_finish2(orl_batch* b, int finish) {
-  hipLaunchKernelGGL(k_finish2, dim3((unsigned)((b->P.B + 255) / 256)), dim3(256), 0, b->stream, b->P, finish, b->d_unfinished + 1);
+  hipLaunchKernelGGL(k_finish2, dim3((unsigned)((b->P.B + 255) / 256)), dim3(256), 0, b->stream, b->P, finish, b->d_unfinished + 17);
 }
 static int flags_to_rc(const orl_batch* b, unsigned int f);
 
@@ -506,7 +507,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     P.q_def_stride = (i64)(B + 16);
     rc |= dalloc(b, &P.q_def, 2 * (size_t)P.q_def_stride);
     rc |= dalloc(b, &b->d_wg_step, (B + 7) / 8 + 16);
-    rc |= dalloc(b, &b->d_unfinished, 16);
+    rc |= dalloc(b, &b->d_unfinished, 32);
+    if (!rc) HIPCHK_B(hipMemset(b->d_unfinished, 0, 32 * sizeof(unsigned int)));
     rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
     rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
   }
@@ -741,9 +743,9 @@ static int flags_to_rc(const orl_batch* b, unsigned int f) {
 // after a synchronous call: report what the kernels flagged (device-resident actions cannot be checked beforehand)
 static int report_flags(orl_batch* b) {
   unsigned int f[2] = {0, 0};
-  HIPCHK(hipMemsetAsync(b->d_unfinished, 0, 2 * sizeof(unsigned int), b->stream));
+  HIPCHK(hipMemsetAsync(b->d_unfinished + 16, 0, 2 * sizeof(unsigned int), b->stream));
   launch_finish2(b, 0);
-  HIPCHK(hipMemcpyAsync(f, b->d_unfinished, sizeof f, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemcpyAsync(f, b->d_unfinished + 16, sizeof f, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   return flags_to_rc(b, f[1]);
@@ -848,7 +850,14 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     // between chunks; after the last one k_finish2 finalises the state and reduces the flags, and ONE 8-byte copy tells
     // the host whether stragglers are left (then: relaunch) and what the envs flagged.
     const unsigned n_wg = (unsigned)((b->P.B + 7) / 8);
-    HIPCHK(hipMemsetAsync(b->d_wg_step, 0, n_wg * sizeof(int), b->stream));
+    // d_wg_step counts steps since run_base was 0: between runs every workgroup stands at run_base, so a run needs no clearing
+    // (a fill kernel in front of every run: ~1 % of a 20-step run)
+    if (b->wg_dirty || b->run_base + n_steps > (int64_t)1 << 30) {
+      HIPCHK(hipMemsetAsync(b->d_wg_step, 0, n_wg * sizeof(int), b->stream));
+      b->run_base = 0;
+    }
+    b->wg_dirty = true;  // until this run has completed
+    const int64_t base = b->run_base;
     int chunk = 64;
     if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
     // A launch occupies the GPU in rounds of `resident` wavefronts, and a last round that is not full leaves CUs idle until
@@ -876,28 +885,34 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
       tgt = (tgt + chunk < n_steps) ? tgt + chunk : n_steps;
       for (;;) {
         b->persist_launches++;
+        unsigned int* cnt[2] = {nullptr, nullptr};  // the slot each half's launch counts into; it clears the other one
         for (int p = 0; p < parts; p++) {
-          HIPCHK(hipMemsetAsync(b->d_unfinished + 4 * p, 0, 2 * sizeof(unsigned int), strm[p]));
-          launch_persist(b, view[p], strm[p], policy_id, (int)tgt, wg_step[p], b->d_unfinished + 4 * p);
+          cnt[p] = b->d_unfinished + 8 * p + 4 * b->un_slot[p];
+          launch_persist(b, view[p], strm[p], policy_id, (int)(base + tgt), wg_step[p], cnt[p], b->d_unfinished + 8 * p + 4 * (b->un_slot[p] ^ 1));
+          b->un_slot[p] ^= 1;
         }
         if (tgt < n_steps) break;  // stragglers catch up in the next chunk's launch
         for (int p = 0; p < parts; p++)  // (harmless for a straggler: it does what that env's next control phase would do first)
-          hipLaunchKernelGGL(k_finish2, dim3((unsigned)((view[p].B + 255) / 256)), dim3(256), 0, strm[p], view[p], 1, b->d_unfinished + 4 * p + 1);
+          hipLaunchKernelGGL(k_finish2, dim3((unsigned)((view[p].B + 255) / 256)), dim3(256), 0, strm[p], view[p], 1, cnt[p] + 1);
         if (parts == 2) {
           HIPCHK(hipEventRecord(b->ev_half, b->stream2));
           HIPCHK(hipStreamWaitEvent(b->stream, b->ev_half, 0));
         }
         HIPCHK(hipEventRecord(b->ev1, b->stream));
-        unsigned int both[8] = {0};
+        unsigned int both[16] = {0};
         HIPCHK(hipMemcpyAsync(both, b->d_unfinished, sizeof both, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
-        tail[0] = both[0] + (parts == 2 ? both[4] : 0);
-        tail[1] = both[1] | (parts == 2 ? both[5] : 0);
+        const unsigned int* c0 = both + (cnt[0] - b->d_unfinished);
+        const unsigned int* c1 = parts == 2 ? both + (cnt[1] - b->d_unfinished) : nullptr;
+        tail[0] = c0[0] + (c1 ? c1[0] : 0);
+        tail[1] = c0[1] | (c1 ? c1[1] : 0);
         if (!tail[0]) break;
       }
     }
     if (n_steps == 0) HIPCHK(hipEventRecord(b->ev1, b->stream));
     have_flags = n_steps > 0;
+    b->run_base = base + n_steps;  // every workgroup stands here now
+    b->wg_dirty = false;
   } else if (time_kernels == 2) {
     for (int64_t s = 0; s < n_steps; s++) {
       HIPCHK(hipEventRecord(pool.ev[3 * s], b->stream));

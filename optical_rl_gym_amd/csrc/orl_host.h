@@ -34,8 +34,14 @@ struct orl_batch {
   int lds_state = 0;     // ... with the slot maps and link statistics of a wavefront's envs resident in LDS
   int two_kernel = 0;    // ORL_ALT_IMPLS builds, ORL_STEP_IMPL=2 ORL_PERSIST=0: the phases of k_persist as separate launches
   int64_t persist_launches = 0;
-  int* d_wg_step = nullptr;        // [ceil(B/8)] steps each workgroup of the persistent kernel has completed in this run
-  unsigned int* d_unfinished = nullptr;  // [0] straggler workgroups of the last persistent launch, [1] OR of the env flag words (k_finish2)
+  int* d_wg_step = nullptr;        // [ceil(B/8)] steps each workgroup of the persistent kernel has completed since run_base was 0
+  int64_t run_base = 0;            // ... all of them, between runs (no per-run clearing of d_wg_step)
+  bool wg_dirty = true;            // a run did not complete (or none has run yet): clear d_wg_step and run_base first
+  int un_slot[2] = {0, 0};         // per half of the batch: the slot of d_unfinished its next launch counts into
+  // per half p and slot s, at 8 p + 4 s: [0] straggler workgroups of a persistent launch, [1] OR of the env flag words
+  // (k_finish2); a launch counts into one slot and clears the other for the launch after it (no memset between launches);
+  // [16..17]: the same pair for report_flags
+  unsigned int* d_unfinished = nullptr;
   int device = 0, wt = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second half of the batch in device-resident runs (see orl_batch_run)
@@ -64,7 +70,8 @@ template <int W> void policy(orl_batch* b, int pol);                       // st
 template <int W> void step64(orl_batch* b, int auto_reset, int want_info, int fused_policy);  // one wavefront per env
 template <int W> void obs(orl_batch* b, int with_terminal);                // DeepRMSA observation
 // k_persist over the env range of view VP up to step `target` of this run, then k_rel_tail, on stream st
-template <int W> void persist(orl_batch* b, const orl::DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished);
+template <int W> void persist(orl_batch* b, const orl::DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished,
+                              unsigned int* clear_next);
 template <int W> int persist_resident(orl_batch* b, int n_cu);              // wavefronts of k_persist the GPU holds at once
 template <int W> int persist_uses_lds(orl_batch* b);                       // 1: the persistent kernel keeps slot maps / link statistics in LDS
 template <int W> int prof_read(unsigned long long* out48, int reset);      // -DORL_TIMING builds: per-phase cycle sums

@@ -437,7 +437,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 // (orl_launch::persist), the kernel is built for 2 or 3.
 template <int ENV, int W, int LDS, int WAVES>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished) {
+k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32* clear_next) {
+  // the counters the NEXT launch of this half of the batch uses (it starts after this one has ended)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clear_next[0] = 0u; clear_next[1] = 0u; }
   persist_body<ENV, W, LDS, (WAVES <= 3)>(P, pol, target, wg_step, n_unfinished);
 }
 
@@ -682,7 +684,8 @@ static size_t persist_tuned_lds(int v, size_t lds) {
 #else
 #define ORL_FULL_LDS_CASES(E_)
 #endif
-template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished) {
+template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished,
+                              unsigned int* clear_next) {
   DevParams VP = VP0;
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64);
   const PersistChoice ch = persist_choose(VP);
@@ -692,7 +695,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
 #define LAUNCH(E_, LDS_, WV_)                                                                                                 \
   do {                                                                                                                       \
     if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<E_, W, LDS_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
-    hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished);            \
+    hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished, clear_next); \
   } while (0)
 #define PER_ENV(E_)                                                                                                          \
   switch (v) {                                                                                                               \
@@ -766,7 +769,7 @@ template int prof_read<ORL_W>(unsigned long long*, int);
 template void policy<ORL_W>(orl_batch*, int);
 template void step64<ORL_W>(orl_batch*, int, int, int);
 template void obs<ORL_W>(orl_batch*, int);
-template void persist<ORL_W>(orl_batch*, const DevParams&, hipStream_t, int, int, int*, unsigned int*);
+template void persist<ORL_W>(orl_batch*, const DevParams&, hipStream_t, int, int, int*, unsigned int*, unsigned int*);
 template int persist_resident<ORL_W>(orl_batch*, int);
 template int persist_uses_lds<ORL_W>(orl_batch*);
 template void step2<ORL_W>(orl_batch*, int);
