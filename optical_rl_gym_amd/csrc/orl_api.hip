@@ -905,7 +905,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
         const unsigned int* c0 = both + (cnt[0] - b->d_unfinished);
         const unsigned int* c1 = parts == 2 ? both + (cnt[1] - b->d_unfinished) : nullptr;
         tail[0] = c0[0] + (c1 ? c1[0] : 0);
-        tail[1] = c0[1] | (c1 ? c1[1] : 0);
+        tail[1] |= c0[1] | (c1 ? c1[1] : 0);  // (accumulated: k_finish2 clears a reported flag in the records, a relaunch would lose it)
         if (!tail[0]) break;
       }
     }
