@@ -852,7 +852,9 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     const unsigned n_wg = (unsigned)((b->P.B + 7) / 8);
     // d_wg_step counts steps since run_base was 0: between runs every workgroup stands at run_base, so a run needs no clearing
     // (a fill kernel in front of every run: ~1 % of a 20-step run)
-    if (b->wg_dirty || b->run_base + n_steps > (int64_t)1 << 30) {
+    int64_t base_limit = (int64_t)1 << 30;  // the counters are ints
+    if (const char* lv = getenv("ORL_RUN_BASE_LIMIT")) { const long long v = atoll(lv); if (v >= 1) base_limit = v; }  // tests
+    if (b->wg_dirty || b->run_base + n_steps > base_limit) {
       HIPCHK(hipMemsetAsync(b->d_wg_step, 0, n_wg * sizeof(int), b->stream));
       b->run_base = 0;
     }

@@ -278,6 +278,40 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         assert out["two"]["serial"] > 100 and out["two2"]["serial"] > 0 and out["persist"]["serial"] > 100
 
 
+def test_step_counters_run_on_between_runs_and_wrap(monkeypatch):
+    """The persistent kernel's per-workgroup step counters are not cleared between runs (no fill kernel in front of a run):
+    they count from a base that is reset only when it would overflow.  With the limit forced down to 100 steps, runs of
+    assorted lengths cross it several times and the state equals the per-env kernel's after every run."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    fam, topo, kw, policy = WORKLOADS["cfg2"]
+    kw = dict(kw, episode_length=60)
+    seeds = [11 + 5 * i for i in range(2048)]
+    lengths = (7, 64, 65, 1, 30, 130, 3, 99, 100, 2)
+    out = {}
+    for name, v, limit in (("wave64", "wave64", None), ("persist", "persist", "100"), ("persist_plain", "persist", None)):
+        force_impl(monkeypatch, v)
+        if limit:
+            monkeypatch.setenv("ORL_RUN_BASE_LIMIT", limit)
+        else:
+            monkeypatch.delenv("ORL_RUN_BASE_LIMIT", raising=False)
+        env = orl.make(fam, topology=topo, num_envs=len(seeds), seeds=seeds, **kw)
+        rec = []
+        for n in lengths:
+            env.run(policy, n)
+            rec.append((env.counters().copy(), env.services().copy(), env.active().copy(), env.slots(77).copy(),
+                        env.link_stats(77).copy(), env.net_stats(77).copy()))
+        out[name] = rec
+        assert not env.flags().any()
+        env.close()
+    chk = _exact("step counters")
+    for name in ("persist", "persist_plain"):
+        for t, (a, b) in enumerate(zip(out[name], out["wave64"])):
+            for k, (x, y) in enumerate(zip(a, b)):
+                chk(t, "%s item %d" % (name, k), x, y)
+
+
 def test_pending_releases_at_the_end_of_a_run(monkeypatch):
     """A wavefront whose env could not put its releases into items leaves its loop, counts as unfinished, and releases them in
     place at the start of its next launch — also when that happens on the LAST step of a run (the host relaunches until no
