@@ -114,10 +114,13 @@ def main():
     seeds = [10 + rank * B + i for i in range(B)]  # seed_i = 10 + global env index
     env = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, device_id=dev_index, **kw)
 
-    def barrier():
+    def device_sync():
         env.sync()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+
+    def barrier():
+        device_sync()
         if dist is not None:
             dist.barrier()
 
@@ -137,9 +140,13 @@ def main():
         barrier()
         t0 = time.perf_counter()
         st_run = env.run(policy, args.steps)   # policy + step, entirely on the device
-        barrier()
-        elapsed = time.perf_counter() - t0
+        device_sync()
+        elapsed = time.perf_counter() - t0     # this rank's K steps, device idle again
         if dist is not None:
+            # the closing barrier, then the MAX over ranks of the per-rank times: the slowest rank's K steps.  (The clock is
+            # read before the gloo barrier — a TCP round trip among N processes takes as long as several of the 20-step
+            # blocks' steps and is not part of any rank's work; all ranks left the opening barrier together.)
+            dist.barrier()
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
