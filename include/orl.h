@@ -250,6 +250,9 @@ int orl_batch_set_state(orl_batch* b, const void* in);
 /* Profiling aid: reads the whole slot-map array once with 8-B (width16 = 0) or 16-B (1) loads per lane and returns the
  * number of bytes read, so that rocprofv3's FETCH_SIZE can be calibrated on a known byte count. */
 int64_t orl_batch_debug_stream_read(orl_batch* b, int width16);
+/* Which instantiation of the persistent kernel the last orl_batch_run used: 0 = the generic one, n > 0 = the n-th entry of
+ * the table of configurations with compile-time sizes (csrc/orl_kernels.hip, kPersistSpecs); -1 = another step form. */
+int orl_batch_debug_persist_spec(orl_batch* b);
 /* Statistics: env-steps whose releases took the serial tail (more than 8 of one step meeting on one link). */
 int64_t orl_batch_debug_serial_count(orl_batch* b);
 /* Diagnostic builds with -DORL_TIMING only (zeros otherwise): shader-clock cycles per phase of the persistent kernel, 48

@@ -1209,6 +1209,10 @@ extern "C" int orl_batch_debug_prof(orl_batch* b, uint64_t* out48, int reset) {
 #undef CALL
   return rc ? fail(ORL_E_HIP, "reading the profile failed") : ORL_OK;
 }
+extern "C" int orl_batch_debug_persist_spec(orl_batch* b) {
+  if (!b) return -1;
+  return b->persist ? b->persist_spec : -1;
+}
 extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
   if (!b) return -1;
   if (hipSetDevice(b->device) != hipSuccess) return -1;

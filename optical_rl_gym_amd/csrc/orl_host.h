@@ -34,6 +34,7 @@ struct orl_batch {
   int lds_state = 0;     // ... with the slot maps and link statistics of a wavefront's envs resident in LDS
   int two_kernel = 0;    // ORL_ALT_IMPLS builds, ORL_STEP_IMPL=2 ORL_PERSIST=0: the phases of k_persist as separate launches
   int64_t persist_launches = 0;
+  int persist_spec = 0;            // the specialised instantiation of k_persist the last launch used (0: the generic kernel)
   int* d_wg_step = nullptr;        // [ceil(B/8)] steps each workgroup of the persistent kernel has completed since run_base was 0
   int64_t run_base = 0;            // ... all of them, between runs (no per-run clearing of d_wg_step)
   bool wg_dirty = true;            // a run did not complete (or none has run yet): clear d_wg_step and run_base first

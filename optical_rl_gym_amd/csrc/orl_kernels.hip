@@ -11,6 +11,7 @@
 //   k_obs8/k_obs DeepRMSA observation of the pending service
 // Launchers (orl_launch::*<W>) are explicitly instantiated at the end; orl_api.hip dispatches on the batch's W.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
@@ -435,11 +436,50 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 // Register budgets: WAVES waves/SIMD -> 512 / WAVES VGPRs.  Global state: 4 (128 VGPRs) for NSFNET-sized RMSA / RWA /
 // DeepRMSA, 3 (168, no spills) for the heavier RMCSA and Germany50 steps.  LDS state: the LDS window decides the residency
 // (orl_launch::persist), the kernel is built for 2 or 3.
-template <int ENV, int W, int LDS, int WAVES>
+// Specialisations.  The sizes of a topology and of the traffic model reach the kernel as ~20 uniform scalars of DevParams
+// (kept in SGPRs for the whole loop — or spilled to VGPR lanes — and multiplied, compared and looped over at run time).
+// For the reference's canonical set-ups they are compile-time constants of an extra instantiation: SPEC = index + 1 into this
+// table, chosen by the launcher only when EVERY listed field of the batch matches (else SPEC = 0, the generic kernel; same
+// code, same results).  cfg2: 1.06e9 -> 1.11e9 env-steps/s.
+struct PersistSpec { int env, W, form, N, E, K, M, S, C, J, bit_rate_mode, br_lo, rand_n, rand_bits, bm_words, cs_words, obs_dim; };
+static constexpr PersistSpec kPersistSpecs[] = {
+    // RMSA, nsfnet_chen (14 nodes, 22 links, k = 5, 6 modulations), 320 slots, bit rates 25..100: BASELINE cfg2
+    {ENV_RMSA, 5, 4, 14, 22, 5, 6, 320, 1, 1, 0, 25, 76, 7, 110, 16, 0},
+    // DeepRMSA, nsfnet_chen, 100 slots, j = 1: BASELINE cfg3
+    {ENV_DEEPRMSA, 2, 5, 14, 22, 5, 6, 100, 1, 1, 0, 25, 76, 7, 44, 16, 54},
+    // RWA, nsfnet_chen, 80 wavelengths: BASELINE cfg1
+    {ENV_RWA, 2, 5, 14, 22, 5, 6, 80, 1, 1, 0, 0, 1, 1, 44, 16, 0},
+    // RMCSA, cost239 (11 nodes, 26 links), 7 cores x 320 slots: BASELINE cfg4
+    {ENV_RMCSA, 5, 1, 11, 26, 5, 6, 320, 7, 1, 0, 25, 76, 7, 910, 32, 0},
+    // RMSA, germany50 (50 nodes, 88 links), 320 slots: BASELINE cfg5
+    {ENV_RMSA, 5, 1, 50, 88, 5, 6, 320, 1, 1, 0, 25, 76, 7, 440, 16, 0},
+};
+constexpr int kNumPersistSpecs = (int)(sizeof(kPersistSpecs) / sizeof(kPersistSpecs[0]));
+template <int SPEC> __device__ __forceinline__ void persist_spec_apply(DevParams& P) {
+  if constexpr (SPEC > 0) {
+    constexpr PersistSpec s = kPersistSpecs[SPEC - 1];
+    P.N = s.N; P.E = s.E; P.K = s.K; P.M = s.M; P.S = s.S; P.W = s.W; P.C = s.C; P.J = s.J;
+    P.bit_rate_mode = s.bit_rate_mode; P.br_lo = s.br_lo; P.rand_n = s.rand_n; P.rand_bits = s.rand_bits;
+    P.bm_words = s.bm_words; P.cs_words = s.cs_words; P.obs_dim = s.obs_dim;
+  }
+}
+static int persist_spec_of(const DevParams& P, int W, int form) {
+  for (int i = 0; i < kNumPersistSpecs; i++) {
+    const PersistSpec& s = kPersistSpecs[i];
+    if (s.env == P.env_type && s.W == W && s.form == form && s.N == P.N && s.E == P.E && s.K == P.K && s.M == P.M && s.S == P.S &&
+        s.C == P.C && s.J == P.J && s.bit_rate_mode == P.bit_rate_mode && s.br_lo == P.br_lo && s.rand_n == P.rand_n &&
+        s.rand_bits == P.rand_bits && s.bm_words == P.bm_words && s.cs_words == P.cs_words && s.obs_dim == P.obs_dim && P.W == W)
+      return i + 1;
+  }
+  return 0;
+}
+
+template <int ENV, int W, int LDS, int WAVES, int SPEC = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32* clear_next) {
   // the counters the NEXT launch of this half of the batch uses (it starts after this one has ended)
   if (blockIdx.x == 0 && threadIdx.x == 0) { clear_next[0] = 0u; clear_next[1] = 0u; }
+  persist_spec_apply<SPEC>(P);
   persist_body<ENV, W, LDS, (WAVES <= 3)>(P, pol, target, wg_step, n_unfinished);
 }
 
@@ -697,6 +737,29 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<E_, W, LDS_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
     hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished, clear_next); \
   } while (0)
+  // a specialised instantiation for this very configuration?  (ORL_PERSIST_SPEC=0: the generic kernel)
+  int spec = persist_spec_of(VP, W, v);
+  if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = 0; }
+  b->persist_spec = spec;
+  if (getenv("ORL_DEBUG_SPEC") && b->persist_launches <= 1)  // what a new row of kPersistSpecs would hold for this batch
+    fprintf(stderr, "orl: k_persist spec %d; {env %d, W %d, form %d, N %d, E %d, K %d, M %d, S %d, C %d, J %d, mode %d, br_lo %d, rand_n %d, rand_bits %d, bm_words %d, cs_words %d, obs_dim %d}\n",
+            spec, VP.env_type, W, v, VP.N, VP.E, VP.K, VP.M, VP.S, VP.C, VP.J, VP.bit_rate_mode, VP.br_lo, VP.rand_n, VP.rand_bits,
+            VP.bm_words, VP.cs_words, VP.obs_dim);
+#define LAUNCH_SPEC(E_, LDS_, WV_, SP_)                                                                                      \
+  do {                                                                                                                       \
+    hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_, SP_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished, clear_next); \
+    return;                                                                                                                  \
+  } while (0)
+  if constexpr (W == 5) {
+    if (spec == 1) LAUNCH_SPEC(ENV_RMSA, 1, 3, 1);
+    if (spec == 4) LAUNCH_SPEC(ENV_RMCSA, 0, 3, 4);
+    if (spec == 5) LAUNCH_SPEC(ENV_RMSA, 0, 3, 5);
+  }
+  if constexpr (W == 2) {
+    if (spec == 2) LAUNCH_SPEC(ENV_DEEPRMSA, 1, 4, 2);
+    if (spec == 3) LAUNCH_SPEC(ENV_RWA, 1, 4, 3);
+  }
+#undef LAUNCH_SPEC
 #define PER_ENV(E_)                                                                                                          \
   switch (v) {                                                                                                               \
     case 0: LAUNCH(E_, 0, 4); break;                                                                                         \

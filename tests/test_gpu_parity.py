@@ -278,6 +278,45 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         assert out["two"]["serial"] > 100 and out["two2"]["serial"] > 0 and out["persist"]["serial"] > 100
 
 
+def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkeypatch):
+    """BASELINE cfg1 - cfg5 run on instantiations of the persistent kernel with their sizes as compile-time constants
+    (kPersistSpecs): the launcher picks them (debug query), any other configuration — here another episode length is fine,
+    another slot count is not — gets the generic kernel, and both leave identical state (ORL_PERSIST_SPEC=0 forces the
+    generic one)."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    force_impl(monkeypatch, "persist")
+    for workload, want in (("cfg2", 1), ("cfg3", 2), ("cfg1", 3), ("cfg4", 4), ("cfg5", 5)):
+        fam, topo, kw, policy = WORKLOADS[workload]
+        kw = dict(kw, episode_length=45)
+        seeds = [31 + 2 * i for i in range(1024 if workload in ("cfg4", "cfg5") else 4096)]
+        out = {}
+        for name, spec_env in (("spec", None), ("generic", "0")):
+            if spec_env is None:
+                monkeypatch.delenv("ORL_PERSIST_SPEC", raising=False)
+            else:
+                monkeypatch.setenv("ORL_PERSIST_SPEC", spec_env)
+            env = orl.make(fam, topology=topo, num_envs=len(seeds), seeds=seeds, **kw)
+            env.run(policy, 130)
+            env.run(policy, 70)
+            assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == (want if spec_env is None else 0)
+            out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.slots(9).copy(),
+                         env.link_stats(9).copy(), env.net_stats(9).copy()]
+            if env.obs_dim:
+                out[name].append(env.device_tensor("obs").cpu().numpy().copy())
+            env.close()
+        chk = _exact(workload + " specialised")
+        for k, (x, y) in enumerate(zip(out["spec"], out["generic"])):
+            chk(k, "item", x, y)
+    monkeypatch.delenv("ORL_PERSIST_SPEC", raising=False)
+    fam, topo, kw, policy = WORKLOADS["cfg2"]
+    env = orl.make(fam, topology=topo, num_envs=64, seeds=list(range(64)), **dict(kw, num_spectrum_resources=300))
+    env.run(policy, 10)
+    assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == 0
+    env.close()
+
+
 def test_step_counters_run_on_between_runs_and_wrap(monkeypatch):
     """The persistent kernel's per-workgroup step counters are not cleared between runs (no fill kernel in front of a run):
     they count from a base that is reset only when it would overflow.  With the limit forced down to 100 steps, runs of
