@@ -453,6 +453,8 @@ static constexpr PersistSpec kPersistSpecs[] = {
     {ENV_RMCSA, 5, 1, 11, 26, 5, 6, 320, 7, 1, 0, 25, 76, 7, 910, 32, 0},
     // RMSA, germany50 (50 nodes, 88 links), 320 slots: BASELINE cfg5
     {ENV_RMSA, 5, 1, 50, 88, 5, 6, 320, 1, 1, 0, 25, 76, 7, 440, 16, 0},
+    // RMSA, nsfnet_chen, 100 slots: RMSAEnv's default spectrum on the reference's default topology
+    {ENV_RMSA, 2, 5, 14, 22, 5, 6, 100, 1, 1, 0, 25, 76, 7, 44, 16, 0},
 };
 constexpr int kNumPersistSpecs = (int)(sizeof(kPersistSpecs) / sizeof(kPersistSpecs[0]));
 template <int SPEC> __device__ __forceinline__ void persist_spec_apply(DevParams& P) {
@@ -758,6 +760,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   if constexpr (W == 2) {
     if (spec == 2) LAUNCH_SPEC(ENV_DEEPRMSA, 1, 4, 2);
     if (spec == 3) LAUNCH_SPEC(ENV_RWA, 1, 4, 3);
+    if (spec == 6) LAUNCH_SPEC(ENV_RMSA, 1, 4, 6);
   }
 #undef LAUNCH_SPEC
 #define PER_ENV(E_)                                                                                                          \

@@ -279,7 +279,7 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
 
 
 def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkeypatch):
-    """BASELINE cfg1 - cfg5 run on instantiations of the persistent kernel with their sizes as compile-time constants
+    """BASELINE cfg1 - cfg5 and RMSAEnv's default spectrum run on instantiations of the persistent kernel with their sizes as compile-time constants
     (kPersistSpecs): the launcher picks them (debug query), any other configuration — here another episode length is fine,
     another slot count is not — gets the generic kernel, and both leave identical state (ORL_PERSIST_SPEC=0 forces the
     generic one)."""
@@ -287,8 +287,12 @@ def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkey
     from bench import WORKLOADS
 
     force_impl(monkeypatch, "persist")
-    for workload, want in (("cfg2", 1), ("cfg3", 2), ("cfg1", 3), ("cfg4", 4), ("cfg5", 5)):
-        fam, topo, kw, policy = WORKLOADS[workload]
+    for workload, want in (("cfg2", 1), ("cfg3", 2), ("cfg1", 3), ("cfg4", 4), ("cfg5", 5), ("rmsa100", 6)):
+        if workload == "rmsa100":  # RMSAEnv's default spectrum
+            fam, topo, kw, policy = WORKLOADS["cfg2"]
+            kw = dict(kw, num_spectrum_resources=100, load=120)
+        else:
+            fam, topo, kw, policy = WORKLOADS[workload]
         kw = dict(kw, episode_length=45)
         seeds = [31 + 2 * i for i in range(1024 if workload in ("cfg4", "cfg5") else 4096)]
         out = {}
