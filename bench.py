@@ -14,10 +14,14 @@ What is timed, however the script is invoked:
   2. the timed block: EXACTLY --steps steps, bracketed by a barrier + device synchronisation on both sides, max over ranks.
      The block is repeated until >= 1 s has been timed (at least 3 blocks); `value` is the median block, `timed_region_s` the
      sum.  `roofline.achieved` comes from the HIP-event duration of the same launches.
-N > 1: one process per GPU (torchrun), every rank owns its own 65 536 envs (weak scaling, no collective on the data path;
-the barrier and the max-over-ranks time go through a gloo group — the data path needs no RCCL).
+N > 1: one process per GPU, every rank owns its own 65 536 envs (weak scaling, no collective on the data path; the barrier
+and the max-over-ranks time go through a gloo group — the data path needs no RCCL).  Started under torchrun the script is one
+rank; started by hand with --gpus N > 1 it launches the N ranks itself (fresh child processes, before any GPU call) and
+refuses to run when fewer than N GPUs are visible.  `n_gpus` in the output is the number of ranks that ran; `per_rank` lists
+each one's own rate.
 
     python bench.py --gpus 1 --steps 300 --warmup 0
+    python bench.py --gpus 8 --steps 300              # starts 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -77,6 +81,44 @@ def algorithmic_bytes(env, mean_hops, active):
     return dict(scan=scan, step=scan + 32 * mean_hops + 128 * mean_hops + lg + fixed)
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` started by hand (no torchrun): this process makes NO GPU call; it starts N fresh children — one
+    rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command line — forwards rank 0's JSON line and
+    exits with the first non-zero child status."""
+    import subprocess
+
+    n = args.gpus
+    if args.device is None and not args.launch_check:
+        import torch
+
+        have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+        if have < n:
+            raise SystemExit("bench: --gpus %d but only %d GPU(s) visible; refusing to measure fewer devices than asked for "
+                             "(--device D puts every rank on GPU D: a functional check, not a scaling number)" % (n, have))
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit("bench: rank(s) %s failed (exit codes %s)" % ([r for r, _ in bad], [c for _, c in bad]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,16 +126,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=0, help="extra untimed steps on top of the mandatory state preparation")
     ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--min-timed-s", type=float, default=1.0, help="repeat the timed block until this much has been timed")
+    ap.add_argument("--min-timed-s", type=float, default=5.0, help="repeat the timed block until this much has been timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--device", type=int, default=None, help="override the GPU index (default LOCAL_RANK)")
+    ap.add_argument("--device", type=int, default=None,
+                    help="put EVERY rank on this GPU index (default: rank r on GPU LOCAL_RANK); with --gpus N > 1 this is a "
+                         "functional check of the N-rank path on one device, not a scaling measurement")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only the N-rank plumbing: ranks rendezvous (gloo), barrier, report; no GPU work (CPU test)")
     args = ap.parse_args()
     if args.steps < 1:
         ap.error("--steps must be >= 1")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N starts them itself)"
+                         % (args.gpus, world))
     import torch
 
     dev_index = local_rank if args.device is None else args.device
@@ -103,8 +156,22 @@ def main():
 
         # envs are independent: no collective on the data path, so no RCCL — a gloo group carries the barrier and the max
         dist.init_process_group("gloo")
-    if torch.cuda.is_available():
-        torch.cuda.set_device(dev_index)
+    if args.launch_check:
+        ranks = [None] * world
+        if dist is not None:
+            dist.barrier()
+            dist.all_gather_object(ranks, dict(rank=rank, device=dev_index, pid=os.getpid()))
+            dist.destroy_process_group()
+        else:
+            ranks = [dict(rank=rank, device=dev_index, pid=os.getpid())]
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": len(ranks), "ranks": ranks}))
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench: no GPU visible; the HIP path is the only path")
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit("bench: rank %d wants GPU %d but only %d GPU(s) are visible" % (rank, dev_index, torch.cuda.device_count()))
+    torch.cuda.set_device(dev_index)
 
     import optical_rl_gym_amd as orl
     from optical_rl_gym_amd import _build
@@ -116,8 +183,7 @@ def main():
 
     def device_sync():
         env.sync()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
 
     def barrier():
         device_sync()
@@ -135,6 +201,7 @@ def main():
 
     # ---- 2. timed blocks of EXACTLY --steps steps ----------------------------------------------------------------
     blocks = []  # (wall seconds max over ranks, RunStats)
+    own = []     # this rank's own block times (reported per rank; `value` uses the max over ranks of every block)
     timed = 0.0
     while len(blocks) < 3 or timed < args.min_timed_s:
         barrier()
@@ -142,6 +209,7 @@ def main():
         st_run = env.run(policy, args.steps)   # policy + step, entirely on the device
         device_sync()
         elapsed = time.perf_counter() - t0     # this rank's K steps, device idle again
+        own.append(elapsed)
         if dist is not None:
             # the closing barrier, then the MAX over ranks of the per-rank times: the slowest rank's K steps.  (The clock is
             # read before the gloo barrier — a TCP round trip among N processes takes as long as several of the 20-step
@@ -154,6 +222,11 @@ def main():
         timed += elapsed
         if len(blocks) >= 2000:
             break
+    per_rank = [dict(rank=rank, device=dev_index, env_steps_per_s=round(B * args.steps / statistics.median(own), 1))]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
     walls = sorted(b[0] for b in blocks)
     elapsed = statistics.median(walls)
     med = min(blocks, key=lambda b: abs(b[0] - elapsed))
@@ -263,7 +336,8 @@ def main():
                       else "env-steps/sec %s" % args.workload,
             "value": round(total_steps / elapsed, 1),
             "unit": "env-steps/s",
-            "n_gpus": world,
+            "n_gpus": len(per_rank),  # the ranks that ran and reported
+            "per_rank": per_rank,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -44,14 +44,57 @@ def _worker(rank, world, port, out):
 
 
 def test_shard_partition():
-    for n, w in ((10, 2), (65536, 8), (7, 3), (262144, 8)):
-        cover = []
-        for r in range(w):
-            lo, hi = shard_range(n, r, w)
-            cover += list(range(lo, hi)) if n < 100 else [lo, hi]
+    for n, w in ((10, 2), (65536, 8), (7, 3), (262144, 8), (65537, 8), (1000003, 7)):
+        bounds = [shard_range(n, r, w) for r in range(w)]
+        # contiguous, in order, covering [0, n) exactly once, balanced to within one env
+        assert bounds[0][0] == 0 and bounds[-1][1] == n
+        for (lo0, hi0), (lo1, _) in zip(bounds, bounds[1:]):
+            assert hi0 == lo1 and lo0 <= hi0
+        sizes = [hi - lo for lo, hi in bounds]
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
         if n < 100:
-            assert cover == list(range(n))
+            assert [i for lo, hi in bounds for i in range(lo, hi)] == list(range(n))
+    assert shard_range(65536, 3, 8) == (24576, 32768) and shard_range(262144, 7, 8) == (229376, 262144)
     assert shard_seeds(10, 10, 1, 2) == [15, 16, 17, 18, 19]
+
+
+def _bench(*flags, env=None):
+    import json
+    import subprocess
+
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), env=e, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_starts_n_ranks():
+    """`bench.py --gpus 2` started by hand launches two ranks itself (the plumbing only: rendezvous, barrier, report)."""
+    p, out = _bench("--gpus", "2", "--launch-check")
+    assert p.returncode == 0, p.stderr
+    assert out["n_gpus"] == 2 and [r["rank"] for r in out["ranks"]] == [0, 1] and [r["device"] for r in out["ranks"]] == [0, 1]
+    assert len({r["pid"] for r in out["ranks"]}) == 2
+    # a world size that contradicts --gpus is an error, not a silent 1-GPU measurement
+    p, _ = _bench("--gpus", "2", "--launch-check", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_device_and_refusal():
+    import torch
+
+    if torch.cuda.device_count() < 2:  # asked for more GPUs than there are: refuse loudly
+        p, out = _bench("--gpus", "2", "--steps", "20", "--no-cpu-baseline")
+        assert p.returncode != 0 and out is None and "only 1 GPU" in p.stderr
+    p, out = _bench("--gpus", "2", "--device", "0", "--batch", "4096", "--steps", "20", "--no-cpu-baseline", "--min-timed-s", "0.2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 2 and len(out["per_rank"]) == 2 and out["scaling"] == "weak"
+    assert out["value"] > 0 and all(r["env_steps_per_s"] > 0 for r in out["per_rank"])
 
 
 @pytest.mark.timeout(300)
