@@ -25,13 +25,16 @@
 extern "C" {
 #endif
 
-#define ORL_ABI_VERSION 1
+/* 2: orl_env_config starts with struct_size and carries the QoSConstrainedRA fields; ORL_E_INTERNAL; orl_multi_* (round 3).
+ * A client compiled against another layout is refused by orl_batch_create (struct_size) and by the loader (version). */
+#define ORL_ABI_VERSION 2
 
 #define ORL_OK 0
 #define ORL_E_INVALID (-1)   /* bad argument / unsupported configuration */
 #define ORL_E_HIP (-2)       /* HIP runtime error (no GPU, out of memory, launch failure) */
 #define ORL_E_ACTION (-3)    /* an action was out of the action space (reference: IndexError, rmsa_env.py:167) */
 #define ORL_E_OVERFLOW (-4)  /* an env exceeded its pending-release capacity */
+#define ORL_E_INTERNAL (-5)  /* a C++ exception (std::bad_alloc, ...) was stopped at the boundary: nothing throws across the ABI */
 
 /* env families (optical_rl_gym/__init__.py:3-26 registry ids) */
 #define ORL_ENV_RMSA 0      /* "RMSA-v0"      optical_rl_gym/envs/rmsa_env.py:18 */
@@ -70,6 +73,7 @@ typedef struct {
  * (optical_network_env.py:14-94, rmsa_env.py:29-161, deeprmsa_env.py:10-46, rwa_env.py:19-94,
  * rmcsa_env.py:29-207).  Float tables are computed on the host with the reference's own expressions. */
 typedef struct {
+  uint32_t struct_size;        /* sizeof(orl_env_config) as the caller compiled it; checked by orl_batch_create */
   int32_t env_type;            /* ORL_ENV_* */
   int32_t num_spectrum_resources;
   int32_t num_spatial_resources; /* cores; 1 unless RMCSA */
@@ -80,7 +84,8 @@ typedef struct {
   int32_t bit_rate_lo, bit_rate_hi;
   int32_t n_bit_rates;         /* rows of the bit-rate tables: hi-lo+1 (continuous) or len(bit_rates) */
   int32_t event_capacity;      /* pending releases per env (0 = derive from load) */
-  int32_t action_histograms;   /* != 0: keep the 2-D actions_output / actions_taken arrays (rmsa_env.py:126-137, rwa_env.py:52-58) */
+  int32_t action_histograms;   /* != 0: keep actions_output / actions_taken per env: [2][k+1][S+1] (rmsa_env.py:126-137,
+                                * rwa_env.py:52-58); RMCSA [2][k+1][M+1][C+1][S+1] (rmcsa_env.py:145-180; 863 KB per env at 7 x 320) */
   double lambda_arrival;       /* 1 / mean_service_inter_arrival_time  (rmsa_env.py:548-550) */
   double lambda_holding;       /* 1 / mean_service_holding_time        (rmsa_env.py:553) */
   const double* cum_src;       /* [n_nodes]          accumulate(node_request_probabilities) */
@@ -220,6 +225,14 @@ int orl_batch_get_counters(orl_batch* b, int64_t* out /*[n_envs][ORL_N_COUNTERS]
 int orl_batch_get_services(orl_batch* b, double* out /*[n_envs][ORL_N_SERVICE]*/);
 int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out /*[cores][links][slots] 0/1*/);
 int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out /*[4][links]: utilization, external_fragmentation, compactness, last_update*/);
+/* the same for every env at once: the slot maps as the device keeps them — bit s of 64-bit word s / 64 of a (core, link) row
+ * set = slot s free, rows of orl_batch_row_words() words, orl_batch_map_words() words per env (cores * links * row words, padded
+ * to an even number) — and [n_envs][4][links] link statistics, [n_envs][4] network statistics */
+int orl_batch_row_words(const orl_batch* b);
+int orl_batch_map_words(const orl_batch* b);
+int orl_batch_get_slots_packed(orl_batch* b, uint64_t* out /*[n_envs][map_words]*/);
+int orl_batch_get_link_stats_all(orl_batch* b, double* out /*[n_envs][4][links]*/);
+int orl_batch_get_net_stats_all(orl_batch* b, double* out /*[n_envs][4]*/);
 /* QoSConstrainedRA: topology.graph["available_spectrum"] of one env (free units per link, optical_network_env.py:189-193) */
 int orl_batch_get_spectrum(orl_batch* b, int64_t env, int32_t* out /*[links]*/);
 int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out /*[4]: throughput, compactness, last_update, current_time*/);
@@ -227,7 +240,8 @@ int orl_batch_get_active(orl_batch* b, int32_t* out /*[n_envs] pending releases*
 int orl_batch_get_flags(orl_batch* b, int32_t* out /*[n_envs] bit0 event overflow, bit1 bad action*/);
 /* actions_output and actions_taken of one env (batch created with action_histograms): int32 [2][k_paths+1][slots+1]
  * (rmsa_env.py:126-137, 167, 201, 211-212; rwa_env.py:52-58, 103, 125, 132-133 — RWA uses the top-left
- * [k+reject][slots+reject] corner) */
+ * [k+reject][slots+reject] corner); RMCSA: int32 [2][k_paths+1][modulations+1][cores+1][slots+1] (rmcsa_env.py:145-180,
+ * 219, 273, 284-289) */
 int orl_batch_get_action_histograms(orl_batch* b, int64_t env, int32_t* out);
 /* The pending releases of one env (the reference's heap `_events`, optical_network_env.py:143-154, unordered): returns
  * their number; fills up to `capacity` entries of time_out[] (release time) and rec_out[][6] = (src*n_nodes+dst, path
@@ -240,6 +254,20 @@ int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted);
  * uint8 [n_envs][2*n_nodes + cores*links*slots] = one-hot(min(src,dst)), one-hot(max(src,dst)), slot map. */
 int orl_batch_matrix_obs_dim(const orl_batch* b);
 int orl_batch_matrix_observation(orl_batch* b, uint8_t* out);
+
+/* Several GPUs of one node from one process (the `n_devices, device_ids` of the batch constructor).  Envs are
+ * independent, so the group is nothing but contiguous shards of the env index range — shard r holds envs
+ * [first_env, first_env + n) on device_ids[r], seeds[first_env ...] — each an ordinary orl_batch bound to its device:
+ * use orl_multi_shard() with every per-batch entry point above (scatter actions / gather results per shard).  No collective,
+ * no peer access.  orl_multi_run drives the device-resident loop of all shards at once, one host thread per shard;
+ * stats: [n_shards] or NULL; returns the first non-zero shard status.  The same device may be listed more than once. */
+typedef struct orl_multi orl_multi;
+int orl_multi_create(const orl_env_config* cfg, const orl_topology_desc* topo, int64_t n_envs, const int64_t* seeds,
+                     int n_devices, const int* device_ids, orl_multi** out);
+int orl_multi_n_shards(const orl_multi* m);
+orl_batch* orl_multi_shard(orl_multi* m, int shard, int64_t* first_env /*nullable*/, int64_t* n_envs /*nullable*/);
+int orl_multi_run(orl_multi* m, int policy_id, int64_t n_steps, orl_run_stats* stats);
+void orl_multi_destroy(orl_multi* m);
 
 /* Snapshot / restore of the complete simulation state of the batch (slot maps, pending releases, RNG, statistics,
  * counters).  The reference has no equivalent (no checkpointing); used for long PPO runs. */

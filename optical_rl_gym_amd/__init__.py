@@ -7,6 +7,7 @@ from .topology import Modulation, Path, Topology, get_best_modulation_format  # 
 __version__ = "0.1.0"
 from .gym_api import (DeepRMSAEnv, PathOnlyFirstFitAction, RMCSAEnv, RMSAEnv, RWAEnv, Service,  # noqa: F401,E402
                       SimpleMatrixObservation, evaluate_heuristic, least_loaded_path_first_fit, random_policy,
+                      start_environment,
                       shortest_available_path_best_modulation_first_core_first_fit,
                       shortest_available_path_first_fit, shortest_available_path_last_fit, shortest_path_first_fit)
 from .sharding import MultiDeviceBatch, shard_range, shard_seeds  # noqa: F401,E402

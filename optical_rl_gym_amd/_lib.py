@@ -14,7 +14,7 @@ class TopologyDesc(C.Structure):
 
 
 class EnvConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in (
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in (
         "env_type", "num_spectrum_resources", "num_spatial_resources", "episode_length", "allow_rejection", "j",
         "bit_rate_mode", "bit_rate_lo", "bit_rate_hi", "n_bit_rates", "event_capacity", "action_histograms")] + [
         ("lambda_arrival", C.c_double), ("lambda_holding", C.c_double)] + [
@@ -31,6 +31,8 @@ class RunStats(C.Structure):
         """[(name, ms per launch)] of one policy+step of the device loop (time_kernels=1)."""
         return [(bytes(self.kernel_name[i].value).decode(), self.ms_kernel[i]) for i in range(self.n_kernels)]
 
+
+ABI_VERSION = 2  # ORL_ABI_VERSION of include/orl.h
 
 EXPORTS = {
     "orl_abi_version": (C.c_int, []),
@@ -78,6 +80,17 @@ EXPORTS = {
     "orl_batch_get_action_histograms": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "orl_batch_get_pending": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "orl_batch_totals": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "orl_batch_row_words": (C.c_int, [C.c_void_p]),
+    "orl_batch_map_words": (C.c_int, [C.c_void_p]),
+    "orl_batch_get_slots_packed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_get_link_stats_all": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_batch_get_net_stats_all": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orl_multi_create": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(TopologyDesc), C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.POINTER(C.c_void_p)]),
+    "orl_multi_n_shards": (C.c_int, [C.c_void_p]),
+    "orl_multi_shard": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "orl_multi_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "orl_multi_destroy": (None, [C.c_void_p]),
 }
 
 
@@ -127,8 +140,9 @@ def lib(variant=None):
             fn = getattr(handle, name)  # AttributeError = ABI mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
-        if handle.orl_abi_version() != 1:
-            raise OrlError("ABI version mismatch")
+        if handle.orl_abi_version() != ABI_VERSION:
+            raise OrlError("%s reports ABI version %d, this binding is written for %d (include/orl.h)"
+                           % (os.path.basename(path), handle.orl_abi_version(), ABI_VERSION))
         _LIBS[variant] = handle
     return _LIBS[variant]
 
@@ -143,4 +157,6 @@ def check(rc, handle=None):
             raise IndexError(text)
         if rc == -4:
             raise OverflowError(text)
+        if rc == -5 and "out of host memory" in text:
+            raise MemoryError(text)
         raise OrlError(text)

@@ -9,7 +9,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <exception>
+#include <memory>
+#include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "orl_host.h"
@@ -179,16 +183,22 @@ __global__ void k_totals(DevParams P, unsigned long long* out) {
 // =============================================================================================
 // host side
 // =============================================================================================
-static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...) {
-  char buf[512];
+// (a fixed buffer: reporting an error must not itself allocate — std::bad_alloc is one of the errors reported)
+static thread_local char g_err[512];
+static int fail(int code, const char* fmt, ...) noexcept {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
-  g_err = buf;
   return code;
 }
+// Exception barrier: nothing throws across the C ABI.  Every entry point with a body that can allocate (new orl_batch,
+// std::vector growth, std::string) is a function-try-block ending in one of these.
+#define ORL_ABI_CATCH_INT                                                                                          \
+  catch (const std::bad_alloc&) { return fail(ORL_E_INTERNAL, "out of host memory"); }                             \
+  catch (const std::exception& e_) { return fail(ORL_E_INTERNAL, "C++ exception at the ABI: %s", e_.what()); }     \
+  catch (...) { return fail(ORL_E_INTERNAL, "unknown C++ exception at the ABI"); }
+#define ORL_ABI_CATCH_VOID catch (...) { fail(ORL_E_INTERNAL, "C++ exception in a destroy call"); }
 #define HIPCHK(x)                                                                                     \
   do {                                                                                                \
     hipError_t _e = (x);                                                                              \
@@ -206,21 +216,23 @@ static int upload_conv(T** out, const S* src, size_t n, std::vector<void*>* trac
 }
 
 extern "C" int orl_abi_version(void) { return ORL_ABI_VERSION; }
-extern "C" const char* orl_last_error(void) { return g_err.c_str(); }
-extern "C" int orl_device_count(void) {
+extern "C" const char* orl_last_error(void) { return g_err; }
+extern "C" int orl_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
-extern "C" int orl_build_has_alt(void) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_build_has_alt(void) try {
 #ifdef ORL_ALT_IMPLS
   return 1;
 #else
   return 0;
 #endif
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, orl_topology** out) {
+extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, orl_topology** out) try {
   if (!d || !out) return fail(ORL_E_INVALID, "null argument");
   if (d->n_nodes < 2 || d->n_nodes > 512 || d->n_links < 1 || d->n_links > 128 || d->k_paths < 1 || d->k_paths > 64 ||
       d->max_hops < 1 || d->max_hops > 30 || d->n_modulations < 1 || d->n_modulations > 255)
@@ -248,7 +260,9 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
     }
   }
   HIPCHK(hipSetDevice(device_id));
-  orl_topology* t = new orl_topology();
+  struct Destroy { void operator()(orl_topology* p) const { orl_topology_destroy(p); } };
+  std::unique_ptr<orl_topology, Destroy> hold(new orl_topology());
+  orl_topology* t = hold.get();
   t->n_paths = nullptr;
   t->path_length = nullptr; t->edge_iter_order = nullptr; t->link_pos = nullptr;
   t->device = device_id;
@@ -267,12 +281,13 @@ extern "C" int orl_topology_create(const orl_topology_desc* d, int device_id, or
     for (int i = 0; i < E; i++) pos[(size_t)d->edge_iter_order[i]] = i;
     rc |= upload_conv(&t->link_pos, pos.data(), (size_t)E, nullptr);
   }
-  if (rc) { orl_topology_destroy(t); return ORL_E_HIP; }
-  *out = t;
+  if (rc) return ORL_E_HIP;
+  *out = hold.release();
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
-extern "C" void orl_topology_destroy(orl_topology* t) {
+extern "C" void orl_topology_destroy(orl_topology* t) try {
   if (!t) return;
   hipSetDevice(t->device);
   if (t->n_paths) hipFree(t->n_paths);
@@ -281,6 +296,7 @@ extern "C" void orl_topology_destroy(orl_topology* t) {
   if (t->link_pos) hipFree(t->link_pos);
   delete t;
 }
+ORL_ABI_CATCH_VOID
 
 // ---- launch dispatch over the row width ---------------------------------------------------------------
 static void launch_reset(orl_batch* b, int full, const unsigned char* dmask) {
@@ -362,6 +378,9 @@ static int policy_ok(const orl_batch* b, int policy_id) {
 static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
                              const int64_t* seeds, orl_batch** out) {
   if (!c || !t || !out || (!mt_state && !seeds) || n_envs < 1) return fail(ORL_E_INVALID, "null/invalid argument");
+  if (c->struct_size != sizeof(orl_env_config))
+    return fail(ORL_E_INVALID, "orl_env_config.struct_size is %u, this library (ABI %d) expects %zu: client built against another header",
+                c->struct_size, ORL_ABI_VERSION, sizeof(orl_env_config));
   if (n_envs > (int64_t)1 << 30) return fail(ORL_E_INVALID, "n_envs must be <= 2^30");
   if (c->env_type < 0 || c->env_type > ORL_ENV_QOS) return fail(ORL_E_INVALID, "unknown env_type %d", c->env_type);
   const bool qos = c->env_type == ORL_ENV_QOS;
@@ -388,13 +407,15 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   if (c->bit_rate_mode == 0 && !no_rates && (rand_n < 1 || rand_n != c->n_bit_rates))
     return fail(ORL_E_INVALID, "continuous mode needs n_bit_rates == hi - lo + 1");
   if (!(c->lambda_arrival > 0) || !(c->lambda_holding > 0)) return fail(ORL_E_INVALID, "rates must be positive");
-  if (c->action_histograms && (c->env_type == ORL_ENV_RMCSA || qos)) return fail(ORL_E_INVALID, "action histograms are not kept for this env family");
+  if (c->action_histograms && qos) return fail(ORL_E_INVALID, "action histograms are not kept for this env family");
   HIPCHK(hipSetDevice(t->device));
-  // every early return below goes through orl_batch_destroy (frees what has been allocated so far)
-  orl_batch* b = new orl_batch();
+  // (owned until the last statement: an early return or an exception on the way frees everything allocated so far)
+  struct Destroy { void operator()(orl_batch* p) const { orl_batch_destroy(p); } };
+  std::unique_ptr<orl_batch, Destroy> hold(new orl_batch());
+  orl_batch* b = hold.get();
   memset(&b->P, 0, sizeof b->P);
   b->device = t->device;
-#define FAIL_B(...) do { int rc_ = fail(__VA_ARGS__); orl_batch_destroy(b); return rc_; } while (0)
+#define FAIL_B(...) do { return fail(__VA_ARGS__); } while (0)
 #define HIPCHK_B(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL_B(ORL_E_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
   DevParams& P = b->P;
   P.env_type = c->env_type;
@@ -522,7 +543,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   if (c->bit_rate_mode == 1 && c->env_type != ORL_ENV_RWA) rc |= dalloc(b, &P.br_hist, B * 2 * P.n_br);
   if (c->env_type == ORL_ENV_RWA) rc |= dalloc(b, &P.act_hist, B * ((P.K + 1) + (S + 1)));
   if (c->action_histograms) {
-    P.act2d_words = 2 * (P.K + 1) * (S + 1);
+    // RMSA / DeepRMSA / RWA: [2][k+1][S+1]; RMCSA: [2][k+1][M+1][C+1][S+1] (rmcsa_env.py:145-180; 863 KB per env at 7 x 320)
+    const long long cells = (long long)(P.K + 1) * (S + 1) * (c->env_type == ORL_ENV_RMCSA ? (long long)(P.M + 1) * (C + 1) : 1);
+    if (2 * cells > INT_MAX) FAIL_B(ORL_E_INVALID, "action histograms too large");
+    P.act2d_words = (int)(2 * cells);
     rc |= dalloc(b, &P.act2d, B * (size_t)P.act2d_words);
   }
   rc |= dalloc(b, &P.path_col, B);
@@ -532,7 +556,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   rc |= dalloc(b, &P.info, B * P.n_info);
   if (P.obs_dim) { rc |= dalloc(b, &P.obs, B * P.obs_dim); rc |= dalloc(b, &P.term_obs, B * P.obs_dim); }
   rc |= dalloc(b, &b->d_totals, 2);
-  if (rc) { orl_batch_destroy(b); return ORL_E_HIP; }
+  if (rc) return ORL_E_HIP;
   HIPCHK_B(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHK_B(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
   HIPCHK_B(hipEventCreateWithFlags(&b->ev_half, hipEventDisableTiming));
@@ -571,22 +595,24 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   if (dseeds) { hipFree(dseeds); b->allocs.erase(std::find(b->allocs.begin(), b->allocs.end(), (void*)dseeds)); }
 #undef FAIL_B
 #undef HIPCHK_B
-  *out = b;
+  *out = hold.release();
   return ORL_OK;
 }
 
 extern "C" int orl_batch_create(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
-                                orl_batch** out) {
+                                orl_batch** out) try {
   if (!mt_state) return fail(ORL_E_INVALID, "mt_state is null");
   return batch_create_impl(c, t, n_envs, mt_state, nullptr, out);
 }
+ORL_ABI_CATCH_INT
 extern "C" int orl_batch_create_seeded(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const int64_t* seeds,
-                                       orl_batch** out) {
+                                       orl_batch** out) try {
   if (!seeds) return fail(ORL_E_INVALID, "seeds is null");
   return batch_create_impl(c, t, n_envs, nullptr, seeds, out);
 }
+ORL_ABI_CATCH_INT
 
-extern "C" void orl_batch_destroy(orl_batch* b) {
+extern "C" void orl_batch_destroy(orl_batch* b) try {
   if (!b) return;
   hipSetDevice(b->device);
   if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
@@ -597,17 +623,19 @@ extern "C" void orl_batch_destroy(orl_batch* b) {
   for (void* p : b->allocs) hipFree(p);
   delete b;
 }
+ORL_ABI_CATCH_VOID
 
 extern "C" int orl_batch_info_dim(const orl_batch* b) { return b ? b->P.n_info : 0; }
 extern "C" int orl_batch_obs_dim(const orl_batch* b) { return b ? b->P.obs_dim : 0; }
 
-extern "C" int orl_batch_sync(orl_batch* b) {
+extern "C" int orl_batch_sync(orl_batch* b) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
 // device copy of a host env mask for the duration of one call
 struct DevMask {
@@ -621,7 +649,7 @@ struct DevMask {
   }
 };
 
-extern "C" int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask) {
+extern "C" int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));
   DevMask m;
@@ -632,8 +660,9 @@ extern "C" int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask) 
   HIPCHK(hipGetLastError());
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_t* env_mask) {
+extern "C" int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_t* env_mask) try {
   if (!b || !seeds) return fail(ORL_E_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
   const size_t B = (size_t)b->P.B;
@@ -666,26 +695,41 @@ extern "C" int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_
   HIPCHK(hipGetLastError());
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_batch_episode_log(orl_batch* b, int32_t capacity) {
+extern "C" int orl_batch_episode_log(orl_batch* b, int32_t capacity) try {
   if (!b || capacity < 0) return fail(ORL_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   const size_t B = (size_t)b->P.B;
-  if (capacity > b->P.ep_cap) {  // (the previous, smaller log stays allocated until the batch is destroyed)
-    int *lg = nullptr, *ct = b->P.ep_count;
+  if (capacity == 0) { b->P.ep_log = nullptr; b->P.ep_cap = 0; return ORL_OK; }  // (the buffer stays for the next arming)
+  if (capacity > b->ep_alloc) {  // grow: the old buffer is released, the log is [n_envs][capacity] from here on
+    int* lg = nullptr;
     HIPCHK(hipMalloc((void**)&lg, B * (size_t)capacity * sizeof(int) + 64));
+    if (b->ep_buf) {
+      hipFree(b->ep_buf);
+      b->allocs.erase(std::find(b->allocs.begin(), b->allocs.end(), (void*)b->ep_buf));
+    }
     b->allocs.push_back(lg);
-    if (!ct) { HIPCHK(hipMalloc((void**)&ct, B * sizeof(int) + 64)); b->allocs.push_back(ct); }
-    b->P.ep_log = lg; b->P.ep_count = ct; b->P.ep_cap = capacity;
+    b->ep_buf = lg;
+    b->ep_alloc = capacity;
   }
-  if (capacity == 0) { b->P.ep_log = nullptr; b->P.ep_cap = 0; return ORL_OK; }
+  if (!b->P.ep_count) {
+    int* ct = nullptr;
+    HIPCHK(hipMalloc((void**)&ct, B * sizeof(int) + 64));
+    b->allocs.push_back(ct);
+    b->P.ep_count = ct;
+  }
+  // the row stride of the log is the ARMED capacity (what orl_batch_get_episode_log copies), whatever the buffer could hold
+  b->P.ep_log = b->ep_buf;
+  b->P.ep_cap = capacity;
   HIPCHK(hipMemsetAsync(b->P.ep_count, 0, B * sizeof(int), b->stream));
   HIPCHK(hipMemsetAsync(b->P.ep_log, 0, B * (size_t)b->P.ep_cap * sizeof(int), b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   return ORL_OK;
 }
-extern "C" int orl_batch_get_episode_log(orl_batch* b, int32_t* counts, int32_t* accepted) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_episode_log(orl_batch* b, int32_t* counts, int32_t* accepted) try {
   if (!b || !counts || !accepted) return fail(ORL_E_INVALID, "null argument");
   if (!b->P.ep_log) return fail(ORL_E_INVALID, "the episode log is not armed (orl_batch_episode_log)");
   HIPCHK(hipSetDevice(b->device));
@@ -694,16 +738,18 @@ extern "C" int orl_batch_get_episode_log(orl_batch* b, int32_t* counts, int32_t*
   HIPCHK(hipMemcpy(accepted, b->P.ep_log, (size_t)b->P.B * b->P.ep_cap * sizeof(int), hipMemcpyDeviceToHost));
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_batch_set_paths(orl_batch* b, const int32_t* paths) {
+extern "C" int orl_batch_set_paths(orl_batch* b, const int32_t* paths) try {
   if (!b || !paths) return fail(ORL_E_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipMemcpyAsync(b->P.path_col, paths, (size_t)b->P.B * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_batch_policy(orl_batch* b, int policy_id, int32_t* actions_out) {
+extern "C" int orl_batch_policy(orl_batch* b, int policy_id, int32_t* actions_out) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   if (!policy_ok(b, policy_id)) return fail(ORL_E_INVALID, "policy %d is not defined for this env family", policy_id);
   HIPCHK(hipSetDevice(b->device));
@@ -715,6 +761,7 @@ extern "C" int orl_batch_policy(orl_batch* b, int policy_id, int32_t* actions_ou
   }
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
 // the index ranges of the reference's actions_output arrays (rmsa_env.py:126-137, 167; rwa_env.py:52-58, 103;
 // rmcsa_env.py:145-153, 219); DeepRMSA takes any integer (deeprmsa_env.py:48-58)
@@ -752,7 +799,7 @@ static int report_flags(orl_batch* b) {
 }
 
 extern "C" int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, double* reward_out,
-                              uint8_t* done_out, double* info_out) {
+                              uint8_t* done_out, double* info_out) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));
   const size_t B = (size_t)b->P.B;
@@ -776,25 +823,29 @@ extern "C" int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_res
   }
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_batch_check(orl_batch* b) {
+extern "C" int orl_batch_check(orl_batch* b) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));
   return report_flags(b);
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_host_alloc(size_t bytes, void** out) {
+extern "C" int orl_host_alloc(size_t bytes, void** out) try {
   if (!out || bytes == 0) return fail(ORL_E_INVALID, "bad argument");
   HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
   memset(*out, 0, bytes);
   return ORL_OK;
 }
-extern "C" int orl_host_free(void* p) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_host_free(void* p) try {
   if (p) HIPCHK(hipHostFree(p));
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_batch_device_buffer(orl_batch* b, int which, void** device_ptr, int64_t* n_elements) {
+extern "C" int orl_batch_device_buffer(orl_batch* b, int which, void** device_ptr, int64_t* n_elements) try {
   if (!b || !device_ptr || !n_elements) return fail(ORL_E_INVALID, "null argument");
   const int64_t B = b->P.B;
   switch (which) {
@@ -809,8 +860,9 @@ extern "C" int orl_batch_device_buffer(orl_batch* b, int which, void** device_pt
   }
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
-extern "C" int orl_batch_observation(orl_batch* b, double* obs_out) {
+extern "C" int orl_batch_observation(orl_batch* b, double* obs_out) try {
   if (!b || !obs_out) return fail(ORL_E_INVALID, "null argument");
   if (!b->P.obs_dim) return fail(ORL_E_INVALID, "this env family has no array observation");
   HIPCHK(hipSetDevice(b->device));
@@ -820,6 +872,7 @@ extern "C" int orl_batch_observation(orl_batch* b, double* obs_out) {
   HIPCHK(hipGetLastError());
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
 // events created for one call, destroyed on every exit path
 struct EventPool {
@@ -827,7 +880,7 @@ struct EventPool {
   ~EventPool() { for (auto& e : ev) hipEventDestroy(e); }
 };
 
-extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels, orl_run_stats* stats) {
+extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int time_kernels, orl_run_stats* stats) try {
   if (!b || n_steps < 0) return fail(ORL_E_INVALID, "bad argument");
   if (n_steps > INT_MAX) return fail(ORL_E_INVALID, "n_steps must be <= %d per call", INT_MAX);
   if (!policy_ok(b, policy_id)) return fail(ORL_E_INVALID, "policy %d is not defined for this env family", policy_id);
@@ -980,6 +1033,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
   }
   return have_flags ? flags_to_rc(b, tail[1]) : report_flags(b);
 }
+ORL_ABI_CATCH_INT
 
 // ---- read-back ----------------------------------------------------------------------------------
 static int fetch_scal(orl_batch* b, std::vector<u64>& host) {
@@ -991,7 +1045,7 @@ static int fetch_scal(orl_batch* b, std::vector<u64>& host) {
 }
 static double as_f64(u64 v) { double d; memcpy(&d, &v, 8); return d; }
 
-extern "C" int orl_batch_get_counters(orl_batch* b, int64_t* out) {
+extern "C" int orl_batch_get_counters(orl_batch* b, int64_t* out) try {
   if (!b || !out) return fail(ORL_E_INVALID, "null argument");
   std::vector<u64> h;
   if (fetch_scal(b, h)) return ORL_E_HIP;
@@ -1003,7 +1057,8 @@ extern "C" int orl_batch_get_counters(orl_batch* b, int64_t* out) {
   }
   return ORL_OK;
 }
-extern "C" int orl_batch_get_services(orl_batch* b, double* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_services(orl_batch* b, double* out) try {
   if (!b || !out) return fail(ORL_E_INVALID, "null argument");
   std::vector<u64> h;
   if (fetch_scal(b, h)) return ORL_E_HIP;
@@ -1016,21 +1071,24 @@ extern "C" int orl_batch_get_services(orl_batch* b, double* out) {
   }
   return ORL_OK;
 }
-extern "C" int orl_batch_get_active(orl_batch* b, int32_t* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_active(orl_batch* b, int32_t* out) try {
   if (!b || !out) return fail(ORL_E_INVALID, "null argument");
   std::vector<u64> h;
   if (fetch_scal(b, h)) return ORL_E_HIP;
   for (i64 i = 0; i < b->P.B; i++) out[i] = (int32_t)(h[(size_t)i * ORL_SCAL_WORDS + SC_EV] >> 32);
   return ORL_OK;
 }
-extern "C" int orl_batch_get_flags(orl_batch* b, int32_t* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_flags(orl_batch* b, int32_t* out) try {
   if (!b || !out) return fail(ORL_E_INVALID, "null argument");
   std::vector<u64> h;
   if (fetch_scal(b, h)) return ORL_E_HIP;
   for (i64 i = 0; i < b->P.B; i++) out[i] = (int32_t)(h[(size_t)i * ORL_SCAL_WORDS + SC_FLAGS] >> 32);
   return ORL_OK;
 }
-extern "C" int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out) try {
   if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -1041,7 +1099,8 @@ extern "C" int orl_batch_get_slots(orl_batch* b, int64_t env, uint8_t* out) {
     for (int s = 0; s < S; s++) out[(size_t)r * S + s] = (uint8_t)((h[(size_t)r * W + (s >> 6)] >> (s & 63)) & 1ull);
   return ORL_OK;
 }
-extern "C" int orl_batch_get_spectrum(orl_batch* b, int64_t env, int32_t* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_spectrum(orl_batch* b, int64_t env, int32_t* out) try {
   if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
   if (b->P.env_type != ENV_QOS) return fail(ORL_E_INVALID, "available_spectrum counters exist for QoSConstrainedRA only");
   HIPCHK(hipSetDevice(b->device));
@@ -1051,7 +1110,8 @@ extern "C" int orl_batch_get_spectrum(orl_batch* b, int64_t env, int32_t* out) {
   for (int l = 0; l < b->P.E; l++) out[l] = (int32_t)h[(size_t)l];
   return ORL_OK;
 }
-extern "C" int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out) try {
   if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -1062,7 +1122,8 @@ extern "C" int orl_batch_get_link_stats(orl_batch* b, int64_t env, double* out) 
     for (int k = 0; k < 4; k++) out[(size_t)k * E + l] = h[(size_t)4 * l + k];
   return ORL_OK;
 }
-extern "C" int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out) try {
   if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -1071,7 +1132,43 @@ extern "C" int orl_batch_get_net_stats(orl_batch* b, int64_t env, double* out) {
   out[0] = as_f64(s[SC_GTHR]); out[1] = as_f64(s[SC_GCOMP]); out[2] = as_f64(s[SC_GLAST]); out[3] = as_f64(s[SC_NOW]);
   return ORL_OK;
 }
-extern "C" int orl_batch_get_action_histograms(orl_batch* b, int64_t env, int32_t* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_row_words(const orl_batch* b) { return b ? b->wt : 0; }
+extern "C" int orl_batch_map_words(const orl_batch* b) { return b ? b->P.bm_words : 0; }
+extern "C" int orl_batch_get_slots_packed(orl_batch* b, uint64_t* out) try {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  if (b->P.env_type == ENV_QOS) return fail(ORL_E_INVALID, "QoSConstrainedRA keeps counters, not slot maps");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out, b->P.bitmap, (size_t)b->P.B * b->P.bm_words * 8, hipMemcpyDeviceToHost));
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_link_stats_all(orl_batch* b, double* out) try {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const size_t E = (size_t)b->P.E, B = (size_t)b->P.B;
+  std::vector<double> h(B * 4 * E);  // device layout [B][E][4] -> ABI layout [B][4][E]
+  HIPCHK(hipMemcpy(h.data(), b->P.lstat, h.size() * 8, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < B; i++)
+    for (size_t l = 0; l < E; l++)
+      for (size_t k = 0; k < 4; k++) out[(i * 4 + k) * E + l] = h[(i * E + l) * 4 + k];
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_net_stats_all(orl_batch* b, double* out) try {
+  if (!b || !out) return fail(ORL_E_INVALID, "null argument");
+  std::vector<u64> h;
+  if (fetch_scal(b, h)) return ORL_E_HIP;
+  for (i64 i = 0; i < b->P.B; i++) {
+    const u64* s = &h[(size_t)i * ORL_SCAL_WORDS];
+    out[4 * i] = as_f64(s[SC_GTHR]); out[4 * i + 1] = as_f64(s[SC_GCOMP]); out[4 * i + 2] = as_f64(s[SC_GLAST]); out[4 * i + 3] = as_f64(s[SC_NOW]);
+  }
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_action_histograms(orl_batch* b, int64_t env, int32_t* out) try {
   if (!b || !out || env < 0 || env >= b->P.B) return fail(ORL_E_INVALID, "bad argument");
   if (!b->P.act2d) return fail(ORL_E_INVALID, "the batch was created without action_histograms");
   HIPCHK(hipSetDevice(b->device));
@@ -1079,7 +1176,8 @@ extern "C" int orl_batch_get_action_histograms(orl_batch* b, int64_t env, int32_
   HIPCHK(hipMemcpy(out, b->P.act2d + env * b->P.act2d_words, (size_t)b->P.act2d_words * sizeof(int), hipMemcpyDeviceToHost));
   return ORL_OK;
 }
-extern "C" int orl_batch_get_pending(orl_batch* b, int64_t env, int32_t capacity, double* time_out, int32_t* rec_out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_pending(orl_batch* b, int64_t env, int32_t capacity, double* time_out, int32_t* rec_out) try {
   if (!b || env < 0 || env >= b->P.B || capacity < 0) return fail(ORL_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -1110,7 +1208,8 @@ extern "C" int orl_batch_get_pending(orl_batch* b, int64_t env, int32_t capacity
   }
   return n;
 }
-extern "C" int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accepted) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipMemsetAsync(b->d_totals, 0, 16, b->stream));
@@ -1123,9 +1222,10 @@ extern "C" int orl_batch_totals(orl_batch* b, int64_t* processed, int64_t* accep
   if (accepted) *accepted = (int64_t)h[1];
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
 /* debug: stream the slot-map array (n_envs * bm_words * 8 bytes) once; returns that byte count */
-extern "C" int64_t orl_batch_debug_stream_read(orl_batch* b, int width16) {
+extern "C" int64_t orl_batch_debug_stream_read(orl_batch* b, int width16) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   if (hipSetDevice(b->device) != hipSuccess) return ORL_E_HIP;
   i64 n_words = b->P.B * b->P.bm_words;
@@ -1133,10 +1233,11 @@ extern "C" int64_t orl_batch_debug_stream_read(orl_batch* b, int width16) {
   if (hipStreamSynchronize(b->stream) != hipSuccess) return ORL_E_HIP;
   return n_words * 8;
 }
+ORL_ABI_CATCH_INT
 
 extern "C" int orl_batch_matrix_obs_dim(const orl_batch* b) { return b ? 2 * b->P.N + b->P.C * b->P.E * b->P.S : 0; }
 
-extern "C" int orl_batch_matrix_observation(orl_batch* b, uint8_t* out) {
+extern "C" int orl_batch_matrix_observation(orl_batch* b, uint8_t* out) try {
   if (!b || !out) return fail(ORL_E_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
   const size_t dim = (size_t)orl_batch_matrix_obs_dim(b), B = (size_t)b->P.B;
@@ -1150,6 +1251,72 @@ extern "C" int orl_batch_matrix_observation(orl_batch* b, uint8_t* out) {
   HIPCHK(hipGetLastError());
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
+
+// ---- several devices, one process: contiguous shards of the env index range, one orl_batch per shard ----------------------
+struct orl_multi {
+  std::vector<orl_topology*> topo;
+  std::vector<orl_batch*> shard;
+  std::vector<int64_t> first;  // [n_shards + 1]
+};
+extern "C" void orl_multi_destroy(orl_multi* m) try {
+  if (!m) return;
+  for (orl_batch* b : m->shard) orl_batch_destroy(b);
+  for (orl_topology* t : m->topo) orl_topology_destroy(t);
+  delete m;
+}
+ORL_ABI_CATCH_VOID
+extern "C" int orl_multi_create(const orl_env_config* cfg, const orl_topology_desc* topo, int64_t n_envs, const int64_t* seeds,
+                                int n_devices, const int* device_ids, orl_multi** out) try {
+  if (!cfg || !topo || !seeds || !device_ids || !out) return fail(ORL_E_INVALID, "null argument");
+  if (n_devices < 1 || n_devices > 64 || n_envs < n_devices) return fail(ORL_E_INVALID, "need 1..64 devices and at least one env per device");
+  const int have = orl_device_count();
+  for (int r = 0; r < n_devices; r++)
+    if (device_ids[r] < 0 || device_ids[r] >= have) return fail(ORL_E_INVALID, "device %d is not visible (%d GPU(s))", device_ids[r], have);
+  struct Destroy { void operator()(orl_multi* p) const { orl_multi_destroy(p); } };
+  std::unique_ptr<orl_multi, Destroy> m(new orl_multi());
+  m->first.push_back(0);
+  const int64_t per = n_envs / n_devices, rem = n_envs % n_devices;  // balanced, contiguous (sharding.shard_range)
+  for (int r = 0; r < n_devices; r++) {
+    const int64_t n = per + (r < rem ? 1 : 0);
+    orl_topology* t = nullptr;
+    int rc = orl_topology_create(topo, device_ids[r], &t);
+    if (rc) return rc;
+    m->topo.push_back(t);
+    orl_batch* b = nullptr;
+    rc = orl_batch_create_seeded(cfg, t, n, seeds + m->first.back(), &b);
+    if (rc) return rc;
+    m->shard.push_back(b);
+    m->first.push_back(m->first.back() + n);
+  }
+  *out = m.release();
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+extern "C" int orl_multi_n_shards(const orl_multi* m) { return m ? (int)m->shard.size() : 0; }
+extern "C" orl_batch* orl_multi_shard(orl_multi* m, int r, int64_t* first_env, int64_t* n_envs) {
+  if (!m || r < 0 || r >= (int)m->shard.size()) { fail(ORL_E_INVALID, "no such shard"); return nullptr; }
+  if (first_env) *first_env = m->first[(size_t)r];
+  if (n_envs) *n_envs = m->first[(size_t)r + 1] - m->first[(size_t)r];
+  return m->shard[(size_t)r];
+}
+extern "C" int orl_multi_run(orl_multi* m, int policy_id, int64_t n_steps, orl_run_stats* stats) try {
+  if (!m) return fail(ORL_E_INVALID, "null group");
+  const size_t n = m->shard.size();
+  std::vector<int> rc(n, 0);
+  std::vector<std::string> msg(n);
+  std::vector<std::thread> th;
+  for (size_t r = 0; r < n; r++)
+    th.emplace_back([&, r] {  // (the error text is thread-local: carried back by value)
+      rc[r] = orl_batch_run(m->shard[r], policy_id, n_steps, 0, stats ? stats + r : nullptr);
+      if (rc[r]) msg[r] = orl_last_error();
+    });
+  for (auto& t : th) t.join();
+  for (size_t r = 0; r < n; r++)
+    if (rc[r]) return fail(rc[r], "shard %zu: %s", r, msg[r].c_str());
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
 
 // ---- snapshot / restore: the per-env arrays, concatenated in a fixed order -------------------------
 struct Section { void* ptr; size_t bytes; };
@@ -1173,13 +1340,14 @@ static std::vector<Section> state_sections(orl_batch* b) {
   if (P.mt2) v.push_back({P.mt2, B * 624 * 4});
   return v;
 }
-extern "C" int64_t orl_batch_state_bytes(orl_batch* b) {
+extern "C" int64_t orl_batch_state_bytes(orl_batch* b) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   int64_t n = 0;
   for (auto& s : state_sections(b)) n += (int64_t)s.bytes;
   return n;
 }
-extern "C" int orl_batch_get_state(orl_batch* b, void* out) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_state(orl_batch* b, void* out) try {
   if (!b || !out) return fail(ORL_E_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -1187,7 +1355,8 @@ extern "C" int orl_batch_get_state(orl_batch* b, void* out) {
   for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(o, s.ptr, s.bytes, hipMemcpyDeviceToHost)); o += s.bytes; }
   return ORL_OK;
 }
-extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_set_state(orl_batch* b, const void* in) try {
   if (!b || !in) return fail(ORL_E_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -1197,9 +1366,10 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) {
   HIPCHK(hipStreamSynchronize(b->stream));
   return ORL_OK;
 }
+ORL_ABI_CATCH_INT
 
 /* diagnostic builds (-DORL_TIMING): shader-clock cycles per phase of the persistent kernel, summed over wavefronts */
-extern "C" int orl_batch_debug_prof(orl_batch* b, uint64_t* out48, int reset) {
+extern "C" int orl_batch_debug_prof(orl_batch* b, uint64_t* out48, int reset) try {
   if (!b || !out48) return fail(ORL_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
@@ -1209,11 +1379,13 @@ extern "C" int orl_batch_debug_prof(orl_batch* b, uint64_t* out48, int reset) {
 #undef CALL
   return rc ? fail(ORL_E_HIP, "reading the profile failed") : ORL_OK;
 }
-extern "C" int orl_batch_debug_persist_spec(orl_batch* b) {
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_debug_persist_spec(orl_batch* b) try {
   if (!b) return -1;
   return b->persist ? b->persist_spec : -1;
 }
-extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
+ORL_ABI_CATCH_INT
+extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) try {
   if (!b) return -1;
   if (hipSetDevice(b->device) != hipSuccess) return -1;
   hipStreamSynchronize(b->stream);
@@ -1221,3 +1393,4 @@ extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) {
   if (hipMemcpy(&v, b->P.q_stat, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int64_t)v;
 }
+ORL_ABI_CATCH_INT

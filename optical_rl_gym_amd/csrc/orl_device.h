@@ -1028,13 +1028,20 @@ __device__ __forceinline__ void episode_log(const DevParams& P, i64 env, i64 acc
   P.ep_count[env] = idx + 1;
 }
 
-// opt-in 2-D action histograms (rmsa_env.py:126-137, 167, 201, 211-212; rwa_env.py:52-58, 103, 125, 132-133):
-// actions_output[path, slot] counts every action, actions_taken[path, slot] the accepted ones and [k, S] the rejections
-__device__ __forceinline__ void act2d_count(const DevParams& P, i64 env, int path, int slot, bool accepted) {
+// opt-in action histograms (rmsa_env.py:126-137, 167, 201, 211-212; rwa_env.py:52-58, 103, 125, 132-133;
+// rmcsa_env.py:145-180, 219, 273, 284-289): actions_output[action] counts every action, actions_taken[action] the accepted
+// ones and its last element ([k, S], RMCSA [k, M, C, S]) the rejections.  `idx`: the action's flat index in one array.
+__device__ __forceinline__ void act_hist_count(const DevParams& P, i64 env, int idx, bool accepted) {
   int* h = P.act2d + env * P.act2d_words;
-  const int S1 = P.S + 1, half = (P.K + 1) * S1;
-  h[path * S1 + slot] += 1;
-  h[half + (accepted ? path * S1 + slot : P.K * S1 + P.S)] += 1;
+  const int half = P.act2d_words >> 1;
+  h[idx] += 1;
+  h[half + (accepted ? idx : half - 1)] += 1;
+}
+__device__ __forceinline__ void act2d_count(const DevParams& P, i64 env, int path, int slot, bool accepted) {
+  act_hist_count(P, env, path * (P.S + 1) + slot, accepted);
+}
+__device__ __forceinline__ void act4d_count(const DevParams& P, i64 env, int path, int mod, int core, int slot, bool accepted) {
+  act_hist_count(P, env, ((path * (P.M + 1) + mod) * (P.C + 1) + core) * (P.S + 1) + slot, accepted);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1262,7 +1269,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
     e.flags |= ORL_FLAG_BAD_ACTION;
     path = K; slot = S; mod = P.M; core = P.C;
   }
-  const int path0 = path, slot0 = slot;
+  const int path0 = path, slot0 = slot, mod0 = mod, core0 = core;
   double prev_comp = 0.0, cur_comp = 0.0;
   if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && info_out) prev_comp = net_compactness(P, e, 0);
   bool accepted = false;
@@ -1307,6 +1314,7 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
   if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
   if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && info_out) cur_comp = net_compactness(P, e, 0);
   if (ENV != ENV_RMCSA && P.act2d && !bad && lane == 0) act2d_count(P, e.env, path0, slot0, accepted);
+  if (ENV == ENV_RMCSA && P.act2d && !bad && lane == 0) act4d_count(P, e.env, path0, mod0, core0, slot0, accepted);
 
   if (ENV == ENV_RWA) {
     // actions_output marginals (rwa_env.py:103, 148-151).  Each lane owns histogram entries, applies this

@@ -359,7 +359,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       e.flags |= ORL_FLAG_BAD_ACTION;
       path = K; slot = S; mod = P.M; core = P.C;
     }
-    const int path0 = path, slot0 = slot;
+    const int path0 = path, slot0 = slot, mod0 = mod, core0 = core;
     ORL_PROFA(2);
     bool accepted = false;
     int pushed_idx = -1;
@@ -422,6 +422,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     if (ENV == ENV_RWA) { e.sp += 1; e.esp += 1; }
     if (ENV == ENV_RMCSA) { e.sp += 1; e.esp += 1; e.brq += e.bit_rate; e.ebrq += e.bit_rate; }
     if (ENV != ENV_RMCSA && P.act2d && !bad && gl == 0) act2d_count(P, env, path0, slot0, accepted);
+    if (ENV == ENV_RMCSA && P.act2d && !bad && gl == 0) act4d_count(P, env, path0, mod0, core0, slot0, accepted);
     if (ENV == ENV_RWA) {  // actions_output marginals (rwa_env.py:103, 148-151)
       i64* h = P.act_hist + env * ((K + 1) + (S + 1));
       const int npa = K + rej, nsa = S + rej;

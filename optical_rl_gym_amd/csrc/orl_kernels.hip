@@ -59,8 +59,9 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
   for (int i = lane; i < P.ev_cap; i += 64) e.ev_time[i] = __builtin_inf();
   if (P.br_hist) for (int i = lane; i < 2 * P.n_br; i += 64) P.br_hist[env * 2 * P.n_br + i] = 0;
   if (P.act_hist) for (int i = lane; i < (P.K + 1) + (P.S + 1); i += 64) P.act_hist[env * ((P.K + 1) + (P.S + 1)) + i] = 0;
-  // RWAEnv.reset clears actions_output / actions_taken (rwa_env.py:194-203); RMSAEnv.reset never does (rmsa_env.py:284-359)
-  if (P.act2d && ENV == ENV_RWA) for (int i = lane; i < P.act2d_words; i += 64) P.act2d[env * P.act2d_words + i] = 0;
+  // RWAEnv.reset and RMCSAEnv.reset clear actions_output / actions_taken (rwa_env.py:194-203, rmcsa_env.py:437-454); RMSAEnv.reset
+  // never does (rmsa_env.py:284-359)
+  if (P.act2d && (ENV == ENV_RWA || ENV == ENV_RMCSA)) for (int i = lane; i < P.act2d_words; i += 64) P.act2d[env * P.act2d_words + i] = 0;
   wave_fence();
   e.now = 0; e.at = 0; e.ht = 0; e.g_thr = 0; e.g_comp = 0; e.g_last = 0;
   e.sp = e.sa = e.esp = e.esa = e.brq = e.brp = e.ebrq = e.ebrp = e.s_br = e.s_nh = 0;
@@ -749,6 +750,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
             VP.bm_words, VP.cs_words, VP.obs_dim);
 #define LAUNCH_SPEC(E_, LDS_, WV_, SP_)                                                                                      \
   do {                                                                                                                       \
+    if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<E_, W, LDS_, WV_, SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
     hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_, SP_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished, clear_next); \
     return;                                                                                                                  \
   } while (0)

@@ -184,12 +184,13 @@ class BatchedOpticalEnv:
                                  _ptr(keep["path_mod"]), _ptr(keep["edge_iter_order"]))
         self._topo_h = C.c_void_p()
         self._ck(self.lib.orl_topology_create(C.byref(desc), device_id, C.byref(self._topo_h)))
-        cfg = _lib.EnvConfig(self.ENV_TYPE, num_spectrum_resources, num_spatial_resources, episode_length,
+        cfg = _lib.EnvConfig(C.sizeof(_lib.EnvConfig), self.ENV_TYPE, num_spectrum_resources, num_spatial_resources, episode_length,
                              int(self.allow_rejection), j, mode, lo, hi, len(table_rates), event_capacity,
                              int(self.action_histograms),
                              lambda_a, lambda_h, _ptr(cum_src), _ptr(keep["cum_dst"]), _ptr(keep["bit_rates"]),
                              _ptr(cum_br), _ptr(keep["n_slots"]), _ptr(lmax_snr), _ptr(lmax_xt),
                              int(num_service_classes) if self.ENV_TYPE == 4 else 0, 0, _ptr(cum_class), _ptr(class_reward))
+        self._cfg, self._desc = cfg, desc  # (kept: what orl_multi_create takes to build the same envs over several devices)
         self._h = C.c_void_p()
         int_seeds = [41 if s_ is None else int(s_) for s_ in self.seeds]
         if all(-2**63 < s_ < 2**63 for s_ in int_seeds):
@@ -303,17 +304,19 @@ class BatchedOpticalEnv:
         self._ck(self.lib.orl_batch_reset(self._h, 0, None))  # the harness's reset() before the first episode (soft)
         self._ck(self.lib.orl_batch_episode_log(self._h, n))
         L = self.steps_per_episode()
-        # the harness stops at the last done without resetting: all steps but the last in one device-resident run (auto
-        # reset between episodes = the harness's reset() at the start of the next one), the last one without auto reset
-        if n * L > 1:
-            self.run(policy, n * L - 1)
-        self.policy(policy, fetch=False)
-        self.step(None, auto_reset=False, fetch=False)
-        self.check()
         counts = np.zeros(self.num_envs, np.int32)
         acc = np.zeros((self.num_envs, n), np.int32)
-        self._ck(self.lib.orl_batch_get_episode_log(self._h, counts.ctypes.data, acc.ctypes.data))
-        self._ck(self.lib.orl_batch_episode_log(self._h, 0))
+        try:
+            # the harness stops at the last done without resetting: all steps but the last in one device-resident run (auto
+            # reset between episodes = the harness's reset() at the start of the next one), the last one without auto reset
+            if n * L > 1:
+                self.run(policy, n * L - 1)
+            self.policy(policy, fetch=False)
+            self.step(None, auto_reset=False, fetch=False)
+            self.check()
+            self._ck(self.lib.orl_batch_get_episode_log(self._h, counts.ctypes.data, acc.ctypes.data))
+        finally:  # whatever happened above, the next run must not append to a log nobody reads
+            self._ck(self.lib.orl_batch_episode_log(self._h, 0))
         assert (counts == n).all(), "every env finishes exactly n episodes in n * steps_per_episode steps"
         rewards = acc.astype(np.float64)
         if self.ENV_TYPE == 1:  # DeepRMSA: +1 accepted, -1 otherwise (deeprmsa_env.py:123-124)
@@ -422,6 +425,25 @@ class BatchedOpticalEnv:
         self._ck(self.lib.orl_batch_get_net_stats(self._h, env, out.ctypes.data))
         return out
 
+    def slots_packed(self):
+        """The slot maps of every env as the device keeps them: [num_envs, map_words] uint64, bit s of word s // 64 of a
+        (core, link) row set = slot s free (`orl_batch_row_words` words per row)."""
+        out = np.zeros((self.num_envs, self.lib.orl_batch_map_words(self._h)), np.uint64)
+        self._ck(self.lib.orl_batch_get_slots_packed(self._h, out.ctypes.data))
+        return out
+
+    def link_stats_all(self):
+        """[num_envs, 4, links]: utilization, external_fragmentation, compactness, last_update of every link of every env."""
+        out = np.zeros((self.num_envs, 4, self.topology.n_links))
+        self._ck(self.lib.orl_batch_get_link_stats_all(self._h, out.ctypes.data))
+        return out
+
+    def net_stats_all(self):
+        """[num_envs, 4]: throughput, compactness, last_update, current_time."""
+        out = np.zeros((self.num_envs, 4))
+        self._ck(self.lib.orl_batch_get_net_stats_all(self._h, out.ctypes.data))
+        return out
+
     def active(self):
         out = np.zeros(self.num_envs, np.int32)
         self._ck(self.lib.orl_batch_get_active(self._h, out.ctypes.data))
@@ -439,7 +461,10 @@ class BatchedOpticalEnv:
         """(actions_output, actions_taken) of env `env` as [k_paths+1, slots+1] int arrays (rmsa_env.py:126-137; RWA's
         arrays are the top-left [k+reject, slots+reject] corner, rwa_env.py:52-58).  Needs action_histograms=True."""
         K1, S1 = self.k_paths + 1, self.num_spectrum_resources + 1
-        out = np.zeros((2, K1, S1), np.int32)
+        shape = (2, K1, S1)
+        if self.ENV_TYPE == 3:  # RMCSA: [k+1, modulations+1, cores+1, slots+1] (rmcsa_env.py:145-180)
+            shape = (2, K1, len(self.modulation_formats) + 1, self.num_spatial_resources + 1, S1)
+        out = np.zeros(shape, np.int32)
         self._ck(self.lib.orl_batch_get_action_histograms(self._h, env, out.ctypes.data))
         return out[0].astype(np.int64), out[1].astype(np.int64)
 
@@ -559,7 +584,7 @@ class BatchedRMCSAEnv(BatchedOpticalEnv):
                  modulation_formats=None, worst_xt=None, node_request_probabilities=None,
                  bit_rate_selection="continuous", bit_rates=(10, 40, 100), bit_rate_probabilities=None,
                  bit_rate_lower_bound=25, bit_rate_higher_bound=100, seed=None, allow_rejection=False, reset=True,
-                 channel_width=12.5, event_capacity=0):
+                 channel_width=12.5, event_capacity=0, action_histograms=False):
         import copy
 
         if seeds is None and seed is not None:
@@ -578,7 +603,7 @@ class BatchedRMCSAEnv(BatchedOpticalEnv):
                     bit_rate_selection=bit_rate_selection, bit_rates=bit_rates,
                     bit_rate_probabilities=bit_rate_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
                     bit_rate_higher_bound=bit_rate_higher_bound, num_spatial_resources=num_spatial_resources,
-                    modulations=mods, worst_xt=worst_xt, event_capacity=event_capacity)
+                    modulations=mods, worst_xt=worst_xt, event_capacity=event_capacity, action_histograms=action_histograms)
         self.info_keys = RMSA_INFO_KEYS[:4]
 
 

@@ -130,7 +130,8 @@ class _SingleEnv:
     def __init__(self, topology=None, seed=None, _backend=None, **kwargs):
         self.rand_seed = 41 if seed is None else seed
         if _backend is None:
-            extra = dict(action_histograms=True) if self.BATCH_CLS.ENV_TYPE in (0, 1, 2) else {}
+            # (RMCSA's 4-D arrays are 860 KB per env at 7 x 320: affordable for the 1-env front end, opt-in for batches)
+            extra = dict(action_histograms=True) if self.BATCH_CLS.ENV_TYPE in (0, 1, 2, 3) else {}
             _backend = self.BATCH_CLS(topology=topology, num_envs=1, seeds=[seed], **extra, **kwargs)
             topo = _backend.topology
         else:
@@ -409,8 +410,9 @@ class RMCSAEnv(_SingleEnv):
         avail = self._slots()
         return not np.any(avail[core][self._links(path), initial_slot:initial_slot + number_slots] == 0)
 
-    def _histograms(self):
-        raise AttributeError("the 4-D action histograms of RMCSAEnv (rmcsa_env.py:145-180) are not kept")
+    def _episode_hist(self, which):  # re-zeroed at every reset and never incremented (rmcsa_env.py:154-180, 391-407)
+        return np.zeros((self.k_paths + 1, len(self.topo.modulations) + 1, self.num_spatial_resources + 1,
+                         self.num_spectrum_resources + 1), dtype=int)
 
 
 # ---- module-level heuristics with the reference's names ---------------------------------------------------
@@ -454,6 +456,20 @@ def shortest_available_path_best_modulation_first_core_first_fit(env):
 def random_policy(env):
     """utils.py:99-100 (the stream is this package's numpy generator, not gym 0.21's)"""
     return env.action_space.sample()
+
+
+def start_environment(env, steps):
+    """utils.py:62-70.  As written upstream the episode loop never runs: `done` starts True, every one of the `steps`
+    iterations resets the env (soft reset) and the inner `while not done` is skipped, so the function returns the env after
+    `steps` soft resets.  Kept with exactly that observable behaviour; an episode that did start is played with random
+    actions until done, as upstream intends."""
+    done = True
+    for _ in range(int(steps)):
+        if done:
+            env.reset()
+        while not done:
+            _, _, done, _ = env.step(env.action_space.sample())
+    return env
 
 
 def evaluate_heuristic(env, heuristic, n_eval_episodes=10, render=False, callback=None, reward_threshold=None,

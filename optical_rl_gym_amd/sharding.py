@@ -29,6 +29,25 @@ def shard_seeds(base_seed, n_envs_total, rank, world):
     return [base_seed + i for i in range(lo, hi)]
 
 
+class MultiRunStats:
+    """RunStats of a run over several shards (see MultiDeviceBatch.run)."""
+
+    def __init__(self, parts):
+        self.shards = list(parts)
+        get = lambda p, name: getattr(p, name, 0) or 0  # (shards need not be HIP batches: from_shards takes any batch object)
+        self.ms_total = max(float(get(p, "ms_total")) for p in parts)
+        self.ms_policy = max(float(get(p, "ms_policy")) for p in parts)
+        self.ms_step = max(float(get(p, "ms_step")) for p in parts)
+        self.launches = sum(int(get(p, "launches")) for p in parts)
+        self.n_kernels = int(get(parts[0], "n_kernels"))
+
+    def kernels(self):
+        if not hasattr(self.shards[0], "kernels"):
+            return []
+        first = self.shards[0].kernels()
+        return [(name, max(p.kernels()[i][1] for p in self.shards)) for i, (name, _) in enumerate(first)]
+
+
 class MultiDeviceBatch:
     """`num_envs` envs spread over `device_ids` (contiguous shards), with the methods of `BatchedOpticalEnv`."""
 
@@ -102,8 +121,11 @@ class MultiDeviceBatch:
         return self._cat([o[0] for o in out]), self._cat([o[1] for o in out]), self._cat([o[2] for o in out]), self._info
 
     def run(self, policy, n_steps, time_kernels=False):
-        """Every shard runs its own device-resident loop concurrently; returns the shards' RunStats."""
-        return self._map(lambda r: self.shards[r].run(policy, n_steps, time_kernels))
+        """Every shard runs its own device-resident loop concurrently.  Returns ONE stats object with the fields of a single
+        batch's RunStats — the shards run side by side, so times are the MAX over shards and launches the sum — plus
+        `.shards`, the per-shard RunStats in env-index order."""
+        parts = self._map(lambda r: self.shards[r].run(policy, n_steps, time_kernels))
+        return MultiRunStats(parts)
 
     def evaluate(self, policy, n_eval_episodes=10):
         out = self._map(lambda r: self.shards[r].evaluate(policy, n_eval_episodes))

@@ -162,11 +162,25 @@ def load_reference_pickle(path):
         def __setstate__(self, state):
             self.__dict__.update(state if isinstance(state, dict) else state[0] or {})
 
+    # A pickle can name any importable callable: only what such a file legitimately holds is resolved — the networkx graph
+    # and view classes, numpy scalars / arrays / dtypes, plain containers — and anything else is refused.
+    safe_builtins = {"set", "frozenset", "list", "dict", "tuple", "int", "float", "complex", "str", "bytes", "bytearray", "bool",
+                     "slice", "range", "object"}
+    safe_numpy = {("numpy", "dtype"), ("numpy", "ndarray"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                  ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                  ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
+
     class _Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
             if module.startswith("optical_rl_gym"):
                 return type(name, (_Attrs,), {})
-            return super().find_class(module, name)
+            top = module.split(".")[0]
+            if (top == "networkx" and module.startswith("networkx.classes.")) or (module, name) in safe_numpy or \
+                    (module == "builtins" and name in safe_builtins) or \
+                    (module == "collections" and name in ("OrderedDict", "defaultdict", "deque")) or \
+                    (module, name) == ("copyreg", "_reconstructor"):
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError("topology file names %s.%s, which a topology pickle has no business loading" % (module, name))
 
     with open(path, "rb") as f:
         g = _Unpickler(f).load()

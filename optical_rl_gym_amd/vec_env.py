@@ -45,7 +45,9 @@ def make_spaces(batch, obs_dtype=np.float64, mod=None):
         act = sp.Discrete(k * batch.j + rej)
     else:
         obs = sp.Dict({"topology": sp.Discrete(10), "current_service": sp.Discrete(10)})
-        if fam == 3:
+        if fam == 4:  # QoSConstrainedRA takes the path index only (qos_constrained_ra.py:69)
+            act = sp.Discrete(k + rej)
+        elif fam == 3:
             act = sp.MultiDiscrete((k + rej, len(batch.modulation_formats), batch.num_spatial_resources + rej, S + rej))
         else:
             act = sp.MultiDiscrete((k + rej, S + rej))

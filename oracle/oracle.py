@@ -189,8 +189,45 @@ class OracleBatch:
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         self.lib.orc_reseed(self.h, st.ctypes.data, None if m is None else m.ctypes.data)
 
+    # ---- bulk read-backs (every-env comparisons at full batch size) ----
+    def slots_packed(self):
+        """[n, cores*links*words (padded to even)] uint64, the product's bit-packed layout (bit s of a row = slot s free)."""
+        words = (self.S + 63) // 64
+        if self.S > 320:
+            words = 8
+        elif self.S > 128:
+            words = 5
+        elif self.S > 64:
+            words = 2
+        stride = (self.C * self.E * words + 1) & ~1
+        out = np.zeros((self.n, stride), np.uint64)
+        self.lib.orc_get_slots_packed_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64]
+        self.lib.orc_get_slots_packed_all(self.h, out.ctypes.data, words, stride)
+        return out
+
+    def link_stats_all(self):
+        out = np.zeros((self.n, 4, self.E))
+        self.lib.orc_get_link_stats_all.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.orc_get_link_stats_all(self.h, out.ctypes.data)
+        return out
+
+    def net_stats_all(self):
+        out = np.zeros((self.n, 4))
+        self.lib.orc_get_net_stats_all.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.orc_get_net_stats_all(self.h, out.ctypes.data)
+        return out
+
+    def active(self):
+        out = np.zeros(self.n, np.int32)
+        self.lib.orc_get_active_all.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.orc_get_active_all(self.h, out.ctypes.data)
+        return out
+
     def action_histograms_of(self, env=0):
-        out = np.zeros((2, self.k + 1, self.S + 1), np.int64)
+        shape = (2, self.k + 1, self.S + 1)
+        if self.cfg.env_type == 3:  # RMCSA (rmcsa_env.py:145-180)
+            shape = (2, self.k + 1, self.cfg.n_mods + 1, self.C + 1, self.S + 1)
+        out = np.zeros(shape, np.int64)
         self.lib.orc_get_action_histograms(self.h, env, out.ctypes.data)
         return out[0], out[1]
 

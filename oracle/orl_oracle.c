@@ -54,6 +54,16 @@ typedef struct {
   double worst_xt; /* RMCSA: value after the +4 dB of rmcsa_env.py:129 */
 } orc_config;
 
+/* cells of one action histogram: actions_output / actions_taken (rmsa_env.py:126-137, rwa_env.py:52-58, rmcsa_env.py:145-180) */
+static size_t hist_cells(const orc_config* c) {
+  size_t n = (size_t)(c->k_paths + 1) * (size_t)(c->num_slots + 1);
+  if (c->env_type == 3 /* RMCSA */) n *= (size_t)(c->n_mods + 1) * (size_t)(c->num_cores + 1);
+  return n;
+}
+static size_t hist4(const orc_config* c, int path, int mod, int core, int slot) { /* numpy C order of [k+1][M+1][C+1][S+1] */
+  return (((size_t)path * (c->n_mods + 1) + mod) * (c->num_cores + 1) + core) * (size_t)(c->num_slots + 1) + slot;
+}
+
 typedef struct {
   const int32_t* n_paths;       /* [N*N] */
   const int32_t* path_hops;     /* [N*N*k] */
@@ -110,7 +120,8 @@ typedef struct {
   int64_t *br_req_hist, *br_prov_hist; /* discrete mode, per bit-rate index */
   int64_t *act_path, *act_slot;        /* RWA: marginals of actions_output */
   int64_t act_total;
-  int64_t *actions_output, *actions_taken; /* [(k+1)][(S+1)] (rmsa_env.py:126-137; RWA uses the top-left corner, rwa_env.py:52-58) */
+  int64_t *actions_output, *actions_taken; /* [(k+1)][(S+1)] (rmsa_env.py:126-137; RWA uses the top-left corner, rwa_env.py:52-58);
+                                            * RMCSA: [(k+1)][(M+1)][(C+1)][(S+1)] (rmcsa_env.py:145-180) */
   int32_t path_choice;                     /* PathOnlyFirstFitAction: the agent's Discrete(k + reject) action */
   int32_t error;
 } orc_env;
@@ -663,8 +674,12 @@ static void env_reset(const orc_batch* b, orc_env* e, int full) {
     for (i = 0; i < b->cfg.num_slots + rej; i++) e->act_slot[i] = 0;
     e->act_total = 0;
     /* rwa_env.py:194-203; RMSAEnv.reset never clears actions_output / actions_taken (rmsa_env.py:284-359) */
-    memset(e->actions_output, 0, sizeof(int64_t) * (size_t)(b->cfg.k_paths + 1) * (b->cfg.num_slots + 1));
-    memset(e->actions_taken, 0, sizeof(int64_t) * (size_t)(b->cfg.k_paths + 1) * (b->cfg.num_slots + 1));
+    memset(e->actions_output, 0, sizeof(int64_t) * hist_cells(&b->cfg));
+    memset(e->actions_taken, 0, sizeof(int64_t) * hist_cells(&b->cfg));
+  }
+  if (t == ENV_RMCSA) { /* rmcsa_env.py:437-454 */
+    memset(e->actions_output, 0, sizeof(int64_t) * hist_cells(&b->cfg));
+    memset(e->actions_taken, 0, sizeof(int64_t) * hist_cells(&b->cfg));
   }
   e->new_service = 0;
   next_service(b, e);
@@ -722,6 +737,7 @@ static int env_step(const orc_batch* b, orc_env* e, const int32_t* action, doubl
     if (path < 0 || path > k || slot < 0 || slot > S) return -2;
   }
   if (t != ENV_RMCSA) e->actions_output[(size_t)path * (S + 1) + slot] += 1; /* rmsa_env.py:167, rwa_env.py:103 */
+  else e->actions_output[hist4(c, path, mod, core, slot)] += 1;                 /* rmcsa_env.py:219 */
   if (t == ENV_RMSA || t == ENV_DEEPRMSA) prev_compactness = network_compactness(b, e, 0);
   e->cur.accepted = 0;
   if (t == ENV_RMCSA) {
@@ -761,6 +777,9 @@ static int env_step(const orc_batch* b, orc_env* e, const int32_t* action, doubl
   if (t != ENV_RMCSA) { /* actions_taken: rmsa_env.py:201, 211-212; rwa_env.py:125, 132-133 */
     if (e->cur.accepted) e->actions_taken[(size_t)path * (S + 1) + slot] += 1;
     else e->actions_taken[(size_t)k * (S + 1) + S] += 1;
+  } else { /* rmcsa_env.py:273, 284-289 */
+    if (e->cur.accepted) e->actions_taken[hist4(c, path, mod, core, slot)] += 1;
+    else e->actions_taken[hist4(c, k, c->n_mods, c->num_cores, S)] += 1;
   }
   if (t == ENV_RMSA || t == ENV_DEEPRMSA) cur_compactness = network_compactness(b, e, 0);
 
@@ -1021,8 +1040,8 @@ orc_batch* orc_create(const orc_config* cfg, const orc_tables* tb, int64_t n_env
       e->br_req_hist = (int64_t*)calloc(cfg->n_bit_rates, 8);
       e->br_prov_hist = (int64_t*)calloc(cfg->n_bit_rates, 8);
     }
-    e->actions_output = (int64_t*)calloc((size_t)(cfg->k_paths + 1) * (cfg->num_slots + 1), 8);
-    e->actions_taken = (int64_t*)calloc((size_t)(cfg->k_paths + 1) * (cfg->num_slots + 1), 8);
+    e->actions_output = (int64_t*)calloc(hist_cells(cfg), 8);
+    e->actions_taken = (int64_t*)calloc(hist_cells(cfg), 8);
     if (cfg->env_type == ENV_RWA) {
       e->act_path = (int64_t*)calloc(cfg->k_paths + rej, 8);
       e->act_slot = (int64_t*)calloc(cfg->num_slots + rej, 8);
@@ -1134,8 +1153,8 @@ void orc_reseed(orc_batch* b, const uint32_t* mt_state /*[n][625]*/, const uint8
       e->mti = (int32_t)mt_state[i * 625 + 624];
     }
 }
-void orc_get_action_histograms(orc_batch* b, int64_t env, int64_t* out /*[2][(k+1)][(S+1)]*/) {
-  size_t n = (size_t)(b->cfg.k_paths + 1) * (b->cfg.num_slots + 1);
+void orc_get_action_histograms(orc_batch* b, int64_t env, int64_t* out /*[2][(k+1)][(S+1)], RMCSA [2][(k+1)][(M+1)][(C+1)][(S+1)]*/) {
+  size_t n = hist_cells(&b->cfg);
   memcpy(out, b->envs[env].actions_output, n * 8);
   memcpy(out + n, b->envs[env].actions_taken, n * 8);
 }
@@ -1162,6 +1181,42 @@ void orc_get_counters(orc_batch* b, int64_t* out /*[n][8]*/) {
 }
 void orc_get_slots(orc_batch* b, int64_t env, uint8_t* out /*[C][E][S]*/) {
   memcpy(out, b->envs[env].avail, (size_t)b->cfg.num_cores * b->cfg.n_links * b->cfg.num_slots);
+}
+/* bulk read-backs for the every-env comparisons: the slot arrays bit-packed (bit s of word s/64 of a row = slot s free; rows
+ * of `words` 64-bit words, `stride` words per env), the link statistics of all envs [n][4][E], the network statistics [n][4] */
+void orc_get_slots_packed_all(orc_batch* b, uint64_t* out, int words, int64_t stride) {
+  int64_t i;
+  const int rows = b->cfg.num_cores * b->cfg.n_links, S = b->cfg.num_slots;
+  for (i = 0; i < b->n_envs; i++) {
+    const uint8_t* a = b->envs[i].avail;
+    uint64_t* o = out + i * stride;
+    int r, s;
+    memset(o, 0, (size_t)stride * 8);
+    for (r = 0; r < rows; r++)
+      for (s = 0; s < S; s++)
+        if (a[(size_t)r * S + s]) o[(size_t)r * words + (s >> 6)] |= 1ull << (s & 63);
+  }
+}
+void orc_get_link_stats_all(orc_batch* b, double* out /*[n][4][E]*/) {
+  int64_t i;
+  const int E = b->cfg.n_links;
+  for (i = 0; i < b->n_envs; i++) {
+    const orc_env* e = &b->envs[i];
+    double* o = out + (size_t)i * 4 * E;
+    memcpy(o, e->l_util, 8 * E); memcpy(o + E, e->l_frag, 8 * E);
+    memcpy(o + 2 * E, e->l_comp, 8 * E); memcpy(o + 3 * E, e->l_last, 8 * E);
+  }
+}
+void orc_get_net_stats_all(orc_batch* b, double* out /*[n][4]*/) {
+  int64_t i;
+  for (i = 0; i < b->n_envs; i++) {
+    const orc_env* e = &b->envs[i];
+    out[4 * i] = e->g_throughput; out[4 * i + 1] = e->g_compactness; out[4 * i + 2] = e->g_last_update; out[4 * i + 3] = e->current_time;
+  }
+}
+void orc_get_active_all(orc_batch* b, int32_t* out /*[n]*/) {
+  int64_t i;
+  for (i = 0; i < b->n_envs; i++) out[i] = b->envs[i].heap_n;
 }
 void orc_get_spectrum(orc_batch* b, int64_t env, int32_t* out /*[E]*/) { /* QoSConstrainedRA: available_spectrum */
   memcpy(out, b->envs[env].spectrum, (size_t)b->cfg.n_links * 4);

@@ -127,6 +127,37 @@ def replay_w(env, g, check):
         assert out.sum() == ro.sum() and taken.sum() == rt.sum()
 
 
+def replay_h(env, g, check):
+    """Replay the h1 fixture (oracle/gen_golden_hist.py): RMCSA under a stored action stream with a full reset in the
+    middle; the 4-D actions_output / actions_taken arrays (rmcsa_env.py:145-180) right before the reset and at the end,
+    compared through their non-zero cells."""
+    meta = g["meta"]
+
+    def cells(a):
+        flat = np.asarray(a, np.int64).ravel()
+        idx = np.flatnonzero(flat)
+        return np.stack([idx, flat[idx]], 1)
+
+    done = True
+    for t in range(meta["n_steps"]):
+        if t == meta["reset_at"]:
+            out, taken = env.action_histograms_of(0)
+            assert list(out.shape) == meta["shape"]
+            check(t, "actions_output before reset", cells(out), g["out_before"])
+            check(t, "actions_taken before reset", cells(taken), g["taken_before"])
+            env.reset(full=True)
+            done = False
+        if done:
+            env.reset(full=False)
+        _, reward, done_a, _ = env.step(g["actions"][t][None, :])
+        done = bool(done_a[0])
+        check(t, "reward", reward[0], g["reward"][t])
+    out, taken = env.action_histograms_of(0)
+    check(meta["n_steps"], "actions_output", cells(out), g["out_final"])
+    check(meta["n_steps"], "actions_taken", cells(taken), g["taken_final"])
+    check(meta["n_steps"], "counters", env.counters()[0], g["counters"])
+
+
 def replay_q(env, g, check):
     """Replay a q* fixture (QoSConstrainedRA, oracle/gen_golden_qos.py) on a 1-env batch object `env`."""
     meta = g["meta"]

@@ -25,7 +25,36 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(raw, n), "include/orl.h declares %s but liborlgpu.so does not export it" % n
         assert n in _lib.EXPORTS, "%s has no ctypes prototype in _lib.py" % n
-    assert lib.orl_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "orl.h")).read()
+    declared_version = int(re.search(r"#define ORL_ABI_VERSION (\d+)", header).group(1))
+    assert lib.orl_abi_version() == declared_version == _lib.ABI_VERSION == 2
+
+
+def test_env_config_binding_matches_the_header_field_for_field():
+    """The ctypes mirror of orl_env_config (and the stub shown in INTEGRATION.md) names the header's fields in the header's
+    order, so a layout change cannot go unnoticed on either side; a wrong struct_size is refused before anything is read."""
+    from optical_rl_gym_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "orl.h")).read()
+    body = re.search(r"typedef struct \{([^}]*)\} orl_env_config;", re.sub(r"/\*.*?\*/", "", header, flags=re.S)).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
+            fields += [n.strip().lstrip("*") for n in names.split(",")]
+    assert [n for n, _ in _lib.EnvConfig._fields_] == fields
+    stub = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub_cfg = stub[stub.index("class EnvConfig"):stub.index("def check(rc)")]
+    assert re.findall(r'"([a-z_]+)"', stub_cfg) == fields
+    # the ctypes layout is the C layout: 13 x 4 bytes, 4 of padding, 2 doubles, 7 pointers, 2 ints, 2 pointers
+    assert ctypes.sizeof(_lib.EnvConfig) == 56 + 16 + 56 + 8 + 16
+    lib = _lib.lib()
+    cfg = _lib.EnvConfig()  # struct_size = 0: a client built against the round-2 header
+    out = ctypes.c_void_p()
+    fake = ctypes.c_void_p(1)
+    assert lib.orl_batch_create_seeded(ctypes.byref(cfg), fake, 1, fake, ctypes.byref(out)) == -1
+    assert b"struct_size" in lib.orl_last_error()
 
 
 def test_no_cpu_fallback():

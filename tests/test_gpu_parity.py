@@ -4,7 +4,7 @@ too (the device evaluates the reference's expressions in the same order and its 
 import numpy as np
 import pytest
 
-from tests.helpers import golden_names, load_golden, replay, replay_q, replay_w
+from tests.helpers import golden_names, load_golden, replay, replay_h, replay_q, replay_w
 
 pytestmark = pytest.mark.gpu
 
@@ -198,6 +198,46 @@ def test_full_size_batch_sampled_envs_match_oracle(workload, batch):
     assert (ad >= 0).all() and (ad <= cd[:, 1]).all()
     p, a = dev.totals()
     assert p == int(cd[:, 0].sum()) and a == int(cd[:, 1].sum())
+    dev.close()
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("workload,batch,steps", [("cfg2", 65536, 300), ("cfg3", 16384, 150), ("cfg1", 16384, 200)])
+def test_full_size_batch_every_env_matches_oracle(workload, batch, steps):
+    """The headline batch against the ORACLE on every env (not a sample, not another HIP form): the OpenMP build of the oracle
+    steps all 65 536 cfg2 envs on the host's cores, and every env's counters, pending service, number of pending releases,
+    whole slot map, link statistics and network statistics must equal the device's — so the branches that occur in one
+    env-step in 10^4..10^7 (release overflow of a work item, list rebuilds, ties) are checked against the reference
+    restatement wherever in the batch they happen."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+    from oracle.oracle import OracleBatch
+
+    fam, topo, kw, policy = WORKLOADS[workload]
+    kw = dict(kw, episode_length=100)
+    seeds = [10 + i for i in range(batch)]
+    dev = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+    dev.run(policy, steps)
+    ora = OracleBatch(fam, topo, seeds, omp=True, **kw)
+    ora.run(policy, steps)
+    chk = _exact(workload + " every env")
+    chk(0, "counters", dev.counters(), ora.counters())
+    chk(0, "services", dev.services(), ora.services())
+    chk(0, "active", dev.active(), ora.active())
+    chk(0, "slot maps", dev.slots_packed(), ora.slots_packed())
+    chk(0, "link statistics", dev.link_stats_all(), ora.link_stats_all())
+    chk(0, "network statistics", dev.net_stats_all(), ora.net_stats_all())
+    if dev.obs_dim:
+        chk(0, "observation", dev.observation(), ora.observation())
+    assert not dev.flags().any()
+    # the bulk read-backs are the per-env ones
+    for i in (0, batch // 2 + 1, batch - 1):
+        W = dev.lib.orl_batch_row_words(dev._h)
+        rows = dev.slots(i).reshape(-1, kw.get("num_spectrum_resources", dev.num_spectrum_resources))
+        packed = dev.slots_packed()[i][: rows.shape[0] * W].reshape(rows.shape[0], W)
+        bits = ((packed[:, :, None] >> np.arange(64, dtype=np.uint64)[None, None, :]) & np.uint64(1)).reshape(rows.shape[0], -1)
+        assert np.array_equal(bits[:, : rows.shape[1]].astype(np.uint8), rows)
+        chk(i, "link_stats", dev.link_stats_all()[i], dev.link_stats(i))
     dev.close()
 
 
@@ -718,6 +758,96 @@ def test_hip_reproduces_wrapper_and_event_fixtures(name):
     replay_w(env, g, _exact(name))
     assert not env.flags().any() or name.startswith("w3_rmsa")  # (w3_rmsa carries the "reseeded" flag)
     env.close()
+
+
+def test_c_abi_multi_device_group_equals_one_batch():
+    """orl_multi_create / orl_multi_run (SURVEY 8e's `n_devices, device_ids` at the C ABI): three shards — all on device 0
+    here — of 50 envs run their device loops at once from three host threads and leave the state of one 50-env batch."""
+    import ctypes as C
+
+    import optical_rl_gym_amd as orl
+    from optical_rl_gym_amd import _lib
+
+    kw = dict(load=300, mean_service_holding_time=25, episode_length=40, num_spectrum_resources=320)
+    seeds = [90 + i for i in range(50)]
+    one = orl.make("RMSA", topology="nsfnet_chen", num_envs=50, seeds=seeds, **kw)
+    lib = one.lib
+    m = C.c_void_p()
+    sd = np.array(seeds, np.int64)
+    devs = (C.c_int * 3)(0, 0, 0)
+    _lib.check(lib.orl_multi_create(C.byref(one._cfg), C.byref(one._desc), 50, sd.ctypes.data, 3, devs, C.byref(m)), lib)
+    assert lib.orl_multi_n_shards(m) == 3
+    stats = (_lib.RunStats * 3)()
+    _lib.check(lib.orl_multi_run(m, 1, 130, stats), lib)
+    one.run("SAP_FF", 130)
+    ref = one.counters()
+    lo = 0
+    for r, want in enumerate((17, 17, 16)):
+        first, n = C.c_int64(), C.c_int64()
+        h = lib.orl_multi_shard(m, r, C.byref(first), C.byref(n))
+        assert (first.value, n.value) == (lo, want) and stats[r].ms_total > 0
+        got = np.zeros((want, 8), np.int64)
+        _lib.check(lib.orl_batch_get_counters(h, got.ctypes.data), lib)
+        assert np.array_equal(got, ref[lo:lo + want])
+        sl = np.zeros((1, one.topology.n_links, 320), np.uint8)
+        _lib.check(lib.orl_batch_get_slots(h, want - 1, sl.ctypes.data), lib)
+        assert np.array_equal(sl, one.slots(lo + want - 1))
+        lo += want
+    bad = (C.c_int * 2)(0, 99)
+    assert lib.orl_multi_create(C.byref(one._cfg), C.byref(one._desc), 50, sd.ctypes.data, 2, bad, C.byref(C.c_void_p())) == -1
+    lib.orl_multi_destroy(m)
+    one.close()
+
+
+def test_episode_log_rearmed_with_a_smaller_capacity():
+    """orl_batch_episode_log: the row stride of the log is the armed capacity, whatever an earlier, larger arming allocated
+    (round-2 advice: a smaller re-arm overflowed the caller's [n_envs][capacity] buffer)."""
+    import optical_rl_gym_amd as orl
+
+    kw = dict(load=300, mean_service_holding_time=25, episode_length=20, num_spectrum_resources=320)
+    env = orl.make("RMSA", topology="nsfnet_chen", num_envs=40, seeds=list(range(40)), **kw)
+    big, _ = env.evaluate("SAP_FF", 6)
+    env2 = orl.make("RMSA", topology="nsfnet_chen", num_envs=40, seeds=list(range(40)), **kw)
+    small, lengths = env2.evaluate("SAP_FF", 2)
+    assert big.shape == (40, 6) and small.shape == (40, 2) and (lengths == 19).all()
+    assert np.array_equal(big[:, :2], small)
+    again, _ = env.evaluate("SAP_FF", 2)   # smaller than the first arming of `env`: guard pages would tell, the values do too
+    more, _ = env2.evaluate("SAP_FF", 6)   # and growing after a small one
+    assert again.shape == (40, 2) and more.shape == (40, 6) and (again >= 0).all() and (again <= 19).all()
+    assert np.array_equal(np.concatenate([small, more], 1)[:, :8], np.concatenate([big, again], 1))
+    env.close()
+    env2.close()
+
+
+def test_hip_reproduces_rmcsa_4d_action_histograms():
+    """RMCSAEnv.actions_output / actions_taken (rmcsa_env.py:145-180, 219, 273, 284-289; a full reset clears them, :437-454)
+    kept on the device as an opt-in [2][k+1][M+1][C+1][S+1] array per env: fixture captured from the reference
+    (oracle/gen_golden_hist.py), host-driven steps; then the device-resident loop against the oracle on a small batch,
+    and the gym-shaped front end's attributes."""
+    from oracle.oracle import OracleBatch
+    import optical_rl_gym_amd as orl
+
+    g = load_golden("h1_rmcsa_hist4d")
+    env = _product(g["meta"], action_histograms=True)
+    replay_h(env, g, _exact("h1_rmcsa_hist4d"))
+    env.close()
+    kw = dict(g["meta"]["kwargs"])
+    kw.pop("seed")
+    seeds = [700 + i for i in range(24)]
+    dev = orl.make("RMCSA", topology="nsfnet_chen", num_envs=24, seeds=seeds, action_histograms=True, **kw)
+    ora = OracleBatch("RMCSA", "nsfnet_chen", seeds, **kw)
+    dev.run("SAP_BM_FC_FF", 300)
+    ora.run("SAP_BM_FC_FF", 300)
+    for e in (0, 7, 23):
+        for a, b in zip(dev.action_histograms_of(e), ora.action_histograms_of(e)):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        assert dev.action_histograms_of(e)[0].sum() == 300
+    dev.close()
+    one = orl.RMCSAEnv(topology="nsfnet_chen", **g["meta"]["kwargs"])
+    for t in range(40):
+        one.step([int(x) for x in g["actions"][t]])
+    assert one.actions_output.shape == tuple(g["meta"]["shape"]) and one.actions_output.sum() == 40 and one.actions_taken.sum() == 40
+    assert one.episode_actions_output.shape == one.actions_output.shape and not one.episode_actions_output.any()
 
 
 @pytest.mark.parametrize("gname,policy", [("g2_rmsa_cfg2_sapff", "SAP_FF"), ("g5_rwa_testcfg_sapff", "SAP_FF"),

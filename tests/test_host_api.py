@@ -289,6 +289,54 @@ def test_reference_pickle_loader(tmp_path):
         assert np.array_equal(real.path_links, t.path_links) and np.array_equal(real.path_length, t.path_length)
 
 
+def test_action_spaces_of_every_family_and_start_environment():
+    """make_spaces mirrors the reference's action spaces (rmsa_env.py:138-151, deeprmsa_env.py:38-45, rwa_env.py:72-85,
+    rmcsa_env.py:181-196, qos_constrained_ra.py:69); start_environment keeps utils.py:62-70's observable behaviour."""
+    from optical_rl_gym_amd import gym_api
+    from optical_rl_gym_amd.vec_env import make_spaces
+
+    qos = OracleBackend("QoSConstrainedRA", "nsfnet_chen", [1, 2], load=50, mean_service_holding_time=10,
+                        num_service_classes=1, classes_arrival_probabilities=[1.0], classes_reward=[1.0])
+    _, act = make_spaces(qos)
+    assert act.n == qos.k_paths + 1  # Discrete(k + reject): the path index only
+    rwa = OracleBackend("RWA", "nsfnet_chen", [1], load=50, mean_service_holding_time=10)
+    assert list(make_spaces(rwa)[1].nvec) == [6, 81]
+    rmcsa = OracleBackend("RMCSA", "nsfnet_chen", [1], load=50, mean_service_holding_time=10, num_spatial_resources=7)
+    assert list(make_spaces(rmcsa)[1].nvec) == [5, 6, 7, 100]
+
+    class Probe:
+        resets = steps = 0
+
+        def reset(self):
+            Probe.resets += 1
+
+        def step(self, a):
+            Probe.steps += 1
+            return None, 0, True, {}
+
+    assert isinstance(gym_api.start_environment(Probe(), 7), Probe) and (Probe.resets, Probe.steps) == (7, 0)
+
+
+def test_reference_pickle_loader_refuses_foreign_globals(tmp_path):
+    """A topology pickle may name networkx / numpy / container classes only: anything else (here os.system) is refused
+    before it is resolved, let alone called."""
+    import pickle
+
+    from optical_rl_gym_amd import topology_io
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+
+    path = tmp_path / "evil.h5"
+    with open(path, "wb") as f:
+        pickle.dump({"ksp": Evil()}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        topology_io.load_reference_pickle(str(path))
+    assert not (tmp_path / "pwned").exists()
+
+
 def test_qos_constrained_ra_front_end():
     """QoSConstrainedRA through the gym-shaped class, its three heuristics and MatrixObservationWithPaths, on the oracle
     backend: the rewards of the fixture captured from the (import-time repaired) reference come out step by step."""

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import OracleBatch
-from tests.helpers import golden_names, load_golden, replay, replay_q, replay_w
+from tests.helpers import golden_names, load_golden, replay, replay_h, replay_q, replay_w
 
 
 def _make(meta):
@@ -41,6 +41,12 @@ def test_oracle_reproduces_wrapper_and_event_fixtures(name):
     g = load_golden(name)
     env = _make(g["meta"])
     replay_w(env, g, _exact(name))
+
+
+def test_oracle_reproduces_rmcsa_4d_action_histograms():
+    """RMCSAEnv.actions_output / actions_taken (rmcsa_env.py:145-180, 219, 273, 284-289; cleared by a full reset, :437-454)."""
+    g = load_golden("h1_rmcsa_hist4d")
+    replay_h(_make(g["meta"]), g, _exact("h1_rmcsa_hist4d"))
 
 
 @pytest.mark.parametrize("name", golden_names("q"))
