@@ -33,6 +33,8 @@ import statistics
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -250,7 +252,7 @@ def main():
     # HBM traffic and L2<->fabric requests from rocprofv3 PMC passes (tools/pmc_traffic.py, FETCH_SIZE x calibration +
     # WRITE_SIZE; TCC_EA0_RDREQ + WRREQ): used only when they were collected for exactly this build, workload, batch and
     # state — otherwise null
-    traffic = req_roof = None
+    traffic = req_roof = valu = traffic_gbs = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
@@ -260,13 +262,32 @@ def main():
                 tj.get("source_hash") == _build.source_hash(with_compiler=False):
             per_step = k["hbm_bytes_per_launch"] / k["steps_per_launch"]
             traffic = int(per_step * steps_per_launch)
+            traffic_gbs = traffic / (ms_launch * 1e-3) / 1e9  # bytes that really crossed the HBM interface / launch time
+            sq = k.get("sq_per_launch") or {}
+            if sq.get("SQ_ACTIVE_INST_VALU"):
+                # issue side of the same launches: a wave64 VALU instruction occupies its SIMD for 4 cycles
+                n_simd = 4 * torch.cuda.get_device_properties(dev_index).multi_processor_count
+                clock_hz = 2.4e9  # MI355X peak engine clock (MI355X_MICROARCH.md)
+                per_step_c = {c: v / k["steps_per_launch"] for c, v in sq.items()}
+                cycles = (elapsed / args.steps) * clock_hz
+                busy = per_step_c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * n_simd)
+                valu = dict(bound="valu_issue", frac=round(busy, 4), simds=n_simd, clock_ghz=clock_hz / 1e9,
+                            valu_insts_per_wavefront_step=round(per_step_c.get("SQ_INSTS_VALU", 0) / ((B + 7) // 8), 1),
+                            salu_insts_per_wavefront_step=round(per_step_c.get("SQ_INSTS_SALU", 0) / ((B + 7) // 8), 1),
+                            wait_frac_of_wave_lifetime=round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 4) if sq.get("SQ_WAVE_CYCLES") else None,
+                            lds_bank_conflict_cycles_per_lds_active_cycle=round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_ACTIVE_INST_LDS"], 3)
+                            if sq.get("SQ_ACTIVE_INST_LDS") and sq.get("SQ_LDS_BANK_CONFLICT") is not None else None,
+                            note="SQ_ACTIVE_INST_VALU x 4 / (cycles of one batched step x SIMDs), counters from profiles/traffic_%s.json "
+                                 "(same build, workload, batch, state)" % args.workload)
             if k.get("dram_requests_per_launch"):
                 rps = k["dram_requests_per_launch"] / k["steps_per_launch"]
                 rate = rps / (elapsed / args.steps)
                 req_roof = dict(bound="dram_requests", requests_per_step=int(rps), peak=RANDOM_ACCESS_PEAK, unit="requests/s",
                                 achieved=round(rate, 1), frac=round(rate / RANDOM_ACCESS_PEAK, 4))
     roofline = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
-                    traffic=traffic, kernel=kernel, us_per_launch=round(ms_launch * 1e3, 2),
+                    traffic=traffic, achieved_traffic_gbs=None if traffic_gbs is None else round(traffic_gbs, 2),
+                    traffic_frac=None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 5), valu=valu,
+                    kernel=kernel, us_per_launch=round(ms_launch * 1e3, 2),
                     steps_per_launch=round(steps_per_launch, 2), algorithmic_bytes_per_env_step=round(alg["step"], 1),
                     algorithmic_bytes_per_launch=int(bytes_per_launch))
 
@@ -275,9 +296,20 @@ def main():
     n_t = 50
     st2 = env.run(policy, n_t, time_kernels=2)
     scan_ach = alg["scan"] * B / (st2.ms_policy * 1e-3) / 1e9
+    # ... and on the bytes the kernel's lanes really request: the rows of the k paths of the pending pair (links shared by
+    # several paths are requested once per path), the 32-byte path records, the descriptor in and the action out
+    hops_sum = t.path_hops.reshape(t.n_nodes, t.n_nodes, -1).sum(-1)
+    np_pair = t.n_paths.reshape(t.n_nodes, t.n_nodes)
+    off = ~np.eye(t.n_nodes, dtype=bool)
+    W_ = (env.num_spectrum_resources + 63) // 64
+    W_ = 1 if W_ <= 1 else (2 if W_ <= 2 else (5 if W_ <= 5 else 8))
+    req_env = float(hops_sum[off].mean()) * W_ * 8 * env.num_spatial_resources + 32.0 * float(np_pair[off].mean()) + 8 + 16
+    scan_req = req_env * B / (st2.ms_policy * 1e-3) / 1e9
     slot_scan = dict(kernel="k_policy", bound="hbm", achieved=round(scan_ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=round(scan_ach / HBM_PEAK_GBS, 5), us_per_launch=round(st2.ms_policy * 1e3, 2),
                      algorithmic_bytes_per_launch=int(alg["scan"] * B),
+                     requested_bytes_per_env=round(req_env, 1), requested_gbs=round(scan_req, 2),
+                     requested_frac=round(scan_req / HBM_PEAK_GBS, 5),
                      note="stand-alone launch (host-side agents); not part of the timed loop, whose scan runs inside " + kernel)
 
     cpu = None
@@ -313,8 +345,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and fam in ("RMSA", "RWA"):
         # SURVEY 8(d) second variant: host-supplied uniform-random actions, reward/done/info fetched every step — the
         # PCIe-inclusive rate of an agent on the host (never `value`)
-        import numpy as np
-
         rng = np.random.RandomState(3)
         n_host = 30
         rej = 1 if kw.get("allow_rejection") else 0

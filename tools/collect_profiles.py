@@ -54,6 +54,20 @@ for name, kern, last, spl in (("k_persist", "k_persist<", run["measured_launches
             rec["dram_requests_per_step"] = int(rq / spl)
     except Exception as exc:  # noqa: BLE001
         print("no request counters for", name, exc)
+    # issue-side counters of the same launches (passes sq1..sq3 of tools/run_profiles.sh), per launch: what bounds a kernel
+    # that moves few bytes (bench.py reports VALU-busy = SQ_ACTIVE_INST_VALU x 4 / (launch cycles x SIMDs) from these)
+    sq = {}
+    for d, names in (("sq1", ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                             "SQ_INSTS_VALU", "SQ_INSTS_SALU")),
+                     ("sq2", ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA")),
+                     ("sq3", ("SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_BRANCH", "SQ_LDS_BANK_CONFLICT"))):
+        for c in names:
+            try:
+                sq[c] = int(mean_last(d, kern, c, last))
+            except Exception:  # noqa: BLE001  (pass not collected)
+                pass
+    if sq:
+        rec["sq_per_launch"] = sq
     out["kernels"][name] = rec
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % workload), "w"), indent=1)
