@@ -519,7 +519,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     P.q_wave = 8 * (P.H > P.E ? P.H : P.E);
     P.item_masks = ORL_IMASKS;
     // test knob: a smaller limit sends far more env-steps through the tally pass and the serial tail
-    if (const char* mv = getenv("ORL_ITEM_MASKS")) { int v = atoi(mv); if (v >= 1 && v <= ORL_IMASKS) P.item_masks = v; }
+    P.rel_limit = 31;
+    if (const char* mv = getenv("ORL_ITEM_MASKS")) { int v = atoi(mv); if (v >= 1 && v <= ORL_IMASKS) { P.item_masks = v; P.rel_limit = v; } }
     P.q_cap = (i64)waves * P.q_wave;
     rc |= dalloc(b, &P.q_a, (size_t)P.q_cap * 2);  // 32-byte items
     rc |= dalloc(b, &P.q_cnt_a, waves);

@@ -113,6 +113,7 @@ struct DevParams {
   int q_wave;       // item slots per wavefront region
   int persist_ic;   // persistent kernel: keep the per-row cache of inner free runs in LDS (set per launch by the host)
   int item_masks;   // releases of one step that may meet on one link before the env falls back to the serial tail (<= 8)
+  int rel_limit;    // compact sink of the persistent kernel: releases of one env-step its mask table takes (<= 31; test knob)
   int pipeline2;    // core_sums[2C..4C) accumulates what the current step's releases add to the sums (persistent kernel)
   i64 q_def_stride; // second q_def buffer (the steps of the two-kernel form alternate)
   u32* q_def;       // [0] = number of envs whose releases this step do not fit the item form, [16..] = their indices

@@ -111,12 +111,19 @@ struct SinkEntry {
   u64 mk1;  // masks 4..7
   u64 crn;  // the core of each mask, 5 bits each (40 bits) | number of masks << 40 | mask 0 is a provision << 44
 };
-// compact form (single-core families in the persistent kernel's LDS window): no cores, 15-bit masks (s0:9 | n:6 — the
-// split pipeline is used for services of at most 63 slots, orl_api.hip)
+// compact form (single-core families in the persistent kernel's LDS window).  A release frees the SAME slots on every link of
+// its path, so the masks need not be copied into per-link entries: per env one table of masks — entry 0 the step's provision,
+// entry k (1..ORL_REL_MAX) its k-th release in heap-pop order, 16 bits each (first slot: 9 | slots: 6 — the split pipeline
+// serves services of at most 63 slots, orl_api.hip) — and per (env, link) ONE 32-bit word of which of them touch the link.
+// Appending is one LDS atomic OR (its return value says whether the entry was empty, i.e. whether a new work item opens);
+// there is no per-link capacity any more (8 masks per 16-byte entry before: a tally pass guarded it), only the 31 releases
+// per env-step of the table; and the table is 4 bytes per link and env instead of 16 (cfg2: 1 216 B with the masks instead
+// of 2 816 B + 192 B of tallies), which is what lets the LDS window of the 4-wave form fit 16 times into a CU.
 struct SinkEntryC {
-  u64 mk0;  // masks 0..3, 15 bits each | number of masks << 60
-  u64 mk1;  // masks 4..7, 15 bits each | mask 0 is a provision << 60
+  u32 bits;  // bit 0: the provision; bit k: the k-th release of this step
 };
+#define ORL_REL_MAX 31
+#define ORL_MTAB 32  // masks per env in the table
 template <bool CP> struct SinkEntryOf { typedef SinkEntry type; };
 template <> struct SinkEntryOf<true> { typedef SinkEntryC type; };
 template <bool CP> struct SinkT {
@@ -124,15 +131,17 @@ template <bool CP> struct SinkT {
   unsigned short* list;  // LDS (persistent kernel, else nullptr): the wavefront's open table entries, (local env << 8) | link ...
   u32* list_n;           // ... and their number, zeroed at the start of the step
   Entry* tab;      // LDS, E entries of this env, mask count zeroed
-  u32* tally;      // LDS, `tw` words per env, zeroed: per-link touch counters (4 x 8 bit per word) for the capacity check
+  u32* tally;      // LDS, `tw` words per env, zeroed: per-link touch counters (4 x 8 bit per word) for the capacity check (!CP)
   int tw;
+  unsigned short* mtab;  // CP: LDS, this env's mask table (ORL_MTAB entries)
+  int nrel;              // CP: releases of this step appended so far (group-uniform)
   bool active;     // item mode decided: the releases of this step fit the item form
   bool deferred;   // they do not: nothing has been touched, k_rel_tail releases them in place
   int cnt;         // links this LANE has opened an item for
 };
 typedef SinkT<false> Sink;
 __device__ __forceinline__ void sink_entry_clear(SinkEntry& t) { t.crn = 0ull; }
-__device__ __forceinline__ void sink_entry_clear(SinkEntryC& t) { t.mk0 = 0ull; }
+__device__ __forceinline__ void sink_entry_clear(SinkEntryC& t) { t.bits = 0u; }
 // appends mask m to the entry; returns the number of masks it held, bit 8: the entry starts with the step's provision
 __device__ __forceinline__ int sink_entry_add(SinkEntry* t, u64 m, int core, bool prov) {
   const u64 crn = t->crn | (prov ? (1ull << 44) : 0ull);  // (a provision is the first thing a step adds)
@@ -142,30 +151,32 @@ __device__ __forceinline__ int sink_entry_add(SinkEntry* t, u64 m, int core, boo
   t->crn = (crn & ((1ull << 44) | 0xffffffffffull)) | ((u64)(u32)core << (5 * j)) | ((u64)(u32)(j + 1) << 40);
   return j | (int)((crn >> 44) & 1) << 8;
 }
-__device__ __forceinline__ int sink_entry_add(SinkEntryC* t, u64 m, int core, bool prov) {
-  u64 m0 = t->mk0;
-  const int j = (int)(m0 >> 60);
-  int pf = prov ? 1 : 0;
-  if (j == 0) t->mk1 = prov ? (1ull << 60) : 0ull;
-  else pf = (int)((t->mk1 >> 60) & 1);
-  if (j < 4) m0 |= m << (15 * j);
-  else t->mk1 |= m << (15 * (j - 4));
-  t->mk0 = (m0 & ~(15ull << 60)) | ((u64)(u32)(j + 1) << 60);
-  return j | pf << 8;
-}
 // lane h of the group appends the mask to the item of hop h's link (the links of one path are distinct)
 template <bool CP>
 __device__ __forceinline__ void sink_add(SinkT<CP>& s, const PathRec& rec, int core, int s0, int n, int lane, bool prov = false) {
   const int hops = path_rec_byte(rec, 0);
-  const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
-  for (int h = lane & 7; h < hops; h += 8) {
-    const int r = sink_entry_add(s.tab + path_rec_byte(rec, 2 + h), m, core, prov);
-    const int j = r & 15;
-    s.cnt += (j == 0) ? 1 : 0;
-    // a new item: the row phase finds it through the list (any order: items are independent).  A link that carries the
-    // step's provision AND a release gets a second entry (bit 15): two lanes share its row work (row_item_lane1)
-    if (s.list && (j == 0 || (j == 1 && (r >> 8))))
-      s.list[atomicAdd(s.list_n, 1u)] = (unsigned short)((j << 15) | (((lane >> 3) & 7) << 8) | path_rec_byte(rec, 2 + h));
+  if constexpr (CP) {
+    const int k = prov ? 0 : ++s.nrel;  // this mask's entry of the env's table (the caller keeps nrel <= ORL_REL_MAX)
+    if ((lane & 7) == 0) s.mtab[k] = (unsigned short)((u32)s0 | ((u32)n << 9));
+    for (int h = lane & 7; h < hops; h += 8) {
+      const int link = path_rec_byte(rec, 2 + h);
+      const u32 old = atomicOr(&s.tab[link].bits, 1u << k);
+      s.cnt += (old == 0u) ? 1 : 0;
+      // a new item: the row phase finds it through the list (any order: items are independent).  A link that carries the
+      // step's provision AND a release gets a second entry (bit 15) when its first release arrives: two lanes share its row
+      // work (row_item_lane1)
+      if (s.list && old <= 1u)  // (old == 1: the provision alone so far, and this is a release — the provision is added first)
+        s.list[atomicAdd(s.list_n, 1u)] = (unsigned short)((old << 15) | (((lane >> 3) & 7) << 8) | link);
+    }
+  } else {
+    const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
+    for (int h = lane & 7; h < hops; h += 8) {
+      const int r = sink_entry_add(s.tab + path_rec_byte(rec, 2 + h), m, core, prov);
+      const int j = r & 15;
+      s.cnt += (j == 0) ? 1 : 0;
+      if (s.list && (j == 0 || (j == 1 && (r >> 8))))
+        s.list[atomicAdd(s.list_n, 1u)] = (unsigned short)((j << 15) | (((lane >> 3) & 7) << 8) | path_rec_byte(rec, 2 + h));
+    }
   }
 }
 
@@ -253,7 +264,7 @@ template <int ENV, int W, bool CP = false>
 __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
                                       const int4* given, u32* s_tally, typename SinkEntryOf<CP>::type* s_tab, int parity,
                                       int* s_deferred, int* done_out, unsigned short* s_list = nullptr, u32* s_list_n = nullptr,
-                                      int tw = 32, SoonRegs* carried = nullptr) {
+                                      int tw = 32, SoonRegs* carried = nullptr, unsigned short* s_mtab = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   if (!O.persistent && blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
   u64 desc_out = 0ull;
@@ -262,16 +273,20 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
   rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
   SinkT<CP> sink;
   sink.tab = nullptr; sink.tally = nullptr; sink.tw = tw; sink.active = false; sink.deferred = false; sink.cnt = 0;
-  sink.list = s_list; sink.list_n = s_list_n;
+  sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0;
   if (s_list_n && lane == 0) *s_list_n = 0u;
   {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
-    u32* ty = s_tally + tw * 8 * (int)(threadIdx.x >> 6);
     typename SinkEntryOf<CP>::type* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
-    for (int i = lane; i < 8 * tw; i += 64) ty[i] = 0u;
+    if constexpr (!CP) {
+      u32* ty = s_tally + tw * 8 * (int)(threadIdx.x >> 6);
+      for (int i = lane; i < 8 * tw; i += 64) ty[i] = 0u;
+      sink.tally = s_tally + tw * (int)(threadIdx.x >> 3);
+    } else {
+      sink.mtab = s_mtab + ORL_MTAB * (int)(threadIdx.x >> 3);  // (entries are written before they are read: nothing to clear)
+    }
     for (int i = lane; i < 8 * P.E; i += 64) sink_entry_clear(tb[i]);
     wave_fence();
     sink.tab = s_tab + P.E * (int)(threadIdx.x >> 3);
-    sink.tally = s_tally + tw * (int)(threadIdx.x >> 3);
   }
   if (valid) {
     EnvG e;
@@ -411,10 +426,11 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         pushed_idx = g8::ev_push(P, e, lane, e.at + e.ht, pushed_info);
         {  // the provision's rows: first mask of their items; they also count towards the per-link limit
           sink_add(sink, rec, core, slot, n, lane, true);
-          for (int h = gl; h < hops; h += 8) {
-            const int link = path_rec_byte(rec, 2 + h);
-            atomicAdd(sink.tally + (link >> 2), 1u << (8 * (link & 3)));
-          }
+          if constexpr (!CP)
+            for (int h = gl; h < hops; h += 8) {
+              const int link = path_rec_byte(rec, 2 + h);
+              atomicAdd(sink.tally + (link >> 2), 1u << (8 * (link & 3)));
+            }
         }
         ORL_PROFA(4);
       }
@@ -503,14 +519,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
   return desc_out;
 }
 
-// persistent kernel: an item of the row phase read from the sink table in place
-__device__ __forceinline__ u64 masks15_to_16(u64 x) {
-  return (x & 0x7fffull) | (((x >> 15) & 0x7fffull) << 16) | (((x >> 30) & 0x7fffull) << 32) | (((x >> 45) & 0x7fffull) << 48);
-}
-__device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntryC& t) {
-  const int nm = (int)(t.mk0 >> 60);
-  return make_item(env, (u32)link, nm, masks15_to_16(t.mk0), nm > 4 ? masks15_to_16(t.mk1) : 0ull, 0ull, 1 | (int)((t.mk1 >> 60) & 1) << 1);
-}
+// persistent kernel: an item of the row phase read from the sink table in place (RMCSA; the single-core families hand the
+// entry's bit word and the env's mask table to row_item_lane1)
 __device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntry& t) {
   const int nm = (int)((t.crn >> 40) & 15);
   return make_item(env, (u32)link, nm, t.mk0, nm > 4 ? t.mk1 : 0ull, t.crn & 0xffffffffffull, 1 | (int)((t.crn >> 44) & 1) << 1);
@@ -681,9 +691,15 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       continue;
     }
     if (!sink.active) {
-      // Item mode needs <= ORL_IMASKS releases meeting on one link.  The number of due releases is known exactly:
-      // the whole list (now < t_soon: nothing outside is due) or the full scan just done.
+      // The number of due releases is known exactly: the whole list (now < t_soon: nothing outside is due) or the full scan
+      // just done.
       const int total = due_all >= 0 ? due_all : tot;
+      if constexpr (CP) {
+        // compact sink: a mask table of ORL_REL_MAX releases per env-step and no limit per link (the number of releases in
+        // a step is geometric with mean ~1: 31 are exceeded once in 10^10 env-steps; the test knob lowers the limit)
+        sink.active = total <= P.rel_limit;
+      } else {
+      // Item mode needs <= ORL_IMASKS releases meeting on one link.
       sink.active = total + extra <= P.item_masks;
       if (!sink.active && total < 200) {
         // More releases than one item holds masks for (the release count per step is geometric: ~0.2 % of env-steps
@@ -722,6 +738,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           mx = mx > m01 ? mx : m01;
         }
         sink.active = g8_max((int)mx) <= P.item_masks;
+      }
       }
       if (!sink.active) {
         ORL_DBG(11, 1);
@@ -945,11 +962,13 @@ __device__ __forceinline__ void row_occ_fb(const u64 (&a)[W], int S, int& occ, i
 // The compactness sums change by (summary after the provision - before) and (final - after the provision), the latter
 // also into rel_sums.
 template <int ENV, int W>
-__device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M, const Item it, int second, Prof& prof, bool early_ls = false) {
+__device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M, const i64 env, const int link, const u32 bits,
+                                               const unsigned short* mtab, int second, Prof& prof, bool early_ls = false) {
+  // `bits`: the (env, link) word of the compact sink — bit 0 the step's provision, bit k its k-th release; `mtab`: the env's
+  // masks, entry k = (first slot: 9 | slots: 6)
   const int E = P.E, S = P.S;
-  const i64 env = (i64)(u32)it.a.x;
-  const int link = (int)((it.a.x >> 32) & 0xff), nmask = (int)((it.a.x >> 40) & 15);
-  const bool prov_first = ((it.a.x >> 45) & 1) != 0;
+  const int nmask = __popc(bits);
+  const bool prov_first = (bits & 1u) != 0;
   const bool shared = prov_first && nmask >= 2;   // two lanes work on this item
   const bool role_b = shared && second;           // ... this one on the releases
   const bool role_a = shared && !second;          // ... this one on the provision
@@ -967,21 +986,27 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
 #pragma unroll
   for (int w = 0; w < W; w++) a[w] = row[w];
   ORL_PROFR(3);
-  // the mask whose statistics this lane evaluates: B the first release (mask 1, after applying the provision), else mask 0
-  const int kf = role_b ? 1 : 0;
+  // the masks of this lane, in table (= bit) order: `first` is the one whose statistics it evaluates — B: the first release
+  // (after applying the provision, entry 0), else the lowest entry — and `rest` the further releases of the step (none for A)
+  u32 rest = bits & (bits - 1u);
+  int first = (int)__builtin_ctz(bits);
   u32 touched = 0u;  // words of the row this lane changes before it summarises it (row_stat_lane's cache)
   if (role_b) {
-    const int s0 = (int)(it.a.y & 0x1ff), n = (int)((it.a.y >> 9) & 0x7f);
+    const u32 mw = mtab[0];
+    const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
     touched = mask_words(s0, n);
 #pragma unroll
     for (int w = 0; w < W; w++) a[w] &= ~word_range(s0 - 64 * w, s0 + n - 64 * w);
+    first = (int)__builtin_ctz(rest);
+    rest &= rest - 1u;
   }
+  if (role_a) rest = 0u;
   int occ0 = 0, fb0 = 0;  // B: the summary after the provision
   if (ENV != ENV_RWA) row_occ_fb<W>(a, S, occ0, fb0);
-  const bool rel_f = !(kf == 0 && prov_first);  // the evaluated mask is a release
+  const bool rel_f = first != 0;  // the evaluated mask is a release
   {
-    const u64 mw = it.a.y >> (16 * kf);
-    const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
+    const u32 mw = mtab[first];
+    const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
     touched |= mask_words(s0, n);
 #pragma unroll
     for (int w = 0; w < W; w++) {
@@ -1014,6 +1039,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
     else cur_comp = 1.0;
   }
   const double clock = rel_f ? now : now_prov;
+  const int n_rest = __popc(rest);
   // the running averages: round 0 every lane but the B lanes, round 1 the B lanes (their link's record has been updated and
   // stored by the A lane of the same wavefront in round 0)
   const u64 any_b = __ballot(role_b);
@@ -1033,8 +1059,8 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
       }
       last_update = clock;
       // further releases of the step on this link: the time_diff == 0 form of the update (never for an A lane)
-      if (!role_a && now > 0)
-        for (int k = kf + 1; k < nmask; k++) {
+      if (now > 0)
+        for (int k = 0; k < n_rest; k++) {
           util = ((util * now) + 0.0) / now;
           if (ENV != ENV_RWA) { frag = ((frag * now) + 0.0) / now; comp = ((comp * now) + 0.0) / now; }
         }
@@ -1045,11 +1071,11 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   }
   ORL_PROFR(6);
   int occL = after.occ, fbL = after.fb;
-  if (!role_a && nmask > kf + 1) {  // the masks of the further releases, then what the row contributes in the end
+  if (rest) {  // the masks of the further releases, then what the row contributes in the end
     u32 later = 0u;
-    for (int k = kf + 1; k < nmask; k++) {
-      const u64 mw = k < 4 ? (it.a.y >> (16 * k)) : (it.b.x >> (16 * (k - 4)));
-      const int s0 = (int)(mw & 0x1ff), n = (int)((mw >> 9) & 0x7f);
+    for (u32 r = rest; r; r &= r - 1u) {
+      const u32 mw = mtab[__builtin_ctz(r)];
+      const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
       later |= mask_words(s0, n);
 #pragma unroll
       for (int w = 0; w < W; w++) a[w] |= word_range(s0 - 64 * w, s0 + n - 64 * w);

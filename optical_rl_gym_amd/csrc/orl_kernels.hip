@@ -226,26 +226,29 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 // row phase and counts as unfinished; at the start of its next launch it releases them in place and resumes from its own
 // step count.
 struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (all multiples of 16)
-  int tab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, total;
+  int tab, mtab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, total;
 };
-// state: 0 = only the per-step tables, 1 = + slot maps, per-core sums and env records, 2 = + link statistics;
-// compact: 16-byte sink entries (single-core families); inner: the per-word longest-run cache of every row
+// state: 0 = only the per-step tables, 1 = + slot maps, per-core sums and env records, 2 = + link statistics, 3 = slot maps and
+// per-core sums but the env records stay in global memory (the window of the 4-wave forms: cfg2 8 832 B, 16 per CU);
+// compact: the bit-word sink of the single-core families (4 bytes per link and env + a mask table per env);
+// inner: the per-word longest-run cache of every row
 __host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, bool inner) {
   PersistLds L;
   int o = 0;
-  L.tab = o; o += 8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry));
-  L.tw = (E + 3) >> 2;
+  L.tab = o; o += (8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry)) + 15) & ~15;
+  L.mtab = o; if (compact) o += 8 * ORL_MTAB * 2;
+  L.tw = compact ? 0 : (E + 3) >> 2;
   L.tally = o; o += 8 * L.tw * 4;
   // one entry per touched link and env, a second one where the step's provision meets a release (at most its hops)
   L.list = o; o += ((8 * (E + (H < E ? H : E)) * 2) + 15) & ~15;
-  L.clk = o; if (state == 0) o += 8 * 2 * 8;  // (state >= 1: the row phase reads the clocks from the record)
+  L.clk = o; if (state == 0 || state == 3) o += 8 * 2 * 8;  // (records in LDS: the row phase reads the clocks from them)
   L.misc = o; o += 16;
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
   L.csw = (4 * C + 3) & ~3;  // sums + their release part, ints per env
   L.cs = o; if (state >= 1) o += 8 * L.csw * 4;
-  L.sc = o; if (state >= 1) o += 8 * ORL_SCAL_WORDS * 8;
+  L.sc = o; if (state == 1 || state == 2) o += 8 * ORL_SCAL_WORDS * 8;
   L.ic = o; if (state >= 1 && inner) o += (8 * E * 4 + 15) & ~15;
-  L.ls = o; if (state >= 2) o += 8 * E * 32;
+  L.ls = o; if (state == 2) o += 8 * E * 32;
   L.total = o;
   return L;
 }
@@ -254,7 +257,8 @@ static inline bool persist_compact(int env_type, int state) { return env_type !=
 // (rows of one or two words: searching both costs less than the bookkeeping — cfg3 measured 1.20e9 without, 1.01e9 with)
 template <int ENV, int W, int LDS> struct PersistInner { static constexpr bool value = LDS >= 1 && W >= 3 && W <= 5 && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA); };
 static inline bool persist_inner(int env_type, int W, int state) { return state >= 1 && W >= 3 && W <= 5 && (env_type == ENV_RMSA || env_type == ENV_DEEPRMSA); }
-// LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics
+// LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics,
+// 3 = slot maps + per-core sums in LDS, env records in global memory
 // PF: early requests of the Mersenne-Twister window and the link statistics (more live registers: the 3-wave forms)
 template <int ENV, int W, int LDS, bool PF>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
@@ -264,6 +268,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, LDS, CP, IC);
   typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
+  unsigned short* s_mtab = (unsigned short*)(orl_lds_raw + L.mtab);
   unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
   int* s_deferred = (int*)(orl_lds_raw + L.misc);  // [2], alternating by step
   u32* s_list_n = (u32*)(orl_lds_raw + L.misc + 8);
@@ -293,7 +298,8 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
   }
   sp::Wmem M = sp::wmem_global(P);
-  if (LDS == 0) {
+  constexpr bool REC = (LDS == 1 || LDS == 2);  // the env records are in the LDS window
+  if (!REC) {
     M.clk = (double*)(orl_lds_raw + L.clk);
     M.clk_env0 = env0;
   }
@@ -321,15 +327,17 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
         for (int i = lane; i < nenv * P.E; i += 64) M.ic0[i] = sp::row_inner_cache<W>(M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W);
       }
     }
-    M.sc0 = (u64*)(orl_lds_raw + L.sc);
-    M.scenv0 = env0;
-    if (step < target) {
-      const ulonglong2* gr = (const ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
-      ulonglong2* lr = (ulonglong2*)M.sc0;
-      for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) lr[i] = gr[i];
+    if (REC) {
+      M.sc0 = (u64*)(orl_lds_raw + L.sc);
+      M.scenv0 = env0;
+      if (step < target) {
+        const ulonglong2* gr = (const ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
+        ulonglong2* lr = (ulonglong2*)M.sc0;
+        for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) lr[i] = gr[i];
+      }
     }
   }
-  if (LDS >= 2) {
+  if (LDS == 2) {
     M.ls0 = (double*)(orl_lds_raw + L.ls);
     M.senv0 = env0;
     if (step < target) {
@@ -376,7 +384,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
       desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
-                                    s_list, s_list_n, L.tw, SR ? &soon_c : nullptr);
+                                    s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab);
     }
     __syncthreads();  // sink table + item list, clocks, env records
     {
@@ -385,9 +393,11 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       for (int idx = lane_i; idx < n_items; idx += 64) {
         const int code = (int)s_list[idx];
         const int el = (code >> 8) & 7, link = code & 0xff, second = code >> 15;
-        const sp::Item it = sp::item_from_sink(env0 + el, link, s_tab[P.E * el + link]);
-        if (ENV == ENV_RMCSA) { if (!second) sp::row_item_lane<ENV, W>(P, M, it, prof); }
-        else sp::row_item_lane1<ENV, W>(P, M, it, second, prof, PF);
+        if constexpr (!CP) {  // RMCSA: 24-byte entries with a core per mask, the general loop
+          if (!second) sp::row_item_lane<ENV, W>(P, M, sp::item_from_sink(env0 + el, link, s_tab[P.E * el + link]), prof);
+        } else {
+          sp::row_item_lane1<ENV, W>(P, M, env0 + el, link, s_tab[P.E * el + link].bits, s_mtab + ORL_MTAB * el, second, prof, PF);
+        }
       }
       ORL_PROFA(13);
     }
@@ -408,11 +418,13 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     const int q = L.csw / 4;
     for (int i = lane; i < nenv * q; i += 64)
       ((int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q] = ((const int4*)M.cs0)[i];
-    ulonglong2* gr = (ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
-    const ulonglong2* lr = (const ulonglong2*)M.sc0;
-    for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) gr[i] = lr[i];
+    if (REC) {
+      ulonglong2* gr = (ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
+      const ulonglong2* lr = (const ulonglong2*)M.sc0;
+      for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) gr[i] = lr[i];
+    }
   }
-  if (LDS >= 2 && step > first_step) {
+  if (LDS == 2 && step > first_step) {
     double2* gs = (double2*)(P.lstat + env0 * 4 * P.E);
     const double2* ls = (const double2*)M.ls0;
     for (int i = lane; i < nenv * 2 * P.E; i += 64) gs[i] = ls[i];
@@ -456,6 +468,8 @@ static constexpr PersistSpec kPersistSpecs[] = {
     {ENV_RMSA, 5, 1, 50, 88, 5, 6, 320, 1, 1, 0, 25, 76, 7, 440, 16, 0},
     // RMSA, nsfnet_chen, 100 slots: RMSAEnv's default spectrum on the reference's default topology
     {ENV_RMSA, 2, 5, 14, 22, 5, 6, 100, 1, 1, 0, 25, 76, 7, 44, 16, 0},
+    // BASELINE cfg2 again, for the 4-wave form with the env records in global memory (form 6)
+    {ENV_RMSA, 5, 6, 14, 22, 5, 6, 320, 1, 1, 0, 25, 76, 7, 110, 16, 0},
 };
 constexpr int kNumPersistSpecs = (int)(sizeof(kPersistSpecs) / sizeof(kPersistSpecs[0]));
 template <int SPEC> __device__ __forceinline__ void persist_spec_apply(DevParams& P) {
@@ -655,7 +669,8 @@ template <int W> void obs(orl_batch* b, int with_terminal) {
 // measured on MI355X: 12 workgroups share a CU's 160 KiB up to 12 800 B each, 11 up to 14 080, 16 up to 10 240 —
 // hipOccupancyMaxActiveBlocksPerMultiprocessor says 12 up to 13 648).
 struct PersistForm { int lds, waves; };
-static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}};
+static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}, {3, 4}};
+constexpr int kNumPersistForms = 7;
 static int lds_wgs_per_cu(size_t lds) {
   if (lds == 0) return 1 << 20;
   const size_t alloc = (lds + 1279) / 1280 * 1280;
@@ -673,14 +688,16 @@ static PersistChoice persist_choose(const DevParams& VP) {
   // window keeps 16 on a CU, the 3-wave form down to 10, and the inner-run cache (+2.5 %) only where it costs no wavefront.
   const bool can_inner = persist_inner(VP.env_type, ORL_W, 1);
   const size_t l0 = persist_window(VP, 1, false), l1 = can_inner ? persist_window(VP, 1, true) : l0;
+  const size_t g0 = persist_window(VP, 3, false), g1 = can_inner ? persist_window(VP, 3, true) : g0;  // records in global memory
   const int r0 = lds_wgs_per_cu(l0), r1 = lds_wgs_per_cu(l1);
   PersistChoice c;
   if (r0 >= 16) { c.form = 5; c.inner = can_inner && r1 >= 16; }
+  else if (lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = can_inner && lds_wgs_per_cu(g1) >= 16; }  // 4 waves per SIMD beat the records in LDS
   else if (r0 >= 10) { c.form = 4; c.inner = can_inner && (r1 < 12 ? r1 : 12) == (r0 < 12 ? r0 : 12); }
   else { c.form = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0; c.inner = false; }
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
-    bool built = f >= 0 && f < 6;
+    bool built = f >= 0 && f < kNumPersistForms;
 #ifndef ORL_ALT_IMPLS
     built = built && f != 2 && f != 3;
 #endif
@@ -758,6 +775,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     if (spec == 1) LAUNCH_SPEC(ENV_RMSA, 1, 3, 1);
     if (spec == 4) LAUNCH_SPEC(ENV_RMCSA, 0, 3, 4);
     if (spec == 5) LAUNCH_SPEC(ENV_RMSA, 0, 3, 5);
+    if (spec == 7) LAUNCH_SPEC(ENV_RMSA, 3, 4, 7);
   }
   if constexpr (W == 2) {
     if (spec == 2) LAUNCH_SPEC(ENV_DEEPRMSA, 1, 4, 2);
@@ -771,6 +789,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     case 1: LAUNCH(E_, 0, 3); break;                                                                                         \
     ORL_FULL_LDS_CASES(E_)                                                                                                   \
     case 4: LAUNCH(E_, 1, 3); break;                                                                                         \
+    case 6: LAUNCH(E_, 3, 4); break;                                                                                         \
     default: LAUNCH(E_, 1, 4); break;                                                                                        \
   }
   ORL_FOR_ENV(b, PER_ENV)
