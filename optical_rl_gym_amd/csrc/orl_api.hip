@@ -565,6 +565,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) b->n_cu = prop.multiProcessorCount;
   }
+  HIPCHK_B(hipHostMalloc((void**)&b->h_tail, 32 * sizeof(unsigned int), hipHostMallocDefault));
   HIPCHK_B(hipEventCreate(&b->ev0));
   HIPCHK_B(hipEventCreate(&b->ev1));
   // everything below is ordered on the batch's own stream
@@ -621,6 +622,7 @@ extern "C" void orl_batch_destroy(orl_batch* b) try {
   if (b->ev_half) hipEventDestroy(b->ev_half);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->h_tail) hipHostFree(b->h_tail);
   for (void* p : b->allocs) hipFree(p);
   delete b;
 }
@@ -790,10 +792,10 @@ static int flags_to_rc(const orl_batch* b, unsigned int f) {
 }
 // after a synchronous call: report what the kernels flagged (device-resident actions cannot be checked beforehand)
 static int report_flags(orl_batch* b) {
-  unsigned int f[2] = {0, 0};
+  unsigned int* f = b->h_tail + 16;
   HIPCHK(hipMemsetAsync(b->d_unfinished + 16, 0, 2 * sizeof(unsigned int), b->stream));
   launch_finish2(b, 0);
-  HIPCHK(hipMemcpyAsync(f, b->d_unfinished + 16, sizeof f, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemcpyAsync(f, b->d_unfinished + 16, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   return flags_to_rc(b, f[1]);
@@ -955,8 +957,8 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
           HIPCHK(hipStreamWaitEvent(b->stream, b->ev_half, 0));
         }
         HIPCHK(hipEventRecord(b->ev1, b->stream));
-        unsigned int both[16] = {0};
-        HIPCHK(hipMemcpyAsync(both, b->d_unfinished, sizeof both, hipMemcpyDeviceToHost, b->stream));
+        unsigned int* both = b->h_tail;
+        HIPCHK(hipMemcpyAsync(both, b->d_unfinished, 16 * sizeof(unsigned int), hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         const unsigned int* c0 = both + (cnt[0] - b->d_unfinished);
         const unsigned int* c1 = parts == 2 ? both + (cnt[1] - b->d_unfinished) : nullptr;

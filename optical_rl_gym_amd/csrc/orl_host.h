@@ -51,6 +51,7 @@ struct orl_batch {
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_totals = nullptr;
+  unsigned int* h_tail = nullptr;  // page-locked: where the straggler count / flag words of a run land (a pageable target is staged)
   int* ep_buf = nullptr;           // episode log buffer (orl_batch_episode_log): [B][ep_alloc] ints, armed with stride P.ep_cap <= ep_alloc
   int ep_alloc = 0;
 };

@@ -257,6 +257,61 @@ static inline bool persist_compact(int env_type, int state) { return env_type !=
 // (rows of one or two words: searching both costs less than the bookkeeping — cfg3 measured 1.20e9 without, 1.01e9 with)
 template <int ENV, int W, int LDS> struct PersistInner { static constexpr bool value = LDS >= 1 && W >= 3 && W <= 5 && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA); };
 static inline bool persist_inner(int env_type, int W, int state) { return state >= 1 && W >= 3 && W <= 5 && (env_type == ENV_RMSA || env_type == ENV_DEEPRMSA); }
+// The LDS window of a wavefront's 8 envs, filled from their (contiguous) global arrays.  Everything is REQUESTED before
+// anything is waited for (blocks of 8 x 64 pieces of 16 bytes; the records and the sums with the first block).  A copy loop
+// `l[i] = g[i]` compiles to load - wait - store per iteration: 13 dependent memory round trips at the start of every
+// wavefront of every launch, all wavefronts of a generation at once — a fixed ~45 us per generation, which made a 20-step
+// launch 15 % slower per step than a 300-step run.
+typedef unsigned long long orl_u64x2 __attribute__((ext_vector_type(2)));  // (a native vector: selects stay in registers)
+typedef int orl_i32x4 __attribute__((ext_vector_type(4)));
+template <bool REC>
+__device__ __forceinline__ void persist_fill_window(const DevParams& P, i64 env0, int nenv, int lane, void* l_bm_, void* l_rec_, void* l_cs_,
+                                                    int q /* 16-byte pieces of the sums per env */) {
+  const orl_u64x2* g = (const orl_u64x2*)(P.bitmap + env0 * P.bm_words);
+  const orl_u64x2* gr = (const orl_u64x2*)(P.scal + env0 * ORL_SCAL_WORDS);
+  orl_u64x2* l_bm = (orl_u64x2*)l_bm_;
+  orl_u64x2* l_rec = (orl_u64x2*)l_rec_;
+  orl_i32x4* l_cs = (orl_i32x4*)l_cs_;
+  const int n_bm = nenv * (P.bm_words / 2), n_rec = nenv * (ORL_SCAL_WORDS / 2);
+  for (int base = 0; base < n_bm; base += 64 * 8) {
+    const int i0 = base + lane;
+    orl_u64x2 b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, r0 = 0, r1 = 0;
+    orl_i32x4 vc = 0;
+    if (i0 < n_bm) b0 = g[i0];
+    if (i0 + 64 < n_bm) b1 = g[i0 + 64];
+    if (i0 + 128 < n_bm) b2 = g[i0 + 128];
+    if (i0 + 192 < n_bm) b3 = g[i0 + 192];
+    if (i0 + 256 < n_bm) b4 = g[i0 + 256];
+    if (i0 + 320 < n_bm) b5 = g[i0 + 320];
+    if (i0 + 384 < n_bm) b6 = g[i0 + 384];
+    if (i0 + 448 < n_bm) b7 = g[i0 + 448];
+    if (base == 0) {
+      if (REC) {
+        if (lane < n_rec) r0 = gr[lane];
+        if (lane + 64 < n_rec) r1 = gr[lane + 64];
+      }
+      if (lane < nenv * q) vc = ((const orl_i32x4*)(P.core_sums + (env0 + lane / q) * P.cs_words))[lane % q];
+    }
+    if (i0 < n_bm) l_bm[i0] = b0;
+    if (i0 + 64 < n_bm) l_bm[i0 + 64] = b1;
+    if (i0 + 128 < n_bm) l_bm[i0 + 128] = b2;
+    if (i0 + 192 < n_bm) l_bm[i0 + 192] = b3;
+    if (i0 + 256 < n_bm) l_bm[i0 + 256] = b4;
+    if (i0 + 320 < n_bm) l_bm[i0 + 320] = b5;
+    if (i0 + 384 < n_bm) l_bm[i0 + 384] = b6;
+    if (i0 + 448 < n_bm) l_bm[i0 + 448] = b7;
+    if (base == 0) {
+      if (REC) {
+        if (lane < n_rec) l_rec[lane] = r0;
+        if (lane + 64 < n_rec) l_rec[lane + 64] = r1;
+      }
+      if (lane < nenv * q) l_cs[lane] = vc;
+      for (int i = lane + 64; i < nenv * q; i += 64)  // (more than 8 cores: the rest of the sums)
+        l_cs[i] = ((const orl_i32x4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q];
+    }
+  }
+}
+
 // LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics,
 // 3 = slot maps + per-core sums in LDS, env records in global memory
 // PF: early requests of the Mersenne-Twister window and the link statistics (more live registers: the 3-wave forms)
@@ -278,13 +333,33 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   const int nenv = (int)(P.B - env0 < 8 ? P.B - env0 : 8);
   int step = wg_step[blockIdx.x];
   sp::Prof prof;
-  {
-    // An env whose releases did not fit the item form in the last step of the previous launch (flag in its record; the
-    // wavefront left its loop right after that step's row phase): they are released in place now, by the wavefront that owns
-    // the env, before anything of this launch reads the state.  (A kernel of its own after every launch — round 1, and
-    // the two-kernel form still — had to wait for a free CU while the other half's launch filled the GPU: 0.5-1 ms on the
-    // stream between two 3 ms launches, rocprofv3 kernel trace r2n.)
-    const bool pend = (env < P.B) && ((P.scal[env * ORL_SCAL_WORDS + SC_ACC] >> 16) & 1ull) != 0ull;
+  // An env whose releases did not fit the item form in the last step of the previous launch (flag in its record; the
+  // wavefront left its loop right after that step's row phase): they are released in place, by the wavefront that owns
+  // the env, before anything of this launch uses the state.  (A kernel of its own after every launch — round 1, and
+  // the two-kernel form still — had to wait for a free CU while the other half's launch filled the GPU: 0.5-1 ms on the
+  // stream between two 3 ms launches, rocprofv3 kernel trace r2n.)  The flag is requested here and looked at after the
+  // LDS window has been requested too (one memory round trip instead of two at the start of every wavefront); in the rare
+  // case the window is filled again afterwards.
+  const bool pend = (env < P.B) && ((P.scal[env * ORL_SCAL_WORDS + SC_ACC] >> 16) & 1ull) != 0ull;
+  sp::Wmem M = sp::wmem_global(P);
+  constexpr bool REC = (LDS == 1 || LDS == 2);  // the env records are in the LDS window
+  if (!REC) {
+    M.clk = (double*)(orl_lds_raw + L.clk);
+    M.clk_env0 = env0;
+  }
+  if (LDS >= 1) {  // the wavefront's envs are contiguous in every array: coalesced 16-byte loads
+    M.bm0 = (u64*)(orl_lds_raw + L.bm);
+    M.env0 = env0;
+    M.cs0 = (int*)(orl_lds_raw + L.cs);
+    M.cenv0 = env0;
+    M.cs_lds = true;
+    M.cs_stride = L.csw;
+    if (REC) {
+      M.sc0 = (u64*)(orl_lds_raw + L.sc);
+      M.scenv0 = env0;
+    }
+#define ORL_FILL_WINDOW() persist_fill_window<REC>(P, env0, nenv, lane, orl_lds_raw + L.bm, orl_lds_raw + L.sc, orl_lds_raw + L.cs, L.csw / 4)
+    if (step < target) ORL_FILL_WINDOW();
     if (__ballot(pend) != 0ull) {
       if (pend) {
         sp::rel_serial<ENV, W>(P, env, lane);
@@ -295,31 +370,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       }
       __threadfence();
       __syncthreads();
+      if (step < target) ORL_FILL_WINDOW();
     }
-  }
-  sp::Wmem M = sp::wmem_global(P);
-  constexpr bool REC = (LDS == 1 || LDS == 2);  // the env records are in the LDS window
-  if (!REC) {
-    M.clk = (double*)(orl_lds_raw + L.clk);
-    M.clk_env0 = env0;
-  }
-  if (LDS >= 1) {  // the wavefront's envs are contiguous in every array: coalesced 16-byte loads
-    M.bm0 = (u64*)(orl_lds_raw + L.bm);
-    M.env0 = env0;
-    if (step < target) {
-      const ulonglong2* g = (const ulonglong2*)(P.bitmap + env0 * P.bm_words);
-      ulonglong2* l = (ulonglong2*)M.bm0;
-      for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) l[i] = g[i];
-    }
-    M.cs0 = (int*)(orl_lds_raw + L.cs);
-    M.cenv0 = env0;
-    M.cs_lds = true;
-    M.cs_stride = L.csw;
-    if (step < target) {
-      const int q = L.csw / 4;  // 16-byte pieces per env
-      for (int i = lane; i < nenv * q; i += 64)
-        ((int4*)M.cs0)[i] = ((const int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q];
-    }
+#undef ORL_FILL_WINDOW
     if (IC) {
       M.ic0 = (u32*)(orl_lds_raw + L.ic);
       if (step < target) {
@@ -327,14 +380,18 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
         for (int i = lane; i < nenv * P.E; i += 64) M.ic0[i] = sp::row_inner_cache<W>(M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W);
       }
     }
-    if (REC) {
-      M.sc0 = (u64*)(orl_lds_raw + L.sc);
-      M.scenv0 = env0;
-      if (step < target) {
-        const ulonglong2* gr = (const ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
-        ulonglong2* lr = (ulonglong2*)M.sc0;
-        for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) lr[i] = gr[i];
+  }
+  if (LDS == 0) {
+    if (__ballot(pend) != 0ull) {
+      if (pend) {
+        sp::rel_serial<ENV, W>(P, env, lane);
+        if (ENV == ENV_DEEPRMSA && P.obs_dim) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          obs8_env<W>(P, P.bitmap + env * P.bm_words, P.scal + env * ORL_SCAL_WORDS, env, lane, P.done[env]);
+        }
       }
+      __threadfence();
+      __syncthreads();
     }
   }
   if (LDS == 2) {
@@ -380,7 +437,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     {
       int a[4];
       policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
-                          (int)((desc >> 48) & 0xffu), lane_i, pol, valid_i ? P.path_col[env_i] : 0, a);
+                          (int)((desc >> 48) & 0xffu), lane_i, pol, (pol == POL_PATH_FF && valid_i) ? P.path_col[env_i] : 0, a);
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
       desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
@@ -691,9 +748,12 @@ static PersistChoice persist_choose(const DevParams& VP) {
   const size_t g0 = persist_window(VP, 3, false), g1 = can_inner ? persist_window(VP, 3, true) : g0;  // records in global memory
   const int r0 = lds_wgs_per_cu(l0), r1 = lds_wgs_per_cu(l1);
   PersistChoice c;
+  // (round 3, cfg2 with the 4-byte sink entries: form 4 with the cache 1.23e9; form 6 — 4 waves per SIMD, 16 per CU, but the
+  // records in global memory, the soon list in memory and 9 spilled VGPRs — 1.14e9: what a wavefront keeps next to itself is
+  // worth more than a fourth wavefront per SIMD.  Form 6 is taken only where the 3-wave window does not fit at all.)
   if (r0 >= 16) { c.form = 5; c.inner = can_inner && r1 >= 16; }
-  else if (lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = can_inner && lds_wgs_per_cu(g1) >= 16; }  // 4 waves per SIMD beat the records in LDS
   else if (r0 >= 10) { c.form = 4; c.inner = can_inner && (r1 < 12 ? r1 : 12) == (r0 < 12 ? r0 : 12); }
+  else if (lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = can_inner && lds_wgs_per_cu(g1) >= 16; }
   else { c.form = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0; c.inner = false; }
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
