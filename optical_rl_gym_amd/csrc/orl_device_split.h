@@ -746,44 +746,114 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         return;
       }
     }
-    // info word + path record of this lane's candidate, requested by all lanes together
-    u64 inf0 = 0;
-    PathRec rc0 = PathRec();
-    if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : ((ci == pre_idx) ? pre_info : e.ev_info[ci]); rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
-    ORL_PROF(6);
-    for (;;) {
-      double bt = ct;
-      int bi = ci, bl = gl;
+    if constexpr (CP) {
+      // Compact sink: nothing in it depends on the order in which masks ARRIVE (a release is a bit in the link words and an
+      // entry of the env's mask table, both addressed by its rank), so only the RANKS are found one after the other — a
+      // light loop: the 8-lane minimum and the holder's bookkeeping — and then every holder lane works on its own release
+      // at the same time: info word and path record (one memory round trip for the wavefront instead of one per release of
+      // its busiest env), the mask, one LDS atomic per hop, its slot of the free-slot stack.  Before, the whole body ran
+      // once per release with 8 lanes cooperating on the hops, and a wavefront took as many rounds as the env with the most
+      // releases (3-4 on average for 8 envs at one release per env-step): the largest item of the phase profile.
+      u32 rk = 0u;  // rank (1-based within this round) of this lane's list entry k, 6 bits each
+      int n_round = 0;
+      for (;;) {
+        double bt = ct;
+        int bi = ci, bl = gl;
 #define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); int ol = dpp_i<CTRL>(bl); \
                              if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; bl = ol; } }
-      ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
+        ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
 #undef ORL_MIN_STEP
-      if (!(bt <= e.now)) break;
-      const u64 info = gget(inf0, bl, lane);
-      PathRec rec;
-      rec.q[0] = gget(rc0.q[0], bl, lane); rec.q[1] = gget(rc0.q[1], bl, lane);
-      rec.q[2] = gget(rc0.q[2], bl, lane); rec.q[3] = gget(rc0.q[3], bl, lane);
-      if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
-      if (gl == bl) {  // the holder drops the entry from its list and moves to its next due entry, if any (rare)
-        dirty |= 1 << ck;
-        ct = INF; ci = 0x7fffffff;
-        int nk = 0;
+        if (!(bt <= e.now)) break;
+        n_round++;
+        if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
+        if (gl == bl) {  // the holder notes the rank, drops the entry from its list and moves to its next due entry, if any (rare)
+          rk |= (u32)n_round << (6 * ck);
+          dirty |= 1 << ck;
+          ct = INF; ci = 0x7fffffff;
+          int nk = 0;
 #pragma unroll
-        for (int k = 0; k < NS; k++) {
-          if (k == ck) st[k] = INF;
-          const bool due = st[k] <= e.now;
-          if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
+          for (int k = 0; k < NS; k++) {
+            if (k == ck) st[k] = INF;
+            const bool due = st[k] <= e.now;
+            if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
+          }
+          ck = nk;
         }
-        ck = nk;
-        if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : ((ci == pre_idx) ? pre_info : e.ev_info[ci]); rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
       }
-      const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
-      const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
-      e.ev_cnt--;
-      g8::free_push(e, gl, bi);
-      sink_add(sink, rec, core, s0, n, lane);
-      e.s_br -= br;
-      e.s_nh -= (i64)n * path_rec_byte(rec, 0);
+      ORL_PROF(6);
+      int d_br = 0, d_nh = 0;
+      const int nfree0 = e.nfree, nrel0 = sink.nrel;
+      unsigned short* fs = (unsigned short*)(e.scal + SC_FREE0);
+      while (rk) {  // (per lane: one entry, rarely two)
+        const int k = (int)__builtin_ctz(rk) / 6;
+        const int r = (int)((rk >> (6 * k)) & 63u);
+        rk &= ~(63u << (6 * k));
+        int idx = si[0];
+#pragma unroll
+        for (int j = 1; j < NS; j++) idx = (k == j) ? si[j] : idx;
+        const u64 info = (idx == pushed_idx) ? pushed_info : ((idx == pre_idx) ? pre_info : e.ev_info[idx]);
+        const PathRec rec = path_rec_load(P, (int)(info & 0xffffffu));
+        const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu), br = (int)((info >> 49) & 0x7fffu);
+        const int hops = path_rec_byte(rec, 0), kk = nrel0 + r;
+        sink.mtab[kk] = (unsigned short)((u32)s0 | ((u32)n << 9));
+        for (int h = 0; h < hops; h++) {
+          const int link = path_rec_byte(rec, 2 + h);
+          const u32 old = atomicOr(&sink.tab[link].bits, 1u << kk);
+          sink.cnt += (old == 0u) ? 1 : 0;
+          if (sink.list && old <= 1u)  // a new item, or the first release on a link of the step's provision (second lane)
+            sink.list[atomicAdd(sink.list_n, 1u)] = (unsigned short)((old << 15) | (((lane >> 3) & 7) << 8) | link);
+        }
+        // the freed slot goes onto the env's free-slot stack at the place its rank gives it (g8::free_push, one by one before)
+        const int fp = nfree0 + r - 1;
+        if (fp < ORL_FREE_SLOTS) fs[fp] = (unsigned short)idx;
+        d_br += br;
+        d_nh += n * hops;
+      }
+      e.ev_cnt -= n_round;
+      e.nfree = (nfree0 + n_round < ORL_FREE_SLOTS) ? nfree0 + n_round : ORL_FREE_SLOTS;
+      sink.nrel = nrel0 + n_round;
+      e.s_br -= (i64)g8_sum(d_br);
+      e.s_nh -= (i64)g8_sum(d_nh);
+    } else {
+    // info word + path record of this lane's candidate, requested by all lanes together
+      u64 inf0 = 0;
+      PathRec rc0 = PathRec();
+      if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : ((ci == pre_idx) ? pre_info : e.ev_info[ci]); rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
+      ORL_PROF(6);
+      for (;;) {
+        double bt = ct;
+        int bi = ci, bl = gl;
+  #define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); int ol = dpp_i<CTRL>(bl); \
+                               if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; bl = ol; } }
+        ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
+  #undef ORL_MIN_STEP
+        if (!(bt <= e.now)) break;
+        const u64 info = gget(inf0, bl, lane);
+        PathRec rec;
+        rec.q[0] = gget(rc0.q[0], bl, lane); rec.q[1] = gget(rc0.q[1], bl, lane);
+        rec.q[2] = gget(rc0.q[2], bl, lane); rec.q[3] = gget(rc0.q[3], bl, lane);
+        if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
+        if (gl == bl) {  // the holder drops the entry from its list and moves to its next due entry, if any (rare)
+          dirty |= 1 << ck;
+          ct = INF; ci = 0x7fffffff;
+          int nk = 0;
+  #pragma unroll
+          for (int k = 0; k < NS; k++) {
+            if (k == ck) st[k] = INF;
+            const bool due = st[k] <= e.now;
+            if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
+          }
+          ck = nk;
+          if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : ((ci == pre_idx) ? pre_info : e.ev_info[ci]); rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
+        }
+        const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu);
+        const int core = (int)((info >> 44) & 0x1fu), br = (int)((info >> 49) & 0x7fffu);
+        e.ev_cnt--;
+        g8::free_push(e, gl, bi);
+        sink_add(sink, rec, core, s0, n, lane);
+        e.s_br -= br;
+        e.s_nh -= (i64)n * path_rec_byte(rec, 0);
+      }
     }
     ORL_PROF(7);
     if (e.now < e.t_soon) break;
