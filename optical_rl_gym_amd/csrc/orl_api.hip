@@ -314,6 +314,11 @@ static void launch_step64(orl_batch* b, int auto_reset, int want_info, int fused
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
+static void launch_agent_step(orl_batch* b, int auto_reset) {
+#define CALL(WW) orl_launch::agent_step<WW>(b, auto_reset)
+  ORL_DISPATCH_W(b, CALL)
+#undef CALL
+}
 static void launch_obs(orl_batch* b, int with_terminal) {
 #define CALL(WW) orl_launch::obs<WW>(b, with_terminal)
   ORL_DISPATCH_W(b, CALL)
@@ -477,6 +482,15 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     }
   }
   P.pipeline2 = (b->persist || b->two_kernel) ? 1 : 0;
+  {
+    // Host- / agent-driven steps with auto reset (what SB3's VecEnv issues) through the phases of the persistent kernel
+    // (k_agent) wherever they apply and the batch is large enough to fill the GPU with 8 envs per wavefront: cfg2 65 536 envs
+    // 305 us per step in k_step (one wavefront per env), ~90 us in k_agent.  ORL_AGENT_STEP=1 forces it for any batch size
+    // (parity tests), 0 disables it.
+    const bool fits = b->persist && (c->env_type == ORL_ENV_RMSA || c->env_type == ORL_ENV_DEEPRMSA) && c->bit_rate_mode == 0 && P.E <= 128;
+    b->agent_step = fits && n_envs >= 2048;
+    if (const char* av = getenv("ORL_AGENT_STEP")) b->agent_step = fits && atoi(av) != 0;
+  }
 
   P.n_paths = t->n_paths;
   P.path_length = t->path_length; P.edge_iter_order = t->edge_iter_order; P.link_pos = t->link_pos;
@@ -679,6 +693,7 @@ extern "C" int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_
     b->allocs.push_back(p);
     b->P.mt2 = p;
     b->persist = 0;
+    b->agent_step = 0;
     b->two_kernel = 0;
     b->P.pipeline2 = 0;
   }
@@ -813,7 +828,8 @@ extern "C" int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_res
                   actions[4 * bad + 1], actions[4 * bad + 2], actions[4 * bad + 3], (long long)bad);
     HIPCHK(hipMemcpyAsync(b->P.actions, actions, B * 4 * sizeof(int), hipMemcpyHostToDevice, b->stream));
   }
-  launch_step64(b, auto_reset ? 1 : 0, 1, -1);
+  if (b->agent_step) launch_agent_step(b, auto_reset ? 1 : 0);
+  else launch_step64(b, auto_reset ? 1 : 0, 1, -1);
   bool any = false;
   if (reward_out) { HIPCHK(hipMemcpyAsync(reward_out, b->P.reward, B * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
   if (done_out) { HIPCHK(hipMemcpyAsync(done_out, b->P.done, B, hipMemcpyDeviceToHost, b->stream)); any = true; }

@@ -247,6 +247,7 @@ struct CtrlOpts {
   bool trusted;     // the action comes from the in-kernel slot scan on the same slot map: is_path_free holds by construction
   bool emit_queue;  // two-kernel form: copy the items into the global queue for the row kernel
   bool prefetch;    // request the Mersenne-Twister window at the start of the phase (costs registers: 3-wave forms only)
+  bool auto_reset;  // an env that reports done is soft-reset right away (the device-resident loop, SB3's VecEnv); k_agent: the caller's choice
 };
 template <int ENV, int W, bool CP>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
@@ -260,11 +261,17 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 // Returns the service descriptor of the NEW pending service (what the next slot scan needs: pair base, bit-rate index,
 // number of paths), and through *n_items_out the number of items this env's step left in its sink table.
 // CP: compact sink entries (SinkEntryC); tw: tally words per env (>= ceil(E / 4))
+// Host- or agent-driven single steps through these phases (k_agent): what info of step() needs beyond the device-resident
+// loop's state (rmsa_env.py:228-264) — the network compactness before the provision, the occupied-slot sum right after it —
+// carried from the control phase to the end of the step; the four blocking rates are stored by the control phase itself.
+struct InfoCarry { double prev_comp; i64 s_nh_prov; };
+
 template <int ENV, int W, bool CP = false>
 __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
                                       const int4* given, u32* s_tally, typename SinkEntryOf<CP>::type* s_tab, int parity,
                                       int* s_deferred, int* done_out, unsigned short* s_list = nullptr, u32* s_list_n = nullptr,
-                                      int tw = 32, SoonRegs* carried = nullptr, unsigned short* s_mtab = nullptr) {
+                                      int tw = 32, SoonRegs* carried = nullptr, unsigned short* s_mtab = nullptr,
+                                      InfoCarry* ic = nullptr) {
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   if (!O.persistent && blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
   u64 desc_out = 0ull;
@@ -342,6 +349,12 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         if (O.persistent && !M.cs_lds) atomicExch(rs + i, 0);
         else rs[i] = 0;
       }
+    }
+    if (ic) {  // _get_network_compactness before the provision (rmsa_env.py:189)
+      int occ, fb;
+      if (O.persistent && !M.cs_lds) { occ = atomicAdd(e.cs, 0); fb = atomicAdd(e.cs + 1, 0); }
+      else { occ = e.cs[0]; fb = e.cs[1]; }
+      ic->prev_comp = (fb > 0) ? ((double)occ / (double)e.s_nh) * ((double)P.E / (double)fb) : 1.0;
     }
     const int4 av = given ? *given : *(const int4*)(P.actions + env * 4);
     int path, mod = 0;
@@ -462,8 +475,18 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     const u64 acc_after = (accepted && ENV != ENV_RWA && e.now > 0)
                               ? (3ull | ((u64)(u32)core << 32) | ((u64)e.s_nh << 37))
                               : pack2(accepted ? 1 : 0, core);
+    if (ic) {  // the counters as info sees them: after this step's decision, before the next service is counted (rmsa_env.py:234-249)
+      ic->s_nh_prov = e.s_nh;
+      if (gl == 0) {
+        double* io = P.info + env * P.n_info;
+        io[0] = (double)(e.sp - e.sa) / (double)e.sp;
+        io[1] = (double)(e.esp - e.esa) / (double)e.esp;
+        io[2] = (double)(e.brq - e.brp) / (double)e.brq;
+        io[3] = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
+      }
+    }
     if (!O.prefetch) g8::rng_fill(e, rng, gl);
-    const bool done = service_part<ENV, W>(P, e, env, lane, 1, accepted, core, O.write_io, rng, prof);
+    const bool done = service_part<ENV, W>(P, e, env, lane, O.auto_reset ? 1 : 0, accepted, core, O.write_io, rng, prof);
     if (done_out) *done_out = done ? 1 : 0;
     desc_out = g8::env_store(P, e, gl, O.write_io);
     if (M.clk && gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
@@ -1033,7 +1056,10 @@ __device__ __forceinline__ void row_occ_fb(const u64 (&a)[W], int S, int& occ, i
 // also into rel_sums.
 template <int ENV, int W>
 __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M, const i64 env, const int link, const u32 bits,
-                                               const unsigned short* mtab, int second, Prof& prof, bool early_ls = false) {
+                                               const unsigned short* mtab, int second, Prof& prof, bool early_ls = false,
+                                               double* stash_env = nullptr) {
+  // `stash_env` (k_agent; LDS, [E][2] of this env): where a lane whose evaluated mask is a release leaves the link's
+  // utilization and compactness as they were BEFORE its update, i.e. after the step's provision — what info's link averages use
   // `bits`: the (env, link) word of the compact sink — bit 0 the step's provision, bit k its k-th release; `mtab`: the env's
   // masks, entry k = (first slot: 9 | slots: 6)
   const int E = P.E, S = P.S;
@@ -1119,6 +1145,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
       if (role_b || !early_ls) { ls01 = *(const double2*)ls; ls23 = *(const double2*)(ls + 2); }
       double last_update = ls23.y;
       double util = ls01.x, frag = ls01.y, comp = ls23.x;
+      if (stash_env && rel_f) { stash_env[2 * link] = util; stash_env[2 * link + 1] = comp; }
       if (clock > 0) {  // the first touch of the link at this clock value
         const double time_diff = clock - last_update;
         util = ((util * last_update) + (cur_util * time_diff)) / clock;

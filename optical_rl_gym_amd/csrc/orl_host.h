@@ -32,6 +32,7 @@ struct orl_batch {
   int parity = 0;        // two-kernel form (ORL_ALT_IMPLS): which deferred-env buffer the next step writes
   int persist = 0;       // device-resident runs go through the persistent kernel (k_persist)
   int lds_state = 0;     // ... with the slot maps and link statistics of a wavefront's envs resident in LDS
+  int agent_step = 0;    // host- / agent-driven steps with auto reset go through k_agent (the phases of k_persist) instead of k_step
   int two_kernel = 0;    // ORL_ALT_IMPLS builds, ORL_STEP_IMPL=2 ORL_PERSIST=0: the phases of k_persist as separate launches
   int64_t persist_launches = 0;
   int persist_spec = 0;            // the specialised instantiation of k_persist the last launch used (0: the generic kernel)
@@ -79,7 +80,8 @@ template <int W> void persist(orl_batch* b, const orl::DevParams& VP, hipStream_
 template <int W> int persist_resident(orl_batch* b, int n_cu);              // wavefronts of k_persist the GPU holds at once
 template <int W> int persist_uses_lds(orl_batch* b);                       // 1: the persistent kernel keeps slot maps / link statistics in LDS
 template <int W> int prof_read(unsigned long long* out48, int reset);      // -DORL_TIMING builds: per-phase cycle sums
-template <int W> void step2(orl_batch* b, int pol);                        // ORL_ALT_IMPLS: k_step_a2 ; k_rows2 ; k_rel_tail
+template <int W> void step2(orl_batch* b, int pol);
+template <int W> void agent_step(orl_batch* b, int auto_reset);                            // k_agent: one step, actions in P.actions, info / obs written                        // ORL_ALT_IMPLS: k_step_a2 ; k_rows2 ; k_rel_tail
 }  // namespace orl_launch
 
 #define ORL_DISPATCH_W(B_, CALL)      \

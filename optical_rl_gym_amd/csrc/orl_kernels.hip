@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_step_a2(DevParams P, int pol, int parit
   sp::Prof prof;
   const sp::Wmem M = sp::wmem_global(P);
   sp::CtrlOpts O;
-  O.persistent = false; O.write_io = true; O.trusted = false; O.emit_queue = true; O.prefetch = false;
+  O.persistent = false; O.write_io = true; O.trusted = false; O.emit_queue = true; O.prefetch = false; O.auto_reset = true;
   ORL_PROFA_BEGIN();
   if (FUSED_POLICY) {
     const i64 env0 = env - ((lane >> 3));  // first env of this wavefront
@@ -433,6 +433,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     O.trusted = true;
     O.emit_queue = false;
     O.prefetch = PF;
+    O.auto_reset = true;
     int done_i = 0;
     {
       int a[4];
@@ -555,6 +556,124 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
   if (blockIdx.x == 0 && threadIdx.x == 0) { clear_next[0] = 0u; clear_next[1] = 0u; }
   persist_spec_apply<SPEC>(P);
   persist_body<ENV, W, LDS, (WAVES <= 3)>(P, pol, target, wg_step, n_unfinished);
+}
+
+
+// ---- one step for an agent in the loop -----------------------------------------------------------------------------------
+// step() of every env with the actions in P.actions (written by the host, or by an agent on the same GPU), as SB3's VecEnv
+// drives it (auto reset): the control phase and the row phase of k_persist for ONE step — 8 lanes per env, 8 envs per
+// wavefront, all state in global memory, the per-step tables in LDS — plus what a host-visible step() owes beyond the
+// device-resident loop: the action is validated (is_path_free), reward / done / info / observation are written, the
+// network-compactness update is finished in the same launch, and releases that do not fit the item form are done in place
+// right away, so that every launch leaves final state.  RMSA and DeepRMSA with continuous bit rates; the other families keep
+// the one-wavefront-per-env kernel (k_step: 305 us per 65 536 envs against ~90 us here).
+// info (rmsa_env.py:234-264): the four blocking rates from the counters before the next service is counted (control
+// phase); network_compactness after the provision = (totals - what this step's releases added) over the occupied-slot sum at
+// provision time, the difference to its value before the provision; the two link averages over topology.edges() in numpy's
+// pairwise order, on the values AFTER the provision and BEFORE the step's releases — a lane of the row phase that applies a
+// release leaves the link's values from before its update in an LDS stash.
+#ifndef ORL_AGENT_WAVES
+#define ORL_AGENT_WAVES 3  // waves per SIMD the register allocator leaves room for
+#endif
+template <int ENV, int W>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGENT_WAVES, ORL_AGENT_WAVES))) k_agent(DevParams P, int auto_reset) {
+  constexpr bool CP = true;
+  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, 0, CP, false);
+  sp::SinkEntryC* s_tab = (sp::SinkEntryC*)(orl_lds_raw + L.tab);
+  unsigned short* s_mtab = (unsigned short*)(orl_lds_raw + L.mtab);
+  unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
+  int* s_deferred = (int*)(orl_lds_raw + L.misc);
+  u32* s_list_n = (u32*)(orl_lds_raw + L.misc + 8);
+  double* s_stash = (double*)(orl_lds_raw + L.total);  // [8][E][2]
+  const int lane = lane_id(), gl = lane & 7, el = lane >> 3;
+  const i64 env0 = (i64)blockIdx.x * 8, env = env0 + el;
+  const bool valid = env < P.B;
+  sp::Prof prof;
+  sp::Wmem M = sp::wmem_global(P);
+  M.clk = (double*)(orl_lds_raw + L.clk);
+  M.clk_env0 = env0;
+  if (threadIdx.x == 0) s_deferred[0] = 0;
+  sp::CtrlOpts O;
+  O.persistent = true; O.write_io = true; O.trusted = false; O.emit_queue = false; O.prefetch = true; O.auto_reset = auto_reset != 0;
+  int done_i = 0;
+  sp::InfoCarry ic;
+  ic.prev_comp = 1.0; ic.s_nh_prov = 0;
+  sp::ctrl_a<ENV, W, CP>(P, M, O, env, valid, lane, prof, nullptr, nullptr, s_tab, 0, s_deferred, &done_i, s_list, s_list_n, 0, nullptr, s_mtab, &ic);
+  __syncthreads();  // sink table + item list, clocks
+  {
+    const int n_items = (int)*s_list_n;
+    for (int idx = lane; idx < n_items; idx += 64) {
+      const int code = (int)s_list[idx];
+      const int iel = (code >> 8) & 7, link = code & 0xff, second = code >> 15;
+      sp::row_item_lane1<ENV, W>(P, M, env0 + iel, link, s_tab[P.E * iel + link].bits, s_mtab + ORL_MTAB * iel, second, prof, true,
+                                 s_stash + 2 * P.E * iel);
+    }
+  }
+  __syncthreads();
+  const bool deferred = s_deferred[0] != 0;
+  u64* rec = P.scal + env * ORL_SCAL_WORDS;
+  double mean_comp = 0.0, mean_util = 0.0;
+  if (valid) {
+    // np.mean over the links in topology.edges() order (numpy pairwise sum, optical_rl_gym_amd/csrc/orl_device.h link_mean):
+    // lane j of the group accumulates x[j], x[8 + j], ...; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); the tail one by one
+    const int E = P.E;
+    const double* ls = P.lstat + env * 4 * E;
+    const double* st = s_stash + 2 * E * el;
+    auto value = [&](int i, double& u, double& c) {
+      const int link = P.edge_iter_order[i];
+      const bool rel = (s_tab[E * el + link].bits >> 1) != 0u;  // a release of this step touched the link: the values from before it
+      u = rel ? st[2 * link] : ls[4 * link];
+      c = rel ? st[2 * link + 1] : ls[4 * link + 2];
+    };
+    double su = 0.0, sc = 0.0;
+    if (E < 8) {
+      for (int i = 0; i < E; i++) { double u, c; value(i, u, c); su += u; sc += c; }
+    } else {
+      double u, c;
+      value(gl, su, sc);
+      int i;
+      for (i = 8; i < E - (E % 8); i += 8) { value(i + gl, u, c); su += u; sc += c; }
+      su += dpp_d<ORL_DPP_XOR1>(su); sc += dpp_d<ORL_DPP_XOR1>(sc);
+      su += dpp_d<ORL_DPP_XOR2>(su); sc += dpp_d<ORL_DPP_XOR2>(sc);
+      su += dpp_d<ORL_DPP_HALF_MIRROR>(su); sc += dpp_d<ORL_DPP_HALF_MIRROR>(sc);
+      for (; i < E; i++) { value(i, u, c); su += u; sc += c; }
+    }
+    mean_util = su / (double)E;
+    mean_comp = sc / (double)E;
+  }
+  if (deferred) {  // (a few env-steps in 10^7) releases that did not fit the item form: in place, now
+    __syncthreads();
+    if (valid) sp::rel_serial<ENV, W>(P, env, lane);
+    __threadfence();
+    __syncthreads();
+  }
+  if (valid) {
+    // network compactness right after the provision: the totals minus what the step's releases added (row phase: L2 atomics)
+    int* cs = P.core_sums + env * P.cs_words;
+    int* rs = cs + 2 * P.C;
+    const int occ = atomicAdd(cs, 0) - atomicAdd(rs, 0), fb = atomicAdd(cs + 1, 0) - atomicAdd(rs + 1, 0);
+    const double cur = (fb > 0) ? ((double)occ / (double)ic.s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
+    if (gl == 0) {
+      const u64 acc = rec[SC_ACC];
+      if ((u32)acc & 2u) {  // the pending average of _update_network_stats (rmsa_env.py:439-462), as k_finish2 finishes it
+        const double a0 = __longlong_as_double((i64)rec[SC_GC_A]), td = __longlong_as_double((i64)rec[SC_GC_TD]);
+        const double now_a = __longlong_as_double((i64)rec[SC_NOWA]);
+        rec[SC_GCOMP] = (u64)__double_as_longlong((a0 + (cur * td)) / now_a);
+        rec[SC_ACC] = acc & ~2ull;
+      }
+      atomicExch(rs, 0);
+      atomicExch(rs + 1, 0);
+      double* io = P.info + env * P.n_info;
+      io[4] = cur;
+      io[5] = ic.prev_comp - cur;
+      io[6] = mean_comp;
+      io[7] = mean_util;
+    }
+    if (ENV == ENV_DEEPRMSA && P.obs_dim) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      obs8_env<W>(P, P.bitmap + env * P.bm_words, rec, env, lane, done_i);
+    }
+  }
 }
 
 // serial tail, one small workgroup per launch: the envs whose releases of this step did not fit the item form (about
@@ -856,6 +975,16 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
 #undef PER_ENV
 #undef LAUNCH
 }
+// one host- or agent-driven step through the phases of the persistent kernel (RMSA / DeepRMSA, continuous bit rates)
+template <int W> void agent_step(orl_batch* b, int auto_reset) {
+  const DevParams& VP = b->P;
+  dim3 g((unsigned)((VP.B + 7) / 8)), blk(64);
+  const size_t lds = (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, 0, true, false).total + (size_t)8 * VP.E * 16;
+  if (VP.env_type == ENV_RMSA) hipLaunchKernelGGL((k_agent<ENV_RMSA, W>), g, blk, lds, b->stream, VP, auto_reset);
+  else hipLaunchKernelGGL((k_agent<ENV_DEEPRMSA, W>), g, blk, lds, b->stream, VP, auto_reset);
+  ORL_TK(b, "k_agent");
+}
+
 // wavefronts of the persistent kernel a GPU of `n_cu` CUs holds at once for this batch (LDS window and register budget)
 template <int W> int persist_resident(orl_batch* b, int n_cu) {
   size_t lds = 0;
@@ -920,5 +1049,6 @@ template void persist<ORL_W>(orl_batch*, const DevParams&, hipStream_t, int, int
 template int persist_resident<ORL_W>(orl_batch*, int);
 template int persist_uses_lds<ORL_W>(orl_batch*);
 template void step2<ORL_W>(orl_batch*, int);
+template void agent_step<ORL_W>(orl_batch*, int);
 
 }  // namespace orl_launch

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 # one-wavefront-per-env kernel (k_step).  The small parity cases run against every implementation by forcing it (the
 # variables are read when a batch is created): "wave64" = k_step for everything, "persist" = the default, "split2" = the
 # phases of the persistent kernel as two separate launches (liborlgpu_alt.so, the -DORL_ALT_IMPLS build).
-IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds"]
+IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds", "agent8"]
 IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             # the persistent kernel in the form the library picks, with all state in global memory, and with slot maps +
@@ -21,7 +21,13 @@ IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT=
             # where it costs no wavefront per CU)
             "persist": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             "persist_global": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="0", ORL_PERSIST_INNER=None),
-            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT="2", ORL_PERSIST_INNER="1")}
+            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT="2", ORL_PERSIST_INNER="1"),
+            # host- / agent-driven steps through k_agent (the phases of the persistent kernel for one step, with info) whatever
+            # the batch size — the library takes it from 2 048 envs — for RMSA / DeepRMSA; device-resident runs as "persist"
+            "agent8": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None,
+                           ORL_AGENT_STEP="1")}
+for _name, _env in IMPL_ENV.items():
+    _env.setdefault("ORL_AGENT_STEP", None)
 
 
 def force_impl(monkeypatch, name):
@@ -562,6 +568,56 @@ def test_zero_copy_device_tensors_drive_the_batch():
         assert np.array_equal(info.cpu().numpy(), i), t
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+def test_agent_in_the_loop_at_full_size(workload):
+    """The path an RL agent on the same GPU drives (SB3 VecEnv semantics: actions in device memory, auto reset, nothing
+    fetched): 65 536 envs stepped through k_agent with actions from the on-device heuristic, against the oracle on sampled
+    envs — reward, done, all info floats and the DeepRMSA observation of the last steps, then the whole state."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+    from oracle.oracle import OracleBatch
+
+    fam, topo, kw, policy = WORKLOADS[workload]
+    kw = dict(kw, episode_length=40)
+    B, steps = 65536, 90
+    seeds = [10 + i for i in range(B)]
+    dev = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, **kw)
+    sample = sorted(set([0, 7, 8, 4095, B // 2, B - 1] + list(np.random.RandomState(9).randint(0, B, 10))))
+    ora = OracleBatch(fam, topo, [seeds[i] for i in sample], **kw)
+    rew, done, info = (dev.device_tensor(n) for n in ("reward", "done", "info"))
+    obs = dev.device_tensor("obs") if dev.obs_dim else None
+    chk = _exact(workload + " agent loop")
+    for t in range(steps):
+        dev.policy(policy, fetch=False)
+        dev.step(None, auto_reset=True, fetch=False)
+        _, r, d, i = ora.step(ora.policy(policy), auto_reset=True)
+        if t % 15 == 14 or t >= steps - 3:
+            dev.sync()
+            chk(t, "reward", rew.cpu().numpy()[sample], r)
+            chk(t, "done", done.cpu().numpy()[sample], d)
+            chk(t, "info", info.cpu().numpy()[sample], i)
+            if obs is not None:
+                chk(t, "obs", obs.cpu().numpy()[sample], ora.observation())
+    dev.check()
+    chk(steps, "counters", dev.counters()[sample], ora.counters())
+    chk(steps, "services", dev.services()[sample], ora.services())
+    for j, e in enumerate(sample):
+        chk(e, "slots", dev.slots(e), ora.slots(j))
+        chk(e, "link_stats", dev.link_stats(e), ora.link_stats(j))
+        chk(e, "net_stats", dev.net_stats(e), ora.net_stats(j))
+    # the device-resident loop continues from that state, and host steps after it
+    dev.run(policy, 70)
+    ora.run(policy, 70)
+    dev.policy(policy, fetch=False)
+    dev.step(None, auto_reset=True, fetch=False)
+    _, r, d, i = ora.step(ora.policy(policy), auto_reset=True)
+    dev.sync()
+    chk(-1, "info after run", info.cpu().numpy()[sample], i)
+    chk(-1, "counters after run", dev.counters()[sample], ora.counters())
+    assert not dev.flags().any()
+    dev.close()
 
 
 def test_terminal_observation_on_device(impl):

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Rate of the loop an agent on the same GPU drives (nothing crosses PCIe): policy(fetch=False) [stand-alone slot scan, in
+place of the agent's network] + step(None, auto_reset=True, fetch=False) for N steps, one sync at the end; and of the
+host-driven step() over PCIe.  usage: agent_loop_rate.py [workload] [batch]   (ORL_AGENT_STEP=0 -> the one-wavefront-per-env kernel)"""
+import json
+import math
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402
+import numpy as np  # noqa: E402
+import optical_rl_gym_amd as orl  # noqa: E402
+from bench import WORKLOADS, workload_load  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+fam, topo, kw, policy = WORKLOADS[name]
+env = orl.make(fam, topology=topo, num_envs=B, seeds=[10 + i for i in range(B)], **kw)
+env.run(policy, max(1500, int(math.ceil(5 * workload_load(kw)))))
+out = dict(workload=name, batch=B, agent_step=os.environ.get("ORL_AGENT_STEP", "default"))
+for label, with_policy in (("step_only", False), ("policy_and_step", True)):
+    env.policy(policy, fetch=False)
+    env.sync()
+    n = 200
+    t0 = time.perf_counter()
+    for _ in range(n):
+        if with_policy:
+            env.policy(policy, fetch=False)
+        env.step(None, auto_reset=True, fetch=False)
+    env.sync()
+    dt = time.perf_counter() - t0
+    out[label] = dict(us_per_step=round(dt / n * 1e6, 2), env_steps_per_s=round(B * n / dt, 1))
+acts = env.policy(policy).copy()
+n = 30
+t0 = time.perf_counter()
+for _ in range(n):
+    env.step(acts, auto_reset=True)
+dt = time.perf_counter() - t0
+out["host_driven_pcie"] = dict(us_per_step=round(dt / n * 1e6, 2), env_steps_per_s=round(B * n / dt, 1))
+print(json.dumps(out))
+env.close()
