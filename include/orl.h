@@ -278,8 +278,18 @@ int orl_batch_set_state(orl_batch* b, const void* in);
 /* Profiling aid: reads the whole slot-map array once with 8-B (width16 = 0) or 16-B (1) loads per lane and returns the
  * number of bytes read, so that rocprofv3's FETCH_SIZE can be calibrated on a known byte count. */
 int64_t orl_batch_debug_stream_read(orl_batch* b, int width16);
-/* Which instantiation of the persistent kernel the last orl_batch_run used: 0 = the generic one, n > 0 = the n-th entry of
- * the table of configurations with compile-time sizes (csrc/orl_kernels.hip, kPersistSpecs); -1 = another step form. */
+/* Specialisation: the persistent kernel with ONE configuration's sizes (topology, spectrum, traffic model, kernel form) as
+ * compile-time constants — same source, same results, 5-12 % faster.  It is a small shared library of its own, built on first
+ * use from csrc/orl_kernels.hip with the -D flags orl_batch_spec_flags() writes (hipcc --offload-arch=gfx950 -O3 -std=c++17
+ * -ffp-contract=off -fPIC <flags> -shared; optical_rl_gym_amd/_build.py build_spec caches it under build/spec/ keyed by the
+ * flags and the source hash) and attached with orl_batch_load_spec(), which compares every field with the batch and refuses
+ * a mismatch.  orl_spec_flags_for() gives the same flags without a device (pre-building).  Both return the string length, 0
+ * when the configuration does not run the persistent kernel.  ORL_PERSIST_SPEC=0 in the environment keeps the generic kernel. */
+int orl_batch_spec_flags(orl_batch* b, char* buf, int capacity);
+int orl_spec_flags_for(const orl_env_config* cfg, const orl_topology_desc* topo, char* buf, int capacity);
+int orl_batch_load_spec(orl_batch* b, const char* so_path);
+/* Whether the last orl_batch_run used the attached specialisation (1) or the generic persistent kernel (0); -1 = another
+ * step form. */
 int orl_batch_debug_persist_spec(orl_batch* b);
 /* Statistics: env-steps whose releases took the serial tail (more than 8 of one step meeting on one link). */
 int64_t orl_batch_debug_serial_count(orl_batch* b);

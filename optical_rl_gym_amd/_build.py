@@ -127,6 +127,40 @@ def build(force=False, verbose=False, variant="default"):
     return lib
 
 
+SPEC_DIR = os.path.join(HERE, "build", "spec")
+
+
+def spec_path(flags):
+    """Where the specialisation library for these flags (orl_batch_spec_flags) lives: keyed by the flags, the sources and the
+    compiler, so a stale one is never picked up."""
+    key = hashlib.sha256((flags + "|" + source_hash()).encode()).hexdigest()[:20]
+    return os.path.join(SPEC_DIR, "liborlspec_%s.so" % key)
+
+
+def build_spec(flags, verbose=False):
+    """k_persist with one configuration's sizes as compile-time constants: csrc/orl_kernels.hip compiled with the -DORL_SPEC_*
+    flags the library wrote for the batch, one kernel instantiation + its launch entry (~15 s of hipcc).  Returns the path of
+    the cached library."""
+    path = spec_path(flags)
+    if os.path.exists(path):
+        return path
+    os.makedirs(SPEC_DIR, exist_ok=True)
+    with open(os.path.join(SPEC_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(path):
+                return path
+            tmp = path + ".tmp.%d" % os.getpid()
+            cmd = [hipcc_path()] + HIPCC_FLAGS + _extra() + flags.split() + ["-shared", os.path.join(CSRC, "orl_kernels.hip"), "-o", tmp]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            os.replace(tmp, path)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return path
+
+
 if __name__ == "__main__":
     import sys
 

@@ -3,6 +3,7 @@
 // Host side: plain HIP runtime, one stream per batch, no torch types.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
 #include <stdarg.h>
@@ -380,6 +381,58 @@ static int policy_ok(const orl_batch* b, int policy_id) {
   return 1;
 }
 
+// the scalar sizes of DevParams that follow from the configuration alone (no device needed: also what keys a specialisation)
+static void derive_sizes(const orl_env_config* c, int N, int E, int K, int H, int M, int64_t n_envs, DevParams& P, int* wt_out) {
+  const bool qos = c->env_type == ORL_ENV_QOS;
+  const int S = c->num_spectrum_resources, C = c->num_spatial_resources;
+  P.env_type = c->env_type;
+  P.N = N; P.E = E; P.K = K; P.H = H; P.M = M;
+  P.S = S; P.C = C;
+  int wt = S <= 64 ? 1 : (S <= 128 ? 2 : (S <= 320 ? 5 : 8));
+  if (qos) wt = 1;  // one counter per link (available_spectrum) instead of a slot row
+  *wt_out = wt;
+  P.W = wt;
+  P.n_classes = qos ? c->n_service_classes : 0;
+  P.episode_length = c->episode_length;
+  P.allow_rejection = c->allow_rejection ? 1 : 0;
+  P.J = c->env_type == ORL_ENV_DEEPRMSA ? c->j : 1;
+  P.bit_rate_mode = c->bit_rate_mode;
+  P.br_lo = c->bit_rate_lo;
+  P.n_br = c->n_bit_rates;
+  P.rand_n = c->bit_rate_hi + 1 - c->bit_rate_lo;
+  P.rand_bits = 0;
+  for (int v = P.rand_n; v > 0; v >>= 1) P.rand_bits++;
+  P.lambda_a = c->lambda_arrival;
+  P.pf_window = 4.0 / c->lambda_arrival;
+  P.lambda_h = c->lambda_holding;
+  P.B = n_envs;
+  int cap = c->event_capacity;
+  if (cap <= 0) {
+    double load = P.lambda_a / P.lambda_h;
+    cap = (int)(load + 10.0 * sqrt(load) + 64.0);
+  }
+  P.ev_cap = (cap + 63) / 64 * 64;
+  int words = C * P.E * wt;
+  P.bm_words = (words + 1) & ~1;
+  int rej = P.allow_rejection;
+  if (qos) P.n_info = 2;
+  else if (c->env_type == ORL_ENV_RWA) P.n_info = 2 + (P.K + rej) + (S + rej);
+  else if (c->env_type == ORL_ENV_RMCSA) P.n_info = 4;
+  else P.n_info = 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
+  P.obs_dim = c->env_type == ORL_ENV_DEEPRMSA ? 1 + 2 * P.N + (2 * P.J + 3) * P.K : 0;
+  P.cs_words = (4 * C + 15) & ~15;  // sums and their release part; whole 64-byte lines per env
+  P.lds_bytes = ((P.bm_words + 4 * P.E + P.E + P.obs_dim) * 8 + P.cs_words * 4 + 15) & ~15;
+  if (P.lds_bytes < 624 * 4) P.lds_bytes = 624 * 4;
+}
+// does the device-resident loop of this configuration go through the persistent kernel? (k <= 8 paths, release slots indexed
+// with 8 + 3 bits, services of at most 63 slots: the row items carry first slot: 9 bits | slots: 6 bits)
+static bool pipeline_applies(const orl_env_config* c, const DevParams& P) {
+  int max_n = 1;
+  if (c->n_slots)
+    for (size_t i = 0; i < (size_t)P.n_br * P.M; i++) max_n = c->n_slots[i] > max_n ? c->n_slots[i] : max_n;
+  return P.K <= 8 && P.ev_cap <= 2048 && c->env_type != ORL_ENV_QOS && max_n <= 63 && P.S <= 512;
+}
+
 static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int64_t n_envs, const uint32_t* mt_state,
                              const int64_t* seeds, orl_batch** out) {
   if (!c || !t || !out || (!mt_state && !seeds) || n_envs < 1) return fail(ORL_E_INVALID, "null/invalid argument");
@@ -423,43 +476,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
 #define FAIL_B(...) do { return fail(__VA_ARGS__); } while (0)
 #define HIPCHK_B(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL_B(ORL_E_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
   DevParams& P = b->P;
-  P.env_type = c->env_type;
-  P.N = t->N; P.E = t->E; P.K = t->K; P.H = t->H; P.M = t->M;
-  P.S = S; P.C = C;
-  b->wt = S <= 64 ? 1 : (S <= 128 ? 2 : (S <= 320 ? 5 : 8));
-  if (qos) b->wt = 1;  // one counter per link (available_spectrum) instead of a slot row
-  P.W = b->wt;
-  P.n_classes = qos ? c->n_service_classes : 0;
-  P.episode_length = c->episode_length;
-  P.allow_rejection = c->allow_rejection ? 1 : 0;
-  P.J = c->env_type == ORL_ENV_DEEPRMSA ? c->j : 1;
-  P.bit_rate_mode = c->bit_rate_mode;
-  P.br_lo = c->bit_rate_lo;
-  P.n_br = c->n_bit_rates;
-  P.rand_n = rand_n;
-  P.rand_bits = 0;
-  for (int v = P.rand_n; v > 0; v >>= 1) P.rand_bits++;
-  P.lambda_a = c->lambda_arrival;
-  P.pf_window = 4.0 / c->lambda_arrival;
-  P.lambda_h = c->lambda_holding;
-  P.B = n_envs;
-  int cap = c->event_capacity;
-  if (cap <= 0) {
-    double load = P.lambda_a / P.lambda_h;
-    cap = (int)(load + 10.0 * sqrt(load) + 64.0);
-  }
-  P.ev_cap = (cap + 63) / 64 * 64;
-  int words = C * P.E * b->wt;
-  P.bm_words = (words + 1) & ~1;
-  int rej = P.allow_rejection;
-  if (qos) P.n_info = 2;
-  else if (c->env_type == ORL_ENV_RWA) P.n_info = 2 + (P.K + rej) + (S + rej);
-  else if (c->env_type == ORL_ENV_RMCSA) P.n_info = 4;
-  else P.n_info = 8 + (c->bit_rate_mode == 1 ? c->n_bit_rates + 1 : 0);
-  P.obs_dim = c->env_type == ORL_ENV_DEEPRMSA ? 1 + 2 * P.N + (2 * P.J + 3) * P.K : 0;
-  P.cs_words = (4 * C + 15) & ~15;  // sums and their release part; whole 64-byte lines per env
-  P.lds_bytes = ((P.bm_words + 4 * P.E + P.E + P.obs_dim) * 8 + P.cs_words * 4 + 15) & ~15;
-  if (P.lds_bytes < 624 * 4) P.lds_bytes = 624 * 4;
+  derive_sizes(c, t->N, t->E, t->K, t->H, t->M, n_envs, P, &b->wt);
   if (P.lds_bytes > 64 * 1024) FAIL_B(ORL_E_INVALID, "per-env LDS window too large (%d B)", P.lds_bytes);
   {
     // The persistent kernel (k_persist) serves the device-resident loop wherever its 8-lanes-per-env slot scan applies
@@ -467,10 +484,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     // 4 096: 1.6e8 vs 7.6e7; 32 768: 6.3e8 vs 4.0e8; RWA 4 096: 2.4e8 vs 8.3e7.  ORL_STEP_IMPL=64 forces the per-env kernel
     // (cross-checks); ORL_STEP_IMPL=2 with ORL_PERSIST=0 selects the two-kernel form in ORL_ALT_IMPLS builds.
     const char* impl = getenv("ORL_STEP_IMPL");
-    int max_n = 1;  // slots of the largest service: the row items of the persistent kernel carry (first slot: 9 bits | slots: 6 bits)
-    if (c->n_slots)
-      for (size_t i = 0; i < (size_t)P.n_br * P.M; i++) max_n = c->n_slots[i] > max_n ? c->n_slots[i] : max_n;
-    const bool pipeline_ok = t->K <= 8 && P.ev_cap <= 2048 && !qos && max_n <= 63 && S <= 512;
+    const bool pipeline_ok = pipeline_applies(c, P);
     b->persist = pipeline_ok && !(impl && atoi(impl) == 64);
     if (const char* pv = getenv("ORL_PERSIST")) {
       if (atoi(pv) == 0 && b->persist) {
@@ -637,6 +651,7 @@ extern "C" void orl_batch_destroy(orl_batch* b) try {
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->h_tail) hipHostFree(b->h_tail);
+  if (b->spec_handle) dlclose(b->spec_handle);
   for (void* p : b->allocs) hipFree(p);
   delete b;
 }
@@ -1268,6 +1283,74 @@ extern "C" int orl_batch_matrix_observation(orl_batch* b, uint8_t* out) try {
   hipFree(d);
   if (e != hipSuccess) return fail(ORL_E_HIP, "matrix observation failed: %s", hipGetErrorString(e));
   HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+
+// ---- specialisation libraries: k_persist with one configuration's sizes as compile-time constants --------------------------
+static void persist_form_of(const DevParams& P, int wt, int* lds, int* waves) {
+  switch (wt) {
+    case 1: orl_launch::persist_form<1>(P, lds, waves); break;
+    case 2: orl_launch::persist_form<2>(P, lds, waves); break;
+    case 5: orl_launch::persist_form<5>(P, lds, waves); break;
+    default: orl_launch::persist_form<8>(P, lds, waves); break;
+  }
+}
+static int spec_flags(const DevParams& P, int wt, char* buf, int capacity) {
+  int lds = 0, waves = 0;
+  persist_form_of(P, wt, &lds, &waves);
+  const int n = snprintf(buf, (size_t)capacity,
+                         "-DORL_SPEC_ONLY -DORL_W=%d -DORL_SPEC_ENV=%d -DORL_SPEC_LDS=%d -DORL_SPEC_WAVES=%d -DORL_SPEC_N=%d -DORL_SPEC_E=%d "
+                         "-DORL_SPEC_K=%d -DORL_SPEC_H=%d -DORL_SPEC_M=%d -DORL_SPEC_S=%d -DORL_SPEC_C=%d -DORL_SPEC_J=%d -DORL_SPEC_BRMODE=%d "
+                         "-DORL_SPEC_BRLO=%d -DORL_SPEC_NBR=%d -DORL_SPEC_RANDN=%d -DORL_SPEC_RANDBITS=%d -DORL_SPEC_EVCAP=%d "
+                         "-DORL_SPEC_BMWORDS=%d -DORL_SPEC_CSWORDS=%d -DORL_SPEC_OBSDIM=%d -DORL_SPEC_NINFO=%d",
+                         wt, P.env_type, lds, waves, P.N, P.E, P.K, P.H, P.M, P.S, P.C, P.J, P.bit_rate_mode, P.br_lo, P.n_br, P.rand_n,
+                         P.rand_bits, P.ev_cap, P.bm_words, P.cs_words, P.obs_dim, P.n_info);
+  return (n > 0 && n < capacity) ? n : 0;
+}
+extern "C" int orl_batch_spec_flags(orl_batch* b, char* buf, int capacity) try {
+  if (!b || !buf || capacity < 1) return 0;
+  buf[0] = 0;
+  if (!b->persist) return 0;
+  return spec_flags(b->P, b->wt, buf, capacity);
+}
+catch (...) { return 0; }
+extern "C" int orl_spec_flags_for(const orl_env_config* cfg, const orl_topology_desc* topo, char* buf, int capacity) try {
+  if (!cfg || !topo || !buf || capacity < 1) return 0;
+  buf[0] = 0;
+  if (cfg->struct_size != sizeof(orl_env_config) || cfg->env_type < 0 || cfg->env_type > ORL_ENV_QOS || !(cfg->lambda_arrival > 0) || !(cfg->lambda_holding > 0)) return 0;
+  DevParams P;
+  memset(&P, 0, sizeof P);
+  int wt = 1;
+  derive_sizes(cfg, topo->n_nodes, topo->n_links, topo->k_paths, topo->max_hops, topo->n_modulations, 1 << 20, P, &wt);
+  if (!pipeline_applies(cfg, P)) return 0;
+  return spec_flags(P, wt, buf, capacity);
+}
+catch (...) { return 0; }
+extern "C" int orl_batch_load_spec(orl_batch* b, const char* so_path) try {
+  if (!b || !so_path) return fail(ORL_E_INVALID, "null argument");
+  if (!b->persist) return fail(ORL_E_INVALID, "this batch does not run the persistent kernel");
+  void* h = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return fail(ORL_E_INVALID, "dlopen(%s): %s", so_path, dlerror());
+  typedef int (*bytes_fn)(void);
+  typedef void (*describe_fn)(int*);
+  bytes_fn bytes = (bytes_fn)dlsym(h, "orl_spec_struct_bytes");
+  describe_fn describe = (describe_fn)dlsym(h, "orl_spec_describe");
+  void* launch = dlsym(h, "orl_spec_launch");
+  if (!bytes || !describe || !launch) { dlclose(h); return fail(ORL_E_INVALID, "%s is not a specialisation library", so_path); }
+  if (bytes() != (int)sizeof(DevParams)) { dlclose(h); return fail(ORL_E_INVALID, "%s was built from other sources (parameter block %d B, here %zu B)", so_path, bytes(), sizeof(DevParams)); }
+  int d[22];
+  describe(d);
+  const DevParams& P = b->P;
+  const int want[22] = {P.env_type, b->wt, d[2], d[3], P.N, P.E, P.K, P.H, P.M, P.S, P.C, P.J, P.bit_rate_mode, P.br_lo, P.n_br, P.rand_n, P.rand_bits,
+                        P.ev_cap, P.bm_words, P.cs_words, P.obs_dim, P.n_info};
+  for (int i = 0; i < 22; i++)
+    if (d[i] != want[i]) { dlclose(h); return fail(ORL_E_INVALID, "%s was built for another configuration (field %d: %d, this batch %d)", so_path, i, d[i], want[i]); }
+  if (b->spec_handle) dlclose(b->spec_handle);
+  b->spec_handle = h;
+  b->spec_launch = (decltype(b->spec_launch))launch;
+  b->spec_lds = d[2];
+  b->spec_waves = d[3];
   return ORL_OK;
 }
 ORL_ABI_CATCH_INT

@@ -509,44 +509,29 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 // (orl_launch::persist), the kernel is built for 2 or 3.
 // Specialisations.  The sizes of a topology and of the traffic model reach the kernel as ~20 uniform scalars of DevParams
 // (kept in SGPRs for the whole loop — or spilled to VGPR lanes — and multiplied, compared and looped over at run time).
-// For the reference's canonical set-ups they are compile-time constants of an extra instantiation: SPEC = index + 1 into this
-// table, chosen by the launcher only when EVERY listed field of the batch matches (else SPEC = 0, the generic kernel; same
-// code, same results).  cfg2: 1.06e9 -> 1.11e9 env-steps/s.
-struct PersistSpec { int env, W, form, N, E, K, M, S, C, J, bit_rate_mode, br_lo, rand_n, rand_bits, bm_words, cs_words, obs_dim; };
-static constexpr PersistSpec kPersistSpecs[] = {
-    // RMSA, nsfnet_chen (14 nodes, 22 links, k = 5, 6 modulations), 320 slots, bit rates 25..100: BASELINE cfg2
-    {ENV_RMSA, 5, 4, 14, 22, 5, 6, 320, 1, 1, 0, 25, 76, 7, 110, 16, 0},
-    // DeepRMSA, nsfnet_chen, 100 slots, j = 1: BASELINE cfg3
-    {ENV_DEEPRMSA, 2, 5, 14, 22, 5, 6, 100, 1, 1, 0, 25, 76, 7, 44, 16, 54},
-    // RWA, nsfnet_chen, 80 wavelengths: BASELINE cfg1
-    {ENV_RWA, 2, 5, 14, 22, 5, 6, 80, 1, 1, 0, 0, 1, 1, 44, 16, 0},
-    // RMCSA, cost239 (11 nodes, 26 links), 7 cores x 320 slots: BASELINE cfg4
-    {ENV_RMCSA, 5, 1, 11, 26, 5, 6, 320, 7, 1, 0, 25, 76, 7, 910, 32, 0},
-    // RMSA, germany50 (50 nodes, 88 links), 320 slots: BASELINE cfg5
-    {ENV_RMSA, 5, 1, 50, 88, 5, 6, 320, 1, 1, 0, 25, 76, 7, 440, 16, 0},
-    // RMSA, nsfnet_chen, 100 slots: RMSAEnv's default spectrum on the reference's default topology
-    {ENV_RMSA, 2, 5, 14, 22, 5, 6, 100, 1, 1, 0, 25, 76, 7, 44, 16, 0},
-    // BASELINE cfg2 again, for the 4-wave form with the env records in global memory (form 6)
-    {ENV_RMSA, 5, 6, 14, 22, 5, 6, 320, 1, 1, 0, 25, 76, 7, 110, 16, 0},
-};
-constexpr int kNumPersistSpecs = (int)(sizeof(kPersistSpecs) / sizeof(kPersistSpecs[0]));
+// With SPEC = 1 they are compile-time constants: the compiler folds the address arithmetic, unrolls the per-word loops and
+// halves the SGPR spills (cfg2 +6 %, cfg3 +12 %; same source, same results).  Round 2 carried a table of the BASELINE
+// configurations inside the library; now ANY configuration gets its own instantiation, built on first use: this file
+// compiled with -DORL_SPEC_ONLY and the sizes as -DORL_SPEC_* macros (optical_rl_gym_amd/_build.py build_spec, the flags
+// from orl_batch_spec_flags) into a small shared library of its own — one k_persist instantiation and the launch entry
+// orl_spec_launch — which orl_batch_load_spec attaches to the batch after comparing every field.  The main library holds the
+// generic kernels only.
+struct PersistSpec { int env, W, lds, waves, N, E, K, H, M, S, C, J, bit_rate_mode, br_lo, n_br, rand_n, rand_bits, ev_cap, bm_words, cs_words, obs_dim, n_info; };
+#ifdef ORL_SPEC_ONLY
+static constexpr PersistSpec kPersistSpec = {ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, ORL_SPEC_N, ORL_SPEC_E, ORL_SPEC_K, ORL_SPEC_H,
+                                             ORL_SPEC_M, ORL_SPEC_S, ORL_SPEC_C, ORL_SPEC_J, ORL_SPEC_BRMODE, ORL_SPEC_BRLO, ORL_SPEC_NBR,
+                                             ORL_SPEC_RANDN, ORL_SPEC_RANDBITS, ORL_SPEC_EVCAP, ORL_SPEC_BMWORDS, ORL_SPEC_CSWORDS,
+                                             ORL_SPEC_OBSDIM, ORL_SPEC_NINFO};
+#else
+static constexpr PersistSpec kPersistSpec = {};  // (the generic library never instantiates SPEC > 0)
+#endif
 template <int SPEC> __device__ __forceinline__ void persist_spec_apply(DevParams& P) {
   if constexpr (SPEC > 0) {
-    constexpr PersistSpec s = kPersistSpecs[SPEC - 1];
-    P.N = s.N; P.E = s.E; P.K = s.K; P.M = s.M; P.S = s.S; P.W = s.W; P.C = s.C; P.J = s.J;
-    P.bit_rate_mode = s.bit_rate_mode; P.br_lo = s.br_lo; P.rand_n = s.rand_n; P.rand_bits = s.rand_bits;
-    P.bm_words = s.bm_words; P.cs_words = s.cs_words; P.obs_dim = s.obs_dim;
+    constexpr PersistSpec s = kPersistSpec;
+    P.N = s.N; P.E = s.E; P.K = s.K; P.H = s.H; P.M = s.M; P.S = s.S; P.W = s.W; P.C = s.C; P.J = s.J;
+    P.bit_rate_mode = s.bit_rate_mode; P.br_lo = s.br_lo; P.n_br = s.n_br; P.rand_n = s.rand_n; P.rand_bits = s.rand_bits;
+    P.ev_cap = s.ev_cap; P.bm_words = s.bm_words; P.cs_words = s.cs_words; P.obs_dim = s.obs_dim; P.n_info = s.n_info;
   }
-}
-static int persist_spec_of(const DevParams& P, int W, int form) {
-  for (int i = 0; i < kNumPersistSpecs; i++) {
-    const PersistSpec& s = kPersistSpecs[i];
-    if (s.env == P.env_type && s.W == W && s.form == form && s.N == P.N && s.E == P.E && s.K == P.K && s.M == P.M && s.S == P.S &&
-        s.C == P.C && s.J == P.J && s.bit_rate_mode == P.bit_rate_mode && s.br_lo == P.br_lo && s.rand_n == P.rand_n &&
-        s.rand_bits == P.rand_bits && s.bm_words == P.bm_words && s.cs_words == P.cs_words && s.obs_dim == P.obs_dim && P.W == W)
-      return i + 1;
-  }
-  return 0;
 }
 
 template <int ENV, int W, int LDS, int WAVES, int SPEC = 0>
@@ -573,7 +558,7 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
 // pairwise order, on the values AFTER the provision and BEFORE the step's releases — a lane of the row phase that applies a
 // release leaves the link's values from before its update in an LDS stash.
 #ifndef ORL_AGENT_WAVES
-#define ORL_AGENT_WAVES 3  // waves per SIMD the register allocator leaves room for
+#define ORL_AGENT_WAVES 4  // waves per SIMD the register allocator leaves room for (cfg2 65 536 envs: 3 -> 114 us, 4 -> 108 us, 5 -> 141 us, 8 -> 193 us per launch)
 #endif
 template <int ENV, int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGENT_WAVES, ORL_AGENT_WAVES))) k_agent(DevParams P, int auto_reset) {
@@ -774,6 +759,23 @@ __global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
   obs8_env<W>(P, P.bitmap + env * P.bm_words, P.scal + env * ORL_SCAL_WORDS, env, lane_id(), with_terminal && P.done[env]);
 }
 
+#ifdef ORL_SPEC_ONLY
+// ---- the whole of a specialisation library: one instantiation and its launch entry ----------------------------------------
+extern "C" int orl_spec_struct_bytes(void) { return (int)sizeof(DevParams); }
+extern "C" void orl_spec_describe(int* out /*[22]*/) {
+  const PersistSpec& s = kPersistSpec;
+  const int v[22] = {s.env, s.W, s.lds, s.waves, s.N, s.E, s.K, s.H, s.M, s.S, s.C, s.J, s.bit_rate_mode, s.br_lo, s.n_br, s.rand_n, s.rand_bits,
+                     s.ev_cap, s.bm_words, s.cs_words, s.obs_dim, s.n_info};
+  for (int i = 0; i < 22; i++) out[i] = v[i];
+}
+extern "C" void orl_spec_launch(const DevParams* VP, unsigned grid, size_t lds, hipStream_t st, int pol, int target, int* wg_step,
+                                unsigned int* unfinished, unsigned int* clear_next) {
+  if (lds > 48 * 1024)
+    hipFuncSetAttribute((const void*)k_persist<ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_persist<ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, 1>), dim3(grid), dim3(64), lds, st, *VP, pol, target, wg_step,
+                     unfinished, clear_next);
+}
+#else
 // =============================================================================================
 // launchers
 // =============================================================================================
@@ -897,6 +899,12 @@ static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
   *lds_bytes = c.lds;
   return c.form;
 }
+// the form the launcher takes for this configuration: what is in the LDS window, waves per SIMD (the key of a specialisation)
+template <int W> void persist_form(const DevParams& VP, int* lds_state, int* waves) {
+  const PersistChoice c = persist_choose(VP);
+  *lds_state = kPersistForms[c.form].lds;
+  *waves = kPersistForms[c.form].waves;
+}
 template <int W> int persist_uses_lds(orl_batch* b) {
   size_t lds;
   return kPersistForms[persist_variant(b->P, &lds)].lds;
@@ -936,32 +944,14 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<E_, W, LDS_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
     hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished, clear_next); \
   } while (0)
-  // a specialised instantiation for this very configuration?  (ORL_PERSIST_SPEC=0: the generic kernel)
-  int spec = persist_spec_of(VP, W, v);
-  if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = 0; }
-  b->persist_spec = spec;
-  if (getenv("ORL_DEBUG_SPEC") && b->persist_launches <= 1)  // what a new row of kPersistSpecs would hold for this batch
-    fprintf(stderr, "orl: k_persist spec %d; {env %d, W %d, form %d, N %d, E %d, K %d, M %d, S %d, C %d, J %d, mode %d, br_lo %d, rand_n %d, rand_bits %d, bm_words %d, cs_words %d, obs_dim %d}\n",
-            spec, VP.env_type, W, v, VP.N, VP.E, VP.K, VP.M, VP.S, VP.C, VP.J, VP.bit_rate_mode, VP.br_lo, VP.rand_n, VP.rand_bits,
-            VP.bm_words, VP.cs_words, VP.obs_dim);
-#define LAUNCH_SPEC(E_, LDS_, WV_, SP_)                                                                                      \
-  do {                                                                                                                       \
-    if (lds_a > 48 * 1024) hipFuncSetAttribute((const void*)k_persist<E_, W, LDS_, WV_, SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a); \
-    hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_, SP_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished, clear_next); \
-    return;                                                                                                                  \
-  } while (0)
-  if constexpr (W == 5) {
-    if (spec == 1) LAUNCH_SPEC(ENV_RMSA, 1, 3, 1);
-    if (spec == 4) LAUNCH_SPEC(ENV_RMCSA, 0, 3, 4);
-    if (spec == 5) LAUNCH_SPEC(ENV_RMSA, 0, 3, 5);
-    if (spec == 7) LAUNCH_SPEC(ENV_RMSA, 3, 4, 7);
+  // an instantiation built for this very configuration (orl_batch_load_spec)?  (ORL_PERSIST_SPEC=0: the generic kernel)
+  bool spec = b->spec_launch != nullptr && b->spec_lds == kPersistForms[v].lds && b->spec_waves == kPersistForms[v].waves;
+  if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = false; }
+  b->persist_spec = spec ? 1 : 0;
+  if (spec) {
+    b->spec_launch(&VP, gc.x, lds_a, st, pol, target, wg_step, unfinished, clear_next);
+    return;
   }
-  if constexpr (W == 2) {
-    if (spec == 2) LAUNCH_SPEC(ENV_DEEPRMSA, 1, 4, 2);
-    if (spec == 3) LAUNCH_SPEC(ENV_RWA, 1, 4, 3);
-    if (spec == 6) LAUNCH_SPEC(ENV_RMSA, 1, 4, 6);
-  }
-#undef LAUNCH_SPEC
 #define PER_ENV(E_)                                                                                                          \
   switch (v) {                                                                                                               \
     case 0: LAUNCH(E_, 0, 4); break;                                                                                         \
@@ -1050,5 +1040,7 @@ template int persist_resident<ORL_W>(orl_batch*, int);
 template int persist_uses_lds<ORL_W>(orl_batch*);
 template void step2<ORL_W>(orl_batch*, int);
 template void agent_step<ORL_W>(orl_batch*, int);
+template void persist_form<ORL_W>(const DevParams&, int*, int*);
 
 }  // namespace orl_launch
+#endif  // ORL_SPEC_ONLY

@@ -10,11 +10,12 @@ rwa_env.py:19-94, rmcsa_env.py:29-207.
 import ctypes as C
 import itertools
 import math
+import os
 import random
 
 import numpy as np
 
-from . import _lib
+from . import _build, _lib
 from .topology import Topology
 
 POLICIES = {"SP_FF": 0, "SAP_FF": 1, "KSP_FF": 1, "LLP_FF": 2, "SAP_LF": 3, "SP": 0, "SAP": 1, "SAP_BM_FC_FF": 1,
@@ -182,14 +183,17 @@ class BatchedOpticalEnv:
         desc = _lib.TopologyDesc(t.n_nodes, t.n_links, t.k_paths, t.max_hops, M, _ptr(keep["n_paths"]),
                                  _ptr(keep["path_hops"]), _ptr(keep["path_links"]), _ptr(keep["path_length"]),
                                  _ptr(keep["path_mod"]), _ptr(keep["edge_iter_order"]))
-        self._topo_h = C.c_void_p()
-        self._ck(self.lib.orl_topology_create(C.byref(desc), device_id, C.byref(self._topo_h)))
         cfg = _lib.EnvConfig(C.sizeof(_lib.EnvConfig), self.ENV_TYPE, num_spectrum_resources, num_spatial_resources, episode_length,
                              int(self.allow_rejection), j, mode, lo, hi, len(table_rates), event_capacity,
                              int(self.action_histograms),
                              lambda_a, lambda_h, _ptr(cum_src), _ptr(keep["cum_dst"]), _ptr(keep["bit_rates"]),
                              _ptr(cum_br), _ptr(keep["n_slots"]), _ptr(lmax_snr), _ptr(lmax_xt),
                              int(num_service_classes) if self.ENV_TYPE == 4 else 0, 0, _ptr(cum_class), _ptr(class_reward))
+        if getattr(self, "_derive_only", False):  # spec_flags(): the configuration without a device
+            self._cfg, self._desc, self._h, self._topo_h = cfg, desc, None, None
+            return
+        self._topo_h = C.c_void_p()
+        self._ck(self.lib.orl_topology_create(C.byref(desc), device_id, C.byref(self._topo_h)))
         self._cfg, self._desc = cfg, desc  # (kept: what orl_multi_create takes to build the same envs over several devices)
         self._h = C.c_void_p()
         int_seeds = [41 if s_ is None else int(s_) for s_ in self.seeds]
@@ -204,6 +208,7 @@ class BatchedOpticalEnv:
                                                  C.byref(self._h)))
         self.n_info = self.lib.orl_batch_info_dim(self._h)
         self.obs_dim = self.lib.orl_batch_obs_dim(self._h)
+        self.specialised = self._attach_specialisation()
         n = self.num_envs
         # host-side I/O arrays in page-locked memory: every step() moves actions in and reward/done/info(/obs) out
         self._act = self._host_array((n, 4), np.int32)
@@ -212,6 +217,45 @@ class BatchedOpticalEnv:
         self._done = self._host_array((n,), np.uint8)
         self._info = self._host_array((n, self.n_info), np.float64)
         self._obs = self._host_array((n, self.obs_dim), np.float64) if self.obs_dim else None
+
+    # ---- the persistent kernel with this configuration's sizes as compile-time constants ------------------------------
+    JIT_MIN_ENVS = 4096
+
+    def _attach_specialisation(self):
+        """Attach the specialisation library of this configuration (include/orl.h, orl_batch_load_spec): a cached one whenever
+        it exists; built on first use (~15 s of hipcc, once per configuration and source state) for batches of at least
+        JIT_MIN_ENVS envs — where 5-12 % of the device loop are worth it — or whenever ORL_JIT_SPEC=1; ORL_JIT_SPEC=0: never.
+        Returns whether one is attached.  Default library only (the cross-implementation builds keep the generic kernels)."""
+        mode = os.environ.get("ORL_JIT_SPEC", "")
+        if mode == "0" or os.environ.get("ORL_LIB_VARIANT", "default") != "default" or _build._extra():
+            return False
+        buf = C.create_string_buffer(1024)
+        if self.lib.orl_batch_spec_flags(self._h, buf, len(buf)) <= 0:
+            return False
+        flags = buf.value.decode()
+        path = _build.spec_path(flags)
+        if not os.path.exists(path):
+            if not (mode == "1" or self.num_envs >= self.JIT_MIN_ENVS):
+                return False
+            try:
+                path = _build.build_spec(flags)
+            except Exception as exc:  # no compiler on this machine: the generic kernel runs
+                import warnings
+
+                warnings.warn("optical_rl_gym_amd: specialisation not built (%s); the generic persistent kernel runs" % exc)
+                return False
+        self._ck(self.lib.orl_batch_load_spec(self._h, path.encode()))
+        return True
+
+    @classmethod
+    def spec_flags(cls, **kwargs):
+        """The -D flags of this configuration's specialisation, computed without a device (pre-building, __graft_entry__.build)."""
+        self = cls.__new__(cls)
+        self._derive_only = True
+        self.__init__(num_envs=1, **kwargs)
+        buf = C.create_string_buffer(1024)
+        n = self.lib.orl_spec_flags_for(C.byref(self._cfg), C.byref(self._desc), buf, len(buf))
+        return buf.value.decode() if n > 0 else None
 
     def _ck(self, rc):
         _lib.check(rc, self.lib)

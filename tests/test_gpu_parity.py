@@ -325,20 +325,25 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
 
 
 def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkeypatch):
-    """BASELINE cfg1 - cfg5 and RMSAEnv's default spectrum run on instantiations of the persistent kernel with their sizes as compile-time constants
-    (kPersistSpecs): the launcher picks them (debug query), any other configuration — here another episode length is fine,
-    another slot count is not — gets the generic kernel, and both leave identical state (ORL_PERSIST_SPEC=0 forces the
-    generic one)."""
+    """Any configuration gets the persistent kernel with ITS sizes as compile-time constants: a small library built on first
+    use from the flags the main library writes for the batch (orl_batch_spec_flags -> _build.build_spec -> orl_batch_load_spec),
+    cached, attached after a field-by-field comparison.  BASELINE cfg1 - cfg5, RMSAEnv's default 100-slot spectrum and a
+    configuration nobody prepared (300 slots, k = 5, another bit-rate range): the launcher uses the attached instantiation
+    (debug query), it leaves the state of the generic kernel (ORL_PERSIST_SPEC=0 forces that one), small batches do not
+    trigger a build unless asked to, and a library built for another configuration is refused."""
     import optical_rl_gym_amd as orl
     from bench import WORKLOADS
+    from optical_rl_gym_amd import _build
 
     force_impl(monkeypatch, "persist")
-    for workload, want in (("cfg2", 1), ("cfg3", 2), ("cfg1", 3), ("cfg4", 4), ("cfg5", 5), ("rmsa100", 6)):
+    monkeypatch.setenv("ORL_JIT_SPEC", "1")
+    paths = {}
+    for workload in ("cfg2", "cfg3", "cfg1", "cfg4", "cfg5", "rmsa100", "odd300"):
+        fam, topo, kw, policy = WORKLOADS["cfg2" if workload in ("rmsa100", "odd300") else workload]
         if workload == "rmsa100":  # RMSAEnv's default spectrum
-            fam, topo, kw, policy = WORKLOADS["cfg2"]
             kw = dict(kw, num_spectrum_resources=100, load=120)
-        else:
-            fam, topo, kw, policy = WORKLOADS[workload]
+        if workload == "odd300":
+            kw = dict(kw, num_spectrum_resources=300, load=250, bit_rate_lower_bound=40, bit_rate_higher_bound=90)
         kw = dict(kw, episode_length=45)
         seeds = [31 + 2 * i for i in range(1024 if workload in ("cfg4", "cfg5") else 4096)]
         out = {}
@@ -348,20 +353,32 @@ def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkey
             else:
                 monkeypatch.setenv("ORL_PERSIST_SPEC", spec_env)
             env = orl.make(fam, topology=topo, num_envs=len(seeds), seeds=seeds, **kw)
+            assert env.specialised
             env.run(policy, 130)
             env.run(policy, 70)
-            assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == (want if spec_env is None else 0)
+            assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == (1 if spec_env is None else 0)
             out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.slots(9).copy(),
                          env.link_stats(9).copy(), env.net_stats(9).copy()]
             if env.obs_dim:
                 out[name].append(env.device_tensor("obs").cpu().numpy().copy())
+            buf = __import__("ctypes").create_string_buffer(1024)
+            assert env.lib.orl_batch_spec_flags(env._h, buf, 1024) > 0
+            paths[workload] = _build.spec_path(buf.value.decode())
             env.close()
         chk = _exact(workload + " specialised")
         for k, (x, y) in enumerate(zip(out["spec"], out["generic"])):
             chk(k, "item", x, y)
+    assert len(set(paths.values())) == len(paths)
+    # a small batch of a configuration without a cached library runs the generic kernel (no 15-s build behind a unit test) ...
+    monkeypatch.delenv("ORL_JIT_SPEC", raising=False)
     monkeypatch.delenv("ORL_PERSIST_SPEC", raising=False)
     fam, topo, kw, policy = WORKLOADS["cfg2"]
-    env = orl.make(fam, topology=topo, num_envs=64, seeds=list(range(64)), **dict(kw, num_spectrum_resources=300))
+    env = orl.make(fam, topology=topo, num_envs=64, seeds=list(range(64)), **dict(kw, num_spectrum_resources=290))
+    env.run(policy, 10)
+    assert not env.specialised and int(env.lib.orl_batch_debug_persist_spec(env._h)) == 0
+    # ... and refuses a library built for another configuration
+    rc = env.lib.orl_batch_load_spec(env._h, paths["cfg2"].encode())
+    assert rc == -1 and b"another configuration" in env.lib.orl_last_error()
     env.run(policy, 10)
     assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == 0
     env.close()
