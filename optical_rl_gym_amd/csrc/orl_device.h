@@ -955,6 +955,26 @@ __device__ __forceinline__ int first_blocks(const Row<W>& m, int S, int n, int w
   return found;
 }
 
+// the same walk for the action decode of DeepRMSAEnv.step (deeprmsa_env.py:48-58), which needs only the start of block
+// number `want - 1`: no arrays (indexed by a run-time block number they lived in scratch memory: the 64 bytes of private
+// segment and a dozen "spilled" registers of every DeepRMSA kernel).  Returns how many of the first `want` blocks exist;
+// `start`: the first slot of the last one found.
+template <int W>
+__device__ __forceinline__ int nth_block(const Row<W>& m, int S, int n, int want, int& start) {
+  Row<W> r = row_runs_ge<W>(m, n);
+  Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
+  int found = 0;
+  while (found < want && row_any<W>(r)) {
+    const int s = row_ctz<W>(r);
+    Row<W> z = row_andn<W>(zeros, row_mask_lo<W>(s));
+    const int end = row_any<W>(z) ? row_ctz<W>(z) : S;
+    start = s;
+    found++;
+    r = row_andn<W>(r, row_mask_lo<W>(end));
+  }
+  return found;
+}
+
 // DeepRMSAEnv.observation (deeprmsa_env.py:60-121); lanes = paths, lane 0 writes the header
 template <int W>
 __device__ __forceinline__ void deep_observation(const DevParams& P, const Env& e, int lane, double* obs_out, double* obs_out2) {
@@ -1120,19 +1140,28 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     int bslot = group_get<GS>(slot, best < 0 ? 0 : best, lane);
     if (best >= 0) { a[0] = best; a[1] = bslot; }
   } else if (ENV == ENV_DEEPRMSA) {
-    a[0] = K * P.J;
+    // a[0]: the action (route * j + block 0); a[1], a[2]: what DeepRMSAEnv.step decodes it to on this very slot map — the
+    // route and the first slot of its first block, (k, S) when the action rejects — so that a control phase fed by this scan
+    // in the same kernel need not walk the blocks again (deeprmsa_env.py:48-58)
+    a[0] = K * P.J; a[1] = K; a[2] = S;
     bool has = false;
+    int first = -1;
     int limit = (pol == POL_SP_FF) ? 1 : np_;
     if (valid && p < limit) {
       int pidx = pb + p;
       PathRec rec = path_rec_load(P, pidx);
       int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
       Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
-      has = row_any<W>(row_runs_ge<W>(m, n));
+      const Row<W> r = row_runs_ge<W>(m, n);
+      has = row_any<W>(r);
+      if (has) first = row_ctz<W>(r);  // the lowest start of n free slots is the start of the first block of >= n
     }
     u64 fit = group_ballot<GS>(has, lane);
+    const int route = (pol == POL_SP_FF) ? 0 : (fit ? (int)__builtin_ctzll(fit) : 0);
+    const int rslot = group_get<GS>(first, route, lane);
     if (pol == POL_SP_FF) a[0] = (!P.allow_rejection || fit) ? 0 : K * P.J;
-    else if (fit) a[0] = (int)__builtin_ctzll(fit) * P.J;
+    else if (fit) a[0] = route * P.J;
+    if ((fit >> route) & 1ull) { a[1] = route; a[2] = rslot; }
   } else if (ENV == ENV_RWA) {
     a[0] = K; a[1] = S;
     int slot = -1, cap = 0, hops = 0;
@@ -1247,14 +1276,14 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
     path = K; slot = S;
     if (aa >= 0 && aa < K * P.J) {
       int route = aa / P.J, block = aa - route * P.J;
-      int starts[8], lens[8];
+      int start = 0;
       int pidx = pair_base(P, e.src, e.dst) + route;
       int nb = 0;
       if (route < P.n_paths[e.src * P.N + e.dst]) {
         Row<W> m = path_and<W>(P, e, pidx, 0);
-        nb = first_blocks<W>(m, S, P.nslots_path[(size_t)pidx * P.n_br + e.br_idx], block + 1, starts, lens);
+        nb = nth_block<W>(m, S, P.nslots_path[(size_t)pidx * P.n_br + e.br_idx], block + 1, start);
       }
-      if (block < nb) { path = route; slot = starts[block]; }
+      if (block < nb) { path = route; slot = start; }
     }
   } else if (ENV == ENV_RMCSA) {
     path = act[0]; mod = act[1]; core = act[2]; slot = act[3];

@@ -362,16 +362,18 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     if (ENV == ENV_DEEPRMSA) {  // deeprmsa_env.py:48-58
       int aa = av.x;
       path = K; slot = S;
-      if (aa >= 0 && aa < K * P.J) {
+      if (O.trusted && given) {  // decoded by the in-kernel scan, on this slot map (policy_g)
+        path = av.y; slot = av.z;
+      } else if (aa >= 0 && aa < K * P.J) {
         int route = aa / P.J, block = aa - route * P.J;
-        int starts[8], lens[8];
+        int start = 0;
         int pidx = pair_base(P, e.src, e.dst) + route;
         int nb = 0;
         if (route < P.n_paths[e.src * P.N + e.dst]) {
           Row<W> m = g8::path_and_global<W>(P, e, pidx);
-          nb = first_blocks<W>(m, S, P.nslots_path[(size_t)pidx * P.n_br + e.br_idx], block + 1, starts, lens);
+          nb = nth_block<W>(m, S, P.nslots_path[(size_t)pidx * P.n_br + e.br_idx], block + 1, start);
         }
-        if (block < nb) { path = route; slot = starts[block]; }
+        if (block < nb) { path = route; slot = start; }
       }
     } else if (ENV == ENV_RMCSA) {
       path = av.x; mod = av.y; core = av.z; slot = av.w;
@@ -398,7 +400,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
       else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
       rec = path_rec_load(P, pidx);
-      bool ok = O.trusted && ENV != ENV_DEEPRMSA;
+      bool ok = O.trusted && (ENV != ENV_DEEPRMSA || given != nullptr);
       if (!ok && slot + n <= S) {  // is_path_free: lane w checks word w of every link row of the path
         const int hops = path_rec_byte(rec, 0);
         bool busy = false;
@@ -464,7 +466,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     if (gl == 0) {
       if (O.write_io) {
         P.reward[env] = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
-        if (given) *(int4*)(P.actions + env * 4) = av;
+        if (given) *(int4*)(P.actions + env * 4) = (ENV == ENV_DEEPRMSA) ? make_int4(av.x, 0, 0, 0) : av;
       }
       e.scal[SC_ACC] = pack2(accepted ? 1 : 0, core);
       e.scal[SC_NOWA] = (u64)__double_as_longlong(e.now);

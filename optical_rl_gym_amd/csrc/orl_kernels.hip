@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(64 * ORL_POLICY_WAVES) k_policy(DevParams P, i
   int a[4];
   policy_g<ENV, W, GS>(P, maps + (size_t)grp * P.bm_words, valid, (int)(u32)d, (int)((d >> 32) & 0xffffu), (int)((d >> 48) & 0xffu),
                        lane, pol, valid ? P.path_col[env] : 0, a);
-  if (valid && (lane & (GS - 1)) == 0) *(int4*)(P.actions + env * 4) = make_int4(a[0], a[1], a[2], a[3]);
+  // (DeepRMSA: columns 1-2 of the scan result are its decoded route / slot for a control phase in the same kernel; the action is column 0)
+  if (valid && (lane & (GS - 1)) == 0) *(int4*)(P.actions + env * 4) = (ENV == ENV_DEEPRMSA) ? make_int4(a[0], 0, 0, 0) : make_int4(a[0], a[1], a[2], a[3]);
 }
 
 #ifndef ORL_STEP_WAVES
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
     int a[4];
     policy_g<ENV, W, 64>(P, e.bm, true, pair_base(P, e.src, e.dst), e.br_idx, P.n_paths[e.src * P.N + e.dst], lane, pol,
                          P.path_col[env], a);
-    av = make_int4(a[0], a[1], a[2], a[3]);
+    av = (ENV == ENV_DEEPRMSA) ? make_int4(a[0], 0, 0, 0) : make_int4(a[0], a[1], a[2], a[3]);
     if (lane == 0) *(int4*)(P.actions + env * 4) = av;
   }
   // Round trip 2: what the scalar record addresses — the MT window of the next service, the pending release times
@@ -717,39 +718,35 @@ __device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, cons
     if (o2) o2[i] = v;
   }
   if (gl < P.K) {
-    double f[19];  // 2 * J + 3 <= 19
-#pragma unroll
-    for (int i = 0; i < 19; i++) f[i] = -1.0;
+    // this lane's path block: -1.0 everywhere first, then the values that exist (stores of one lane to one address keep their
+    // order) — a register array of 2 j + 3 <= 19 doubles, written at the end, was 38 live VGPRs in the middle of the
+    // persistent kernel's loop
+    double* sp = o + 1 + 2 * N + gl * WD;
+    double* sp2 = o2 ? o2 + 1 + 2 * N + gl * WD : nullptr;
+    for (int i = 0; i < WD; i++) { sp[i] = -1.0; if (sp2) sp2[i] = -1.0; }
     if (gl < P.n_paths[src * N + dst]) {
       const int pidx = (src * N + dst) * P.K + gl;
       const Row<W> m = path_and_rec<W>(path_rec_load(P, pidx), bm, P.E, S, 0);
       const int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
       Row<W> r = row_runs_ge<W>(m, n);
       const Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
-#pragma unroll
-      for (int b = 0; b < 8; b++) {
-        if (b < J && row_any<W>(r)) {
-          const int st = row_ctz<W>(r);
-          const Row<W> z = row_andn<W>(zeros, row_mask_lo<W>(st));
-          const int end = row_any<W>(z) ? row_ctz<W>(z) : S;
-          f[2 * b] = 2 * ((double)st - 0.5 * (double)S) / (double)S;
-          f[2 * b + 1] = (double)(end - st - 8) / 8;
-          r = row_andn<W>(r, row_mask_lo<W>(end));
-        }
+      for (int b = 0; b < J && row_any<W>(r); b++) {
+        const int st = row_ctz<W>(r);
+        const Row<W> z = row_andn<W>(zeros, row_mask_lo<W>(st));
+        const int end = row_any<W>(z) ? row_ctz<W>(z) : S;
+        const double f0 = 2 * ((double)st - 0.5 * (double)S) / (double)S, f1 = (double)(end - st - 8) / 8;
+        sp[2 * b] = f0; sp[2 * b + 1] = f1;
+        if (sp2) { sp2[2 * b] = f0; sp2[2 * b + 1] = f1; }
+        r = row_andn<W>(r, row_mask_lo<W>(end));
       }
       const double fn = ((double)n - 5.5) / 3.5;
       const int tot = row_popc<W>(m);
       const double ft = 2 * ((double)tot - 0.5 * (double)S) / (double)S;
       const int nruns = row_popc<W>(row_starts<W>(m));
       const double fr = (nruns > 0) ? ((double)tot / (double)nruns - 4) / 4 : -1.0;
-      // f[2J], f[2J+1], f[2J+2] with a run-time J: written below by position
-#pragma unroll
-      for (int i = 0; i < 19; i++) f[i] = (i == 2 * J) ? fn : (i == 2 * J + 1) ? ft : (i == 2 * J + 2) ? fr : f[i];
+      sp[2 * J] = fn; sp[2 * J + 1] = ft; sp[2 * J + 2] = fr;
+      if (sp2) { sp2[2 * J] = fn; sp2[2 * J + 1] = ft; sp2[2 * J + 2] = fr; }
     }
-    double* sp = o + 1 + 2 * N + gl * WD;
-#pragma unroll
-    for (int i = 0; i < 19; i++)
-      if (i < WD) { sp[i] = f[i]; if (o2) o2[1 + 2 * N + gl * WD + i] = f[i]; }
   }
 }
 template <int W>
