@@ -222,7 +222,7 @@ def main():
             elapsed = float(t.item())
         blocks.append((elapsed, st_run.ms_total, int(st_run.launches), st_run.n_kernels == 1 and st_run.kernels()[0][0] == "k_persist"))
         timed += elapsed
-        if len(blocks) >= 2000:
+        if len(blocks) >= 20000:
             break
     per_rank = [dict(rank=rank, device=dev_index, env_steps_per_s=round(B * args.steps / statistics.median(own), 1))]
     if dist is not None:

@@ -73,7 +73,9 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % workload), "w"), indent=1)
 print(json.dumps(out["kernels"]))
 shutil.copy(newest(O + "/stats/**/*kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_cfg2_kernel_stats.csv" % tag))
-for f in glob.glob(O + "/bench_*.json") + glob.glob(O + "/phase_*.txt"):
+if os.path.isdir(O + "/stats20"):
+    shutil.copy(newest(O + "/stats20/**/*kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_cfg2_steps20_kernel_stats.csv" % tag))
+for f in glob.glob(O + "/bench_*.json") + glob.glob(O + "/phase_*.txt") + glob.glob(O + "/agent_loop_*.json"):
     shutil.copy(f, os.path.join(ROOT, "profiles", "%s_%s" % (tag, os.path.basename(f))))
 passes = [os.path.join(O, d) for d in ("sq1", "sq2", "sq3", "hit", "ea", "tr_f", "tr_w") if os.path.isdir(os.path.join(O, d))]
 txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + passes, capture_output=True, text=True).stdout

@@ -9,14 +9,19 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --gpus 1 --steps 300 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 tail -c 1500 $O/bench_cfg2.json
-python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg2_steps20.json 2> $O/bench_cfg2_steps20.err
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --min-timed-s 2 > $O/bench_cfg2_steps20.json 2> $O/bench_cfg2_steps20.err
 python3 -c "import json; d=json.load(open('$O/bench_cfg2_steps20.json')); print('steps20', d['value'], d['timing'], d['roofline']['frac'])"
-rm -rf $O/stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --gpus 1 --steps 300 --no-cpu-baseline > $O/stats.log 2>&1
+rm -rf $O/stats $O/stats20
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --gpus 1 --steps 300 --no-cpu-baseline --min-timed-s 1 > $O/stats.log 2>&1
+# the driver's own invocation (20-step blocks: one launch each)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats20 -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --min-timed-s 1 > $O/stats20.log 2>&1
+python3 $R/tools/agent_loop_rate.py cfg2 65536 2> /dev/null | grep "^{" > $O/agent_loop_cfg2.json
+python3 $R/tools/agent_loop_rate.py cfg3 65536 2> /dev/null | grep "^{" > $O/agent_loop_cfg3.json
+cat $O/agent_loop_cfg2.json $O/agent_loop_cfg3.json
 if [ "$QUICK" != "quick" ]; then
-for cfg in "cfg1 4096" "cfg3 4096" "cfg4 16384" "cfg5 32768" "cfg2 4096"; do
+for cfg in "cfg1 4096" "cfg3 4096" "cfg4 16384" "cfg5 32768" "cfg2 4096" "cfg1 65536" "cfg3 65536"; do
   set -- $cfg
-  python3 $R/bench.py --workload $1 --batch $2 --steps 200 --no-cpu-baseline > $O/bench_$1_$2.json 2> $O/bench_$1_$2.err
+  python3 $R/bench.py --workload $1 --batch $2 --steps 200 --no-cpu-baseline --min-timed-s 1 > $O/bench_$1_$2.json 2> $O/bench_$1_$2.err
   python3 -c "import json; d=json.load(open('$O/bench_$1_$2.json')); print('$1 B=$2', d['value'], d['roofline']['frac'], d['state'])"
 done
 fi
