@@ -117,7 +117,7 @@ typedef struct {
   double ms_step;    /* time_kernels == 2: average duration of the launches of one step() */
   int64_t launches;  /* kernel launches issued */
   /* time_kernels == 0 with the persistent kernel: n_kernels = 1, kernel_name[0] = "k_persist", launches = number of its
-   * launches (chunks of 64 steps), ms_kernel[0] = their average duration (ms_total / launches).
+   * launches (chunks of 128 steps), ms_kernel[0] = their average duration (ms_total / launches).
    * time_kernels == 1: the kernels one policy+step of the device loop launches, in launch order, each bracketed by HIP
    * events on the stream it runs on; average duration per launch */
   int32_t n_kernels;

@@ -947,7 +947,10 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     }
     b->wg_dirty = true;  // until this run has completed
     const int64_t base = b->run_base;
-    int chunk = 64;
+    // (launches of 128 steps: every launch boundary costs a wavefront its window fill / write-back and a cold first step —
+    // cfg2 1.265e9 with 64-step launches, 1.295e9 with 128; with the bit-word sink a wavefront practically never has to
+    // leave its loop early, so longer launches leave no stragglers behind)
+    int chunk = 128;
     if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
     // A launch occupies the GPU in rounds of `resident` wavefronts, and a last round that is not full leaves CUs idle until
     // the launch ends (cfg2: 8 192 wavefronts over 3 072 resident = 2.67 rounds, 11 % of the machine-time lost).  When the

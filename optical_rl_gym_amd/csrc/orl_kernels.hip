@@ -216,11 +216,11 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 #endif  // ORL_ALT_IMPLS
 
 // ---- persistent kernel -------------------------------------------------------------------------------------------------
-// Envs never interact, so a wavefront can own its 8 envs for a whole launch (64 steps): control phase -> row phase over the
+// Envs never interact, so a wavefront can own its 8 envs for a whole launch (128 steps): control phase -> row phase over the
 // items the wavefront itself just collected (one lane per touched link) -> next step, with no kernel boundary and no
 // grid-wide tail between the phases; the wavefronts of a launch drift out of phase and keep the memory system uniformly busy.
 // LDS forms (the 8 envs' slot maps, records and per-core sums fit the wavefront's share of the CU's LDS): that state is
-// loaded once per launch, every scan / validation / row update of the 64 steps works on LDS, and it is written back at the
+// loaded once per launch, every scan / validation / row update of the launch works on LDS, and it is written back at the
 // end — the slot map is read ~14 times and rewritten ~5 times per env-step, none of which reaches memory any more.  Work
 // items never leave LDS either (the sink table is read in place through a dense index list).
 // A wavefront in which an env's releases did not fit the item form (one env-step in 10^7) leaves the loop after that step's

@@ -1,5 +1,9 @@
-"""Randomised configurations: every step implementation must leave every env in the same state (debug / soak aid)."""
+"""Randomised configurations: every step implementation must leave EVERY env in the same state (debug / soak aid): the
+one-wavefront-per-env kernel, the persistent kernel (generic instantiation; with ORL_JIT_SPEC=1 in the environment also the
+one built for the configuration), and — RMSA / DeepRMSA — a loop of agent-driven single steps (k_agent) in the middle of the
+run.  usage: fuzz_cross.py [seed] [cases]"""
 import os, sys
+os.environ.setdefault("ORL_JIT_SPEC", "0")
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import optical_rl_gym_amd as orl
@@ -37,12 +41,17 @@ for case in range(n_cases):
     try:
         for v in ("64", "1", "2"):
             os.environ["ORL_STEP_IMPL"] = v
+            os.environ["ORL_AGENT_STEP"] = "1" if v == "2" else "0"
             env = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, **kw)
             env.run(policy, steps // 2)
-            env.run(policy, steps - steps // 2)
+            n_host = 12 if fam in ("RMSA", "DeepRMSA") else 0  # in the middle: host- / agent-driven steps (v == "2": k_agent)
+            for _ in range(n_host):
+                env.policy(policy, fetch=False)
+                env.step(None, auto_reset=True, fetch=False)
+            env.run(policy, steps - steps // 2 - n_host)
+            env.check()
             out[v] = (env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy(),
-                      np.stack([env.net_stats(i) for i in (0, B // 2, B - 1)]), np.stack([env.link_stats(i) for i in (0, B // 2, B - 1)]),
-                      np.stack([env.slots(i) for i in (0, B // 2, B - 1)]))
+                      env.net_stats_all().copy(), env.link_stats_all().copy(), env.slots_packed().copy())
             env.close()
     except Exception as exc:  # configuration not supported by the host side: report and go on
         print("case", case, fam, topo, kw, "->", type(exc).__name__, exc)

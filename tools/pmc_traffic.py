@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workload driver for the rocprofv3 counter passes (tools/run_profiles.sh): state preparation to the steady state, one
 calibration stream over the slot maps with 8-B and with 16-B loads (known byte count), then MEASURED launches of the
-persistent kernel — 10 x run(policy, 64), i.e. ten single 64-step launches, the production chunk length — and 20 launches
+persistent kernel — 10 x run(policy, 128), i.e. ten single 128-step launches, the production chunk length — and 20 launches
 of the stand-alone slot-scan kernel on the same steady-state slot maps.  tools/collect_profiles.py turns the counters of the
 LAST 10 k_persist dispatches into per-launch / per-step figures (profiles/traffic_<workload>.json).
 
@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import optical_rl_gym_amd as orl  # noqa: E402
 from bench import WORKLOADS, workload_load  # noqa: E402
 
-STEPS_PER_LAUNCH = 64
+STEPS_PER_LAUNCH = 128
 MEASURED_LAUNCHES = 10
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
