@@ -357,7 +357,20 @@ def main():
         hdt = time.perf_counter() - h0_
         host = dict(value=round(B * n_host / hdt, 1), unit="env-steps/s", steps=n_host,
                     note="host-driven step(): 16 B/env of actions in, reward+done+info (%d B/env) out per step over PCIe, "
-                         "synchronous, one-wavefront-per-env kernel with info" % (8 + 1 + 8 * env.n_info))
+                         "synchronous, uniform-random actions (most are rejected); k_agent (RMSA / DeepRMSA from 2 048 envs) "
+                         "or the one-wavefront-per-env kernel" % (8 + 1 + 8 * env.n_info))
+        # the loop an agent on the same GPU drives: actions stay in device memory, nothing is fetched, one sync at the end
+        n_loop = 100
+        env.policy(policy, fetch=False)
+        env.sync()
+        l0 = time.perf_counter()
+        for _ in range(n_loop):
+            env.step(None, auto_reset=True, fetch=False)
+        env.sync()
+        ldt = time.perf_counter() - l0
+        host["agent_loop_zero_copy"] = dict(value=round(B * n_loop / ldt, 1), unit="env-steps/s", us_per_step=round(ldt / n_loop * 1e6, 2),
+                                            note="step(None, auto_reset=True, fetch=False) x %d on device-resident actions, one launch of "
+                                                 "k_agent per step, info / reward / done written in place" % n_loop)
 
     if rank == 0:
         total_steps = B * world * args.steps

@@ -165,7 +165,10 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 #define ORL_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each group of 8
 #define ORL_DPP_MIRROR 0x140      // lane i <-> 15-i inside each row of 16
 #define ORL_DPP_SHR1 0x111        // row_shr:1: lane i reads lane i-1 of its 16-lane row
-template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// (bound_ctrl = 1 with full row / bank masks: a source lane that is out of range or disabled reads as 0 — what `old` = 0 gave
+// with bound_ctrl = 0 — but the destination need not be initialised first: one v_mov_b32_dpp instead of v_mov + v_mov_dpp, and
+// foldable into the consuming instruction)
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
   i64 b = __double_as_longlong(v);
   u32 lo = (u32)dpp_i<CTRL>((int)(u32)b), hi = (u32)dpp_i<CTRL>((int)(u32)((u64)b >> 32));
