@@ -872,7 +872,9 @@ static PersistChoice persist_choose(const DevParams& VP) {
   if (r0 >= 16) { c.form = 5; c.inner = can_inner && r1 >= 16; }
   else if (r0 >= 10) { c.form = 4; c.inner = can_inner && (r1 < 12 ? r1 : 12) == (r0 < 12 ? r0 : 12); }
   else if (lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = can_inner && lds_wgs_per_cu(g1) >= 16; }
-  else { c.form = (VP.env_type == ENV_RMCSA || VP.E >= 64) ? 1 : 0; c.inner = false; }
+  // (global state: the 4-wave form except for RMCSA — round 3, with the 4-byte sink entries: cfg5 Germany50 32 768 envs 5.6e8 at 4
+  // waves per SIMD, 5.2e8 at 3; cfg4 RMCSA 5.0e8 / 5.3e8)
+  else { c.form = (VP.env_type == ENV_RMCSA) ? 1 : 0; c.inner = false; }
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
     bool built = f >= 0 && f < kNumPersistForms;
