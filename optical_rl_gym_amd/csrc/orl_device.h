@@ -940,26 +940,8 @@ template <int ENV> __device__ __forceinline__ void soft_reset(Env& e) {
   if (ENV != ENV_RWA && ENV != ENV_QOS && e.new_service) { e.esp += 1; e.ebrq += e.bit_rate; }
 }
 
-// get_available_blocks: the first `want` free runs of m with length >= n; returns how many were found
-template <int W>
-__device__ __forceinline__ int first_blocks(const Row<W>& m, int S, int n, int want, int* starts, int* lens) {
-  Row<W> r = row_runs_ge<W>(m, n);
-  Row<W> zeros = row_andn<W>(row_mask_lo<W>(S), m);
-  int found = 0;
-  while (found < want && row_any<W>(r)) {
-    int s = row_ctz<W>(r);
-    Row<W> z = row_andn<W>(zeros, row_mask_lo<W>(s));
-    int end = row_any<W>(z) ? row_ctz<W>(z) : S;
-    starts[found] = s;
-    lens[found] = end - s;
-    found++;
-    r = row_andn<W>(r, row_mask_lo<W>(end));
-  }
-  return found;
-}
-
-// the same walk for the action decode of DeepRMSAEnv.step (deeprmsa_env.py:48-58), which needs only the start of block
-// number `want - 1`: no arrays (indexed by a run-time block number they lived in scratch memory: the 64 bytes of private
+// get_available_blocks (rmsa_env.py:667-697): the free runs of m with length >= n, low to high — for the action decode of
+// DeepRMSAEnv.step (deeprmsa_env.py:48-58), which needs only the start of block number `want - 1`: no arrays (indexed by a run-time block number they lived in scratch memory: the 64 bytes of private
 // segment and a dozen "spilled" registers of every DeepRMSA kernel).  Returns how many of the first `want` blocks exist;
 // `start`: the first slot of the last one found.
 template <int W>
