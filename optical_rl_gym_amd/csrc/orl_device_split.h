@@ -1024,6 +1024,20 @@ __device__ __forceinline__ u32 row_inner_cache(const u64* row) {
 }
 // the 64-slot words the slots [s0, s0 + n) lie in
 __device__ __forceinline__ u32 mask_words(int s0, int n) { return (1u << (s0 >> 6)) | (1u << ((s0 + n - 1) >> 6)); }
+// The slots [s0, s0 + n), 1 <= n <= 63, as bits of the (at most two) 64-slot words they lie in: word s0 >> 6 gets `lo`, the
+// next one `hi`.  word_range() per word of the row — two clamps, two 64-bit shifts and half a dozen selects, times W words,
+// times two or three masks per item — was a tenth of the persistent kernel's instruction stream.
+struct Mask2 { u64 lo, hi; int w0; };
+__device__ __forceinline__ Mask2 mask2(int s0, int n) {
+  Mask2 m;
+  const int b = s0 & 63;
+  const u64 ones = (1ull << n) - 1ull;
+  m.w0 = s0 >> 6;
+  m.lo = ones << b;
+  m.hi = (b + n > 64) ? (ones >> (64 - b)) : 0ull;  // (b + n > 64 implies b >= 2: the shift is in range)
+  return m;
+}
+__device__ __forceinline__ u64 mask2_word(const Mask2& m, int w) { return (w == m.w0) ? m.lo : ((w == m.w0 + 1) ? m.hi : 0ull); }
 
 // the part of the row summary the compactness sums need: used blocks, lambda_min, lambda_max
 template <int W>
@@ -1093,8 +1107,9 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
     const u32 mw = mtab[0];
     const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
     touched = mask_words(s0, n);
+    const Mask2 mm = mask2(s0, n);
 #pragma unroll
-    for (int w = 0; w < W; w++) a[w] &= ~word_range(s0 - 64 * w, s0 + n - 64 * w);
+    for (int w = 0; w < W; w++) a[w] &= ~mask2_word(mm, w);
     first = (int)__builtin_ctz(rest);
     rest &= rest - 1u;
   }
@@ -1106,9 +1121,10 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
     const u32 mw = mtab[first];
     const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
     touched |= mask_words(s0, n);
+    const Mask2 mm = mask2(s0, n);
 #pragma unroll
     for (int w = 0; w < W; w++) {
-      const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
+      const u64 m = mask2_word(mm, w);
       a[w] = rel_f ? (a[w] | m) : (a[w] & ~m);
     }
   }
@@ -1176,8 +1192,9 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
       const u32 mw = mtab[__builtin_ctz(r)];
       const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
       later |= mask_words(s0, n);
+      const Mask2 mm = mask2(s0, n);
 #pragma unroll
-      for (int w = 0; w < W; w++) a[w] |= word_range(s0 - 64 * w, s0 + n - 64 * w);
+      for (int w = 0; w < W; w++) a[w] |= mask2_word(mm, w);
     }
     if (ENV != ENV_RWA) row_occ_fb<W>(a, S, occL, fbL);
     if (icw) {  // the cache word describes the row before these masks: their words become unknown
