@@ -227,13 +227,15 @@ struct Wmem {
   int cs_stride; // ints per env in cs0
   u32* ic0;      // LDS [8][E]: per link row, the longest free run strictly inside each 64-slot word (6 bits per word, 63 =
                  // unknown), or nullptr; indexed with cenv0 (row_stat_lane)
+  u32* oc0;      // LDS [8][E]: per link row, its contribution to the compactness sums, (occ << 16) | free blocks inside, or
+                 // nullptr (then the row phase recomputes it from the row before it changes it); indexed with cenv0
   double* clk;   // LDS [8][2] {provision clock, step clock} of the wavefront's envs, or nullptr (row phase reads SC_NOWA / SC_NOW)
   i64 clk_env0;  // first env of the wavefront (index base of clk)
   bool cs_lds;   // the sums are in the wavefront's LDS window: plain reads; else they are read through L2 where the row phase's atomics land
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
@@ -1114,8 +1116,15 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
     rest &= rest - 1u;
   }
   if (role_a) rest = 0u;
-  int occ0 = 0, fb0 = 0;  // B: the summary after the provision
-  if (ENV != ENV_RWA) row_occ_fb<W>(a, S, occ0, fb0);
+  // what the row contributes to the compactness sums before this lane's masks (B: after the provision): from the row's
+  // cache word where the launch keeps one — B's is what the A lane of the same item leaves there, read after A's round —
+  // else from the row itself (a hundred instructions for five words)
+  u32* ocw = (ENV != ENV_RWA && M.oc0) ? M.oc0 + (env - M.cenv0) * E + link : nullptr;
+  int occ0 = 0, fb0 = 0;
+  if (ENV != ENV_RWA) {
+    if (!ocw) row_occ_fb<W>(a, S, occ0, fb0);
+    else if (!role_b) { const u32 c = *ocw; occ0 = (int)(c >> 16); fb0 = (int)(c & 0xffffu); }
+  }
   const bool rel_f = first != 0;  // the evaluated mask is a release
   {
     const u32 mw = mtab[first];
@@ -1152,6 +1161,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
     if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
     else cur_comp = 1.0;
   }
+  if (ocw && role_a) *ocw = ((u32)after.occ << 16) | (u32)after.fb;  // (B reads it after the fence that ends round 0)
   const double clock = rel_f ? now : now_prov;
   const int n_rest = __popc(rest);
   // the running averages: round 0 every lane but the B lanes, round 1 the B lanes (their link's record has been updated and
@@ -1185,6 +1195,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
     wave_fence();
   }
   ORL_PROFR(6);
+  if (ocw && role_b) { const u32 c = *ocw; occ0 = (int)(c >> 16); fb0 = (int)(c & 0xffffu); }
   int occL = after.occ, fbL = after.fb;
   if (rest) {  // the masks of the further releases, then what the row contributes in the end
     u32 later = 0u;
@@ -1217,6 +1228,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   if (!role_a) {
 #pragma unroll
     for (int w = 0; w < W; w++) row[w] = a[w];
+    if (ocw) *ocw = ((u32)occL << 16) | (u32)fbL;
   }
   ORL_PROFR(7);
 }

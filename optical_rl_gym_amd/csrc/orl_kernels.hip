@@ -227,13 +227,14 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 // row phase and counts as unfinished; at the start of its next launch it releases them in place and resumes from its own
 // step count.
 struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (all multiples of 16)
-  int tab, mtab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, total;
+  int tab, mtab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, total;  // (ic: inner-run cache, then the occ / fb cache)
 };
 // state: 0 = only the per-step tables, 1 = + slot maps, per-core sums and env records, 2 = + link statistics, 3 = slot maps and
 // per-core sums but the env records stay in global memory (the window of the 4-wave forms: cfg2 8 832 B, 16 per CU);
 // compact: the bit-word sink of the single-core families (4 bytes per link and env + a mask table per env);
-// inner: the per-word longest-run cache of every row
-__host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, bool inner) {
+// inner: 0 = no row caches, 1 = the per-word longest-run cache of every row, 2 = + every row's contribution to the compactness
+// sums, (occ << 16) | free blocks (4 bytes per row each)
+__host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, int inner) {
   PersistLds L;
   int o = 0;
   L.tab = o; o += (8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry)) + 15) & ~15;
@@ -248,7 +249,7 @@ __host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_wo
   L.csw = (4 * C + 3) & ~3;  // sums + their release part, ints per env
   L.cs = o; if (state >= 1) o += 8 * L.csw * 4;
   L.sc = o; if (state == 1 || state == 2) o += 8 * ORL_SCAL_WORDS * 8;
-  L.ic = o; if (state >= 1 && inner) o += (8 * E * 4 + 15) & ~15;
+  L.ic = o; if (state >= 1 && inner) o += inner * ((8 * E * 4 + 15) & ~15);
   L.ls = o; if (state == 2) o += 8 * E * 32;
   L.total = o;
   return L;
@@ -319,9 +320,10 @@ __device__ __forceinline__ void persist_fill_window(const DevParams& P, i64 env0
 template <int ENV, int W, int LDS, bool PF>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
-  const bool IC = PersistInner<ENV, W, LDS>::value && P.persist_ic != 0;  // (the host decides: only where it costs no wavefront)
+  const int ICL = PersistInner<ENV, W, LDS>::value ? P.persist_ic : 0;  // (the host decides: only where it costs no wavefront)
+  const bool IC = ICL >= 1, OC = ICL >= 2;
   constexpr bool SR = PF;  // soon list in registers: the forms with registers to spare
-  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, LDS, CP, IC);
+  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, LDS, CP, ICL);
   typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_mtab = (unsigned short*)(orl_lds_raw + L.mtab);
@@ -379,6 +381,19 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       if (step < target) {
         __syncthreads();  // the rows are in LDS
         for (int i = lane; i < nenv * P.E; i += 64) M.ic0[i] = sp::row_inner_cache<W>(M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W);
+      }
+      if (OC) {  // what every row contributes to the compactness sums, as the launch finds it (kept exact by the row phase)
+        M.oc0 = (u32*)(orl_lds_raw + L.ic + ((8 * P.E * 4 + 15) & ~15));
+        if (step < target)
+          for (int i = lane; i < nenv * P.E; i += 64) {
+            const u64* row = M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W;
+            u64 a[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) a[w] = row[w];
+            int occ, fb;
+            sp::row_occ_fb<W>(a, P.S, occ, fb);
+            M.oc0[i] = ((u32)occ << 16) | (u32)fb;
+          }
       }
     }
   }
@@ -851,8 +866,8 @@ static int lds_wgs_per_cu(size_t lds) {
   const size_t alloc = (lds + 1279) / 1280 * 1280;
   return (int)((size_t)(160 * 1024) / alloc);
 }
-struct PersistChoice { int form; size_t lds; bool inner; };
-static size_t persist_window(const DevParams& VP, int state, bool inner) {
+struct PersistChoice { int form; size_t lds; int inner; };
+static size_t persist_window(const DevParams& VP, int state, int inner) {
   return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, state, persist_compact(VP.env_type, state), inner).total;
 }
 static PersistChoice persist_choose(const DevParams& VP) {
@@ -862,34 +877,45 @@ static PersistChoice persist_choose(const DevParams& VP) {
   // 4 waves) 1.18e9; cfg3: 1.25e9 / 1.27e9.  A wavefront more per CU is worth 3-5 %: the 4-wave form is taken if its
   // window keeps 16 on a CU, the 3-wave form down to 10, and the inner-run cache (+2.5 %) only where it costs no wavefront.
   const bool can_inner = persist_inner(VP.env_type, ORL_W, 1);
-  const size_t l0 = persist_window(VP, 1, false), l1 = can_inner ? persist_window(VP, 1, true) : l0;
-  const size_t g0 = persist_window(VP, 3, false), g1 = can_inner ? persist_window(VP, 3, true) : g0;  // records in global memory
-  const int r0 = lds_wgs_per_cu(l0), r1 = lds_wgs_per_cu(l1);
+  // the row caches (level 1: inner free runs, +2.5 %; level 2: + each row's occ / free-block contribution, +2 %) are taken at the
+  // highest level that costs no wavefront per CU
+  auto level = [&](int state, int cap) {
+    if (!can_inner) return 0;
+    const int r_none = lds_wgs_per_cu(persist_window(VP, state, 0));
+    for (int lv = 2; lv >= 1; lv--) {
+      const int r = lds_wgs_per_cu(persist_window(VP, state, lv));
+      if ((r < cap ? r : cap) == (r_none < cap ? r_none : cap)) return lv;
+    }
+    return 0;
+  };
+  const size_t l0 = persist_window(VP, 1, 0), g0 = persist_window(VP, 3, 0);  // (g: records in global memory)
+  const int r0 = lds_wgs_per_cu(l0);
   PersistChoice c;
   // (round 3, cfg2 with the 4-byte sink entries: form 4 with the cache 1.23e9; form 6 — 4 waves per SIMD, 16 per CU, but the
   // records in global memory, the soon list in memory and 9 spilled VGPRs — 1.14e9: what a wavefront keeps next to itself is
   // worth more than a fourth wavefront per SIMD.  Form 6 is taken only where the 3-wave window does not fit at all.)
-  if (r0 >= 16) { c.form = 5; c.inner = can_inner && r1 >= 16; }
-  else if (r0 >= 10) { c.form = 4; c.inner = can_inner && (r1 < 12 ? r1 : 12) == (r0 < 12 ? r0 : 12); }
-  else if (lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = can_inner && lds_wgs_per_cu(g1) >= 16; }
+  if (r0 >= 16) { c.form = 5; c.inner = level(1, 16); }
+  else if (r0 >= 10) { c.form = 4; c.inner = level(1, 12); }
+  else if (lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = level(3, 16); }
   // (global state: the 4-wave form except for RMCSA — round 3, with the 4-byte sink entries: cfg5 Germany50 32 768 envs 5.6e8 at 4
   // waves per SIMD, 5.2e8 at 3; cfg4 RMCSA 5.0e8 / 5.3e8)
-  else { c.form = (VP.env_type == ENV_RMCSA) ? 1 : 0; c.inner = false; }
+  else { c.form = (VP.env_type == ENV_RMCSA) ? 1 : 0; c.inner = 0; }
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
     bool built = f >= 0 && f < kNumPersistForms;
 #ifndef ORL_ALT_IMPLS
     built = built && f != 2 && f != 3;
 #endif
-    if (built && persist_window(VP, kPersistForms[f].lds, persist_inner(VP.env_type, ORL_W, kPersistForms[f].lds)) <= 64 * 1024 && f != c.form) {
+    if (built && persist_window(VP, kPersistForms[f].lds, 0) <= 64 * 1024 && f != c.form) {
       c.form = f;
-      const int st = kPersistForms[f].lds, cap = 4 * kPersistForms[f].waves;
-      const bool ci = persist_inner(VP.env_type, ORL_W, st);
-      const int a0 = lds_wgs_per_cu(persist_window(VP, st, false)), a1 = lds_wgs_per_cu(persist_window(VP, st, ci));
-      c.inner = ci && (a1 < cap ? a1 : cap) == (a0 < cap ? a0 : cap);
+      const int st = kPersistForms[f].lds;
+      c.inner = (st >= 1 && persist_inner(VP.env_type, ORL_W, st)) ? level(st, 4 * kPersistForms[f].waves) : 0;
     }
   }
-  if (const char* e = getenv("ORL_PERSIST_INNER")) c.inner = atoi(e) != 0 && persist_inner(VP.env_type, ORL_W, kPersistForms[c.form].lds);  // A/B
+  if (const char* e = getenv("ORL_PERSIST_INNER")) {  // A/B and cross-checks: 0 = no row caches, 1 = inner runs, 2 = + occ / free blocks
+    const int v = atoi(e);
+    c.inner = (v >= 0 && v <= 2 && persist_inner(VP.env_type, ORL_W, kPersistForms[c.form].lds)) ? v : 0;
+  }
   c.lds = persist_window(VP, kPersistForms[c.form].lds, c.inner);
   return c;
 }
@@ -936,7 +962,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64);
   const PersistChoice ch = persist_choose(VP);
   const int v = ch.form;
-  VP.persist_ic = ch.inner ? 1 : 0;
+  VP.persist_ic = ch.inner;
   size_t lds_a = persist_tuned_lds(v, ch.lds);
 #define LAUNCH(E_, LDS_, WV_)                                                                                                 \
   do {                                                                                                                       \

@@ -21,7 +21,7 @@ IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT=
             # where it costs no wavefront per CU)
             "persist": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             "persist_global": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="0", ORL_PERSIST_INNER=None),
-            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT="2", ORL_PERSIST_INNER="1"),
+            "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT="2", ORL_PERSIST_INNER="2"),
             # host- / agent-driven steps through k_agent (the phases of the persistent kernel for one step, with info) whatever
             # the batch size — the library takes it from 2 048 envs — for RMSA / DeepRMSA; device-resident runs as "persist"
             "agent8": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None,
