@@ -344,6 +344,22 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   // LDS window has been requested too (one memory round trip instead of two at the start of every wavefront); in the rare
   // case the window is filled again afterwards.
   const bool pend = (env < P.B) && ((P.scal[env * ORL_SCAL_WORDS + SC_ACC] >> 16) & 1ull) != 0ull;
+  const bool valid = env < P.B;
+  // carried from step to step in registers: the pending service's descriptor and (SR) this lane's entries of the env's soon
+  // list.  Requested together with the LDS window, before the row caches are built from it (their latency hides behind
+  // that); requested again in the rare case that pending releases are done first.
+  u64 desc = 0ull;
+  sp::SoonRegs soon_c;
+  soon_c.dirty = 0;
+#define ORL_LOAD_CARRIED()                                                                                  \
+  do {                                                                                                      \
+    desc = valid ? P.svc_desc[env] : 0ull;                                                                  \
+    _Pragma("unroll") for (int k = 0; k < ORL_SOON_PER_LANE; k++) {                                         \
+      const bool ld = SR && valid && step < target;                                                         \
+      soon_c.t[k] = ld ? P.soon_t[env * ORL_SOON + (lane & 7) + 8 * k] : __builtin_inf();                   \
+      soon_c.i[k] = ld ? (int)P.soon_i[env * ORL_SOON + (lane & 7) + 8 * k] : 0;                            \
+    }                                                                                                       \
+  } while (0)
   sp::Wmem M = sp::wmem_global(P);
   constexpr bool REC = (LDS == 1 || LDS == 2);  // the env records are in the LDS window
   if (!REC) {
@@ -363,6 +379,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
 #define ORL_FILL_WINDOW() persist_fill_window<REC>(P, env0, nenv, lane, orl_lds_raw + L.bm, orl_lds_raw + L.sc, orl_lds_raw + L.cs, L.csw / 4)
     if (step < target) ORL_FILL_WINDOW();
+    ORL_LOAD_CARRIED();
     if (__ballot(pend) != 0ull) {
       if (pend) {
         sp::rel_serial<ENV, W>(P, env, lane);
@@ -374,6 +391,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       __threadfence();
       __syncthreads();
       if (step < target) ORL_FILL_WINDOW();
+      ORL_LOAD_CARRIED();
     }
 #undef ORL_FILL_WINDOW
     if (IC) {
@@ -409,7 +427,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       __threadfence();
       __syncthreads();
     }
+    ORL_LOAD_CARRIED();
   }
+#undef ORL_LOAD_CARRIED
   if (LDS == 2) {
     M.ls0 = (double*)(orl_lds_raw + L.ls);
     M.senv0 = env0;
@@ -420,16 +440,6 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
   }
   if (threadIdx.x == 0) s_deferred[0] = s_deferred[1] = 0;
-  const bool valid = env < P.B;
-  u64 desc = valid ? P.svc_desc[env] : 0ull;  // carried from step to step in registers
-  sp::SoonRegs soon_c;  // ... and so are this lane's entries of the env's soon list (LDS forms)
-  soon_c.dirty = 0;
-#pragma unroll
-  for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
-    const bool ld = SR && valid && step < target;
-    soon_c.t[k] = ld ? P.soon_t[env * ORL_SOON + (lane & 7) + 8 * k] : __builtin_inf();
-    soon_c.i[k] = ld ? (int)P.soon_i[env * ORL_SOON + (lane & 7) + 8 * k] : 0;
-  }
   const int first_step = step;
   bool left_pending = false;  // the loop ended on a step whose releases are still to be done
   ORL_PROF_BEGIN();
