@@ -117,7 +117,7 @@ __device__ __forceinline__ u64 env_store(const DevParams& P, const EnvG& e, int 
 }
 
 // ---- MT19937, 16-word window per refill (lane w holds window words w and w+8) ----------------------
-struct RngG { u32 out0, out1, nx0, nx1; int used; };
+struct RngG { u32 out0, out1, nx0, nx1; int used; int pend_pos, pend_used; };  // pend_*: a commit whose stores are still to be done
 
 __device__ __forceinline__ void mt_one(const u32* mt, int i, u32& out, u32& nx) {
   int i0 = i >= 624 ? i - 624 : i;
@@ -137,6 +137,21 @@ __device__ __forceinline__ void rng_fill(const EnvG& e, RngG& r, int gl) {
   mt_one(e.mt, e.mt_pos + gl, r.out0, r.nx0);
   mt_one(e.mt, e.mt_pos + 8 + gl, r.out1, r.nx1);
   r.used = 0;
+  r.pend_used = 0;
+}
+// the commit of next_service in two halves: the stream position now (the record needs it), the stores of the regenerated
+// words later, behind the loads of the release detection (rng_commit_stores)
+__device__ __forceinline__ void rng_commit_pos(EnvG& e, RngG& r) {
+  r.pend_pos = e.mt_pos;
+  r.pend_used = r.used;
+  int p = e.mt_pos + r.used;
+  e.mt_pos = p >= 624 ? p - 624 : p;
+  r.used = 0;
+}
+__device__ __forceinline__ void rng_commit_stores(EnvG& e, RngG& r, int gl) {
+  if (gl < r.pend_used) { int i = r.pend_pos + gl; e.mt[i >= 624 ? i - 624 : i] = r.nx0; }
+  if (gl + 8 < r.pend_used) { int i = r.pend_pos + 8 + gl; e.mt[i >= 624 ? i - 624 : i] = r.nx1; }
+  r.pend_used = 0;
 }
 __device__ __forceinline__ void rng_commit(EnvG& e, RngG& r, int gl) {
   if (gl < r.used) { int i = e.mt_pos + gl; e.mt[i >= 624 ? i - 624 : i] = r.nx0; }
@@ -263,7 +278,9 @@ __device__ __forceinline__ void soon_set(EnvG& e, int gl, int slot, double t, in
   }
 }
 // ---- pending releases: slot i belongs to lane i % 8 -------------------------------------------------
-__device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info) {
+// store = false: the caller writes ev_time[idx] / ev_info[idx] itself (lane idx % 8), behind the loads that follow — vector
+// stores and loads share one in-order counter, so a load issued after a store is not back before the store is acknowledged
+__device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, double t, u64 info, bool store = true) {
   const int gl = lane & 7;
   // a slot for the entry: the top of the free-slot stack (fed by the releases and by the rebuild scan of control
   // kernel B2); a dense table appends; only a table with holes nobody recorded is searched
@@ -293,7 +310,7 @@ __device__ __forceinline__ int ev_push(const DevParams& P, EnvG& e, int lane, do
     if (e.ev_hwm >= P.ev_cap) { e.flags |= ORL_FLAG_EV_OVERFLOW; return -1; }
     idx = e.ev_hwm++;
   }
-  if (gl == (idx & 7)) { e.ev_time[idx] = t; e.ev_info[idx] = info; }
+  if (store && gl == (idx & 7)) { e.ev_time[idx] = t; e.ev_info[idx] = info; }
   e.ev_cnt++;
   e.next_rel = t < e.next_rel ? t : e.next_rel;  // -inf (unknown) stays -inf
   ORL_DBG(5, t < e.t_soon ? 1 : 0);
@@ -432,7 +449,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
       bit_rate = P.bit_rates[br_idx];
     }
   }
-  rng_commit(e, r, gl);
+  rng_commit_pos(e, r);  // (the caller stores the regenerated words: rng_commit_stores)
   e.id = (int)e.esp;
   e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
   e.new_service = 1;

@@ -396,6 +396,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     bool accepted = false;
     int pushed_idx = -1;
     u64 pushed_info = 0ull;
+    double pushed_t = 0.0;
     bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
     if (in_range && path < P.n_paths[e.src * P.N + e.dst]) {
       int pidx = pair_base(P, e.src, e.dst) + path;
@@ -440,7 +441,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         e.esa += 1;
         accepted = true;
         pushed_info = ev_pack(pidx, slot, n, core, e.bit_rate);
-        pushed_idx = g8::ev_push(P, e, lane, e.at + e.ht, pushed_info);
+        pushed_t = e.at + e.ht;
+        pushed_idx = g8::ev_push(P, e, lane, pushed_t, pushed_info, false);  // (its two stores: after the next service's loads)
         {  // the provision's rows: first mask of their items; they also count towards the per-link limit
           sink_add(sink, rec, core, slot, n, lane, true);
           if constexpr (!CP)
@@ -492,6 +494,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     if (!O.prefetch) g8::rng_fill(e, rng, gl);
     const bool done = service_part<ENV, W>(P, e, env, lane, O.auto_reset ? 1 : 0, accepted, core, O.write_io, rng, prof);
     if (done_out) *done_out = done ? 1 : 0;
+    // the pending-release slot of this step's provision (the rebuild scan of the release detection must find it in memory)
+    if (pushed_idx >= 0 && gl == (pushed_idx & 7)) { e.ev_time[pushed_idx] = pushed_t; e.ev_info[pushed_idx] = pushed_info; }
     desc_out = g8::env_store(P, e, gl, O.write_io);
     if (M.clk && gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
     ORL_PROFA(8);
@@ -501,6 +505,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       // detection); those fields are written again below when the detection changed them.
       SoonRegs soon;
       release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
+      g8::rng_commit_stores(e, rng, gl);  // the Mersenne-Twister words of next_service: behind the detection's loads
       ORL_PROFA(10);
       if (sink.deferred) {
         // more releases meet on one link than an item holds masks for: the release state stays as stored and the
