@@ -54,6 +54,9 @@ def make_spaces(batch, obs_dtype=np.float64, mod=None):
     return obs, act
 
 
+_NO_INFO = {}  # shared by every env without episode information in a step (never written to by this module)
+
+
 class OpticalVecEnv:
     metadata = {"render_modes": []}
     render_mode = None
@@ -93,8 +96,11 @@ class OpticalVecEnv:
         self._ep_ret += reward
         self._ep_len += 1
         obs = self._obs(obs)
-        infos = [{} for _ in range(self.num_envs)]
+        # SB3 wants one dict per env and only ever READS the ones of envs that did not finish an episode: those share one empty
+        # dict (65 536 fresh dicts per step cost ten times the step itself); an env that reports done gets a dict of its own
+        infos = [_NO_INFO] * self.num_envs
         for i in np.flatnonzero(done):
+            infos[i] = {}
             row = dict(r=float(self._ep_ret[i]), l=int(self._ep_len[i]), t=round(time.time() - self._t0, 6))
             for k, j in zip(self.info_keywords, self._kw_idx):
                 row[k] = float(info[i, j])
