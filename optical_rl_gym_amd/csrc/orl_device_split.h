@@ -352,7 +352,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         else rs[i] = 0;
       }
     }
-    if (ic) {  // _get_network_compactness before the provision (rmsa_env.py:189)
+    if (ic && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA)) {  // _get_network_compactness before the provision (rmsa_env.py:189)
       int occ, fb;
       if (O.persistent && !M.cs_lds) { occ = atomicAdd(e.cs, 0); fb = atomicAdd(e.cs + 1, 0); }
       else { occ = e.cs[0]; fb = e.cs[1]; }
@@ -464,7 +464,13 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       for (int i = gl; i < npa + nsa; i += 8) {
         int hi = (i < npa) ? i : (K + 1) + (i - npa);
         bool hit = !bad && ((i < npa) ? (i == path0) : (i - npa == slot0));
-        if (hit) h[hi] += 1;
+        if (ic) {  // k_agent: path_action_probability / wavelength_action_probability of info (rwa_env.py:148-151): updated count / services_processed
+          const i64 v = h[hi] + (hit ? 1 : 0);
+          if (hit) h[hi] = v;
+          P.info[env * P.n_info + 2 + i] = (double)v / (double)e.sp;
+        } else if (hit) {
+          h[hi] += 1;
+        }
       }
     }
     if (gl == 0) {
@@ -487,8 +493,10 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         double* io = P.info + env * P.n_info;
         io[0] = (double)(e.sp - e.sa) / (double)e.sp;
         io[1] = (double)(e.esp - e.esa) / (double)e.esp;
-        io[2] = (double)(e.brq - e.brp) / (double)e.brq;
-        io[3] = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
+        if (ENV != ENV_RWA) {  // (RWA: info goes on with the action probabilities, written beside the histogram update)
+          io[2] = (double)(e.brq - e.brp) / (double)e.brq;
+          io[3] = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
+        }
       }
     }
     if (!O.prefetch) g8::rng_fill(e, rng, gl);

@@ -576,8 +576,10 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
 // wavefront, all state in global memory, the per-step tables in LDS — plus what a host-visible step() owes beyond the
 // device-resident loop: the action is validated (is_path_free), reward / done / info / observation are written, the
 // network-compactness update is finished in the same launch, and releases that do not fit the item form are done in place
-// right away, so that every launch leaves final state.  RMSA and DeepRMSA with continuous bit rates; the other families keep
-// the one-wavefront-per-env kernel (k_step: 305 us per 65 536 envs against ~90 us here).
+// right away, so that every launch leaves final state.  All four families (RMSA / DeepRMSA with continuous bit rates: the
+// per-rate info entries of the discrete mode keep the one-wavefront-per-env kernel, k_step: 305 us per 65 536 envs against
+// ~106 us here).  RWA's info carries the action probabilities (written beside the histogram update of the control phase),
+// RMCSA's the four blocking rates.
 // info (rmsa_env.py:234-264): the four blocking rates from the counters before the next service is counted (control
 // phase); network_compactness after the provision = (totals - what this step's releases added) over the occupied-slot sum at
 // provision time, the difference to its value before the provision; the two link averages over topology.edges() in numpy's
@@ -588,14 +590,16 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
 #endif
 template <int ENV, int W>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGENT_WAVES, ORL_AGENT_WAVES))) k_agent(DevParams P, int auto_reset) {
-  constexpr bool CP = true;
-  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, 0, CP, false);
-  sp::SinkEntryC* s_tab = (sp::SinkEntryC*)(orl_lds_raw + L.tab);
+  constexpr bool CP = ENV != ENV_RMCSA;                                  // RMCSA: sink entries with a core per mask, the general row loop
+  constexpr bool LINK_INFO = (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA);   // info carries network compactness and the two link averages
+  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, 0, CP, 0);
+  typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
+  u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_mtab = (unsigned short*)(orl_lds_raw + L.mtab);
   unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
   int* s_deferred = (int*)(orl_lds_raw + L.misc);
   u32* s_list_n = (u32*)(orl_lds_raw + L.misc + 8);
-  double* s_stash = (double*)(orl_lds_raw + L.total);  // [8][E][2]
+  double* s_stash = (double*)(orl_lds_raw + L.total);  // [8][E][2] (LINK_INFO)
   const int lane = lane_id(), gl = lane & 7, el = lane >> 3;
   const i64 env0 = (i64)blockIdx.x * 8, env = env0 + el;
   const bool valid = env < P.B;
@@ -609,48 +613,55 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   int done_i = 0;
   sp::InfoCarry ic;
   ic.prev_comp = 1.0; ic.s_nh_prov = 0;
-  sp::ctrl_a<ENV, W, CP>(P, M, O, env, valid, lane, prof, nullptr, nullptr, s_tab, 0, s_deferred, &done_i, s_list, s_list_n, 0, nullptr, s_mtab, &ic);
+  sp::ctrl_a<ENV, W, CP>(P, M, O, env, valid, lane, prof, nullptr, s_tally, s_tab, 0, s_deferred, &done_i, s_list, s_list_n, L.tw, nullptr, s_mtab, &ic);
   __syncthreads();  // sink table + item list, clocks
   {
     const int n_items = (int)*s_list_n;
     for (int idx = lane; idx < n_items; idx += 64) {
       const int code = (int)s_list[idx];
       const int iel = (code >> 8) & 7, link = code & 0xff, second = code >> 15;
-      sp::row_item_lane1<ENV, W>(P, M, env0 + iel, link, s_tab[P.E * iel + link].bits, s_mtab + ORL_MTAB * iel, second, prof, true,
-                                 s_stash + 2 * P.E * iel);
+      if constexpr (!CP) {
+        if (!second) sp::row_item_lane<ENV, W>(P, M, sp::item_from_sink(env0 + iel, link, s_tab[P.E * iel + link]), prof);
+      } else {
+        sp::row_item_lane1<ENV, W>(P, M, env0 + iel, link, s_tab[P.E * iel + link].bits, s_mtab + ORL_MTAB * iel, second, prof, true,
+                                   LINK_INFO ? s_stash + 2 * P.E * iel : nullptr);
+      }
     }
   }
   __syncthreads();
   const bool deferred = s_deferred[0] != 0;
   u64* rec = P.scal + env * ORL_SCAL_WORDS;
   double mean_comp = 0.0, mean_util = 0.0;
-  if (valid) {
-    // np.mean over the links in topology.edges() order (numpy pairwise sum, optical_rl_gym_amd/csrc/orl_device.h link_mean):
-    // lane j of the group accumulates x[j], x[8 + j], ...; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); the tail one by one
-    const int E = P.E;
-    const double* ls = P.lstat + env * 4 * E;
-    const double* st = s_stash + 2 * E * el;
-    auto value = [&](int i, double& u, double& c) {
-      const int link = P.edge_iter_order[i];
-      const bool rel = (s_tab[E * el + link].bits >> 1) != 0u;  // a release of this step touched the link: the values from before it
-      u = rel ? st[2 * link] : ls[4 * link];
-      c = rel ? st[2 * link + 1] : ls[4 * link + 2];
-    };
-    double su = 0.0, sc = 0.0;
-    if (E < 8) {
-      for (int i = 0; i < E; i++) { double u, c; value(i, u, c); su += u; sc += c; }
-    } else {
-      double u, c;
-      value(gl, su, sc);
-      int i;
-      for (i = 8; i < E - (E % 8); i += 8) { value(i + gl, u, c); su += u; sc += c; }
-      su += dpp_d<ORL_DPP_XOR1>(su); sc += dpp_d<ORL_DPP_XOR1>(sc);
-      su += dpp_d<ORL_DPP_XOR2>(su); sc += dpp_d<ORL_DPP_XOR2>(sc);
-      su += dpp_d<ORL_DPP_HALF_MIRROR>(su); sc += dpp_d<ORL_DPP_HALF_MIRROR>(sc);
-      for (; i < E; i++) { value(i, u, c); su += u; sc += c; }
+  if constexpr (LINK_INFO) {
+    if (valid) {
+      // np.mean over the links in topology.edges() order (numpy pairwise sum, optical_rl_gym_amd/csrc/orl_device.h link_mean):
+      // lane j of the group accumulates x[j], x[8 + j], ...; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); the tail one by one
+      const int E = P.E;
+      const double* ls = P.lstat + env * 4 * E;
+      const double* st = s_stash + 2 * E * el;
+      auto value = [&](int i, double& u, double& c) {
+        const int link = P.edge_iter_order[i];
+        bool rel = false;  // a release of this step touched the link: the values from before it
+        if constexpr (CP) rel = (s_tab[E * el + link].bits >> 1) != 0u;
+        u = rel ? st[2 * link] : ls[4 * link];
+        c = rel ? st[2 * link + 1] : ls[4 * link + 2];
+      };
+      double su = 0.0, sc = 0.0;
+      if (E < 8) {
+        for (int i = 0; i < E; i++) { double u, c; value(i, u, c); su += u; sc += c; }
+      } else {
+        double u, c;
+        value(gl, su, sc);
+        int i;
+        for (i = 8; i < E - (E % 8); i += 8) { value(i + gl, u, c); su += u; sc += c; }
+        su += dpp_d<ORL_DPP_XOR1>(su); sc += dpp_d<ORL_DPP_XOR1>(sc);
+        su += dpp_d<ORL_DPP_XOR2>(su); sc += dpp_d<ORL_DPP_XOR2>(sc);
+        su += dpp_d<ORL_DPP_HALF_MIRROR>(su); sc += dpp_d<ORL_DPP_HALF_MIRROR>(sc);
+        for (; i < E; i++) { value(i, u, c); su += u; sc += c; }
+      }
+      mean_util = su / (double)E;
+      mean_comp = sc / (double)E;
     }
-    mean_util = su / (double)E;
-    mean_comp = sc / (double)E;
   }
   if (deferred) {  // (a few env-steps in 10^7) releases that did not fit the item form: in place, now
     __syncthreads();
@@ -659,26 +670,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
     __syncthreads();
   }
   if (valid) {
-    // network compactness right after the provision: the totals minus what the step's releases added (row phase: L2 atomics)
-    int* cs = P.core_sums + env * P.cs_words;
-    int* rs = cs + 2 * P.C;
-    const int occ = atomicAdd(cs, 0) - atomicAdd(rs, 0), fb = atomicAdd(cs + 1, 0) - atomicAdd(rs + 1, 0);
-    const double cur = (fb > 0) ? ((double)occ / (double)ic.s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
-    if (gl == 0) {
+    if constexpr (ENV != ENV_RWA) {
+      // network compactness right after the provision: the totals minus what the step's releases added (row phase: L2
+      // atomics), over the occupied-slot sum at provision time; the pending average of _update_network_stats
+      // (rmsa_env.py:439-462) is finished with it, as k_finish2 does at the end of a device-resident run
+      int* cs = P.core_sums + env * P.cs_words;
+      int* rs = cs + 2 * P.C;
       const u64 acc = rec[SC_ACC];
-      if ((u32)acc & 2u) {  // the pending average of _update_network_stats (rmsa_env.py:439-462), as k_finish2 finishes it
+      const int c0 = (int)((acc >> 32) & 31);
+      const int occ = atomicAdd(cs + 2 * c0, 0) - atomicAdd(rs + 2 * c0, 0), fb = atomicAdd(cs + 2 * c0 + 1, 0) - atomicAdd(rs + 2 * c0 + 1, 0);
+      const double cur = (fb > 0) ? ((double)occ / (double)ic.s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
+      if (gl == 0 && ((u32)acc & 2u)) {
         const double a0 = __longlong_as_double((i64)rec[SC_GC_A]), td = __longlong_as_double((i64)rec[SC_GC_TD]);
         const double now_a = __longlong_as_double((i64)rec[SC_NOWA]);
         rec[SC_GCOMP] = (u64)__double_as_longlong((a0 + (cur * td)) / now_a);
         rec[SC_ACC] = acc & ~2ull;
       }
-      atomicExch(rs, 0);
-      atomicExch(rs + 1, 0);
-      double* io = P.info + env * P.n_info;
-      io[4] = cur;
-      io[5] = ic.prev_comp - cur;
-      io[6] = mean_comp;
-      io[7] = mean_util;
+      for (int i = gl; i < 2 * P.C; i += 8) atomicExch(rs + i, 0);
+      if (LINK_INFO && gl == 0) {
+        double* io = P.info + env * P.n_info;
+        io[4] = cur;
+        io[5] = ic.prev_comp - cur;
+        io[6] = mean_comp;
+        io[7] = mean_util;
+      }
     }
     if (ENV == ENV_DEEPRMSA && P.obs_dim) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1000,13 +1015,14 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
 #undef PER_ENV
 #undef LAUNCH
 }
-// one host- or agent-driven step through the phases of the persistent kernel (RMSA / DeepRMSA, continuous bit rates)
+// one host- or agent-driven step through the phases of the persistent kernel
 template <int W> void agent_step(orl_batch* b, int auto_reset) {
   const DevParams& VP = b->P;
   dim3 g((unsigned)((VP.B + 7) / 8)), blk(64);
-  const size_t lds = (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, 0, true, false).total + (size_t)8 * VP.E * 16;
-  if (VP.env_type == ENV_RMSA) hipLaunchKernelGGL((k_agent<ENV_RMSA, W>), g, blk, lds, b->stream, VP, auto_reset);
-  else hipLaunchKernelGGL((k_agent<ENV_DEEPRMSA, W>), g, blk, lds, b->stream, VP, auto_reset);
+  const size_t lds = (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, 0, VP.env_type != ENV_RMCSA, 0).total + (size_t)8 * VP.E * 16;
+#define PER_ENV(E_) hipLaunchKernelGGL((k_agent<E_, W>), g, blk, lds, b->stream, VP, auto_reset);
+  ORL_FOR_ENV(b, PER_ENV)
+#undef PER_ENV
   ORL_TK(b, "k_agent");
 }
 
