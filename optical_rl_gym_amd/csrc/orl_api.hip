@@ -501,9 +501,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     // (k_agent) wherever they apply and the batch is large enough to fill the GPU with 8 envs per wavefront: cfg2 65 536 envs
     // 305 us per step in k_step (one wavefront per env), ~90 us in k_agent.  ORL_AGENT_STEP=1 forces it for any batch size
     // (parity tests), 0 disables it.
-    // (RMSA / DeepRMSA with discrete bit rates carry per-rate blocking entries in info: those keep k_step)
-    const bool rmsa_like = c->env_type == ORL_ENV_RMSA || c->env_type == ORL_ENV_DEEPRMSA;
-    const bool fits = b->persist && (rmsa_like ? c->bit_rate_mode == 0 : true) && P.E <= 128;
+    const bool fits = b->persist && P.E <= 128;
     b->agent_step = fits && n_envs >= 2048;
     if (const char* av = getenv("ORL_AGENT_STEP")) b->agent_step = fits && atoi(av) != 0;
   }

@@ -497,6 +497,19 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
           io[2] = (double)(e.brq - e.brp) / (double)e.brq;
           io[3] = (double)(e.ebrq - e.ebrp) / (double)e.ebrq;
         }
+        if ((ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) && P.bit_rate_mode == 1) {  // discrete bit rates: blocking per rate + fairness (rmsa_env.py:217-227, 268-273)
+          const i64* rq = P.br_hist + env * 2 * P.n_br;
+          const i64* pv = rq + P.n_br;
+          double mxv = -__builtin_inf(), mnv = __builtin_inf();
+          for (int i = 0; i < P.n_br; i++) {
+            double bl = 0.0;
+            if (rq[i] > 0) bl = (double)(rq[i] - pv[i]) / (double)rq[i];
+            io[8 + i] = bl;
+            mxv = bl > mxv ? bl : mxv;
+            mnv = bl < mnv ? bl : mnv;
+          }
+          io[8 + P.n_br] = mxv - mnv;
+        }
       }
     }
     if (!O.prefetch) g8::rng_fill(e, rng, gl);
