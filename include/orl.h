@@ -189,6 +189,10 @@ int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double*
 
 /* DeepRMSAEnv.observation() for the pending service (deeprmsa_env.py:60-121). */
 int orl_batch_observation(orl_batch* b, double* obs_out);
+/* The observation array the last orl_batch_step / orl_batch_observation / orl_batch_reset left on the device (ORL_BUF_OBS), cast
+ * to float32 ON THE DEVICE and copied out — half the PCIe bytes and no conversion pass on the host for agents that work in
+ * float32 (SB3's default); the float64 values stay the parity-checked ones.  obs_out: [n_envs][obs_dim] float. */
+int orl_batch_get_obs_f32(orl_batch* b, float* obs_out);
 
 /* n_steps x { policy ; step(auto_reset) } entirely on the device (the loop of utils.evaluate_heuristic,
  * utils.py:113-128, with VecEnv-style auto reset).  time_kernels: 0 = production run (the persistent kernel where it

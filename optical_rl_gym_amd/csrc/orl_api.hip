@@ -172,6 +172,11 @@ __global__ void k_calib_read(const u64* __restrict__ src, i64 n_words, int width
   if (acc == 0x123456789abcdefull) *sink = acc;  // keep the loads alive
 }
 
+// observation array -> float32 (orl_batch_get_obs_f32)
+__global__ void k_cast_f32(const double* __restrict__ src, float* __restrict__ dst, i64 n) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+
 // sums of services_processed / services_accepted over the batch (two atomics per wave)
 __global__ void k_totals(DevParams P, unsigned long long* out) {
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -902,6 +907,23 @@ extern "C" int orl_batch_observation(orl_batch* b, double* obs_out) try {
   HIPCHK(hipSetDevice(b->device));
   launch_obs(b, 0);
   HIPCHK(hipMemcpyAsync(obs_out, b->P.obs, (size_t)b->P.B * b->P.obs_dim * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+
+extern "C" int orl_batch_get_obs_f32(orl_batch* b, float* obs_out) try {
+  if (!b || !obs_out) return fail(ORL_E_INVALID, "null argument");
+  if (!b->P.obs_dim) return fail(ORL_E_INVALID, "this env family has no array observation");
+  HIPCHK(hipSetDevice(b->device));
+  const i64 n = b->P.B * b->P.obs_dim;
+  if (!b->obs_f32) {
+    HIPCHK(hipMalloc((void**)&b->obs_f32, (size_t)n * sizeof(float) + 64));
+    b->allocs.push_back(b->obs_f32);
+  }
+  hipLaunchKernelGGL(k_cast_f32, dim3(2048), dim3(256), 0, b->stream, b->P.obs, b->obs_f32, n);
+  HIPCHK(hipMemcpyAsync(obs_out, b->obs_f32, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   return ORL_OK;

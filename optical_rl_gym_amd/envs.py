@@ -260,6 +260,10 @@ class BatchedOpticalEnv:
     def _ck(self, rc):
         _lib.check(rc, self.lib)
 
+    def host_array(self, shape, dtype):
+        """A page-locked numpy array (copies to and from it run at the full PCIe rate), e.g. for `step(obs_out=...)`."""
+        return self._host_array(shape, dtype)
+
     def _host_array(self, shape, dtype):
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = C.c_void_p()
@@ -305,9 +309,12 @@ class BatchedOpticalEnv:
         self._ck(self.lib.orl_batch_policy(self._h, pid, self._act.ctypes.data if fetch else None))
         return self._act if fetch else None
 
-    def step(self, actions, auto_reset=False, fetch=True):
+    def step(self, actions, auto_reset=False, fetch=True, obs_out=None):
         """actions: [num_envs, n_action] ints, or None to use the device-resident result of policy(fetch=False).
-        Returns (obs, reward, done, info) arrays; info is [num_envs, n_info] in `info_keys` order."""
+        Returns (obs, reward, done, info) arrays; info is [num_envs, n_info] in `info_keys` order.  The arrays are this
+        object's page-locked staging buffers, overwritten by the next step.  `obs_out`: a caller-owned [num_envs, obs_dim]
+        float64 or float32 array (ideally from `host_array`) that receives the observation instead — float32 is cast on the
+        device (half the PCIe bytes, no host pass)."""
         a = None
         if actions is not None:
             actions = np.asarray(actions)
@@ -316,9 +323,17 @@ class BatchedOpticalEnv:
             a = self._act_in  # columns beyond the family's action width stay zero from allocation
             a[:, : actions.shape[1]] = actions
         if fetch:
-            self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), _ptr(self._obs), self._reward.ctypes.data,
+            obs = self._obs
+            if obs_out is not None and self.obs_dim:
+                assert obs_out.shape == (self.num_envs, self.obs_dim) and obs_out.flags.c_contiguous
+                obs = obs_out if obs_out.dtype == np.float64 else None
+            self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), _ptr(obs), self._reward.ctypes.data,
                                                self._done.ctypes.data, self._info.ctypes.data))
-            return self._obs, self._reward, self._done, self._info
+            if obs is None and self.obs_dim:
+                assert obs_out.dtype == np.float32
+                self._ck(self.lib.orl_batch_get_obs_f32(self._h, obs_out.ctypes.data))
+                obs = obs_out
+            return obs, self._reward, self._done, self._info
         self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), None, None, None, None))
         return None
 

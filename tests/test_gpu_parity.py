@@ -1143,8 +1143,14 @@ def test_vecenv_on_hip_dlpack_and_monitor_file(tmp_path):
     assert obs.dtype == np.float32 and obs.shape == (16, 54)
     rs = np.random.RandomState(0)
     total_done = 0
+    held = []  # SB3 keeps the previous observation across one further step: the arrays of the last two steps must stay intact
     for t in range(2000 // 16):
         obs, rew, done, infos = venv.step(rs.randint(0, 5, 16))
+        # float32 cast on the device of the float64 observation the batch holds; written into a ring of three host arrays
+        assert obs.dtype == np.float32 and np.array_equal(obs, batch.observation().astype(np.float32))
+        for prev, copy in held:
+            assert np.array_equal(prev, copy)
+        held = (held + [(obs, obs.copy())])[-2:]
         total_done += int(done.sum())
         for i in np.flatnonzero(done):
             assert infos[i]["episode"]["l"] == 49 and infos[i]["terminal_observation"].dtype == np.float32

@@ -10,7 +10,7 @@ for name in ("cfg3","cfg2"):
     fam,topo,kw,pol=WORKLOADS[name]
     B=65536
     b=orl.make(fam, topology=topo, num_envs=B, seeds=[10+i for i in range(B)], **kw)
-    v=OpticalVecEnv(b)
+    v=OpticalVecEnv(b, obs_dtype=np.float32 if "f32" in sys.argv else np.float64)
     v.reset()
     a=b.policy(pol)[:, :b.N_ACTION].copy() if fam!="DeepRMSA" else b.policy(pol)[:,0].copy()
     v.step(a)
