@@ -4,7 +4,7 @@ envs per MI355X, on-device KSP-FF policy (BASELINE.json `metric`; SURVEY.md §8d
 
 One "step" = one batched policy + env.step() over the whole batch, entirely on the device: the persistent kernel
 k_persist — one wavefront owns 8 envs for the whole run and alternates a control phase (slot scan + all per-env control +
-release detection -> work items) with a row phase (one lane per touched link row); K steps are ceil(K/64) launches.
+release detection -> work items) with a row phase (one lane per touched link row); K steps are ceil(K/128) launches.
 Inputs are resident in HBM before the timed region.
 
 What is timed, however the script is invoked:
@@ -12,7 +12,7 @@ What is timed, however the script is invoked:
      steps, plus --warmup more; the mean number of active services is then checked (cfg2: 288 +- 5 %) and reported as
      `state_before`.  --warmup adds to this preparation, it never replaces it.
   2. the timed block: EXACTLY --steps steps, bracketed by a barrier + device synchronisation on both sides, max over ranks.
-     The block is repeated until >= 1 s has been timed (at least 3 blocks); `value` is the median block, `timed_region_s` the
+     The block is repeated until >= 5 s have been timed (--min-timed-s; at least 3 blocks); `value` is the median block, `timed_region_s` the
      sum.  `roofline.achieved` comes from the HIP-event duration of the same launches.
 N > 1: one process per GPU, every rank owns its own 65 536 envs (weak scaling, no collective on the data path; the barrier
 and the max-over-ranks time go through a gloo group — the data path needs no RCCL).  Started under torchrun the script is one

@@ -551,7 +551,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     const size_t waves = ((B + 31) / 32 + 16) * 4;
     P.q_wave = 8 * (P.H > P.E ? P.H : P.E);
     P.item_masks = ORL_IMASKS;
-    // test knob: a smaller limit sends far more env-steps through the tally pass and the serial tail
+    // test knob: a smaller limit sends far more env-steps through the serial tail (and, RMCSA, the tally pass)
     P.rel_limit = 31;
     if (const char* mv = getenv("ORL_ITEM_MASKS")) { int v = atoi(mv); if (v >= 1 && v <= ORL_IMASKS) { P.item_masks = v; P.rel_limit = v; } }
     P.q_cap = (i64)waves * P.q_wave;

@@ -162,6 +162,7 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 // all of them the 3-step reductions over an 8-lane row group.  All lanes of the reading group are always active.
 #define ORL_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
 #define ORL_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define ORL_DPP_XOR3 0x1B         // quad_perm [3,2,1,0]
 #define ORL_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each group of 8
 #define ORL_DPP_MIRROR 0x140      // lane i <-> 15-i inside each row of 16
 #define ORL_DPP_SHR1 0x111        // row_shr:1: lane i reads lane i-1 of its 16-lane row

@@ -1,27 +1,28 @@
-// orl_device_split.h — step() as a pipeline of kernels: per-env control -> work items -> one lane per touched link row.
+// orl_device_split.h — step() as two phases: per-env control -> work items -> one lane per touched link row.
 //
-// Persistent kernel k_persist (orl_gpu.hip; the default of the device-resident loop): one wavefront owns 8 envs for a whole
-// run and alternates the control phase and the row phase below, which the two-kernel pipeline runs as separate launches:
-//   k_step_a2   8 lanes per env: the slot scan (policy), then — the action still in registers — decode + validate,
-//               counters, reward, the release push, network throughput, the next service (RNG, node pair, bit rate),
-//               done / auto reset, and the due releases of the step through the env's soon list.  Output: one queue of
-//               32-byte MIXED work items, one per touched link: the provision's mask first, then the release masks.
-//   k_rows2     one lane per item: clear / set the slots, per-link statistics, compactness sums (integer atomics)
-//   k_rel_tail  one workgroup: the rare envs whose releases did not fit the item form release them in place
-//   The network-compactness average needs the sums between the provision and the releases: the next launch of k_step_a2
-//   finishes it from totals - rel_sums (k_finish2 at the end of a run).
-// Four-kernel split (step_impl 1; also the host-driven step() of large batches, where info needs the compactness right
-// after the provision): k_policy_ctrl_a | k_ctrl_a (+ k_ctrl_b1), k_rows1(provision items), k_ctrl_b2 (release
-// detection), k_rows1(release items), k_rel_tail.
+// Persistent kernel k_persist (orl_kernels.hip; the device-resident loop): one wavefront owns 8 envs for a whole launch and
+// alternates the two phases below; k_agent runs them once, for an agent-driven step, and adds validation, info and the
+// observation; the two-kernel test form (-DORL_ALT_IMPLS) runs them as separate launches:
+//   control     8 lanes per env (ctrl_a): the slot scan (policy) or the agent's action, decode + validate, counters, reward,
+//               the release push, network throughput, the next service (RNG, node pair, bit rate), done / auto reset, and
+//               the due releases of the step through the env's soon list (release_soon).  Output: work items in an LDS
+//               sink, one per touched link — the provision's mask first, then the release masks (single-core families: one
+//               bit word per link + a mask table per env; RMCSA / two-kernel form: 24-byte entries, 32-byte queue items)
+//   rows        one lane per item (row_item_lane1 / row_item_lane): clear / set the slots, per-link statistics, compactness
+//               sums (integer atomics)
+//   rel_serial  the rare envs whose releases did not fit the item form release them in place (start of the owning
+//               wavefront's next launch; k_agent: same launch; two-kernel form: k_rel_tail)
+//   The network-compactness average needs the sums between the provision and the releases: the next control phase finishes
+//   it from totals - rel_sums (k_finish2 at the end of a run, k_agent at the end of its launch).
 //
 // Why: in the monolithic kernels the row work (bit tricks + float64 running averages) ran under per-env control
 // flow — one or two link rows per pass, multiplied by the worst hop count and release count among the envs sharing a
-// wavefront.  Flattened into queues, the row kernel is a flat loop over independent items and the control kernels
-// shrink to the genuinely serial part.  What bounds these kernels is not bytes but dependent memory round trips of
-// the slowest wavefront (an 8 192-env launch takes 60 % of the time of a 65 536-env one) and, at full batch, the number
-// of scattered DRAM requests; so the design rules here are: request everything a phase needs in one batch, keep
-// stores behind the last load (they share the in-order memory counter), no workgroup barriers, no per-slot searches
-// (free-slot stack, soon list), branch-free selection, rare paths out of line (a launch of their own).
+// wavefront.  Flattened into items, the row phase is a flat loop over independent items and the control phase shrinks to
+// the genuinely serial part.  Design rules: request everything a phase needs in one batch, keep stores behind the last
+// load (they share the in-order memory counter), no per-slot searches (free-slot stack, soon list), branch-free
+// selection, rare paths out of line.  Round 3: the kernel is bound by instruction issue (VALU ~76 % busy at 3 waves per
+// SIMD), so the rules that matter now are about instruction count — masks applied as the two words they lie in, row
+// summaries cached per row, the releases of a wavefront-step applied by their holder lanes in parallel.
 // Semantics, operation order of every float64 expression and the reference line ranges are those of orl_device.h /
 // orl_device_g8.h; the parity suite runs every case against these paths and compares them with the monolithic one on
 // every env of full-size batches.
@@ -809,28 +810,63 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       // releases (3-4 on average for 8 envs at one release per env-step): the largest item of the phase profile.
       u32 rk = 0u;  // rank (1-based within this round) of this lane's list entry k, 6 bits each
       int n_round = 0;
-      for (;;) {
-        double bt = ct;
-        int bi = ci, bl = gl;
+      if (e.sr_on && __ballot(ndl > 1) == 0ull) {
+        // (the forms with registers to spare — soon list in registers, 3 waves per SIMD: in the 128-VGPR forms this path
+        // spills, cfg3 -9 %)  No lane of the wavefront holds more than one due entry (the usual case): every lane ranks its entry against the
+        // seven other lanes of its group directly — the partners i^1, i^2, i^3 (quad permutations), i^7 (half mirror) and
+        // the quad permutations of the mirrored value (i^6, i^5, i^4) — instead of one 8-lane minimum per release: ~100
+        // instructions whatever the number of releases, where the loop below costs ~70 per release of the busiest env.
+        // Each due entry's release time is cleared by the lane that scans its slot, which sees it either as its own or as
+        // exactly one partner's.
+        int r = 1;
+#define ORL_RANK_STEP(OT, OI) { const double ot_ = (OT); const int oi_ = (OI); \
+                                r += (ot_ < ct || (ot_ == ct && oi_ < ci)) ? 1 : 0; \
+                                if (ot_ < INF && gl == (oi_ & 7)) e.ev_time[oi_] = INF; }
+        ORL_RANK_STEP(dpp_d<ORL_DPP_XOR1>(ct), dpp_i<ORL_DPP_XOR1>(ci))
+        ORL_RANK_STEP(dpp_d<ORL_DPP_XOR2>(ct), dpp_i<ORL_DPP_XOR2>(ci))
+        ORL_RANK_STEP(dpp_d<ORL_DPP_XOR3>(ct), dpp_i<ORL_DPP_XOR3>(ci))
+        {
+          const double mt = dpp_d<ORL_DPP_HALF_MIRROR>(ct);  // lane i^7; its quad permutations are i^6, i^5, i^4
+          const int mi = dpp_i<ORL_DPP_HALF_MIRROR>(ci);
+          ORL_RANK_STEP(mt, mi)
+          ORL_RANK_STEP(dpp_d<ORL_DPP_XOR1>(mt), dpp_i<ORL_DPP_XOR1>(mi))
+          ORL_RANK_STEP(dpp_d<ORL_DPP_XOR2>(mt), dpp_i<ORL_DPP_XOR2>(mi))
+          ORL_RANK_STEP(dpp_d<ORL_DPP_XOR3>(mt), dpp_i<ORL_DPP_XOR3>(mi))
+        }
+#undef ORL_RANK_STEP
+        n_round = tot;
+        if (ndl == 1) {
+          if (gl == (ci & 7)) e.ev_time[ci] = INF;
+          rk = (u32)r << (6 * ck);
+          dirty |= 1 << ck;
+#pragma unroll
+          for (int k = 0; k < NS; k++)
+            if (k == ck) st[k] = INF;
+        }
+      } else {
+        for (;;) {
+          double bt = ct;
+          int bi = ci, bl = gl;
 #define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); int ol = dpp_i<CTRL>(bl); \
                              if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; bl = ol; } }
-        ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
+          ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
 #undef ORL_MIN_STEP
-        if (!(bt <= e.now)) break;
-        n_round++;
-        if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
-        if (gl == bl) {  // the holder notes the rank, drops the entry from its list and moves to its next due entry, if any (rare)
-          rk |= (u32)n_round << (6 * ck);
-          dirty |= 1 << ck;
-          ct = INF; ci = 0x7fffffff;
-          int nk = 0;
+          if (!(bt <= e.now)) break;
+          n_round++;
+          if (gl == (bi & 7)) e.ev_time[bi] = INF;  // written by the lane that scans this slot
+          if (gl == bl) {  // the holder notes the rank, drops the entry from its list and moves to its next due entry, if any (rare)
+            rk |= (u32)n_round << (6 * ck);
+            dirty |= 1 << ck;
+            ct = INF; ci = 0x7fffffff;
+            int nk = 0;
 #pragma unroll
-          for (int k = 0; k < NS; k++) {
-            if (k == ck) st[k] = INF;
-            const bool due = st[k] <= e.now;
-            if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
+            for (int k = 0; k < NS; k++) {
+              if (k == ck) st[k] = INF;
+              const bool due = st[k] <= e.now;
+              if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
+            }
+            ck = nk;
           }
-          ck = nk;
         }
       }
       ORL_PROF(6);
