@@ -133,8 +133,18 @@ SPEC_DIR = os.path.join(HERE, "build", "spec")
 def spec_path(flags):
     """Where the specialisation library for these flags (orl_batch_spec_flags) lives: keyed by the flags, the sources and the
     compiler, so a stale one is never picked up."""
-    key = hashlib.sha256((flags + "|" + source_hash()).encode()).hexdigest()[:20]
-    return os.path.join(SPEC_DIR, "liborlspec_%s.so" % key)
+    src = source_hash()
+    key = hashlib.sha256((flags + "|" + src).encode()).hexdigest()[:20]
+    return os.path.join(SPEC_DIR, "liborlspec_%s_%s.so" % (src[:8], key))
+
+
+def prune_specs():
+    """Drop the cached specialisations of other source states (they can never be loaded again)."""
+    keep = "liborlspec_%s_" % source_hash()[:8]
+    if os.path.isdir(SPEC_DIR):
+        for f in os.listdir(SPEC_DIR):
+            if f.startswith("liborlspec_") and not f.startswith(keep):
+                os.unlink(os.path.join(SPEC_DIR, f))
 
 
 def build_spec(flags, verbose=False):

@@ -46,6 +46,8 @@ def _lib(omp=False):
     key = bool(omp)
     if key not in _LIBS:
         so = build()
+        if os.environ.get("ORL_ORACLE_SO") and not omp:  # e.g. the -fsanitize build of tools/sanitize_oracle.sh
+            so = os.environ["ORL_ORACLE_SO"]
         if omp:
             so = so.replace("liborloracle.so", "liborloracle_omp.so")
         lib = C.CDLL(so)
