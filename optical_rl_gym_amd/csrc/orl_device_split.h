@@ -972,8 +972,17 @@ __device__ __forceinline__ void rel_serial(const DevParams& P, i64 env, int lane
   if (P.pipeline2) e.rs = e.cs + 2 * P.C;  // two-kernel pipeline: the next step needs what releases added
   g8::release_due<ENV, W>(P, e, lane);
   e.t_soon = -__builtin_inf();  // released in place: the soon list is stale
-  if (gl == 0) s[SC_ACC] = s[SC_ACC] & ~(1ull << 16);
-  g8::env_store(P, e, gl);
+  if (gl == 0) {
+    // only what releases change goes back (the whole record, as env_store writes it, kept every word of it live through
+    // release_due: the spills of the 128-VGPR forms sat here)
+    s[SC_ACC] = s[SC_ACC] & ~(1ull << 16);
+    s[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
+    s[SC_TSOON] = (u64)__double_as_longlong(e.t_soon);
+    s[SC_SBR] = (u64)e.s_br;
+    s[SC_SNH] = (u64)e.s_nh;
+    s[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
+    s[SC_HINT] = pack2(e.nfree, 0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

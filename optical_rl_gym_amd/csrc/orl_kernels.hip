@@ -635,30 +635,46 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   if constexpr (LINK_INFO) {
     if (valid) {
       // np.mean over the links in topology.edges() order (numpy pairwise sum, optical_rl_gym_amd/csrc/orl_device.h link_mean):
-      // lane j of the group accumulates x[j], x[8 + j], ...; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); the tail one by one
+      // lane j of the group accumulates x[j], x[8 + j], ...; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); the tail one by one.
+      // Every round's link indices are requested together, then the values of all of them (the loop that fetched index and
+      // value entry by entry cost NSFNET's 22 links sixteen dependent memory round trips at the end of every wavefront).
       const int E = P.E;
       const double* ls = P.lstat + env * 4 * E;
       const double* st = s_stash + 2 * E * el;
-      auto value = [&](int i, double& u, double& c) {
-        const int link = P.edge_iter_order[i];
+      auto value = [&](int link, double& u, double& c) {
         bool rel = false;  // a release of this step touched the link: the values from before it
         if constexpr (CP) rel = (s_tab[E * el + link].bits >> 1) != 0u;
-        u = rel ? st[2 * link] : ls[4 * link];
-        c = rel ? st[2 * link + 1] : ls[4 * link + 2];
+        const double gu = ls[4 * link], gc = ls[4 * link + 2], lu = st[2 * link], lc = st[2 * link + 1];
+        u = rel ? lu : gu;
+        c = rel ? lc : gc;
       };
-      double su = 0.0, sc = 0.0;
-      if (E < 8) {
-        for (int i = 0; i < E; i++) { double u, c; value(i, u, c); su += u; sc += c; }
-      } else {
-        double u, c;
-        value(gl, su, sc);
-        int i;
-        for (i = 8; i < E - (E % 8); i += 8) { value(i + gl, u, c); su += u; sc += c; }
+      const int nfull = (E < 8) ? 0 : E - (E % 8), ntail = E - nfull;
+      const int tl = (gl < ntail) ? P.edge_iter_order[nfull + gl] : 0;  // lane t holds tail entry t
+      double su = 0.0, sc = 0.0, tu = 0.0, tc = 0.0;
+      for (int b = 0; b < nfull; b += 32) {
+        int lk[4];
+        double uu[4], cc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) lk[k] = (b + 8 * k < nfull) ? P.edge_iter_order[b + 8 * k + gl] : 0;
+        if (b == 0 && gl < ntail) value(tl, tu, tc);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { uu[k] = 0.0; cc[k] = 0.0; if (b + 8 * k < nfull) value(lk[k], uu[k], cc[k]); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (b + 8 * k < nfull) {
+            if (b == 0 && k == 0) { su = uu[0]; sc = cc[0]; } else { su += uu[k]; sc += cc[k]; }
+          }
+        }
+      }
+      if (nfull == 0 && gl < ntail) value(tl, tu, tc);
+      if (nfull > 0) {
         su += dpp_d<ORL_DPP_XOR1>(su); sc += dpp_d<ORL_DPP_XOR1>(sc);
         su += dpp_d<ORL_DPP_XOR2>(su); sc += dpp_d<ORL_DPP_XOR2>(sc);
         su += dpp_d<ORL_DPP_HALF_MIRROR>(su); sc += dpp_d<ORL_DPP_HALF_MIRROR>(sc);
-        for (; i < E; i++) { value(i, u, c); su += u; sc += c; }
       }
+#pragma unroll
+      for (int t = 0; t < 7; t++)
+        if (t < ntail) { su += g8::gget(tu, t, lane); sc += g8::gget(tc, t, lane); }
       mean_util = su / (double)E;
       mean_comp = sc / (double)E;
     }
