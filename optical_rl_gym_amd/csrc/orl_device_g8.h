@@ -50,6 +50,7 @@ struct EnvG {
   u32* soon_i;
   // persistent kernel: this lane's soon-list entries (gl + 8k) live in registers for the whole launch
   bool sr_on;
+  bool rank_pairs;  // release_soon: rank the due releases all-pairs (the forms with registers to spare)
   double sr_t[ORL_SOON_PER_LANE];
   int sr_i[ORL_SOON_PER_LANE];
   u32* mt;
@@ -92,6 +93,7 @@ __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env, u
   e.soon_t = P.soon_t + env * ORL_SOON;
   e.soon_i = P.soon_i + env * ORL_SOON;
   e.sr_on = false;
+  e.rank_pairs = false;
   e.mt = P.mt + env * 624;
 }
 __device__ __forceinline__ void env_load(const DevParams& P, EnvG& e, i64 env) { env_load(P, e, env, P.scal + env * ORL_SCAL_WORDS); }

@@ -251,6 +251,7 @@ struct CtrlOpts {
   bool emit_queue;  // two-kernel form: copy the items into the global queue for the row kernel
   bool prefetch;    // request the Mersenne-Twister window at the start of the phase (costs registers: 3-wave forms only)
   bool auto_reset;  // an env that reports done is soft-reset right away (the device-resident loop, SB3's VecEnv); k_agent: the caller's choice
+  bool rank_pairs;  // (soon list in registers) rank the due releases all-pairs over DPP: needs the 168-VGPR budget
 };
 template <int ENV, int W, bool CP>
 __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
@@ -304,6 +305,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     // the Mersenne-Twister window the next service draws from: requested now, used after the provision
     if (carried) {  // persistent kernel: the soon list stays in registers from step to step
       e.sr_on = true;
+      e.rank_pairs = O.rank_pairs;
 #pragma unroll
       for (int k = 0; k < ORL_SOON_PER_LANE; k++) { e.sr_t[k] = carried->t[k]; e.sr_i[k] = carried->i[k]; }
     }
@@ -810,7 +812,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       // releases (3-4 on average for 8 envs at one release per env-step): the largest item of the phase profile.
       u32 rk = 0u;  // rank (1-based within this round) of this lane's list entry k, 6 bits each
       int n_round = 0;
-      if (e.sr_on && __ballot(ndl > 1) == 0ull) {
+      if (e.rank_pairs && __ballot(ndl > 1) == 0ull) {
         // (the forms with registers to spare — soon list in registers, 3 waves per SIMD: in the 128-VGPR forms this path
         // spills, cfg3 -9 %)  No lane of the wavefront holds more than one due entry (the usual case): every lane ranks its entry against the
         // seven other lanes of its group directly — the partners i^1, i^2, i^3 (quad permutations), i^7 (half mirror) and

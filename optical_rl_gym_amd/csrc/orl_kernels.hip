@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_step_a2(DevParams P, int pol, int parit
   sp::Prof prof;
   const sp::Wmem M = sp::wmem_global(P);
   sp::CtrlOpts O;
-  O.persistent = false; O.write_io = true; O.trusted = false; O.emit_queue = true; O.prefetch = false; O.auto_reset = true;
+  O.persistent = false; O.write_io = true; O.trusted = false; O.emit_queue = true; O.prefetch = false; O.auto_reset = true; O.rank_pairs = false;
   ORL_PROFA_BEGIN();
   if (FUSED_POLICY) {
     const i64 env0 = env - ((lane >> 3));  // first env of this wavefront
@@ -460,6 +460,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     O.emit_queue = false;
     O.prefetch = PF;
     O.auto_reset = true;
+    O.rank_pairs = SR;
     int done_i = 0;
     {
       int a[4];
@@ -610,10 +611,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   if (threadIdx.x == 0) s_deferred[0] = 0;
   sp::CtrlOpts O;
   O.persistent = true; O.write_io = true; O.trusted = false; O.emit_queue = false; O.prefetch = true; O.auto_reset = auto_reset != 0;
+  O.rank_pairs = false;
   int done_i = 0;
   sp::InfoCarry ic;
   ic.prev_comp = 1.0; ic.s_nh_prov = 0;
-  sp::ctrl_a<ENV, W, CP>(P, M, O, env, valid, lane, prof, nullptr, s_tally, s_tab, 0, s_deferred, &done_i, s_list, s_list_n, L.tw, nullptr, s_mtab, &ic);
+  // (the env's soon list requested with its record and kept in registers through the control phase, as the 3-wave forms of
+  // k_persist do — two dependent memory round trips less, but at 128 VGPRs it costs more than it saves: cfg2 86 -> 101 us
+  // per launch, cfg1 the same; DeepRMSA / RMCSA spill with it.  Off.)
+  constexpr bool SOONR = false;
+  sp::SoonRegs soon_c;
+  soon_c.dirty = 0;
+  if constexpr (SOONR) {
+#pragma unroll
+    for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+      soon_c.t[k] = valid ? P.soon_t[env * ORL_SOON + gl + 8 * k] : __builtin_inf();
+      soon_c.i[k] = valid ? (int)P.soon_i[env * ORL_SOON + gl + 8 * k] : 0;
+    }
+  }
+  sp::ctrl_a<ENV, W, CP>(P, M, O, env, valid, lane, prof, nullptr, s_tally, s_tab, 0, s_deferred, &done_i, s_list, s_list_n, L.tw,
+                         SOONR ? &soon_c : nullptr, s_mtab, &ic);
+  if constexpr (SOONR) {
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+        P.soon_t[env * ORL_SOON + gl + 8 * k] = soon_c.t[k];
+        P.soon_i[env * ORL_SOON + gl + 8 * k] = (u32)soon_c.i[k];
+      }
+    }
+  }
   __syncthreads();  // sink table + item list, clocks
   {
     const int n_items = (int)*s_list_n;
