@@ -1279,3 +1279,56 @@ def test_qos_batches_match_oracle_and_run_equals_stepping():
         with pytest.raises(IndexError):
             dev.step(np.full((n, 1), 6))
         dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_nodes,chords", [(5, 0), (6, 2), (4, 2)])  # 5, 8 and 6 links: fewer than a group's 8 lanes, exactly 8, a tail of 6
+@pytest.mark.parametrize("fam", ["RMSA", "DeepRMSA", "RWA"])
+def test_tiny_topologies_through_every_step_form(n_nodes, chords, fam, impl, tmp_path):
+    """Rings of 4-6 nodes (with chords): the link loops of every kernel — numpy's pairwise mean over the links in info (8-lane
+    partial sums only from 8 links on, then a tail), the cumulative tables of random.choices with 3-5 entries, the row phase
+    with fewer links than lanes — against the oracle, for host-driven steps (info, reward, done, observation) and a
+    device-resident run, in every step implementation."""
+    import optical_rl_gym_amd as orl
+    from optical_rl_gym_amd.topology_io import build_topology, save_topology
+    from oracle.oracle import OracleBatch
+
+    links = [(i + 1, (i + 1) % n_nodes + 1, 400 + 150 * i) for i in range(n_nodes)]
+    links += [(1 + c, 1 + (c + 2) % n_nodes, 900 + 100 * c) for c in range(chords)]
+    raw = tmp_path / "ring.txt"
+    raw.write_text("# ring\n%d\n%d\n%s\n" % (n_nodes, len(links), "\n".join("%d %d %d" % l for l in links)))
+    npz = str(tmp_path / "ring_5-paths_6-modulations.npz")
+    save_topology(build_topology(str(raw), name="ring", k_paths=3), npz)
+    kw = dict(episode_length=25, mean_service_holding_time=8.0)
+    if fam == "DeepRMSA":
+        kw.update(mean_service_inter_arrival_time=0.25, j=2, num_spectrum_resources=64)
+    elif fam == "RWA":
+        kw.update(load=20, num_spectrum_resources=16, allow_rejection=True)
+    else:
+        kw.update(load=60, num_spectrum_resources=70, allow_rejection=True)
+    policy = "SAP" if fam == "DeepRMSA" else "SAP_FF"
+    B = 24
+    seeds = [77 + i for i in range(B)]
+    dev = orl.make(fam, topology=npz, num_envs=B, seeds=seeds, **kw)
+    ora = OracleBatch(fam, npz, seeds, **kw)
+    chk = _exact("ring %d+%d %s %s" % (n_nodes, chords, fam, impl))
+    for t in range(60):
+        a = ora.policy(policy)
+        chk(t, "policy", dev.policy(policy), a)
+        o1, r1, d1, i1 = dev.step(a, auto_reset=True)
+        o2, r2, d2, i2 = ora.step(a, auto_reset=True)
+        chk(t, "reward", r1, r2)
+        chk(t, "done", d1, d2)
+        chk(t, "info", i1, i2)
+        if dev.obs_dim:
+            chk(t, "obs", dev.observation(), ora.observation())
+    dev.run(policy, 150)
+    ora.run(policy, 150)
+    chk(0, "counters", dev.counters(), ora.counters())
+    chk(0, "services", dev.services(), ora.services())
+    for i in range(B):
+        chk(i, "slots", dev.slots(i), ora.slots(i))
+        chk(i, "link_stats", dev.link_stats(i), ora.link_stats(i))
+        chk(i, "net_stats", dev.net_stats(i), ora.net_stats(i))
+    dev.check()
+    dev.close()
