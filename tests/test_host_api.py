@@ -371,3 +371,62 @@ def test_qos_constrained_ra_front_end():
     assert np.array_equal(env.topology.graph["available_spectrum"], g["spectrum"][299])
     with pytest.raises(IndexError):
         env.step(6)
+
+
+def test_spaces_are_built_with_gymnasiums_signatures(monkeypatch):
+    """With gymnasium (or gym) importable, make_spaces / OpticalVecEnv build THEIR space classes.  Neither is installed in the
+    build image, so a stand-in `gymnasium.spaces` whose constructors accept exactly gymnasium's parameters (Box(low, high,
+    shape, dtype), Discrete(n), MultiDiscrete(nvec), Dict(spaces)) and validate them as gymnasium does is put on sys.modules:
+    the calls of every env family and of the matrix observation must be well-formed for it."""
+    import sys
+    import types
+    from optical_rl_gym_amd import vec_env
+
+    made = []
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32, seed=None):
+            assert shape is not None and all(int(s) > 0 for s in shape) and np.dtype(dtype).kind in "fiu"
+            assert np.all(np.asarray(low) <= np.asarray(high))
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(int(s) for s in shape), np.dtype(dtype)
+            made.append(self)
+
+    class Discrete:
+        def __init__(self, n, seed=None, start=0):
+            assert isinstance(n, (int, np.integer)) and n > 0
+            self.n = int(n)
+            made.append(self)
+
+    class MultiDiscrete:
+        def __init__(self, nvec, dtype=np.int64, seed=None, start=None):
+            self.nvec = np.asarray(nvec, dtype)
+            assert self.nvec.ndim == 1 and (self.nvec > 0).all()
+            made.append(self)
+
+    class Dict:
+        def __init__(self, spaces=None, seed=None, **kw):
+            assert isinstance(spaces, dict) and all(isinstance(k, str) for k in spaces)
+            self.spaces = spaces
+            made.append(self)
+
+    fake = types.ModuleType("gymnasium")
+    fake.spaces = types.ModuleType("gymnasium.spaces")
+    for c in (Box, Discrete, MultiDiscrete, Dict):
+        setattr(fake.spaces, c.__name__, c)
+    monkeypatch.setitem(sys.modules, "gymnasium", fake)
+    monkeypatch.setitem(sys.modules, "gymnasium.spaces", fake.spaces)
+    assert vec_env._space_module() is fake.spaces
+    cases = [("RMSA", {}), ("RWA", {}), ("DeepRMSA", dict(j=2)), ("RMCSA", dict(num_spatial_resources=7)),
+             ("QoSConstrainedRA", dict(num_service_classes=1, classes_arrival_probabilities=[1.0], classes_reward=[1.0]))]
+    for fam, extra in cases:
+        kw = dict(load=50, mean_service_holding_time=10)
+        if fam == "DeepRMSA":
+            kw = dict(mean_service_holding_time=7.5)
+        b = OracleBackend(fam, "nsfnet_chen", [1, 2], **kw, **extra)
+        obs, act = vec_env.make_spaces(b, np.float32)
+        assert type(act) in (Discrete, MultiDiscrete) and type(obs) in (Box, Dict)
+        if fam == "DeepRMSA":
+            assert obs.shape == (b.obs_dim,) and obs.dtype == np.float32 and act.n == b.k_paths * b.j + (1 if b.allow_rejection else 0)
+    v = vec_env.OpticalVecEnv(OracleBackend("RMSA", "nsfnet_chen", [1, 2], load=50, mean_service_holding_time=10), observation="matrix")
+    assert type(v.observation_space) is Box and v.observation_space.dtype == np.uint8
+    assert type(v.action_space) is MultiDiscrete and list(v.action_space.nvec) == [6, 101]
