@@ -429,4 +429,4 @@ def test_spaces_are_built_with_gymnasiums_signatures(monkeypatch):
             assert obs.shape == (b.obs_dim,) and obs.dtype == np.float32 and act.n == b.k_paths * b.j + (1 if b.allow_rejection else 0)
     v = vec_env.OpticalVecEnv(OracleBackend("RMSA", "nsfnet_chen", [1, 2], load=50, mean_service_holding_time=10), observation="matrix")
     assert type(v.observation_space) is Box and v.observation_space.dtype == np.uint8
-    assert type(v.action_space) is MultiDiscrete and list(v.action_space.nvec) == [6, 101]
+    assert type(v.action_space) is MultiDiscrete and list(v.action_space.nvec) == [5, 100]
