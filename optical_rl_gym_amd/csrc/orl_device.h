@@ -58,6 +58,10 @@ enum {
   SC_COUNT
 };
 #define ORL_SCAL_WORDS 32
+// the records of a wavefront's 8 envs in its LDS window lie 34 words apart: at 32 (256 bytes = 64 banks' worth) word k of all
+// eight records falls into the same bank, and every record load / store of the control phase — ~44 LDS instructions per step,
+// 8 lanes per env on the same word — was an 8-way bank conflict
+#define ORL_SCAL_LDS_WORDS 34
 #define ORL_FREE_SLOTS 16
 #define ORL_IMASKS 8  // masks one work item can carry = releases of one step that may meet on one link (orl_device_split.h)
 #define ORL_FLAG_EV_OVERFLOW 1

@@ -223,7 +223,8 @@ struct Wmem {
   i64 env0;      // index base of bm0
   i64 senv0;     // index base of ls0
   i64 cenv0;     // index base of cs0
-  u64* sc0;      // [..][ORL_SCAL_WORDS] env records
+  u64* sc0;      // [..][sc_stride] env records
+  int sc_stride; // words between two records: ORL_SCAL_WORDS in global memory, ORL_SCAL_LDS_WORDS in the LDS window
   i64 scenv0;    // index base of sc0
   int cs_stride; // ints per env in cs0
   u32* ic0;      // LDS [8][E]: per link row, the longest free run strictly inside each 64-slot word (6 bits per word, 63 =
@@ -236,12 +237,12 @@ struct Wmem {
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.sc_stride = ORL_SCAL_WORDS; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
 __device__ __forceinline__ double* wm_ls(const DevParams& P, const Wmem& m, i64 env) { return m.ls0 + (env - m.senv0) * 4 * P.E; }
-__device__ __forceinline__ u64* wm_scal(const DevParams& P, const Wmem& m, i64 env) { return m.sc0 + (env - m.scenv0) * ORL_SCAL_WORDS; }
+__device__ __forceinline__ u64* wm_scal(const DevParams& P, const Wmem& m, i64 env) { return m.sc0 + (env - m.scenv0) * m.sc_stride; }
 __device__ __forceinline__ int* wm_cs(const DevParams& P, const Wmem& m, i64 env) { return m.cs0 + (env - m.cenv0) * m.cs_stride; }
 
 struct CtrlOpts {

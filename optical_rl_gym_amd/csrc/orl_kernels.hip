@@ -248,7 +248,7 @@ __host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_wo
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
   L.csw = (4 * C + 3) & ~3;  // sums + their release part, ints per env
   L.cs = o; if (state >= 1) o += 8 * L.csw * 4;
-  L.sc = o; if (state == 1 || state == 2) o += 8 * ORL_SCAL_WORDS * 8;
+  L.sc = o; if (state == 1 || state == 2) o += 8 * ORL_SCAL_LDS_WORDS * 8;
   L.ic = o; if (state >= 1 && inner) o += inner * ((8 * E * 4 + 15) & ~15);
   L.ls = o; if (state == 2) o += 8 * E * 32;
   L.total = o;
@@ -304,8 +304,9 @@ __device__ __forceinline__ void persist_fill_window(const DevParams& P, i64 env0
     if (i0 + 448 < n_bm) l_bm[i0 + 448] = b7;
     if (base == 0) {
       if (REC) {
-        if (lane < n_rec) l_rec[lane] = r0;
-        if (lane + 64 < n_rec) l_rec[lane + 64] = r1;
+        // (16 pieces of 16 bytes per record, records ORL_SCAL_LDS_WORDS apart)
+        if (lane < n_rec) l_rec[(lane >> 4) * (ORL_SCAL_LDS_WORDS / 2) + (lane & 15)] = r0;
+        if (lane + 64 < n_rec) l_rec[((lane + 64) >> 4) * (ORL_SCAL_LDS_WORDS / 2) + (lane & 15)] = r1;
       }
       if (lane < nenv * q) l_cs[lane] = vc;
       for (int i = lane + 64; i < nenv * q; i += 64)  // (more than 8 cores: the rest of the sums)
@@ -376,6 +377,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if (REC) {
       M.sc0 = (u64*)(orl_lds_raw + L.sc);
       M.scenv0 = env0;
+      M.sc_stride = ORL_SCAL_LDS_WORDS;
     }
 #define ORL_FILL_WINDOW() persist_fill_window<REC>(P, env0, nenv, lane, orl_lds_raw + L.bm, orl_lds_raw + L.sc, orl_lds_raw + L.cs, L.csw / 4)
     if (step < target) ORL_FILL_WINDOW();
@@ -506,7 +508,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if (REC) {
       ulonglong2* gr = (ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
       const ulonglong2* lr = (const ulonglong2*)M.sc0;
-      for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) gr[i] = lr[i];
+      for (int i = lane; i < nenv * (ORL_SCAL_WORDS / 2); i += 64) gr[i] = lr[(i >> 4) * (ORL_SCAL_LDS_WORDS / 2) + (i & 15)];
     }
   }
   if (LDS == 2 && step > first_step) {
