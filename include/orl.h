@@ -193,6 +193,11 @@ int orl_batch_observation(orl_batch* b, double* obs_out);
  * to float32 ON THE DEVICE and copied out — half the PCIe bytes and no conversion pass on the host for agents that work in
  * float32 (SB3's default); the float64 values stay the parity-checked ones.  obs_out: [n_envs][obs_dim] float. */
 int orl_batch_get_obs_f32(orl_batch* b, float* obs_out);
+/* Rows env_index[0..n) of the info array the last orl_batch_step left on the device (ORL_BUF_INFO), gathered on the device and
+ * copied out: info_out [n][info_dim] double.  What a VecEnv needs of info is the rows of the envs that just finished an episode
+ * (SB3 reads `info["episode"]` there and nothing elsewhere, DeepRMSA.ipynb:272-302 with Monitor's info_keywords): a handful of
+ * rows instead of the whole [n_envs][info_dim] array (4 MB per step at 65 536 RMSA envs) over PCIe.  Synchronous. */
+int orl_batch_get_info_rows(orl_batch* b, const int64_t* env_index, int64_t n, double* info_out);
 
 /* n_steps x { policy ; step(auto_reset) } entirely on the device (the loop of utils.evaluate_heuristic,
  * utils.py:113-128, with VecEnv-style auto reset).  time_kernels: 0 = production run (the persistent kernel where it

@@ -177,6 +177,12 @@ __global__ void k_cast_f32(const double* __restrict__ src, float* __restrict__ d
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = (float)src[i];
 }
 
+// rows idx[0..n) of a [B][w] array -> out[n][w] (orl_batch_get_info_rows)
+__global__ void k_gather_rows(const double* __restrict__ src, const long long* __restrict__ idx, i64 n, int w, double* __restrict__ out) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * w) out[i] = src[idx[i / w] * w + (i % w)];
+}
+
 // sums of services_processed / services_accepted over the batch (two atomics per wave)
 __global__ void k_totals(DevParams P, unsigned long long* out) {
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -924,6 +930,34 @@ extern "C" int orl_batch_get_obs_f32(orl_batch* b, float* obs_out) try {
   }
   hipLaunchKernelGGL(k_cast_f32, dim3(2048), dim3(256), 0, b->stream, b->P.obs, b->obs_f32, n);
   HIPCHK(hipMemcpyAsync(obs_out, b->obs_f32, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+
+extern "C" int orl_batch_get_info_rows(orl_batch* b, const int64_t* env_index, int64_t n, double* info_out) try {
+  if (!b || n < 0 || (n > 0 && (!env_index || !info_out))) return fail(ORL_E_INVALID, "bad argument");
+  if (n == 0) return ORL_OK;
+  if (n > b->P.B) return fail(ORL_E_INVALID, "more rows than envs");
+  for (int64_t i = 0; i < n; i++)
+    if (env_index[i] < 0 || env_index[i] >= b->P.B) return fail(ORL_E_INVALID, "env index %lld out of range", (long long)env_index[i]);
+  HIPCHK(hipSetDevice(b->device));
+  const int w = b->P.n_info;
+  if (n > b->gather_cap) {
+    int64_t cap = b->gather_cap > 0 ? b->gather_cap : 1024;
+    while (cap < n) cap *= 2;
+    if (cap > b->P.B) cap = b->P.B;
+    HIPCHK(hipMalloc((void**)&b->gather_idx, (size_t)cap * sizeof(long long) + 64));
+    b->allocs.push_back(b->gather_idx);
+    HIPCHK(hipMalloc((void**)&b->gather_out, (size_t)cap * w * sizeof(double) + 64));
+    b->allocs.push_back(b->gather_out);
+    b->gather_cap = cap;
+  }
+  HIPCHK(hipMemcpyAsync(b->gather_idx, env_index, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, b->stream));
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n * w + 255) / 256)), dim3(256), 0, b->stream, (const double*)b->P.info,
+                     (const long long*)b->gather_idx, (i64)n, w, b->gather_out);
+  HIPCHK(hipMemcpyAsync(info_out, b->gather_out, (size_t)n * w * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   return ORL_OK;

@@ -57,6 +57,9 @@ struct orl_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_totals = nullptr;
   unsigned int* h_tail = nullptr;  // page-locked: where the straggler count / flag words of a run land (a pageable target is staged)
+  long long* gather_idx = nullptr;  // orl_batch_get_info_rows: row indices and gathered rows on the device, grown on demand
+  double* gather_out = nullptr;
+  int64_t gather_cap = 0;
   float* obs_f32 = nullptr;        // device copy of the observation array in float32 (orl_batch_get_obs_f32), allocated on first use
   int* ep_buf = nullptr;           // episode log buffer (orl_batch_episode_log): [B][ep_alloc] ints, armed with stride P.ep_cap <= ep_alloc
   int ep_alloc = 0;

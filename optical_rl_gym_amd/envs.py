@@ -309,12 +309,13 @@ class BatchedOpticalEnv:
         self._ck(self.lib.orl_batch_policy(self._h, pid, self._act.ctypes.data if fetch else None))
         return self._act if fetch else None
 
-    def step(self, actions, auto_reset=False, fetch=True, obs_out=None):
+    def step(self, actions, auto_reset=False, fetch=True, obs_out=None, fetch_info=True):
         """actions: [num_envs, n_action] ints, or None to use the device-resident result of policy(fetch=False).
         Returns (obs, reward, done, info) arrays; info is [num_envs, n_info] in `info_keys` order.  The arrays are this
         object's page-locked staging buffers, overwritten by the next step.  `obs_out`: a caller-owned [num_envs, obs_dim]
         float64 or float32 array (ideally from `host_array`) that receives the observation instead — float32 is cast on the
-        device (half the PCIe bytes, no host pass)."""
+        device (half the PCIe bytes, no host pass).  `fetch_info=False`: info stays on the device (None is returned for it);
+        `info_rows(indices)` reads the rows that are needed afterwards."""
         a = None
         if actions is not None:
             actions = np.asarray(actions)
@@ -328,14 +329,23 @@ class BatchedOpticalEnv:
                 assert obs_out.shape == (self.num_envs, self.obs_dim) and obs_out.flags.c_contiguous
                 obs = obs_out if obs_out.dtype == np.float64 else None
             self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), _ptr(obs), self._reward.ctypes.data,
-                                               self._done.ctypes.data, self._info.ctypes.data))
+                                               self._done.ctypes.data, self._info.ctypes.data if fetch_info else None))
             if obs is None and self.obs_dim:
                 assert obs_out.dtype == np.float32
                 self._ck(self.lib.orl_batch_get_obs_f32(self._h, obs_out.ctypes.data))
                 obs = obs_out
-            return obs, self._reward, self._done, self._info
+            return obs, self._reward, self._done, (self._info if fetch_info else None)
         self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), None, None, None, None))
         return None
+
+    def info_rows(self, indices):
+        """Rows `indices` of the info array the last step left on the device: [len(indices), n_info] float64 (gathered on the
+        device; a VecEnv needs the rows of the envs that just finished an episode, not 4 MB of info per step)."""
+        idx = np.ascontiguousarray(indices, np.int64)
+        out = np.empty((len(idx), self.n_info), np.float64)
+        if len(idx):
+            self._ck(self.lib.orl_batch_get_info_rows(self._h, idx.ctypes.data, len(idx), out.ctypes.data))
+        return out
 
     def run(self, policy, n_steps, time_kernels=False):
         """n_steps x (policy; step with auto reset) without leaving the device; returns RunStats."""

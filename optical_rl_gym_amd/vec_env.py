@@ -82,6 +82,8 @@ class OpticalVecEnv:
         import inspect
 
         self._direct_obs = "obs_out" in inspect.signature(batch.step).parameters
+        # (... and leave info on the device, handing out the rows of the envs that finished an episode)
+        self._sparse_info = "fetch_info" in inspect.signature(batch.step).parameters and hasattr(batch, "info_rows")
         self._ep_ret = np.zeros(self.num_envs)
         self._ep_len = np.zeros(self.num_envs, np.int64)
         self._t0 = time.time()
@@ -110,21 +112,26 @@ class OpticalVecEnv:
     def step_wait(self):
         direct = (self.observation_mode != "matrix" and getattr(self.batch, "obs_dim", 0)
                   and self.obs_dtype in (np.dtype(np.float64), np.dtype(np.float32)) and self._direct_obs)
+        kw = dict(fetch_info=False) if self._sparse_info else {}
         if direct:
-            obs, reward, done, info = self.batch.step(self._actions, auto_reset=True, obs_out=self._next_obs_buffer())
+            obs, reward, done, info = self.batch.step(self._actions, auto_reset=True, obs_out=self._next_obs_buffer(), **kw)
         else:
-            obs, reward, done, info = self.batch.step(self._actions, auto_reset=True)
+            obs, reward, done, info = self.batch.step(self._actions, auto_reset=True, **kw)
             obs = self._obs(obs)
         self._ep_ret += reward
         self._ep_len += 1
+        finished = np.flatnonzero(done)
+        if self._sparse_info:  # info stayed on the device: the rows of the envs that report done (row i of `rows` = finished[i])
+            rows = self.batch.info_rows(finished)
+            info = None
         # SB3 wants one dict per env and only ever READS the ones of envs that did not finish an episode: those share one empty
         # dict (65 536 fresh dicts per step cost ten times the step itself); an env that reports done gets a dict of its own
         infos = [_NO_INFO] * self.num_envs
-        for i in np.flatnonzero(done):
+        for n_, i in enumerate(finished):
             infos[i] = {}
             row = dict(r=float(self._ep_ret[i]), l=int(self._ep_len[i]), t=round(time.time() - self._t0, 6))
             for k, j in zip(self.info_keywords, self._kw_idx):
-                row[k] = float(info[i, j])
+                row[k] = float(rows[n_, j] if info is None else info[i, j])
             infos[i]["episode"] = row
             # the in-kernel reset is soft: the pending service (hence the observation) is unchanged by it
             infos[i]["terminal_observation"] = None if obs is None else np.array(obs[i])

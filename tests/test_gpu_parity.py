@@ -1332,3 +1332,41 @@ def test_tiny_topologies_through_every_step_form(n_nodes, chords, fam, impl, tmp
         chk(i, "net_stats", dev.net_stats(i), ora.net_stats(i))
     dev.check()
     dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fam,kw,policy", [("RMSA", dict(load=300, mean_service_holding_time=25, num_spectrum_resources=320), "SAP_FF"),
+                                            ("DeepRMSA", dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=0.1, j=1), "SAP")])
+def test_vecenv_sparse_info_equals_the_whole_info_array(fam, kw, policy):
+    """OpticalVecEnv leaves info on the device and reads the rows of the envs that finished an episode
+    (orl_batch_get_info_rows): the episode rows must be the ones the whole [n_envs][info_dim] array gives — same batch, same
+    seeds, stepped once through the VecEnv and once through step() with everything fetched — in both the k_agent range
+    (4 096 envs) and the one-wavefront-per-env range (300 envs); the row reader is also checked against the array directly."""
+    import optical_rl_gym_amd as orl
+
+    for B in (300, 4096):
+        seeds = [5 + i for i in range(B)]
+        a = orl.make(fam, topology="nsfnet_chen", num_envs=B, seeds=seeds, episode_length=9 + (B % 7), **kw)
+        b = orl.make(fam, topology="nsfnet_chen", num_envs=B, seeds=seeds, episode_length=9 + (B % 7), **kw)
+        venv = orl.OpticalVecEnv(a)
+        assert venv._sparse_info
+        venv.reset()
+        keys = venv.info_keywords
+        cols = [a.info_keys.index(k) for k in keys]
+        n_rows = 0
+        for t in range(30):
+            act = b.policy(policy).copy()
+            _, rew, done, infos = venv.step(act if fam != "DeepRMSA" else act[:, 0].copy())
+            _, r2, d2, i2 = b.step(act, auto_reset=True)
+            assert np.array_equal(rew, r2) and np.array_equal(done, d2.astype(bool))
+            for i in np.flatnonzero(d2):
+                n_rows += 1
+                assert [infos[i]["episode"][k] for k in keys] == [float(i2[i, j]) for j in cols]
+            pick = np.random.RandomState(t).randint(0, B, 17)
+            assert np.array_equal(b.info_rows(pick), i2[pick], equal_nan=True)
+            assert b.info_rows([]).shape == (0, b.n_info)
+        assert n_rows >= 2 * B
+        with pytest.raises(orl._lib.OrlError):
+            b.info_rows([B])
+        venv.close()
+        b.close()
