@@ -113,12 +113,50 @@ class MultiDeviceBatch:
         out = self._map(lambda r: self.shards[r].policy(policy, fetch=fetch, paths=self._cut(paths, r)))
         return self._cat(out) if fetch else None
 
-    def step(self, actions, auto_reset=False, fetch=True):
-        out = self._map(lambda r: self.shards[r].step(self._cut(actions, r), auto_reset=auto_reset, fetch=fetch))
+    def step(self, actions, auto_reset=False, fetch=True, obs_out=None, fetch_info=True):
+        """As a single batch's step().  `obs_out` (a caller-owned [num_envs, obs_dim] array: every shard writes its rows) and
+        `fetch_info=False` (info stays on the devices, `info_rows` reads what is needed) are handed to shards that take them —
+        the HIP batches — and emulated for others (the oracle stand-in of the CPU tests)."""
+        import inspect
+
+        def one(r):
+            sh = self.shards[r]
+            params = inspect.signature(sh.step).parameters
+            kw = {}
+            if fetch and obs_out is not None and "obs_out" in params:
+                kw["obs_out"] = obs_out[self.bounds[r]:self.bounds[r + 1]]
+            if fetch and not fetch_info and "fetch_info" in params:
+                kw["fetch_info"] = False
+            out = sh.step(self._cut(actions, r), auto_reset=auto_reset, fetch=fetch, **kw)
+            if fetch and obs_out is not None and "obs_out" not in kw and out[0] is not None:
+                obs_out[self.bounds[r]:self.bounds[r + 1]] = out[0]
+            return out
+
+        out = self._map(one)
         if not fetch:
             return None
-        self._info = self._cat([o[3] for o in out])
-        return self._cat([o[0] for o in out]), self._cat([o[1] for o in out]), self._cat([o[2] for o in out]), self._info
+        infos = [o[3] for o in out]
+        self._info_parts = infos  # (a shard that ignored fetch_info=False returned its array: info_rows reads from it)
+        self._info = None if any(i is None for i in infos) else self._cat(infos)
+        obs = obs_out if (obs_out is not None and getattr(self, "obs_dim", 0)) else self._cat([o[0] for o in out])
+        return obs, self._cat([o[1] for o in out]), self._cat([o[2] for o in out]), (self._info if fetch_info else None)
+
+    def info_rows(self, indices):
+        """Rows `indices` of the info arrays the last step left on the devices, in the order asked for."""
+        idx = np.asarray(indices, np.int64).reshape(-1)
+        out = np.empty((len(idx), self.n_info), np.float64)
+        owner = np.searchsorted(self.bounds, idx, side="right") - 1
+        for r in np.unique(owner):
+            sel = np.flatnonzero(owner == r)
+            local = idx[sel] - self.bounds[r]
+            part = getattr(self, "_info_parts", [None] * len(self.shards))[r]
+            out[sel] = part[local] if part is not None else self.shards[r].info_rows(local)
+        return out
+
+    def host_array(self, shape, dtype):
+        """Page-locked host memory when the shards offer it (copies from every device then run at the full PCIe rate)."""
+        first = self.shards[0]
+        return first.host_array(shape, dtype) if hasattr(first, "host_array") else np.zeros(shape, dtype)
 
     def run(self, policy, n_steps, time_kernels=False):
         """Every shard runs its own device-resident loop concurrently.  Returns ONE stats object with the fields of a single

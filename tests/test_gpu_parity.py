@@ -1351,17 +1351,27 @@ def test_vecenv_sparse_info_equals_the_whole_info_array(fam, kw, policy):
         venv = orl.OpticalVecEnv(a)
         assert venv._sparse_info
         venv.reset()
+        # ... and the same through two shards behind one VecEnv (both on device 0 here): obs_out slices, per-shard info rows
+        m = orl.make(fam, topology="nsfnet_chen", num_envs=B, seeds=seeds, episode_length=9 + (B % 7), device_ids=[0, 0], **kw)
+        mvenv = orl.OpticalVecEnv(m, obs_dtype=np.float32)
+        assert mvenv._sparse_info and mvenv._direct_obs
+        mvenv.reset()
         keys = venv.info_keywords
         cols = [a.info_keys.index(k) for k in keys]
         n_rows = 0
         for t in range(30):
             act = b.policy(policy).copy()
-            _, rew, done, infos = venv.step(act if fam != "DeepRMSA" else act[:, 0].copy())
+            o1, rew, done, infos = venv.step(act if fam != "DeepRMSA" else act[:, 0].copy())
+            o3, r3, d3, infos3 = mvenv.step(act if fam != "DeepRMSA" else act[:, 0].copy())
             _, r2, d2, i2 = b.step(act, auto_reset=True)
             assert np.array_equal(rew, r2) and np.array_equal(done, d2.astype(bool))
+            assert np.array_equal(r3, r2) and np.array_equal(d3, d2.astype(bool))
+            if o1 is not None:
+                assert o3.dtype == np.float32 and np.array_equal(o3, o1.astype(np.float32))
             for i in np.flatnonzero(d2):
                 n_rows += 1
                 assert [infos[i]["episode"][k] for k in keys] == [float(i2[i, j]) for j in cols]
+                assert [infos3[i]["episode"][k] for k in keys] == [float(i2[i, j]) for j in cols]
             pick = np.random.RandomState(t).randint(0, B, 17)
             assert np.array_equal(b.info_rows(pick), i2[pick], equal_nan=True)
             assert b.info_rows([]).shape == (0, b.n_info)
@@ -1369,4 +1379,5 @@ def test_vecenv_sparse_info_equals_the_whole_info_array(fam, kw, policy):
         with pytest.raises(orl._lib.OrlError):
             b.info_rows([B])
         venv.close()
+        mvenv.close()
         b.close()
