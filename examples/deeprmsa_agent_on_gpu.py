@@ -2,7 +2,8 @@
 """An agent on the same GPU as the envs — the loop the reference's examples/stable_baselines3/DeepRMSA.ipynb runs through SB3,
 without anything crossing PCIe: DeepRMSA-v0 observations, rewards and dones are read as torch tensors over the batch's own
 device arrays, the policy network writes its actions into the batch's action array, and one `step(None, fetch=False)` is one
-launch of the step kernel for every env.
+launch of the step kernel for every env.  The network runs on the batch's own HIP stream (`env.torch_stream()`), so the step
+kernel and the network's kernels are ordered by the stream: the host only queues work and never waits inside a rollout.
 
 The policy is a small MLP trained with a plain policy-gradient update (reward-to-go over a short rollout, batch-mean baseline,
 entropy bonus); the point of the example is the data path, not the learning algorithm — the SAP-FF heuristic's acceptance on
@@ -42,32 +43,32 @@ net = torch.nn.Sequential(torch.nn.Linear(env.obs_dim, 128), torch.nn.ELU(), tor
 opt = torch.optim.Adam(net.parameters(), lr=3e-4)
 env.reset()
 env.observation()  # the kernels keep `obs` current from here on
+torch.cuda.synchronize()
 t0 = time.time()
 steps = 0
-for u in range(UPDATES):
-    logps, rewards, entropies = [], [], []
-    for t in range(T):
-        dist = torch.distributions.Categorical(logits=net(obs.float()))
-        a = dist.sample()
-        act[:, 0] = a.int()
-        torch.cuda.synchronize()  # the batch runs on its own stream: the actions must be there before the launch
-        env.step(None, auto_reset=True, fetch=False)
-        env.sync()  # reward / done / obs of this step are in place
-        logps.append(dist.log_prob(a))
-        entropies.append(dist.entropy())
-        rewards.append(rew.float().clone())
-        steps += B
-    ret = torch.zeros(B, device=dev)
-    loss = 0.0
-    for t in reversed(range(T)):  # reward-to-go, discounted
-        ret = rewards[t] + 0.95 * ret
-        loss = loss - (logps[t] * (ret - ret.mean())).mean() - 0.01 * entropies[t].mean()
-    opt.zero_grad()
-    (loss / T).backward()
-    opt.step()
-    if u % 10 == 9 or u == UPDATES - 1:
-        mean_r = torch.stack(rewards).mean().item()  # +1 accepted, -1 blocked (deeprmsa_env.py:123-124)
-        print("update %3d: accepted %.4f of the requests of its rollout, %.2f M env-steps/s incl. the network and the update"
-              % (u + 1, 0.5 + 0.5 * mean_r, steps / (time.time() - t0) / 1e6))
+with torch.cuda.stream(env.torch_stream()):  # everything below is queued on the stream the step kernel runs on
+    for u in range(UPDATES):
+        logps, rewards, entropies = [], [], []
+        for t in range(T):
+            dist = torch.distributions.Categorical(logits=net(obs.float()))
+            a = dist.sample()
+            act[:, 0] = a.int()
+            env.step(None, auto_reset=True, fetch=False)  # one launch; reward / done / obs are rewritten in place
+            logps.append(dist.log_prob(a))
+            entropies.append(dist.entropy())
+            rewards.append(rew.float().clone())
+            steps += B
+        ret = torch.zeros(B, device=dev)
+        loss = 0.0
+        for t in reversed(range(T)):  # reward-to-go, discounted
+            ret = rewards[t] + 0.95 * ret
+            loss = loss - (logps[t] * (ret - ret.mean())).mean() - 0.01 * entropies[t].mean()
+        opt.zero_grad()
+        (loss / T).backward()
+        opt.step()
+        if u % 10 == 9 or u == UPDATES - 1:
+            mean_r = torch.stack(rewards).mean().item()  # (.item() waits) +1 accepted, -1 blocked (deeprmsa_env.py:123-124)
+            print("update %3d: accepted %.4f of the requests of its rollout, %.2f M env-steps/s incl. the network and the update"
+                  % (u + 1, 0.5 + 0.5 * mean_r, steps / (time.time() - t0) / 1e6))
 env.check()
 env.close()

@@ -228,6 +228,11 @@ int orl_host_free(void* p);
 #define ORL_BUF_TERM_OBS 5 /* f64   [n_envs][obs_dim]: observation before an auto reset */
 #define ORL_BUF_PATHS 6    /* int32 [n_envs]: path column of ORL_POLICY_PATH_FF */
 int orl_batch_device_buffer(orl_batch* b, int which, void** device_ptr, int64_t* n_elements);
+/* The HIP stream (hipStream_t) the batch queues its launches on.  An agent on the same GPU that queues ITS kernels on this
+ * stream too (torch: `torch.cuda.ExternalStream(ptr)`) needs no synchronisation between its network and orl_batch_step: the
+ * step kernel runs after the kernels that wrote the actions, the network's next forward pass after the step kernel that wrote
+ * the observation.  (orl_batch_run also uses a second stream internally and returns synchronised.) */
+int orl_batch_stream(orl_batch* b, void** hip_stream_out);
 
 /* state read-back (parity tests, Python attribute surface) */
 int orl_batch_get_counters(orl_batch* b, int64_t* out /*[n_envs][ORL_N_COUNTERS]*/);

@@ -56,6 +56,7 @@ EXPORTS = {
     "orl_batch_observation": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_obs_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_info_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "orl_batch_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(RunStats)]),
     "orl_batch_sync": (C.c_int, [C.c_void_p]),
     "orl_batch_get_counters": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -936,6 +936,12 @@ extern "C" int orl_batch_get_obs_f32(orl_batch* b, float* obs_out) try {
 }
 ORL_ABI_CATCH_INT
 
+extern "C" int orl_batch_stream(orl_batch* b, void** hip_stream_out) {
+  if (!b || !hip_stream_out) return fail(ORL_E_INVALID, "null argument");
+  *hip_stream_out = (void*)b->stream;
+  return ORL_OK;
+}
+
 extern "C" int orl_batch_get_info_rows(orl_batch* b, const int64_t* env_index, int64_t n, double* info_out) try {
   if (!b || n < 0 || (n > 0 && (!env_index || !info_out))) return fail(ORL_E_INVALID, "bad argument");
   if (n == 0) return ORL_OK;

@@ -456,6 +456,20 @@ class BatchedOpticalEnv:
 
         return torch.as_tensor(self.device_array(name), device="cuda:%d" % self.device_id)
 
+    def stream_ptr(self):
+        """The HIP stream (an integer hipStream_t) this batch queues its launches on."""
+        p = C.c_void_p()
+        self._ck(self.lib.orl_batch_stream(self._h, C.byref(p)))
+        return int(p.value or 0)
+
+    def torch_stream(self):
+        """The batch's stream as a `torch.cuda.ExternalStream`: inside `with torch.cuda.stream(env.torch_stream()):` an agent's
+        kernels and `step(None, fetch=False)` are ordered by the stream — no synchronisation between the policy network and
+        the step kernel, the host only queues work."""
+        import torch
+
+        return torch.cuda.ExternalStream(self.stream_ptr(), device="cuda:%d" % self.device_id)
+
     def observation(self):
         if not self.obs_dim:
             return None

@@ -1381,3 +1381,54 @@ def test_vecenv_sparse_info_equals_the_whole_info_array(fam, kw, policy):
         venv.close()
         mvenv.close()
         b.close()
+
+
+@pytest.mark.gpu
+def test_agent_on_the_batchs_own_stream_needs_no_synchronisation():
+    """orl_batch_stream / env.torch_stream(): a torch "agent" whose kernels are queued on the batch's stream — actions computed
+    from the observation on the device, written into the action array, step(None, fetch=False), no host synchronisation in
+    the loop — must leave exactly the state of the same loop with a synchronisation around every step."""
+    import torch
+
+    import optical_rl_gym_amd as orl
+
+    kw = dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=0.1, j=1, episode_length=30)
+    B = 4096
+    seeds = [3 + i for i in range(B)]
+    envs = [orl.make("DeepRMSA", topology="nsfnet_chen", num_envs=B, seeds=seeds, **kw) for _ in range(2)]
+    assert envs[0].stream_ptr() != 0 and envs[0].stream_ptr() != envs[1].stream_ptr()
+    n_act = envs[0].k_paths * envs[0].j
+
+    def agent(obs):  # any deterministic function of the observation that keeps the device busy for a while
+        x = obs.float()
+        for _ in range(6):
+            x = torch.tanh(x @ torch.ones(x.shape[1], x.shape[1], device=x.device) * 1e-3 + x)
+        return (x.abs().sum(1) * 1000).long() % n_act
+
+    for env in envs:
+        env.reset()
+        env.observation()
+    torch.cuda.synchronize()
+    e = envs[0]
+    obs, act = e.device_tensor("obs"), e.device_tensor("actions")
+    with torch.cuda.stream(e.torch_stream()):
+        for t in range(120):
+            act[:, 0] = agent(obs).int()
+            e.step(None, auto_reset=True, fetch=False)
+    e.sync()
+    e = envs[1]
+    obs, act = e.device_tensor("obs"), e.device_tensor("actions")
+    for t in range(120):
+        act[:, 0] = agent(obs).int()
+        torch.cuda.synchronize()
+        e.step(None, auto_reset=True, fetch=False)
+        e.sync()
+    chk = _exact("agent on the batch's stream")
+    chk(0, "counters", envs[0].counters(), envs[1].counters())
+    chk(0, "services", envs[0].services(), envs[1].services())
+    chk(0, "slots", envs[0].slots_packed(), envs[1].slots_packed())
+    chk(0, "obs", envs[0].device_tensor("obs").cpu().numpy(), envs[1].device_tensor("obs").cpu().numpy())
+    assert envs[0].counters()[:, 1].sum() > 0
+    for env in envs:
+        env.check()
+        env.close()
