@@ -75,6 +75,27 @@ print(json.dumps(out["kernels"]))
 shutil.copy(newest(O + "/stats/**/*kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_cfg2_kernel_stats.csv" % tag))
 if os.path.isdir(O + "/stats20"):
     shutil.copy(newest(O + "/stats20/**/*kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_cfg2_steps20_kernel_stats.csv" % tag))
+    # the stats file averages over EVERY k_persist dispatch of the command — the 128-step launches of the state preparation
+    # (1 500 steps) and the warm-up included; the timed blocks are the 20-step launches: their durations from the kernel trace
+    import csv
+    import statistics
+
+    dur = []
+    for r in csv.DictReader(open(newest(O + "/stats20/**/*kernel_trace.csv"))):
+        if "k_persist" in r["Kernel_Name"]:
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    if dur:
+        cut = 2.5 * statistics.median(dur)
+        short, long_ = [d for d in dur if d <= cut], [d for d in dur if d > cut]
+        with open(os.path.join(ROOT, "profiles", "%s_bench_cfg2_steps20_launches.txt" % tag), "w") as f:
+            f.write("rocprofv3 --kernel-trace of `bench.py --gpus 1 --steps 20 --warmup 5` (tools/run_profiles.sh), k_persist dispatches:\n")
+            f.write("  %d launches of 20 steps (warm-up + timed blocks): median %.1f us, mean %.1f us, min %.1f, max %.1f\n"
+                    % (len(short), statistics.median(short), sum(short) / len(short), min(short), max(short)))
+            if long_:
+                f.write("  %d launches of up to 128 steps (state preparation: 1 500 steps before the timed region): mean %.1f us\n"
+                        % (len(long_), sum(long_) / len(long_)))
+            f.write("  (the *_kernel_stats.csv average of %.1f us is over all %d dispatches; bench.py's roofline.us_per_launch is the HIP-event\n"
+                    "   time of the timed 20-step launches)\n" % (sum(dur) / len(dur), len(dur)))
 for f in glob.glob(O + "/bench_*.json") + glob.glob(O + "/phase_*.txt") + glob.glob(O + "/agent_loop_*.json"):
     shutil.copy(f, os.path.join(ROOT, "profiles", "%s_%s" % (tag, os.path.basename(f))))
 passes = [os.path.join(O, d) for d in ("sq1", "sq2", "sq3", "hit", "ea", "tr_f", "tr_w") if os.path.isdir(os.path.join(O, d))]
