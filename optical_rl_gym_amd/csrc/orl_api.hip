@@ -311,7 +311,16 @@ extern "C" void orl_topology_destroy(orl_topology* t) try {
 ORL_ABI_CATCH_VOID
 
 // ---- launch dispatch over the row width ---------------------------------------------------------------
+// Anything but the persistent kernel is about to write slot maps: the row caches the persistent kernel left with the state
+// (DevParams::row_cache) no longer describe them.  The key of the next persistent launch differs from every stored stamp.
+static void slot_maps_change(orl_batch* b) {
+  if (++b->cache_epoch >= (1 << 22)) {  // (the key keeps 22 bits of it: start over with no stamp left standing)
+    if (b->P.row_cache_stamp) hipMemsetAsync(b->P.row_cache_stamp, 0, (size_t)((b->P.B + 7) / 8) * sizeof(int), b->stream);
+    b->cache_epoch = 1;
+  }
+}
 static void launch_reset(orl_batch* b, int full, const unsigned char* dmask) {
+  slot_maps_change(b);
 #define CALL(WW) orl_launch::reset<WW>(b, full, dmask)
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
@@ -322,11 +331,13 @@ static void launch_policy(orl_batch* b, int pol) {
 #undef CALL
 }
 static void launch_step64(orl_batch* b, int auto_reset, int want_info, int fused_policy) {
+  slot_maps_change(b);
 #define CALL(WW) orl_launch::step64<WW>(b, auto_reset, want_info, fused_policy)
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
 static void launch_agent_step(orl_batch* b, int auto_reset) {
+  slot_maps_change(b);
 #define CALL(WW) orl_launch::agent_step<WW>(b, auto_reset)
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
@@ -357,6 +368,7 @@ static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
   if (q.mt2) q.mt2 += lo * 624;
   q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
   q.soon_t += lo * ORL_SOON; q.soon_i += lo * ORL_SOON;
+  q.row_cache += (lo / 8) * 2 * (i64)P.row_cache_words; q.row_cache_stamp += lo / 8;
   if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
   if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (P.S + 1));
   if (q.act2d) q.act2d += lo * P.act2d_words;
@@ -369,6 +381,7 @@ static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
   return q;
 }
 static void launch_step2(orl_batch* b, int pol) {
+  slot_maps_change(b);
 #define CALL(WW) orl_launch::step2<WW>(b, pol)
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
@@ -570,6 +583,10 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     rc |= dalloc(b, &b->d_wg_step, (B + 7) / 8 + 16);
     rc |= dalloc(b, &b->d_unfinished, 32);
     if (!rc) HIPCHK_B(hipMemset(b->d_unfinished, 0, 32 * sizeof(unsigned int)));
+    P.row_cache_words = ((8 * P.E * 4 + 15) & ~15) / 4;
+    rc |= dalloc(b, &P.row_cache, ((B + 7) / 8) * 2 * (size_t)P.row_cache_words);
+    rc |= dalloc(b, &P.row_cache_stamp, (B + 7) / 8 + 16);
+    if (!rc) HIPCHK_B(hipMemset(P.row_cache_stamp, 0, ((B + 7) / 8 + 16) * sizeof(int)));
     rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
     rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
   }
@@ -1529,6 +1546,7 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) try {
   HIPCHK(hipStreamSynchronize(b->stream));
   const unsigned char* o = (const unsigned char*)in;
   for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(s.ptr, o, s.bytes, hipMemcpyHostToDevice)); o += s.bytes; }
+  slot_maps_change(b);
   if (b->P.obs_dim) launch_obs(b, 0);
   HIPCHK(hipStreamSynchronize(b->stream));
   return ORL_OK;

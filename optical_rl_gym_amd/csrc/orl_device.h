@@ -116,6 +116,13 @@ struct DevParams {
   u32* q_cnt_a;     // [ceil(B/8)] items each control wavefront put into its region
   int q_wave;       // item slots per wavefront region
   int persist_ic;   // persistent kernel: keep the per-row cache of inner free runs in LDS (set per launch by the host)
+  // the row caches of the persistent kernel travel with the state from launch to launch instead of being rebuilt from the
+  // slot maps at the start of every launch (~0.3 step's worth of instructions per wavefront: 3 % of a 20-step launch)
+  u32* row_cache;        // [ceil(B/8)][2][row_cache_words] per wavefront: inner-run words, then occ / free-block words
+  int* row_cache_stamp;  // [ceil(B/8)] the key the wavefront's copy was written under (0 = none)
+  int row_cache_words;   // u32 words per cache level and wavefront (8 envs x E links, padded to 16 bytes)
+  int row_cache_key;     // this launch's key: changes whenever anything but the persistent kernel may have touched the slot maps,
+                         // or the form / cache level differs (set per launch by the host; 0 = do not use stored caches)
   int item_masks;   // releases of one step that may meet on one link before the env falls back to the serial tail (<= 8)
   int rel_limit;    // compact sink of the persistent kernel: releases of one env-step its mask table takes (<= 31; test knob)
   int pipeline2;    // core_sums[2C..4C) accumulates what the current step's releases add to the sums (persistent kernel)

@@ -57,6 +57,7 @@ struct orl_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_totals = nullptr;
   unsigned int* h_tail = nullptr;  // page-locked: where the straggler count / flag words of a run land (a pageable target is staged)
+  int cache_epoch = 1;             // bumped by every call that may change slot maps outside the persistent kernel (DevParams::row_cache_key)
   long long* gather_idx = nullptr;  // orl_batch_get_info_rows: row indices and gathered rows on the device, grown on demand
   double* gather_out = nullptr;
   int64_t gather_cap = 0;

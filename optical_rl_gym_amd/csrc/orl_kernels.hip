@@ -382,7 +382,15 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 #define ORL_FILL_WINDOW() persist_fill_window<REC>(P, env0, nenv, lane, orl_lds_raw + L.bm, orl_lds_raw + L.sc, orl_lds_raw + L.cs, L.csw / 4)
     if (step < target) ORL_FILL_WINDOW();
     ORL_LOAD_CARRIED();
+    // the row caches this wavefront left with the state at the end of its previous launch are still good when nothing but the
+    // persistent kernel has touched the slot maps since (the host's key) and no release is pending in place
+    bool cache_stored = false;
+    if (IC && P.row_cache_key != 0) {
+      const int stamp = P.row_cache_stamp[blockIdx.x];
+      cache_stored = (stamp == P.row_cache_key) && __ballot(pend) == 0ull;
+    }
     if (__ballot(pend) != 0ull) {
+      if (IC && P.row_cache_key != 0 && threadIdx.x == 0) P.row_cache_stamp[blockIdx.x] = 0;  // (rel_serial writes slot maps)
       if (pend) {
         sp::rel_serial<ENV, W>(P, env, lane);
         if (ENV == ENV_DEEPRMSA && P.obs_dim) {
@@ -398,13 +406,22 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 #undef ORL_FILL_WINDOW
     if (IC) {
       M.ic0 = (u32*)(orl_lds_raw + L.ic);
+      const u32* g_cache = P.row_cache + (size_t)blockIdx.x * 2 * P.row_cache_words;
       if (step < target) {
         __syncthreads();  // the rows are in LDS
-        for (int i = lane; i < nenv * P.E; i += 64) M.ic0[i] = sp::row_inner_cache<W>(M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W);
+        if (cache_stored) {  // (both levels with one batch of requests)
+          for (int i = lane; i < nenv * P.E; i += 64) {
+            const u32 a = g_cache[i], c = OC ? g_cache[P.row_cache_words + i] : 0u;
+            M.ic0[i] = a;
+            if (OC) ((u32*)(orl_lds_raw + L.ic + ((8 * P.E * 4 + 15) & ~15)))[i] = c;
+          }
+        } else {
+          for (int i = lane; i < nenv * P.E; i += 64) M.ic0[i] = sp::row_inner_cache<W>(M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W);
+        }
       }
       if (OC) {  // what every row contributes to the compactness sums, as the launch finds it (kept exact by the row phase)
         M.oc0 = (u32*)(orl_lds_raw + L.ic + ((8 * P.E * 4 + 15) & ~15));
-        if (step < target)
+        if (step < target && !cache_stored)
           for (int i = lane; i < nenv * P.E; i += 64) {
             const u64* row = M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W;
             u64 a[W];
@@ -505,6 +522,14 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     const int q = L.csw / 4;
     for (int i = lane; i < nenv * q; i += 64)
       ((int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q] = ((const int4*)M.cs0)[i];
+    if (IC && P.row_cache_key != 0) {  // the row caches go with the state; the stamp says under which key they were written
+      u32* g_cache = P.row_cache + (size_t)blockIdx.x * 2 * P.row_cache_words;
+      for (int i = lane; i < nenv * P.E; i += 64) {
+        g_cache[i] = M.ic0[i];
+        if (OC) g_cache[P.row_cache_words + i] = M.oc0[i];
+      }
+      if (threadIdx.x == 0) P.row_cache_stamp[blockIdx.x] = left_pending ? 0 : P.row_cache_key;
+    }
     if (REC) {
       ulonglong2* gr = (ulonglong2*)(P.scal + env0 * ORL_SCAL_WORDS);
       const ulonglong2* lr = (const ulonglong2*)M.sc0;
@@ -1031,6 +1056,8 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   const PersistChoice ch = persist_choose(VP);
   const int v = ch.form;
   VP.persist_ic = ch.inner;
+  VP.row_cache_key = VP.row_cache ? ((b->cache_epoch << 8) | (v << 4) | ch.inner) : 0;
+  if (const char* e = getenv("ORL_ROW_CACHE_KEEP")) { if (atoi(e) == 0) VP.row_cache_key = 0; }  // A/B: rebuild at every launch
   size_t lds_a = persist_tuned_lds(v, ch.lds);
 #define LAUNCH(E_, LDS_, WV_)                                                                                                 \
   do {                                                                                                                       \

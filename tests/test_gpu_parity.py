@@ -1432,3 +1432,68 @@ def test_agent_on_the_batchs_own_stream_needs_no_synchronisation():
     for env in envs:
         env.check()
         env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+def test_row_caches_kept_between_launches_follow_every_change_of_the_slot_maps(workload, monkeypatch):
+    """The persistent kernel leaves its per-row caches with the state and the next launch loads them instead of rebuilding them
+    from the slot maps — valid only while nothing else has written slot maps.  Short runs interleaved with everything that
+    does: agent-driven steps (k_agent), host steps of a few envs through the one-wavefront kernel is not possible on the same
+    batch size, so: k_agent steps, a masked full reset, set_state back to an earlier snapshot, forced deferrals (releases in
+    place at the start of the next launch).  Against the oracle on every env after each stage, and against the same sequence
+    with the caches rebuilt at every launch."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+    from oracle.oracle import OracleBatch
+
+    fam, topo, kw, policy = WORKLOADS[workload]
+    kw = dict(kw, episode_length=60)
+    B = 4096
+    seeds = [21 + i for i in range(B)]
+    chk = _exact(workload + " kept row caches")
+
+    def sequence(dev, ora):
+        def same(tag):
+            chk(0, tag + " counters", dev.counters(), ora.counters())
+            chk(0, tag + " slots", dev.slots_packed(), ora.slots_packed())
+            chk(0, tag + " link stats", dev.link_stats_all(), ora.link_stats_all())
+            chk(0, tag + " net stats", dev.net_stats_all(), ora.net_stats_all())
+        for n in (20, 20, 7, 150, 20):  # launches that load what the previous one stored (150: two launches in one run)
+            dev.run(policy, n); ora.run(policy, n)
+        same("runs")
+        for _ in range(3):  # agent-driven steps change the maps behind the stored caches
+            a = ora.policy(policy)
+            dev.step(a, auto_reset=True); ora.step(a, auto_reset=True)
+        dev.run(policy, 20); ora.run(policy, 20)
+        same("after agent steps")
+        snap = dev.get_state()
+        mask = (np.arange(B) % 3 == 0).astype(np.uint8)
+        dev.reset(full=True, mask=mask); ora.reset(full=True, mask=mask)
+        dev.run(policy, 25); ora.run(policy, 25)
+        same("after a masked full reset")
+        after = dev.counters().copy()
+        dev.set_state(snap)
+        dev.run(policy, 25)
+        assert not np.array_equal(dev.counters(), after)  # (a different state than the reset one)
+        dev2 = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, **kw)
+        dev2.set_state(snap)
+        dev2.run(policy, 25)
+        chk(0, "set_state: counters", dev.counters(), dev2.counters())
+        chk(0, "set_state: slots", dev.slots_packed(), dev2.slots_packed())
+        chk(0, "set_state: link stats", dev.link_stats_all(), dev2.link_stats_all())
+        dev2.close()
+
+    dev = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, **kw)
+    sequence(dev, OracleBatch(fam, topo, seeds, omp=True, **kw))
+    dev.close()
+    # forced deferrals: releases done in place at the start of the next launch invalidate that wavefront's stored caches
+    monkeypatch.setenv("ORL_ITEM_MASKS", "1")
+    dev = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, **kw)
+    ora = OracleBatch(fam, topo, seeds, omp=True, **kw)
+    for n in (20, 20, 20, 130):
+        dev.run(policy, n); ora.run(policy, n)
+    chk(0, "deferrals: counters", dev.counters(), ora.counters())
+    chk(0, "deferrals: slots", dev.slots_packed(), ora.slots_packed())
+    chk(0, "deferrals: link stats", dev.link_stats_all(), ora.link_stats_all())
+    dev.close()
