@@ -1431,6 +1431,7 @@ extern "C" int orl_batch_load_spec(orl_batch* b, const char* so_path) try {
   if (b->spec_handle) dlclose(b->spec_handle);
   b->spec_handle = h;
   b->spec_launch = (decltype(b->spec_launch))launch;
+  b->spec_agent_launch = (decltype(b->spec_agent_launch))dlsym(h, "orl_spec_agent_launch");  // (k_agent with the same constants)
   b->spec_lds = d[2];
   b->spec_waves = d[3];
   return ORL_OK;

@@ -39,6 +39,7 @@ struct orl_batch {
   // a specialisation library attached by orl_batch_load_spec: k_persist with this batch's sizes as compile-time constants
   void* spec_handle = nullptr;
   void (*spec_launch)(const orl::DevParams*, unsigned, size_t, hipStream_t, int, int, int*, unsigned int*, unsigned int*) = nullptr;
+  void (*spec_agent_launch)(const orl::DevParams*, unsigned, size_t, hipStream_t, int) = nullptr;  // k_agent of the same library
   int spec_lds = -1, spec_waves = -1;
   int* d_wg_step = nullptr;        // [ceil(B/8)] steps each workgroup of the persistent kernel has completed since run_base was 0
   int64_t run_base = 0;            // ... all of them, between runs (no per-run clearing of d_wg_step)

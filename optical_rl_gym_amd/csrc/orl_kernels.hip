@@ -616,8 +616,10 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
 #ifndef ORL_AGENT_WAVES
 #define ORL_AGENT_WAVES 4  // waves per SIMD the register allocator leaves room for (cfg2 65 536 envs: 3 -> 114 us, 4 -> 108 us, 5 -> 141 us, 8 -> 193 us per launch)
 #endif
-template <int ENV, int W>
+// SPEC: the configuration's sizes as compile-time constants (the instantiation a specialisation library carries beside k_persist)
+template <int ENV, int W, int SPEC = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGENT_WAVES, ORL_AGENT_WAVES))) k_agent(DevParams P, int auto_reset) {
+  persist_spec_apply<SPEC>(P);
   constexpr bool CP = ENV != ENV_RMCSA;                                  // RMCSA: sink entries with a core per mask, the general row loop
   constexpr bool LINK_INFO = (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA);   // info carries network compactness and the two link averages
   const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, 0, CP, 0);
@@ -880,6 +882,9 @@ extern "C" void orl_spec_launch(const DevParams* VP, unsigned grid, size_t lds, 
   hipLaunchKernelGGL((k_persist<ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, 1>), dim3(grid), dim3(64), lds, st, *VP, pol, target, wg_step,
                      unfinished, clear_next);
 }
+extern "C" void orl_spec_agent_launch(const DevParams* VP, unsigned grid, size_t lds, hipStream_t st, int auto_reset) {
+  hipLaunchKernelGGL((k_agent<ORL_SPEC_ENV, ORL_W, 1>), dim3(grid), dim3(64), lds, st, *VP, auto_reset);
+}
 #else
 // =============================================================================================
 // launchers
@@ -1090,6 +1095,14 @@ template <int W> void agent_step(orl_batch* b, int auto_reset) {
   const DevParams& VP = b->P;
   dim3 g((unsigned)((VP.B + 7) / 8)), blk(64);
   const size_t lds = (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, 0, VP.env_type != ENV_RMCSA, 0).total + (size_t)8 * VP.E * 16;
+  // the instantiation built for this configuration, when a specialisation library is attached (ORL_PERSIST_SPEC=0: generic)
+  bool spec = b->spec_agent_launch != nullptr;
+  if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = false; }
+  if (spec) {
+    b->spec_agent_launch(&VP, g.x, lds, b->stream, auto_reset);
+    ORL_TK(b, "k_agent");
+    return;
+  }
 #define PER_ENV(E_) hipLaunchKernelGGL((k_agent<E_, W>), g, blk, lds, b->stream, VP, auto_reset);
   ORL_FOR_ENV(b, PER_ENV)
 #undef PER_ENV
