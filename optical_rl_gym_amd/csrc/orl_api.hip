@@ -348,8 +348,8 @@ static void launch_obs(orl_batch* b, int with_terminal) {
 #undef CALL
 }
 static void launch_persist(orl_batch* b, const DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished,
-                           unsigned int* clear_next) {
-#define CALL(WW) orl_launch::persist<WW>(b, VP, st, pol, target, wg_step, unfinished, clear_next)
+                           unsigned int* clear_next, int finish) {
+#define CALL(WW) orl_launch::persist<WW>(b, VP, st, pol, target, wg_step, unfinished, clear_next, finish)
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
@@ -1054,17 +1054,22 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     b->persist_launches = 0;
     for (int64_t tgt = 0; tgt < n_steps;) {
       tgt = (tgt + chunk < n_steps) ? tgt + chunk : n_steps;
-      for (;;) {
+      for (int attempt = 0;; attempt++) {
         b->persist_launches++;
         unsigned int* cnt[2] = {nullptr, nullptr};  // the slot each half's launch counts into; it clears the other one
+        // the launch that reaches the end of the run finishes the state itself (pending network-compactness update, flags:
+        // DevParams::persist_finish); only a relaunch for stragglers — wavefronts that left that launch with releases still
+        // to do in place — is followed by k_finish2, which does the same for every env in a launch of its own
+        const int finish = (tgt >= n_steps && attempt == 0) ? 1 : 0;
         for (int p = 0; p < parts; p++) {
           cnt[p] = b->d_unfinished + 8 * p + 4 * b->un_slot[p];
-          launch_persist(b, view[p], strm[p], policy_id, (int)(base + tgt), wg_step[p], cnt[p], b->d_unfinished + 8 * p + 4 * (b->un_slot[p] ^ 1));
+          launch_persist(b, view[p], strm[p], policy_id, (int)(base + tgt), wg_step[p], cnt[p], b->d_unfinished + 8 * p + 4 * (b->un_slot[p] ^ 1), finish);
           b->un_slot[p] ^= 1;
         }
         if (tgt < n_steps) break;  // stragglers catch up in the next chunk's launch
-        for (int p = 0; p < parts; p++)  // (harmless for a straggler: it does what that env's next control phase would do first)
-          hipLaunchKernelGGL(k_finish2, dim3((unsigned)((view[p].B + 255) / 256)), dim3(256), 0, strm[p], view[p], 1, cnt[p] + 1);
+        if (attempt > 0)
+          for (int p = 0; p < parts; p++)  // (harmless for a straggler: it does what that env's next control phase would do first)
+            hipLaunchKernelGGL(k_finish2, dim3((unsigned)((view[p].B + 255) / 256)), dim3(256), 0, strm[p], view[p], 1, cnt[p] + 1);
         if (parts == 2) {
           HIPCHK(hipEventRecord(b->ev_half, b->stream2));
           HIPCHK(hipStreamWaitEvent(b->stream, b->ev_half, 0));

@@ -86,7 +86,7 @@ template <int W> void step64(orl_batch* b, int auto_reset, int want_info, int fu
 template <int W> void obs(orl_batch* b, int with_terminal);                // DeepRMSA observation
 // k_persist over the env range of view VP up to step `target` of this run, then k_rel_tail, on stream st
 template <int W> void persist(orl_batch* b, const orl::DevParams& VP, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished,
-                              unsigned int* clear_next);
+                              unsigned int* clear_next, int finish);  // finish: this launch ends the run (DevParams::persist_finish)
 template <int W> int persist_resident(orl_batch* b, int n_cu);              // wavefronts of k_persist the GPU holds at once
 template <int W> int persist_uses_lds(orl_batch* b);                       // 1: the persistent kernel keeps slot maps / link statistics in LDS
 template <int W> int prof_read(unsigned long long* out48, int reset);      // -DORL_TIMING builds: per-phase cycle sums

@@ -514,6 +514,50 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if (deferred) { left_pending = true; break; }
   }
   ORL_PROF_END();
+  if (P.persist_finish && step > first_step && !left_pending) {
+    // the end of a run: what k_finish2 (orl_api.hip) does for every env in a launch of its own — the network-compactness update
+    // the last step left pending (rmsa_env.py:439-462 with the sums right after that step's provision), the release part of
+    // the sums cleared, the env's flag word reported — on the records and sums where this wavefront has them
+    __syncthreads();  // the last row phase is done
+    u32 f = 0u;
+    // (the env index recomputed from the thread index behind an opaque copy: kept live across the step loop for this block it
+    // cost the 128-VGPR forms a spilled register)
+    int tid_f = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_f));
+    const i64 env_f = env0 + (tid_f >> 3);
+    if (env_f < P.B && (tid_f & 7) == 0) {
+      u64* s = sp::wm_scal(P, M, env_f);
+      int* cs = sp::wm_cs(P, M, env_f);
+      int* rs = cs + 2 * P.C;
+      const u64 acc = s[SC_ACC];
+      if ((u32)acc & 2u) {
+        const int c0 = (int)((acc >> 32) & 31);
+        const i64 s_nh_prov = (i64)(acc >> 37);
+        int occ, fb;
+        if (!M.cs_lds) {  // (global sums are updated by L2 atomics: read through L2 as well)
+          occ = atomicAdd(cs + 2 * c0, 0) - atomicAdd(rs + 2 * c0, 0);
+          fb = atomicAdd(cs + 2 * c0 + 1, 0) - atomicAdd(rs + 2 * c0 + 1, 0);
+        } else {
+          occ = cs[2 * c0] - rs[2 * c0];
+          fb = cs[2 * c0 + 1] - rs[2 * c0 + 1];
+        }
+        const double a0 = __longlong_as_double((i64)s[SC_GC_A]), td = __longlong_as_double((i64)s[SC_GC_TD]);
+        const double now_a = __longlong_as_double((i64)s[SC_NOWA]);
+        const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
+        s[SC_GCOMP] = (u64)__double_as_longlong((a0 + (cmp * td)) / now_a);
+        s[SC_ACC] = acc & ~2ull;
+      }
+      for (int i = 0; i < 2 * P.C; i++) {
+        if (!M.cs_lds) atomicExch(rs + i, 0);
+        else rs[i] = 0;
+      }
+      const u64 v = s[SC_FLAGS];
+      f = (u32)(v >> 32);
+      if (f & ORL_FLAG_BAD_ACTION) s[SC_FLAGS] = v & ~((u64)ORL_FLAG_BAD_ACTION << 32);
+    }
+    for (int o = 32; o > 0; o >>= 1) f |= (u32)__shfl_xor((int)f, o, 64);
+    if ((tid_f & 63) == 0 && f) atomicOr(n_unfinished + 1, f);
+  }
   if (LDS >= 1 && step > first_step) {
     __syncthreads();
     ulonglong2* g = (ulonglong2*)(P.bitmap + env0 * P.bm_words);
@@ -1055,8 +1099,9 @@ static size_t persist_tuned_lds(int v, size_t lds) {
 #define ORL_FULL_LDS_CASES(E_)
 #endif
 template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st, int pol, int target, int* wg_step, unsigned int* unfinished,
-                              unsigned int* clear_next) {
+                              unsigned int* clear_next, int finish) {
   DevParams VP = VP0;
+  VP.persist_finish = finish;
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64);
   const PersistChoice ch = persist_choose(VP);
   const int v = ch.form;
@@ -1169,7 +1214,7 @@ template int prof_read<ORL_W>(unsigned long long*, int);
 template void policy<ORL_W>(orl_batch*, int);
 template void step64<ORL_W>(orl_batch*, int, int, int);
 template void obs<ORL_W>(orl_batch*, int);
-template void persist<ORL_W>(orl_batch*, const DevParams&, hipStream_t, int, int, int*, unsigned int*, unsigned int*);
+template void persist<ORL_W>(orl_batch*, const DevParams&, hipStream_t, int, int, int*, unsigned int*, unsigned int*, int);
 template int persist_resident<ORL_W>(orl_batch*, int);
 template int persist_uses_lds<ORL_W>(orl_batch*);
 template void step2<ORL_W>(orl_batch*, int);
