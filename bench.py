@@ -91,30 +91,55 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def visible_gpus():
+    """Number of GPUs a rank will see, counted in a throwaway child: the launcher itself must make no GPU call at all (on
+    ROCm `torch.cuda.device_count()` may fall back to hipGetDeviceCount, which loads the HSA runtime and opens /dev/kfd —
+    and the ranks are started from this process)."""
+    import subprocess
+
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None  # unknown: every rank checks its own device before the rendezvous
+
+
 def launch_ranks(args, argv):
     """`bench.py --gpus N` started by hand (no torchrun): this process makes NO GPU call; it starts N fresh children — one
-    rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command line — forwards rank 0's JSON line and
-    exits with the first non-zero child status."""
+    rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command line — supervises them (the first rank
+    that fails ends its siblings: a rank waiting in a gloo barrier for a dead peer would sit there for half an hour),
+    forwards rank 0's JSON line and exits non-zero when any rank did."""
     import subprocess
+    import tempfile
 
     n = args.gpus
     if args.device is None and not args.launch_check:
-        import torch
-
-        have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             raise SystemExit("bench: --gpus %d but only %d GPU(s) visible; refusing to measure fewer devices than asked for "
                              "(--device D puts every rank on GPU D: a functional check, not a scaling number)" % (n, have))
     port = free_port()
-    procs = []
+    procs, outs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+        outs.append(tempfile.TemporaryFile())  # (a file, not a pipe: nobody has to drain it while the ranks run)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=outs[-1]))
+    codes = [None] * n
+    failed = False
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if not failed and any(c not in (None, 0) for c in codes):
+            failed = True
+            for r, p in enumerate(procs):  # exactly the children started above
+                if codes[r] is None:
+                    p.terminate()
+        time.sleep(0.05)
+    outs[0].seek(0)
+    sys.stdout.write(outs[0].read().decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -152,12 +177,19 @@ def main():
     import torch
 
     dev_index = local_rank if args.device is None else args.device
+    if not args.launch_check:  # before the rendezvous: a rank without its device fails at once, and the launcher ends the others
+        if not torch.cuda.is_available():
+            raise SystemExit("bench: no GPU visible; the HIP path is the only path")
+        if dev_index >= torch.cuda.device_count():
+            raise SystemExit("bench: rank %d wants GPU %d but only %d GPU(s) are visible" % (rank, dev_index, torch.cuda.device_count()))
     dist = None
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
         # envs are independent: no collective on the data path, so no RCCL — a gloo group carries the barrier and the max
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
     if args.launch_check:
         ranks = [None] * world
         if dist is not None:
@@ -169,10 +201,6 @@ def main():
         if rank == 0:
             print(json.dumps({"launch_check": True, "n_gpus": len(ranks), "ranks": ranks}))
         return
-    if not torch.cuda.is_available():
-        raise SystemExit("bench: no GPU visible; the HIP path is the only path")
-    if dev_index >= torch.cuda.device_count():
-        raise SystemExit("bench: rank %d wants GPU %d but only %d GPU(s) are visible" % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
 
     import optical_rl_gym_amd as orl
@@ -284,7 +312,28 @@ def main():
                 rate = rps / (elapsed / args.steps)
                 req_roof = dict(bound="dram_requests", requests_per_step=int(rps), peak=RANDOM_ACCESS_PEAK, unit="requests/s",
                                 achieved=round(rate, 1), frac=round(rate / RANDOM_ACCESS_PEAK, 4))
+    # SURVEY 8(d) "report both": beside the 8 TB/s spec peak, what a plain device copy achieves on THIS GPU, measured now
+    # (read + write bytes of a 1 GiB copy, HIP events, best of 10)
+    peak_meas = None
+    try:
+        src_t = torch.empty(1 << 28, dtype=torch.float32, device="cuda:%d" % dev_index).fill_(1.0)
+        dst_t = torch.empty_like(src_t)
+        best = None
+        for _ in range(12):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst_t.copy_(src_t)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None or ms < best else best
+        peak_meas = 2.0 * src_t.numel() * 4 / (best * 1e-3) / 1e9
+        del src_t, dst_t
+    except Exception:  # (a GPU too full for the two buffers: the spec peak alone)
+        peak_meas = None
     roofline = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                    peak_measured=None if peak_meas is None else round(peak_meas, 1),
+                    frac_of_measured=None if peak_meas is None else round(ach / peak_meas, 5),
                     traffic=traffic, achieved_traffic_gbs=None if traffic_gbs is None else round(traffic_gbs, 2),
                     traffic_frac=None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 5), valu=valu,
                     kernel=kernel, us_per_launch=round(ms_launch * 1e3, 2),
@@ -384,6 +433,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "timed_region_s": round(timed, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

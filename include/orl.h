@@ -305,6 +305,9 @@ int orl_batch_load_spec(orl_batch* b, const char* so_path);
 /* Whether the last orl_batch_run used the attached specialisation (1) or the generic persistent kernel (0); -1 = another
  * step form. */
 int orl_batch_debug_persist_spec(orl_batch* b);
+/* Which kernel orl_batch_step launches for this batch: 2 = k_agent (8 lanes per env, the persistent kernel's phases for one
+ * step), 0 = k_step (one wavefront per env). */
+int orl_batch_debug_step_kernel(orl_batch* b);
 /* Statistics: env-steps whose releases took the serial tail (more than 8 of one step meeting on one link). */
 int64_t orl_batch_debug_serial_count(orl_batch* b);
 /* Diagnostic builds with -DORL_TIMING only (zeros otherwise): shader-clock cycles per phase of the persistent kernel, 48

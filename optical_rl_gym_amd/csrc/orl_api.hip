@@ -1576,6 +1576,11 @@ extern "C" int orl_batch_debug_persist_spec(orl_batch* b) try {
   return b->persist ? b->persist_spec : -1;
 }
 ORL_ABI_CATCH_INT
+extern "C" int orl_batch_debug_step_kernel(orl_batch* b) try {
+  if (!b) return -1;
+  return b->agent_step ? 2 : 0;
+}
+ORL_ABI_CATCH_INT
 extern "C" int64_t orl_batch_debug_serial_count(orl_batch* b) try {
   if (!b) return -1;
   if (hipSetDevice(b->device) != hipSuccess) return -1;

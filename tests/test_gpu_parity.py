@@ -23,7 +23,8 @@ IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT=
             "persist_global": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="0", ORL_PERSIST_INNER=None),
             "persist_lds": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT="2", ORL_PERSIST_INNER="2"),
             # host- / agent-driven steps through k_agent (the phases of the persistent kernel for one step, with info) whatever
-            # the batch size — the library takes it from 2 048 envs — for RMSA / DeepRMSA; device-resident runs as "persist"
+            # the batch size — the library takes it from 2 048 envs — for all four families (RMSA, DeepRMSA, RWA, RMCSA: every
+            # g* / w* / h* fixture of theirs replays through it); device-resident runs as "persist"
             "agent8": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None,
                            ORL_AGENT_STEP="1")}
 for _name, _env in IMPL_ENV.items():
@@ -208,7 +209,10 @@ def test_full_size_batch_sampled_envs_match_oracle(workload, batch):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("workload,batch,steps", [("cfg2", 65536, 300), ("cfg3", 16384, 150), ("cfg1", 16384, 200)])
+@pytest.mark.parametrize("workload,batch,steps", [("cfg2", 65536, 300), ("cfg3", 16384, 150), ("cfg1", 16384, 200),
+                                                  # RMCSA: the 24-byte-entry sink and the serial release loop; Germany50: the
+                                                  # global-state form (the per-GPU shard of BASELINE's 262 144 envs)
+                                                  ("cfg4", 16384, 120), ("cfg5", 32768, 120)])
 def test_full_size_batch_every_env_matches_oracle(workload, batch, steps):
     """The headline batch against the ORACLE on every env (not a sample, not another HIP form): the OpenMP build of the oracle
     steps all 65 536 cfg2 envs on the host's cores, and every env's counters, pending service, number of pending releases,
@@ -587,8 +591,8 @@ def test_zero_copy_device_tensors_drive_the_batch():
     b.close()
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
-def test_agent_in_the_loop_at_full_size(workload):
+@pytest.mark.parametrize("workload,B", [("cfg2", 65536), ("cfg3", 65536), ("cfg1", 32768), ("cfg4", 16384)])
+def test_agent_in_the_loop_at_full_size(workload, B):
     """The path an RL agent on the same GPU drives (SB3 VecEnv semantics: actions in device memory, auto reset, nothing
     fetched): 65 536 envs stepped through k_agent with actions from the on-device heuristic, against the oracle on sampled
     envs — reward, done, all info floats and the DeepRMSA observation of the last steps, then the whole state."""
@@ -598,9 +602,10 @@ def test_agent_in_the_loop_at_full_size(workload):
 
     fam, topo, kw, policy = WORKLOADS[workload]
     kw = dict(kw, episode_length=40)
-    B, steps = 65536, 90
+    steps = 90
     seeds = [10 + i for i in range(B)]
     dev = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, **kw)
+    assert int(dev.lib.orl_batch_debug_step_kernel(dev._h)) == 2  # every family's host / agent steps go through k_agent at this size
     sample = sorted(set([0, 7, 8, 4095, B // 2, B - 1] + list(np.random.RandomState(9).randint(0, B, 10))))
     ora = OracleBatch(fam, topo, [seeds[i] for i in sample], **kw)
     rew, done, info = (dev.device_tensor(n) for n in ("reward", "done", "info"))
