@@ -368,6 +368,7 @@ static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
   if (q.mt2) q.mt2 += lo * 624;
   q.lstat += lo * 4 * P.E; q.scal += lo * ORL_SCAL_WORDS; q.svc_desc += lo; q.core_sums += lo * P.cs_words;
   q.soon_t += lo * ORL_SOON; q.soon_i += lo * ORL_SOON;
+  q.svc_q += lo * 8; q.svc_ht += lo * 8; q.svc_pk += lo * 8; q.svc_cnt += lo * 8;  // (64 lanes per 8 envs; lo is a multiple of 8)
   q.row_cache += (lo / 8) * 2 * (i64)P.row_cache_words; q.row_cache_stamp += lo / 8;
   if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
   if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (P.S + 1));
@@ -589,6 +590,14 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     if (!rc) HIPCHK_B(hipMemset(P.row_cache_stamp, 0, ((B + 7) / 8 + 16) * sizeof(int)));
     rc |= dalloc(b, &P.soon_t, B * ORL_SOON);
     rc |= dalloc(b, &P.soon_i, B * ORL_SOON);
+    {
+      const size_t n_lanes = ((B + 7) / 8) * 64;
+      rc |= dalloc(b, &P.svc_q, n_lanes);
+      rc |= dalloc(b, &P.svc_ht, n_lanes);
+      rc |= dalloc(b, &P.svc_pk, n_lanes);
+      rc |= dalloc(b, &P.svc_cnt, n_lanes);
+      if (!rc) HIPCHK_B(hipMemset(P.svc_cnt, 0, n_lanes * sizeof(int)));  // nothing drawn ahead
+    }
   }
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
   rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
@@ -1433,7 +1442,12 @@ extern "C" int orl_batch_load_spec(orl_batch* b, const char* so_path) try {
                         P.ev_cap, P.bm_words, P.cs_words, P.obs_dim, P.n_info};
   for (int i = 0; i < 22; i++)
     if (d[i] != want[i]) { dlclose(h); return fail(ORL_E_INVALID, "%s was built for another configuration (field %d: %d, this batch %d)", so_path, i, d[i], want[i]); }
-  if (b->spec_handle) dlclose(b->spec_handle);
+  if (b->spec_handle) {  // kernels of the library being replaced may still be queued
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
+    dlclose(b->spec_handle);
+  }
   b->spec_handle = h;
   b->spec_launch = (decltype(b->spec_launch))launch;
   b->spec_agent_launch = (decltype(b->spec_agent_launch))dlsym(h, "orl_spec_agent_launch");  // (k_agent with the same constants)

@@ -131,6 +131,12 @@ struct DevParams {
   i64 q_def_stride; // second q_def buffer (the steps of the two-kernel form alternate)
   u32* q_def;       // [0] = number of envs whose releases this step do not fit the item form, [16..] = their indices
   u32* q_stat;      // [1] env-steps that took the serial release path (statistics)
+  // service look-ahead of the persistent kernel (orl_device_split.h, svc_generate): what a wavefront held when it left its loop,
+  // [ceil(B/8)][64] each, indexed by wavefront and lane.  Between runs every count says "empty".
+  double* svc_q;    // inter-arrival time
+  double* svc_ht;   // holding time
+  u32* svc_pk;      // source | destination << 10 | bit-rate index << 20
+  int* svc_cnt;     // services in the group's batch << 8 | next one to take
   double* soon_t;   // [B][ORL_SOON] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8, ...
   u32* soon_i;      // [B][ORL_SOON] their slots in ev_time / ev_info
   i64 q_cap;

@@ -203,11 +203,175 @@ __device__ __forceinline__ void emit_items(const DevParams& P, i64 env, const Si
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Service look-ahead of the persistent kernel.  _next_service (rmsa_env.py:545-597, rwa_env.py:258-288,
+// rmcsa_env.py:690-739) draws the next arrival from the env's own random.Random — inter-arrival time, holding time, source,
+// destination, bit rate — and nothing it draws depends on the state of the network: the traffic is open-loop.  Drawn inside
+// the step it is the same arithmetic on all 8 lanes of an env's group (two glibc-exact logarithms, two float64 divisions, two
+// table searches, a dozen cross-lane word fetches: every instruction of it serves 8 envs per wavefront) and a chain of three
+// dependent memory round trips (logarithm table, source table, destination table).  Here every 8 steps the group draws its
+// next 8 services AT ONCE, lane j the j-th: the lanes regenerate a window of 96 Mersenne-Twister words together (12 per lane),
+// find where each service starts in the word stream (random.randint is a rejection loop, so a service takes 8 + r words: a
+// walk over the window's accept bits), and each lane evaluates its own service — same operations on the same operands as
+// the in-step draw, which the one-step kernels keep.  A step then takes (inter-arrival time, holding time, source,
+// destination, bit-rate index) of its service from the lane that holds it.  Words are committed (regenerated words stored,
+// stream position advanced) for exactly the services generated, and never more services than the launch has steps left: the
+// Mersenne-Twister state a launch leaves is the state after the services its steps consumed.  A wavefront that leaves its
+// loop early (releases to be done in place, orl_kernels.hip) parks what it holds in DevParams::svc_* and picks it up at the
+// start of its next launch.
+// ---------------------------------------------------------------------------------------------------------------
+#define ORL_SVC_WIN 12  // Mersenne-Twister words per lane and batch: 8 services take 64 (+ 2 x 8 in the discrete bit-rate mode) or
+                        // 64 + rejected bit-rate draws (8 x 0.68 expected for 76 rates out of 128; more than 32: once in 10^5
+                        // batches — the group then gets the services that fit and draws again when they are used up)
+struct SvcBuf {
+  double q, ht;  // this lane's service of the batch: inter-arrival time, holding time
+  u32 pk;        // source | destination << 10 | bit-rate index << 20 (<= 512 nodes, <= 4 096 bit rates: orl_api.hip)
+  int cnt;       // group-uniform: services in the batch << 8 | next one to take
+};
+__device__ __forceinline__ bool svc_empty(const SvcBuf& b) { return (b.cnt & 0xff) >= (b.cnt >> 8); }
+__device__ __forceinline__ int svc_wrap(int i) { return i >= 624 ? i - 624 : i; }
+// bisect(cum_weights, x, 0, n - 1) of random.choices: the number of entries cum[0 .. n-2] that are <= x
+__device__ __forceinline__ int svc_choice(const double* cum, int n, double u) {
+  const double x = u * (cum[n - 1] + 0.0);
+  int cnt = 0;
+  if (n <= 33) {  // every entry requested before the first comparison (one memory round trip)
+    for (int base = 0; base < n - 1; base += 8) {
+      double c[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) c[k] = cum[base + k < n - 1 ? base + k : n - 2];
+#pragma unroll
+      for (int k = 0; k < 8; k++) cnt += (base + k < n - 1 && c[k] <= x) ? 1 : 0;
+    }
+  } else {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cum[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    cnt = lo;
+  }
+  return cnt;
+}
+// `rec`: the env's record (LDS window or global), `mt`: its Mersenne-Twister state, `active`: this group draws (its buffer
+// is used up), `n_want`: services wanted (<= 8: the steps the launch has left).  All 64 lanes call.
+template <int ENV>
+__device__ __forceinline__ void svc_generate(const DevParams& P, u64* rec, u32* mt, int lane, int n_want, SvcBuf& sb, bool active) {
+  const int gl = lane & 7;
+  const bool seek = (ENV != ENV_RWA) && P.bit_rate_mode == 0;  // random.randint: words are drawn until one is below rand_n
+  const int FIXED = (ENV == ENV_RWA) ? 8 : (P.bit_rate_mode == 0 ? 8 : 10);
+  const u32 sh = 32u - (u32)P.rand_bits, rn = (u32)P.rand_n;
+  const u64 idw = active ? rec[SC_ID_MTPOS] : 0ull;
+  const int pos = (int)(idw >> 32);
+  // the window: word t of the stream (t = 0 at the env's position) is held by lane t % 8 as its entry t / 8.  A position keeps
+  // the current generation's word until that word is handed out and the next generation's afterwards ("update-behind",
+  // orl_device_g8.h), so word t needs positions t, t + 1 (current) and t + 397 (mod 624: whichever generation is there) —
+  // none of which another word of a 96-word window regenerates before it is read: all requested together
+  u32 cur[ORL_SVC_WIN], nxt[ORL_SVC_WIN], far[ORL_SVC_WIN];
+#pragma unroll
+  for (int k = 0; k < ORL_SVC_WIN; k++) {
+    const int i0 = svc_wrap(pos + gl + 8 * k);
+    cur[k] = active ? mt[i0] : 0u;
+    nxt[k] = active ? mt[svc_wrap(i0 + 1)] : 0u;
+    far[k] = active ? mt[svc_wrap(i0 + 397)] : 0u;
+  }
+  u32 nx[ORL_SVC_WIN];
+  u32 acc0 = 0u, acc1 = 0u, acc2 = 0u;  // the group's accept bits: bit t = word t is a valid bit-rate draw
+#pragma unroll
+  for (int k = 0; k < ORL_SVC_WIN; k++) {
+    const u32 y = (cur[k] & 0x80000000u) | (nxt[k] & 0x7fffffffu);
+    nx[k] = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    if (seek) {
+      u32 t = cur[k];
+      t ^= (t >> 11);
+      t ^= (t << 7) & 0x9d2c5680u;
+      t ^= (t << 15) & 0xefc60000u;
+      t ^= (t >> 18);
+      const u32 byte = gballot((t >> sh) < rn, lane);
+      if (k < 4) acc0 |= byte << (8 * (k & 3));
+      else if (k < 8) acc1 |= byte << (8 * (k & 3));
+      else acc2 |= byte << (8 * (k & 3));
+    }
+  }
+  // where the services start: a walk over the accept bits, the same on all lanes of the group; lane j keeps service j's
+  int o = 0, my_o = 0, my_a = 0, got = 0;
+  {
+    const u64 m_lo = (u64)acc0 | ((u64)acc1 << 32);
+    bool ok = active;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (ok && j < n_want) {
+        const int c = o + FIXED;
+        int a = c - 1;
+        if (seek) {
+          u64 x = 0ull;
+          if (c < 64) x = (m_lo >> c) | ((u64)acc2 << (64 - c));  // (c >= 8: the shift is in range)
+          else if (c < 8 * ORL_SVC_WIN) x = (u64)(acc2 >> (c - 64));
+          if (x == 0ull) ok = false;
+          else a = c + (int)__builtin_ctzll(x);
+        } else if (c > 8 * ORL_SVC_WIN) {
+          ok = false;
+        }
+        if (ok) {
+          if (gl == j) { my_o = o; my_a = a; }
+          o = seek ? a + 1 : c;
+          got = j + 1;
+        }
+      }
+    }
+  }
+  // lane j evaluates service j.  Its words are spread over the group's lanes: read again from memory (just read: cache hits),
+  // requested before the regenerated words are stored below (same wavefront: the loads are served first)
+  const bool mine = active && gl < got;
+  u32 w[10], wa = 0u;
+#pragma unroll
+  for (int t = 0; t < 10; t++) w[t] = (mine && t < FIXED) ? mt[svc_wrap(pos + my_o + t)] : 0u;
+  if (seek && mine) wa = mt[svc_wrap(pos + my_a)];
+#pragma unroll
+  for (int k = 0; k < ORL_SVC_WIN; k++)
+    if (active && gl + 8 * k < o) mt[svc_wrap(pos + gl + 8 * k)] = nx[k];
+  if (active && gl == 0) rec[SC_ID_MTPOS] = (idw & 0xffffffffull) | ((u64)(u32)svc_wrap(pos + o) << 32);
+  if (mine) {
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+      u32 v = w[t];
+      v ^= (v >> 11);
+      v ^= (v << 7) & 0x9d2c5680u;
+      v ^= (v << 15) & 0xefc60000u;
+      v ^= (v >> 18);
+      w[t] = v;
+    }
+#define ORL_SVC_RND(A, B) ((((double)((A) >> 5)) * 67108864.0 + (double)((B) >> 6)) * (1.0 / 9007199254740992.0))
+    const double u1 = ORL_SVC_RND(w[0], w[1]), u2 = ORL_SVC_RND(w[2], w[3]);
+    const double us = ORL_SVC_RND(w[4], w[5]), ud = ORL_SVC_RND(w[6], w[7]);
+    // at = now + expovariate(1 / mean_iat), ht = expovariate(1 / mean_ht) (rmsa_env.py:548-553; random.expovariate)
+    sb.q = -orl_log(1.0 - u1) / P.lambda_a;
+    sb.ht = -orl_log(1.0 - u2) / P.lambda_h;
+    const int src = svc_choice(P.cum_src, P.N, us);
+    const int dst = svc_choice(P.cum_dst + src * P.N, P.N, ud);
+    int br_idx = 0;
+    if (ENV != ENV_RWA) {
+      if (P.bit_rate_mode == 0) {
+        u32 v = wa;
+        v ^= (v >> 11);
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= (v >> 18);
+        br_idx = (int)(v >> sh);
+      } else {
+        br_idx = svc_choice(P.cum_br, P.n_br, ORL_SVC_RND(w[8], w[9]));
+      }
+    }
+#undef ORL_SVC_RND
+    sb.pk = (u32)src | ((u32)dst << 10) | ((u32)br_idx << 20);
+  }
+  if (active) sb.cnt = got << 8;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // control kernel A: everything of step() up to (and excluding) the effects of the provision on the link rows
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
 __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             bool write_io, g8::RngG& rng, Prof& prof);
+                                             bool write_io, g8::RngG& rng, Prof& prof, SvcBuf* svc);
 #ifndef ORL_SCAN_BATCH
 #define ORL_SCAN_BATCH 8  // release times a lane requests per round of the rebuild scan
 #endif
@@ -276,7 +440,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
                                       const int4* given, u32* s_tally, typename SinkEntryOf<CP>::type* s_tab, int parity,
                                       int* s_deferred, int* done_out, unsigned short* s_list = nullptr, u32* s_list_n = nullptr,
                                       int tw = 32, SoonRegs* carried = nullptr, unsigned short* s_mtab = nullptr,
-                                      InfoCarry* ic = nullptr) {
+                                      InfoCarry* ic = nullptr, SvcBuf* svc = nullptr) {
+  // `svc` (persistent kernel): the group's batch of services drawn ahead (svc_generate); else the step draws its own
   const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
   if (!O.persistent && blockIdx.x == 0 && threadIdx.x == 0) P.q_def[(size_t)(parity ^ 1) * P.q_def_stride] = 0u;  // the buffer the next step appends to
   u64 desc_out = 0ull;
@@ -324,7 +489,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       if (pt <= e.now + P.pf_window && e.t_soon > -__builtin_inf() && (u32)pi < (u32)P.ev_cap) { pre_idx = pi; pre_info = e.ev_info[pi]; }
     }
     g8::RngG rng;
-    if (O.prefetch) g8::rng_fill(e, rng, gl);
+    rng.used = 0; rng.pend_used = 0;
+    if (O.prefetch && !svc) g8::rng_fill(e, rng, gl);
     e.bm = wm_bm(P, M, env);
     e.ls = wm_ls(P, M, env);
     e.cs = wm_cs(P, M, env);
@@ -516,8 +682,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         }
       }
     }
-    if (!O.prefetch) g8::rng_fill(e, rng, gl);
-    const bool done = service_part<ENV, W>(P, e, env, lane, O.auto_reset ? 1 : 0, accepted, core, O.write_io, rng, prof);
+    if (!O.prefetch && !svc) g8::rng_fill(e, rng, gl);
+    const bool done = service_part<ENV, W>(P, e, env, lane, O.auto_reset ? 1 : 0, accepted, core, O.write_io, rng, prof, svc);
     if (done_out) *done_out = done ? 1 : 0;
     // the pending-release slot of this step's provision (the rebuild scan of the release detection must find it in memory)
     if (pushed_idx >= 0 && gl == (pushed_idx & 7)) { e.ev_time[pushed_idx] = pushed_t; e.ev_info[pushed_idx] = pushed_info; }
@@ -530,7 +696,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       // detection); those fields are written again below when the detection changed them.
       SoonRegs soon;
       release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
-      g8::rng_commit_stores(e, rng, gl);  // the Mersenne-Twister words of next_service: behind the detection's loads
+      if (!svc) g8::rng_commit_stores(e, rng, gl);  // the Mersenne-Twister words of next_service: behind the detection's loads
       ORL_PROFA(10);
       if (sink.deferred) {
         // more releases meet on one link than an item holds masks for: the release state stays as stored and the
@@ -588,7 +754,7 @@ __device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntr
 // ---------------------------------------------------------------------------------------------------------------
 template <int ENV, int W>
 __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 env, int lane, int auto_reset, bool accepted, int core,
-                                             bool write_io, g8::RngG& rng, Prof& prof) {
+                                             bool write_io, g8::RngG& rng, Prof& prof, SvcBuf* svc) {
   const int gl = lane & 7;
   if (accepted && ENV != ENV_RWA) {  // _update_network_stats (rmsa_env.py:439-462)
     double last_update = e.g_last, time_diff = e.now - last_update;
@@ -607,7 +773,32 @@ __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 en
   }
   e.new_service = 0;
   ORL_PROFA(6);
-  g8::next_service<ENV, W>(P, e, lane, rng);  // the due releases are release_soon's job
+  if (svc) {
+    // _next_service with the draws done ahead (svc_generate): the service comes from the lane of the group that holds it
+    if (!e.new_service) {
+      const int k = svc->cnt & 0xff;
+      const double q = gget(svc->q, k, lane), ht = gget(svc->ht, k, lane);
+      const u32 pk = gget(svc->pk, k, lane);
+      svc->cnt += 1;
+      const double at = e.now + q;
+      e.now = at;
+      const int br_idx = (int)(pk >> 20);
+      int bit_rate = 0;
+      if (ENV != ENV_RWA) bit_rate = (P.bit_rate_mode == 0) ? P.br_lo + br_idx : P.bit_rates[br_idx];
+      e.id = (int)e.esp;
+      e.src = (int)(pk & 0x3ffu); e.dst = (int)((pk >> 10) & 0x3ffu); e.at = at; e.ht = ht;
+      e.bit_rate = bit_rate; e.br_idx = (ENV != ENV_RWA) ? br_idx : 0;
+      e.new_service = 1;
+      if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) { e.sp += 1; e.esp += 1; }
+      if (ENV != ENV_RWA) {
+        e.brq += bit_rate;
+        e.ebrq += bit_rate;
+        if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;
+      }
+    }
+  } else {
+    g8::next_service<ENV, W>(P, e, lane, rng);  // the due releases are release_soon's job
+  }
   ORL_PROFA(7);
   bool done = (e.esp == (i64)P.episode_length);
   if (done && P.ep_log && gl == 0) episode_log(P, env, e.esa);

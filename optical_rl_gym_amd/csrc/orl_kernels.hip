@@ -33,6 +33,8 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
   const i64 env = blockIdx.x;
   const int lane = lane_id();
   if (mask && !mask[env]) return;
+  // (services the persistent kernel drew ahead for a run that was abandoned — an overflow error — are dropped with the reset)
+  if (lane < 8) P.svc_cnt[(env >> 3) * 64 + (env & 7) * 8 + lane] = 0;
   Env e;
   env_load(P, e, env, lane);
   if (!full) {
@@ -318,9 +320,14 @@ __device__ __forceinline__ void persist_fill_window(const DevParams& P, i64 env0
 // LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics,
 // 3 = slot maps + per-core sums in LDS, env records in global memory
 // PF: early requests of the Mersenne-Twister window and the link statistics (more live registers: the 3-wave forms)
+// SVC: services drawn 8 steps ahead, one per lane of an env's group (sp::svc_generate)
+#ifndef ORL_PERSIST_SVC
+#define ORL_PERSIST_SVC 1
+#endif
 template <int ENV, int W, int LDS, bool PF>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
+  constexpr bool SVC = ORL_PERSIST_SVC != 0;
   const int ICL = PersistInner<ENV, W, LDS>::value ? P.persist_ic : 0;  // (the host decides: only where it costs no wavefront)
   const bool IC = ICL >= 1, OC = ICL >= 2;
   constexpr bool SR = PF;  // soon list in registers: the forms with registers to spare
@@ -352,9 +359,16 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   u64 desc = 0ull;
   sp::SoonRegs soon_c;
   soon_c.dirty = 0;
+  sp::SvcBuf svb;
+  svb.q = 0.0; svb.ht = 0.0; svb.pk = 0u; svb.cnt = 0;
 #define ORL_LOAD_CARRIED()                                                                                  \
   do {                                                                                                      \
     desc = valid ? P.svc_desc[env] : 0ull;                                                                  \
+    if (SVC && valid && step < target) {                                                                    \
+      const size_t sl_ = (size_t)blockIdx.x * 64 + (size_t)lane;                                            \
+      svb.cnt = P.svc_cnt[sl_];                                                                             \
+      if (!sp::svc_empty(svb)) { svb.q = P.svc_q[sl_]; svb.ht = P.svc_ht[sl_]; svb.pk = P.svc_pk[sl_]; }   \
+    }                                                                                                       \
     _Pragma("unroll") for (int k = 0; k < ORL_SOON_PER_LANE; k++) {                                         \
       const bool ld = SR && valid && step < target;                                                         \
       soon_c.t[k] = ld ? P.soon_t[env * ORL_SOON + (lane & 7) + 8 * k] : __builtin_inf();                   \
@@ -471,6 +485,13 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     asm volatile("" : "+v"(env_lo), "+v"(lane_i));
     const i64 env_i = (i64)env_lo;
     const bool valid_i = env_i < P.B;
+    if (SVC) {  // a group whose batch of services is used up draws the next one: as many as the launch has steps left, 8 at most
+      const bool need = valid_i && sp::svc_empty(svb);
+      if (__ballot(need) != 0ull) {
+        const int left = target - step;
+        sp::svc_generate<ENV>(P, sp::wm_scal(P, M, valid_i ? env_i : M.scenv0), P.mt + (valid_i ? env_i : 0) * 624, lane_i, left < 8 ? left : 8, svb, need);
+      }
+    }
     ORL_PROFA(0);
     sp::CtrlOpts O;
     O.persistent = true;
@@ -488,7 +509,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
       desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
-                                    s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab);
+                                    s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab, nullptr, SVC ? &svb : nullptr);
     }
     __syncthreads();  // sink table + item list, clocks, env records
     {
@@ -584,6 +605,13 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     double2* gs = (double2*)(P.lstat + env0 * 4 * P.E);
     const double2* ls = (const double2*)M.ls0;
     for (int i = lane; i < nenv * 2 * P.E; i += 64) gs[i] = ls[i];
+  }
+  if (SVC && step > first_step && valid) {
+    // what the group drew ahead and did not use: nothing when the loop ran to the launch's target; a wavefront that left early
+    // (releases to be done in place) parks it for its next launch
+    const size_t sl = (size_t)blockIdx.x * 64 + (size_t)lane;
+    P.svc_cnt[sl] = svb.cnt;
+    if (!sp::svc_empty(svb)) { P.svc_q[sl] = svb.q; P.svc_ht[sl] = svb.ht; P.svc_pk[sl] = svb.pk; }
   }
   if (SR && step > first_step && valid) {
 #pragma unroll

@@ -227,12 +227,15 @@ class BatchedOpticalEnv:
         JIT_MIN_ENVS envs — where 5-12 % of the device loop are worth it — or whenever ORL_JIT_SPEC=1; ORL_JIT_SPEC=0: never.
         Returns whether one is attached.  Default library only (the cross-implementation builds keep the generic kernels)."""
         mode = os.environ.get("ORL_JIT_SPEC", "")
-        if mode == "0" or os.environ.get("ORL_LIB_VARIANT", "default") != "default" or _build._extra():
+        variant = os.environ.get("ORL_LIB_VARIANT", "default")
+        if mode == "0" or variant not in ("default", "exp") or (_build._extra() and variant != "exp"):
             return False
         buf = C.create_string_buffer(1024)
         if self.lib.orl_batch_spec_flags(self._h, buf, len(buf)) <= 0:
             return False
         flags = buf.value.decode()
+        if os.environ.get("ORL_SPEC_EXTRA"):  # A/B experiments on the specialised kernels only: extra compiler flags (part of the cache key)
+            flags += " " + os.environ["ORL_SPEC_EXTRA"]
         path = _build.spec_path(flags)
         if not os.path.exists(path):
             if not (mode == "1" or self.num_envs >= self.JIT_MIN_ENVS):
@@ -244,7 +247,18 @@ class BatchedOpticalEnv:
 
                 warnings.warn("optical_rl_gym_amd: specialisation not built (%s); the generic persistent kernel runs" % exc)
                 return False
-        self._ck(self.lib.orl_batch_load_spec(self._h, path.encode()))
+        try:
+            self._ck(self.lib.orl_batch_load_spec(self._h, path.encode()))
+        except _lib.OrlError as exc:  # a cached library that no longer loads (another ROCm, a damaged file): optional, never fatal
+            import warnings
+
+            warnings.warn("optical_rl_gym_amd: specialisation %s not attached (%s); the generic persistent kernel runs"
+                          % (os.path.basename(path), exc))
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+            return False
         return True
 
     @classmethod
