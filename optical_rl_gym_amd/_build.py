@@ -130,11 +130,26 @@ def build(force=False, verbose=False, variant="default"):
 SPEC_DIR = os.path.join(HERE, "build", "spec")
 
 
+# Code-generation choices of the specialised kernels, measured on MI355X (profiles/r4*).  LLVM's machine-level
+# loop-invariant code motion keeps ~35 constants and addresses in registers across the whole step loop: without it the cfg2
+# kernel needs 126 VGPRs instead of 161-168 at the same speed, and the 4-wave forms (cfg1 / cfg3 / cfg5, 128-VGPR budget) have
+# room for what the 3-wave forms keep in registers — the soon list and the early requests (ORL_PF_WAVES=4): cfg1 +12 %, cfg3
+# +7 %, cfg5 +4 %.  RMCSA (3-wave form, 168 VGPRs, nothing to gain from a fourth wave at 16 384 envs) measured 1 % slower
+# without the hoisting and keeps it.
+SPEC_TUNING = ["-mllvm", "-disable-machine-licm", "-DORL_PF_WAVES=4"]
+
+
+def spec_tuning(flags):
+    if "-DORL_SPEC_ENV=3" in flags.split() or "-DORL_PF_WAVES" in flags or os.environ.get("ORL_SPEC_TUNING", "1") == "0":
+        return []
+    return list(SPEC_TUNING)
+
+
 def spec_path(flags):
     """Where the specialisation library for these flags (orl_batch_spec_flags) lives: keyed by the flags, the sources and the
     compiler, so a stale one is never picked up."""
     src = source_hash()
-    key = hashlib.sha256((flags + "|" + src).encode()).hexdigest()[:20]
+    key = hashlib.sha256((flags + " " + " ".join(spec_tuning(flags)) + "|" + src).encode()).hexdigest()[:20]
     return os.path.join(SPEC_DIR, "liborlspec_%s_%s.so" % (src[:8], key))
 
 
@@ -161,7 +176,7 @@ def build_spec(flags, verbose=False):
             if os.path.exists(path):
                 return path
             tmp = path + ".tmp.%d" % os.getpid()
-            cmd = [hipcc_path()] + HIPCC_FLAGS + _extra() + flags.split() + ["-shared", os.path.join(CSRC, "orl_kernels.hip"), "-o", tmp]
+            cmd = [hipcc_path()] + HIPCC_FLAGS + _extra() + flags.split() + spec_tuning(flags) + ["-shared", os.path.join(CSRC, "orl_kernels.hip"), "-o", tmp]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

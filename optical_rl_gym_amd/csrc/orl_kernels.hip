@@ -666,7 +666,10 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
   // the counters the NEXT launch of this half of the batch uses (it starts after this one has ended)
   if (blockIdx.x == 0 && threadIdx.x == 0) { clear_next[0] = 0u; clear_next[1] = 0u; }
   persist_spec_apply<SPEC>(P);
-  persist_body<ENV, W, LDS, (WAVES <= 3)>(P, pol, target, wg_step, n_unfinished);
+  #ifndef ORL_PF_WAVES
+#define ORL_PF_WAVES 3  // forms of at most this many waves per SIMD keep the soon list in registers and request early
+#endif
+  persist_body<ENV, W, LDS, (WAVES <= ORL_PF_WAVES)>(P, pol, target, wg_step, n_unfinished);
 }
 
 
@@ -676,10 +679,11 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
 // wavefront, all state in global memory, the per-step tables in LDS — plus what a host-visible step() owes beyond the
 // device-resident loop: the action is validated (is_path_free), reward / done / info / observation are written, the
 // network-compactness update is finished in the same launch, and releases that do not fit the item form are done in place
-// right away, so that every launch leaves final state.  All four families (RMSA / DeepRMSA with continuous bit rates: the
-// per-rate info entries of the discrete mode keep the one-wavefront-per-env kernel, k_step: 305 us per 65 536 envs against
-// ~106 us here).  RWA's info carries the action probabilities (written beside the histogram update of the control phase),
-// RMCSA's the four blocking rates.
+// right away, so that every launch leaves final state.  All four families, both bit-rate modes (the discrete mode's per-rate
+// blocking entries and their spread, io[8..], are written by the control phase; tests: the g9 discrete-bit-rate fixtures under
+// the forced `agent8` form); the one-wavefront-per-env kernel k_step serves batches below 2 048 envs, reseeded batches and
+// QoSConstrainedRA (305 us per 65 536 cfg2 envs against ~84 us here).  RWA's info carries the action probabilities (written
+// beside the histogram update of the control phase), RMCSA's the four blocking rates.
 // info (rmsa_env.py:234-264): the four blocking rates from the counters before the next service is counted (control
 // phase); network_compactness after the provision = (totals - what this step's releases added) over the occupied-slot sum at
 // provision time, the difference to its value before the provision; the two link averages over topology.edges() in numpy's

@@ -54,7 +54,12 @@ def make_spaces(batch, obs_dtype=np.float64, mod=None):
     return obs, act
 
 
-_NO_INFO = {}  # shared by every env without episode information in a step (never written to by this module)
+# Shared by every env without episode information in a step: a READ-ONLY empty mapping (get / in / copy work like a dict's; a
+# wrapper or callback that tries to write a key into it gets a TypeError instead of leaking the key into all 65 536 envs).
+# An env that reports done gets a dict of its own.
+import types as _types
+
+_NO_INFO = _types.MappingProxyType({})
 
 
 class OpticalVecEnv:
