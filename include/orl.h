@@ -162,6 +162,9 @@ int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_t* env_mask
  * orl_batch_get_episode_log: counts[n_envs], accepted[n_envs][capacity]. */
 int orl_batch_episode_log(orl_batch* b, int32_t capacity);
 int orl_batch_get_episode_log(orl_batch* b, int32_t* counts, int32_t* accepted);
+/* QoSConstrainedRA (reward = the accepted service's class reward, qos_constrained_ra.py:131-136): the harness's episode_reward of
+ * every logged episode — the float64 sum of the step rewards in step order, from 0.0 (utils.py:125-131) — [n_envs][capacity]. */
+int orl_batch_get_episode_rewards(orl_batch* b, double* rewards);
 
 /* ORL_POLICY_PATH_FF: the path index chosen for every env, [n_envs] int32 (>= k_paths = reject). */
 int orl_batch_set_paths(orl_batch* b, const int32_t* paths);
@@ -186,6 +189,18 @@ int orl_batch_policy(orl_batch* b, int policy_id, int32_t* actions_out);
  *                   (the reference's heap is unbounded); recreate the batch with a larger event_capacity. */
 int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, double* reward_out,
                    uint8_t* done_out, double* info_out);
+
+/* step() in two halves, for a caller that has work of its own between issuing a step and needing its results (SB3's
+ * VecEnv.step_async / step_wait, examples/stable_baselines3/DeepRMSA.ipynb:272-302 drives the env through them).
+ * orl_batch_step_async: the checks of orl_batch_step (ORL_E_ACTION before anything is modified), then everything is QUEUED on the
+ * batch's stream — actions in, the step kernel, the requested results out — and the call returns.  The output buffers (any may
+ * be NULL; obs_f32_out receives the observation cast to float32 on the device) must stay valid and untouched until
+ * orl_batch_step_wait returns; give page-locked ones (orl_host_alloc) or the copies are staged synchronously.
+ * orl_batch_step_wait: waits for that step and reports what orl_batch_step would have (ORL_E_OVERFLOW, flagged device-resident
+ * actions).  One step may be pending per batch; any other call on the batch in between is ordered behind it by the stream. */
+int orl_batch_step_async(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, float* obs_f32_out,
+                         double* reward_out, uint8_t* done_out, double* info_out);
+int orl_batch_step_wait(orl_batch* b);
 
 /* DeepRMSAEnv.observation() for the pending service (deeprmsa_env.py:60-121). */
 int orl_batch_observation(orl_batch* b, double* obs_out);

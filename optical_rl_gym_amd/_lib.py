@@ -59,6 +59,8 @@ EXPORTS = {
     "orl_batch_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(RunStats)]),
     "orl_batch_sync": (C.c_int, [C.c_void_p]),
+    "orl_batch_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orl_batch_step_wait": (C.c_int, [C.c_void_p]),
     "orl_batch_get_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_services": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_slots": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -80,6 +82,7 @@ EXPORTS = {
     "orl_batch_set_paths": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_episode_log": (C.c_int, [C.c_void_p, C.c_int32]),
     "orl_batch_get_episode_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orl_batch_get_episode_rewards": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_check": (C.c_int, [C.c_void_p]),
     "orl_batch_get_action_histograms": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "orl_batch_get_pending": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

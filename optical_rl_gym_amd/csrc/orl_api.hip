@@ -374,6 +374,7 @@ static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
   if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (P.S + 1));
   if (q.act2d) q.act2d += lo * P.act2d_words;
   if (q.ep_log) { q.ep_log += lo * P.ep_cap; q.ep_count += lo; }
+  if (q.ep_rew) { q.ep_rew += lo * P.ep_cap; q.ep_rew_acc += lo; }
   q.path_col += lo;
   q.actions += lo * 4; q.reward += lo; q.done += lo; q.info += lo * P.n_info;
   if (q.obs) { q.obs += lo * P.obs_dim; q.term_obs += lo * P.obs_dim; }
@@ -772,7 +773,7 @@ extern "C" int orl_batch_episode_log(orl_batch* b, int32_t capacity) try {
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   const size_t B = (size_t)b->P.B;
-  if (capacity == 0) { b->P.ep_log = nullptr; b->P.ep_cap = 0; return ORL_OK; }  // (the buffer stays for the next arming)
+  if (capacity == 0) { b->P.ep_log = nullptr; b->P.ep_rew = nullptr; b->P.ep_cap = 0; return ORL_OK; }  // (the buffers stay for the next arming)
   if (capacity > b->ep_alloc) {  // grow: the old buffer is released, the log is [n_envs][capacity] from here on
     int* lg = nullptr;
     HIPCHK(hipMalloc((void**)&lg, B * (size_t)capacity * sizeof(int) + 64));
@@ -782,7 +783,23 @@ extern "C" int orl_batch_episode_log(orl_batch* b, int32_t capacity) try {
     }
     b->allocs.push_back(lg);
     b->ep_buf = lg;
+    if (b->P.env_type == ENV_QOS) {  // + the float64 reward sums (class rewards)
+      double* rw = nullptr;
+      HIPCHK(hipMalloc((void**)&rw, B * (size_t)capacity * sizeof(double) + 64));
+      if (b->ep_rew_buf) {
+        hipFree(b->ep_rew_buf);
+        b->allocs.erase(std::find(b->allocs.begin(), b->allocs.end(), (void*)b->ep_rew_buf));
+      }
+      b->allocs.push_back(rw);
+      b->ep_rew_buf = rw;
+    }
     b->ep_alloc = capacity;
+  }
+  if (b->P.env_type == ENV_QOS && !b->P.ep_rew_acc) {
+    double* ac = nullptr;
+    HIPCHK(hipMalloc((void**)&ac, B * sizeof(double) + 64));
+    b->allocs.push_back(ac);
+    b->P.ep_rew_acc = ac;
   }
   if (!b->P.ep_count) {
     int* ct = nullptr;
@@ -795,7 +812,21 @@ extern "C" int orl_batch_episode_log(orl_batch* b, int32_t capacity) try {
   b->P.ep_cap = capacity;
   HIPCHK(hipMemsetAsync(b->P.ep_count, 0, B * sizeof(int), b->stream));
   HIPCHK(hipMemsetAsync(b->P.ep_log, 0, B * (size_t)b->P.ep_cap * sizeof(int), b->stream));
+  if (b->P.env_type == ENV_QOS) {
+    b->P.ep_rew = b->ep_rew_buf;
+    HIPCHK(hipMemsetAsync(b->P.ep_rew, 0, B * (size_t)b->P.ep_cap * sizeof(double), b->stream));
+    HIPCHK(hipMemsetAsync(b->P.ep_rew_acc, 0, B * sizeof(double), b->stream));
+  }
   HIPCHK(hipStreamSynchronize(b->stream));
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_get_episode_rewards(orl_batch* b, double* rewards) try {
+  if (!b || !rewards) return fail(ORL_E_INVALID, "null argument");
+  if (!b->P.ep_log || !b->P.ep_rew) return fail(ORL_E_INVALID, "no reward log: QoSConstrainedRA batches with the episode log armed keep one");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(rewards, b->P.ep_rew, (size_t)b->P.B * b->P.ep_cap * sizeof(double), hipMemcpyDeviceToHost));
   return ORL_OK;
 }
 ORL_ABI_CATCH_INT
@@ -893,6 +924,59 @@ extern "C" int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_res
     HIPCHK(hipGetLastError());
   }
   return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+
+// step() in two halves (SB3's VecEnv.step_async / step_wait): the first validates the host actions and QUEUES everything — the
+// copy of the actions, the step kernel, the copies of whatever results are asked for (into the caller's buffers, which must
+// stay valid until the second half; page-locked ones from orl_host_alloc make the copies asynchronous), the flag word — on the
+// batch's stream and returns; the second waits for the stream and reports like orl_batch_step.  Host work done in between
+// (the agent's bookkeeping of the previous step) overlaps the device's.
+extern "C" int orl_batch_step_async(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, float* obs_f32_out,
+                                    double* reward_out, uint8_t* done_out, double* info_out) try {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  if (b->step_pending) return fail(ORL_E_INVALID, "orl_batch_step_async: the previous step has not been waited for");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t B = (size_t)b->P.B;
+  if (actions) {
+    const int64_t bad = first_bad_action(b, actions);
+    if (bad >= 0)
+      return fail(ORL_E_ACTION, "action (%d, %d, %d, %d) of env %lld is outside the action space", actions[4 * bad],
+                  actions[4 * bad + 1], actions[4 * bad + 2], actions[4 * bad + 3], (long long)bad);
+    HIPCHK(hipMemcpyAsync(b->P.actions, actions, B * 4 * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  }
+  if (b->agent_step) launch_agent_step(b, auto_reset ? 1 : 0);
+  else launch_step64(b, auto_reset ? 1 : 0, 1, -1);
+  if (reward_out) HIPCHK(hipMemcpyAsync(reward_out, b->P.reward, B * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  if (done_out) HIPCHK(hipMemcpyAsync(done_out, b->P.done, B, hipMemcpyDeviceToHost, b->stream));
+  if (info_out) HIPCHK(hipMemcpyAsync(info_out, b->P.info, B * b->P.n_info * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  if (b->P.obs_dim && obs_out)
+    HIPCHK(hipMemcpyAsync(obs_out, b->P.obs, B * b->P.obs_dim * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  if (b->P.obs_dim && obs_f32_out) {
+    const i64 n = b->P.B * b->P.obs_dim;
+    if (!b->obs_f32) {
+      HIPCHK(hipMalloc((void**)&b->obs_f32, (size_t)n * sizeof(float) + 64));
+      b->allocs.push_back(b->obs_f32);
+    }
+    hipLaunchKernelGGL(k_cast_f32, dim3(2048), dim3(256), 0, b->stream, b->P.obs, b->obs_f32, n);
+    HIPCHK(hipMemcpyAsync(obs_f32_out, b->obs_f32, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  }
+  // what the kernels flagged (device-resident actions cannot be checked beforehand), as report_flags gathers it
+  HIPCHK(hipMemsetAsync(b->d_unfinished + 16, 0, 2 * sizeof(unsigned int), b->stream));
+  launch_finish2(b, 0);
+  HIPCHK(hipMemcpyAsync(b->h_tail + 16, b->d_unfinished + 16, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, b->stream));
+  b->step_pending = 1;
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_step_wait(orl_batch* b) try {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  if (!b->step_pending) return fail(ORL_E_INVALID, "orl_batch_step_wait without orl_batch_step_async");
+  HIPCHK(hipSetDevice(b->device));
+  b->step_pending = 0;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipGetLastError());
+  return flags_to_rc(b, b->h_tail[17]);
 }
 ORL_ABI_CATCH_INT
 

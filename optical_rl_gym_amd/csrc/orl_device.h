@@ -151,6 +151,10 @@ struct DevParams {
   int* ep_log;      // [B][ep_cap] or null: episode_services_accepted of every finished episode (evaluate_heuristic on the device)
   int* ep_count;    // [B] episodes finished since the log was armed
   int ep_cap;
+  // QoSConstrainedRA: the reward is the accepted service's class reward (qos_constrained_ra.py:131-136), so the harness's
+  // episode_reward (utils.py:125-131: += reward per step, from 0.0) is kept as a float64 sum in step order
+  double* ep_rew;      // [B][ep_cap] or null: sum of rewards of every finished episode
+  double* ep_rew_acc;  // [B] the running episode's sum
   // I/O (device resident; the C-ABI copies to/from host buffers)
   int* actions;            // [B][4]
   double* reward;          // [B]
@@ -1266,6 +1270,14 @@ __device__ __forceinline__ void step(const DevParams& P, Env& e, int lane, const
     e.new_service = 0;
     next_service<ENV, W, EVL>(P, e, lane, prefilled, pf);
     const bool doneq = (e.esp == (i64)P.episode_length);
+    if (P.ep_log && P.ep_rew && lane == 0) {
+      const double acc = P.ep_rew_acc[e.env] + rew;
+      if (doneq) {
+        const int idx = P.ep_count[e.env];
+        if (idx < P.ep_cap) P.ep_rew[e.env * P.ep_cap + idx] = acc;
+      }
+      P.ep_rew_acc[e.env] = doneq ? 0.0 : acc;
+    }
     if (doneq && P.ep_log && lane == 0) episode_log(P, e.env, e.esa);
     if (doneq && auto_reset) soft_reset<ENV>(e);
     if (lane == 0) {

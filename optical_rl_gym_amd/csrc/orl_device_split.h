@@ -229,26 +229,34 @@ struct SvcBuf {
 };
 __device__ __forceinline__ bool svc_empty(const SvcBuf& b) { return (b.cnt & 0xff) >= (b.cnt >> 8); }
 __device__ __forceinline__ int svc_wrap(int i) { return i >= 624 ? i - 624 : i; }
-// bisect(cum_weights, x, 0, n - 1) of random.choices: the number of entries cum[0 .. n-2] that are <= x
+// bisect(cum_weights, x, 0, n - 1) of random.choices: the number of entries cum[0 .. n-2] that are <= x (cum is non-decreasing).
+// Two rounds of independent requests instead of a chain of log2(n) dependent ones: every eighth entry first (the block the
+// answer lies in), then that block's entries — Germany50's 49 entries took six dependent memory round trips per table.
 __device__ __forceinline__ int svc_choice(const double* cum, int n, double u) {
   const double x = u * (cum[n - 1] + 0.0);
-  int cnt = 0;
-  if (n <= 33) {  // every entry requested before the first comparison (one memory round trip)
-    for (int base = 0; base < n - 1; base += 8) {
-      double c[8];
+  const int m = n - 1;  // entries searched
+  if (m <= 0) return 0;
+  int b = 0;
+  if (m > 8 && m <= 72) {
+    double p[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) c[k] = cum[base + k < n - 1 ? base + k : n - 2];
+    for (int j = 0; j < 8; j++) p[j] = cum[8 * j + 7 < m ? 8 * j + 7 : m - 1];
 #pragma unroll
-      for (int k = 0; k < 8; k++) cnt += (base + k < n - 1 && c[k] <= x) ? 1 : 0;
-    }
-  } else {
-    int lo = 0, hi = n - 1;
+    for (int j = 0; j < 8; j++) b += (8 * j + 7 < m && p[j] <= x) ? 1 : 0;
+  } else if (m > 72) {
+    int lo = 0, hi = m;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (cum[mid] <= x) lo = mid + 1; else hi = mid;
     }
-    cnt = lo;
+    return lo;
   }
+  double c[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) c[k] = cum[8 * b + k < m ? 8 * b + k : m - 1];
+  int cnt = 8 * b;
+#pragma unroll
+  for (int k = 0; k < 8; k++) cnt += (8 * b + k < m && c[k] <= x) ? 1 : 0;
   return cnt;
 }
 // `rec`: the env's record (LDS window or global), `mt`: its Mersenne-Twister state, `active`: this group draws (its buffer

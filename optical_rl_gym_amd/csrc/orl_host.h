@@ -57,6 +57,7 @@ struct orl_batch {
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_totals = nullptr;
+  int step_pending = 0;            // orl_batch_step_async queued a step that orl_batch_step_wait has not collected yet
   unsigned int* h_tail = nullptr;  // page-locked: where the straggler count / flag words of a run land (a pageable target is staged)
   int cache_epoch = 1;             // bumped by every call that may change slot maps outside the persistent kernel (DevParams::row_cache_key)
   long long* gather_idx = nullptr;  // orl_batch_get_info_rows: row indices and gathered rows on the device, grown on demand
@@ -65,6 +66,7 @@ struct orl_batch {
   float* obs_f32 = nullptr;        // device copy of the observation array in float32 (orl_batch_get_obs_f32), allocated on first use
   int* ep_buf = nullptr;           // episode log buffer (orl_batch_episode_log): [B][ep_alloc] ints, armed with stride P.ep_cap <= ep_alloc
   int ep_alloc = 0;
+  double* ep_rew_buf = nullptr;    // QoSConstrainedRA: the float64 reward sums beside it, same shape
 };
 
 #define ORL_TK(B_, NAME)                                                                 \

@@ -352,6 +352,36 @@ class BatchedOpticalEnv:
         self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), None, None, None, None))
         return None
 
+    def step_async(self, actions, auto_reset=False, obs_out=None, fetch_info=True):
+        """First half of step() (include/orl.h, orl_batch_step_async): checks the actions, queues the copies and the kernel on
+        the batch's stream and returns at once.  `step_wait()` collects what `step()` would have returned."""
+        a = None
+        if actions is not None:
+            actions = np.asarray(actions)
+            if actions.ndim == 1:
+                actions = actions[:, None]
+            a = self._act_in
+            a[:, : actions.shape[1]] = actions
+        obs64 = obs32 = None
+        if self.obs_dim:
+            obs = self._obs if obs_out is None else obs_out
+            assert obs.shape == (self.num_envs, self.obs_dim) and obs.flags.c_contiguous
+            if obs.dtype == np.float32:
+                obs32 = obs
+            else:
+                assert obs.dtype == np.float64
+                obs64 = obs
+            self._pending_obs = obs
+        else:
+            self._pending_obs = None
+        self._pending_info = self._info if fetch_info else None
+        self._ck(self.lib.orl_batch_step_async(self._h, _ptr(a), int(auto_reset), _ptr(obs64), _ptr(obs32), self._reward.ctypes.data,
+                                                 self._done.ctypes.data, self._info.ctypes.data if fetch_info else None))
+
+    def step_wait(self):
+        self._ck(self.lib.orl_batch_step_wait(self._h))
+        return self._pending_obs, self._reward, self._done, self._pending_info
+
     def info_rows(self, indices):
         """Rows `indices` of the info array the last step left on the device: [len(indices), n_info] float64 (gathered on the
         device; a VecEnv needs the rows of the envs that just finished an episode, not 4 MB of info per step)."""
@@ -382,8 +412,6 @@ class BatchedOpticalEnv:
         accounting (reset -> loop until done -> sum of rewards): returns (episode_rewards [num_envs, n_eval_episodes],
         episode_lengths).  One device-resident run; the kernels log each finished episode."""
         n = int(n_eval_episodes)
-        if self.ENV_TYPE == 4:
-            raise NotImplementedError("QoSConstrainedRA rewards depend on the service class: evaluate it with the host loop")
         self._ck(self.lib.orl_batch_reset(self._h, 0, None))  # the harness's reset() before the first episode (soft)
         self._ck(self.lib.orl_batch_episode_log(self._h, n))
         L = self.steps_per_episode()
@@ -398,10 +426,14 @@ class BatchedOpticalEnv:
             self.step(None, auto_reset=False, fetch=False)
             self.check()
             self._ck(self.lib.orl_batch_get_episode_log(self._h, counts.ctypes.data, acc.ctypes.data))
+            qos_rewards = None
+            if self.ENV_TYPE == 4:  # class rewards: the kernels kept the float64 sums (qos_constrained_ra.py:131-136)
+                qos_rewards = np.zeros((self.num_envs, n), np.float64)
+                self._ck(self.lib.orl_batch_get_episode_rewards(self._h, qos_rewards.ctypes.data))
         finally:  # whatever happened above, the next run must not append to a log nobody reads
             self._ck(self.lib.orl_batch_episode_log(self._h, 0))
         assert (counts == n).all(), "every env finishes exactly n episodes in n * steps_per_episode steps"
-        rewards = acc.astype(np.float64)
+        rewards = acc.astype(np.float64) if qos_rewards is None else qos_rewards
         if self.ENV_TYPE == 1:  # DeepRMSA: +1 accepted, -1 otherwise (deeprmsa_env.py:123-124)
             rewards = 2.0 * rewards - L
         return rewards, np.full((self.num_envs, n), L, np.int64)

@@ -89,6 +89,8 @@ class OpticalVecEnv:
         self._direct_obs = "obs_out" in inspect.signature(batch.step).parameters
         # (... and leave info on the device, handing out the rows of the envs that finished an episode)
         self._sparse_info = "fetch_info" in inspect.signature(batch.step).parameters and hasattr(batch, "info_rows")
+        self._async = hasattr(batch, "step_async") and self._sparse_info  # (the HIP batches)
+        self._queued = False
         self._ep_ret = np.zeros(self.num_envs)
         self._ep_len = np.zeros(self.num_envs, np.int64)
         self._t0 = time.time()
@@ -101,7 +103,15 @@ class OpticalVecEnv:
         return self._obs(self.batch.reset(full=False))
 
     def step_async(self, actions):
+        """Queues the whole step on the batch's stream — actions to the device, the step kernel, reward / done (/ observation)
+        back into page-locked arrays — and returns: what the caller does until step_wait() overlaps the device's work."""
         self._actions = np.asarray(actions)
+        self._queued = False
+        if self._async:
+            direct = self._direct()
+            self.batch.step_async(self._actions, auto_reset=True, obs_out=self._next_obs_buffer() if direct else None,
+                                  fetch_info=not self._sparse_info)
+            self._queued = True
 
     def _next_obs_buffer(self):
         """Observations go straight into one of THREE page-locked arrays of the requested dtype, used in turn: the array a
@@ -114,11 +124,19 @@ class OpticalVecEnv:
         self._obs_turn = (self._obs_turn + 1) % 3
         return self._obs_ring[self._obs_turn]
 
+    def _direct(self):
+        return bool(self.observation_mode != "matrix" and getattr(self.batch, "obs_dim", 0)
+                    and self.obs_dtype in (np.dtype(np.float64), np.dtype(np.float32)) and self._direct_obs)
+
     def step_wait(self):
-        direct = (self.observation_mode != "matrix" and getattr(self.batch, "obs_dim", 0)
-                  and self.obs_dtype in (np.dtype(np.float64), np.dtype(np.float32)) and self._direct_obs)
+        direct = self._direct()
         kw = dict(fetch_info=False) if self._sparse_info else {}
-        if direct:
+        if self._queued:
+            self._queued = False
+            obs, reward, done, info = self.batch.step_wait()
+            if not direct:
+                obs = self._obs(obs)
+        elif direct:
             obs, reward, done, info = self.batch.step(self._actions, auto_reset=True, obs_out=self._next_obs_buffer(), **kw)
         else:
             obs, reward, done, info = self.batch.step(self._actions, auto_reset=True, **kw)

@@ -1286,6 +1286,39 @@ def test_qos_batches_match_oracle_and_run_equals_stepping():
         dev.close()
 
 
+def test_qos_evaluate_on_device_equals_the_harness():
+    """evaluate_heuristic (utils.py:103-141) for QoSConstrainedRA on the device: the reward of an accepted service is its
+    class's reward (qos_constrained_ra.py:131-136), so the kernels keep each episode's float64 reward sum in step order;
+    against the harness's accounting played on the oracle (reset, steps until done, += reward), with rewards that do not sum
+    exactly in another order."""
+    import optical_rl_gym_amd as orl
+    from oracle.oracle import OracleBatch
+
+    kw = dict(load=700, mean_service_holding_time=25, episode_length=37, num_spectrum_resources=24, num_service_classes=3,
+              classes_arrival_probabilities=[0.2, 0.5, 0.3], classes_reward=[0.7, 0.1, 1.0 / 3.0], allow_rejection=True)
+    n, n_ep = 40, 4
+    seeds = [900 + 5 * i for i in range(n)]
+    for policy in ("SP_FF", "SAP_FF"):
+        dev = orl.make("QoSConstrainedRA-v0", topology="nsfnet_chen", num_envs=n, seeds=seeds, **kw)
+        ora = OracleBatch("QoSConstrainedRA", "nsfnet_chen", seeds, **kw)
+        dev.run(policy, 55); ora.run(policy, 55)  # somewhere inside an episode
+        rewards, lengths = dev.evaluate(policy, n_ep)
+        ora.reset(full=False)
+        exp = np.zeros((n, n_ep))
+        for ep in range(n_ep):
+            for t in range(kw["episode_length"]):
+                last = ep == n_ep - 1 and t == kw["episode_length"] - 1
+                _, r, d, _ = ora.step(ora.policy(policy), auto_reset=not last)
+                exp[:, ep] += r
+            assert d.all()
+        assert np.array_equal(rewards, exp) and (lengths == kw["episode_length"]).all()
+        assert len(np.unique(rewards)) > n  # class rewards, not counts
+        _exact("qos evaluate")(0, "counters", dev.counters(), ora.counters())
+        again, _ = dev.evaluate(policy, 2)  # re-armed with a smaller capacity
+        assert again.shape == (n, 2) and (again > 0).all()
+        dev.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_nodes,chords", [(5, 0), (6, 2), (4, 2)])  # 5, 8 and 6 links: fewer than a group's 8 lanes, exactly 8, a tail of 6
 @pytest.mark.parametrize("fam", ["RMSA", "DeepRMSA", "RWA"])
