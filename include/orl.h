@@ -192,14 +192,17 @@ int orl_batch_step(orl_batch* b, const int32_t* actions, int auto_reset, double*
 
 /* step() in two halves, for a caller that has work of its own between issuing a step and needing its results (SB3's
  * VecEnv.step_async / step_wait, examples/stable_baselines3/DeepRMSA.ipynb:272-302 drives the env through them).
+ * actions: [n_envs][action_width] (1..4 columns: the family's action, in the column order of orl_batch_step) of int32 or int64
+ * (action_elem_bytes 4 / 8), C-contiguous — the array an agent hands to VecEnv.step as it is — or NULL for the device-resident
+ * ones; checked and widened in one pass into the library's own page-locked staging rows.
  * orl_batch_step_async: the checks of orl_batch_step (ORL_E_ACTION before anything is modified), then everything is QUEUED on the
  * batch's stream — actions in, the step kernel, the requested results out — and the call returns.  The output buffers (any may
  * be NULL; obs_f32_out receives the observation cast to float32 on the device) must stay valid and untouched until
  * orl_batch_step_wait returns; give page-locked ones (orl_host_alloc) or the copies are staged synchronously.
  * orl_batch_step_wait: waits for that step and reports what orl_batch_step would have (ORL_E_OVERFLOW, flagged device-resident
  * actions).  One step may be pending per batch; any other call on the batch in between is ordered behind it by the stream. */
-int orl_batch_step_async(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, float* obs_f32_out,
-                         double* reward_out, uint8_t* done_out, double* info_out);
+int orl_batch_step_async(orl_batch* b, const void* actions, int action_width, int action_elem_bytes, int auto_reset,
+                         double* obs_out, float* obs_f32_out, double* reward_out, uint8_t* done_out, double* info_out);
 int orl_batch_step_wait(orl_batch* b);
 
 /* DeepRMSAEnv.observation() for the pending service (deeprmsa_env.py:60-121). */

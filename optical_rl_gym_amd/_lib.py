@@ -59,7 +59,8 @@ EXPORTS = {
     "orl_batch_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(RunStats)]),
     "orl_batch_sync": (C.c_int, [C.c_void_p]),
-    "orl_batch_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orl_batch_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     "orl_batch_step_wait": (C.c_int, [C.c_void_p]),
     "orl_batch_get_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_services": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -689,6 +689,7 @@ extern "C" void orl_batch_destroy(orl_batch* b) try {
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->h_tail) hipHostFree(b->h_tail);
+  if (b->h_actions) hipHostFree(b->h_actions);
   if (b->spec_handle) dlclose(b->spec_handle);
   for (void* p : b->allocs) hipFree(p);
   delete b;
@@ -932,18 +933,46 @@ ORL_ABI_CATCH_INT
 // stay valid until the second half; page-locked ones from orl_host_alloc make the copies asynchronous), the flag word — on the
 // batch's stream and returns; the second waits for the stream and reports like orl_batch_step.  Host work done in between
 // (the agent's bookkeeping of the previous step) overlaps the device's.
-extern "C" int orl_batch_step_async(orl_batch* b, const int32_t* actions, int auto_reset, double* obs_out, float* obs_f32_out,
-                                    double* reward_out, uint8_t* done_out, double* info_out) try {
+// one pass over the caller's compact action rows: range check (the reference's IndexError) and expansion into the [n][4] int32
+// rows the kernels read; returns the first bad env or -1
+template <typename T> static int64_t stage_actions(const orl_batch* b, const T* src, int width, int32_t* dst) {
+  const DevParams& P = b->P;
+  const int rej = P.allow_rejection ? 1 : 0;
+  int hi[4] = {0, 0, 0, 0};  // exclusive upper bounds per column (0: any value, DeepRMSA)
+  if (P.env_type == ENV_RMSA) { hi[0] = P.K + 1; hi[1] = P.S + 1; }
+  else if (P.env_type == ENV_RWA) { hi[0] = P.K + rej; hi[1] = P.S + rej; }
+  else if (P.env_type == ENV_RMCSA) { hi[0] = P.K + 1; hi[1] = P.M + 1; hi[2] = P.C + 1; hi[3] = P.S + 1; }
+  else if (P.env_type == ENV_QOS) { hi[0] = P.K + rej; }
+  int64_t bad = -1;
+  for (i64 i = 0; i < P.B; i++) {
+    const T* r = src + (size_t)i * width;
+    int32_t* d = dst + 4 * i;
+    for (int c = 0; c < 4; c++) {
+      const long long v = c < width ? (long long)r[c] : 0;
+      if (hi[c] > 0 && c < width && (v < 0 || v >= hi[c]) && bad < 0) bad = i;
+      d[c] = (int32_t)v;
+    }
+  }
+  return bad;
+}
+
+extern "C" int orl_batch_step_async(orl_batch* b, const void* actions, int action_width, int action_elem_bytes, int auto_reset,
+                                    double* obs_out, float* obs_f32_out, double* reward_out, uint8_t* done_out, double* info_out) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   if (b->step_pending) return fail(ORL_E_INVALID, "orl_batch_step_async: the previous step has not been waited for");
   HIPCHK(hipSetDevice(b->device));
   const size_t B = (size_t)b->P.B;
   if (actions) {
-    const int64_t bad = first_bad_action(b, actions);
-    if (bad >= 0)
-      return fail(ORL_E_ACTION, "action (%d, %d, %d, %d) of env %lld is outside the action space", actions[4 * bad],
-                  actions[4 * bad + 1], actions[4 * bad + 2], actions[4 * bad + 3], (long long)bad);
-    HIPCHK(hipMemcpyAsync(b->P.actions, actions, B * 4 * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    if (action_width < 1 || action_width > 4 || (action_elem_bytes != 4 && action_elem_bytes != 8))
+      return fail(ORL_E_INVALID, "actions: 1..4 columns of int32 or int64");
+    if (!b->h_actions) HIPCHK(hipHostMalloc((void**)&b->h_actions, B * 4 * sizeof(int32_t), hipHostMallocDefault));
+    const int64_t bad = action_elem_bytes == 4 ? stage_actions(b, (const int32_t*)actions, action_width, b->h_actions)
+                                               : stage_actions(b, (const int64_t*)actions, action_width, b->h_actions);
+    if (bad >= 0) {
+      const int32_t* r = b->h_actions + 4 * bad;
+      return fail(ORL_E_ACTION, "action (%d, %d, %d, %d) of env %lld is outside the action space", r[0], r[1], r[2], r[3], (long long)bad);
+    }
+    HIPCHK(hipMemcpyAsync(b->P.actions, b->h_actions, B * 4 * sizeof(int), hipMemcpyHostToDevice, b->stream));
   }
   if (b->agent_step) launch_agent_step(b, auto_reset ? 1 : 0);
   else launch_step64(b, auto_reset ? 1 : 0, 1, -1);

@@ -1207,7 +1207,6 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
     const u64 maskw = word_mask_lo(S - 64 * w);
     const u64 used = ~a[w] & maskw;
     const u64 prev_top = (w == 0) ? 0ull : (a[w - 1] >> 63);
-    const u64 carry_a = (w == 0) ? 0ull : prev_top;
     const u64 carry_u = (w == 0) ? 0ull : (prev_top ^ 1ull);  // slot 64w-1 < S for every w < W
     nu += __popcll(used & ~((used << 1) | carry_u));
     if (used) {
@@ -1216,26 +1215,26 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
       hi = 64 * w + 64 - (int)__builtin_clzll(used);  // w ascending: the last word with a used slot wins
     }
     free_ += __popcll(a[w]);
-    nf += __popcll(a[w] & ~((a[w] << 1) | carry_a));
     // longest run of free slots (runs continue across word boundaries)
-    if (a[w] == ~0ull) {
+    if (CACHED) {
+      // the runs that touch a word boundary here, branch-free (a lane whose word is entirely free and one whose word is not
+      // took both sides of an if / else before): lead / trail read 64 for a free word, which then only lengthens the run
+      // that crosses it; inter[w]: the word without its leading and trailing runs
+      const u64 na = ~a[w];
+      const bool full = na == 0ull;
+      const int lead = full ? 64 : (int)__builtin_ctzll(na), trail = full ? 64 : (int)__builtin_clzll(na);
+      best = (c + lead) > best ? (c + lead) : best;
+      c = full ? c + 64 : trail;
+      inter[CACHED ? w : 0] = full ? 0ull : (a[w] & ~word_range(0, lead) & ~word_range(64 - trail, 64));
+    } else if (a[w] == ~0ull) {
       c += 64;
       best = c > best ? c : best;
-      if (CACHED) inter[CACHED ? w : 0] = 0ull;
     } else {
       const int lead = (int)__builtin_ctzll(~a[w]);
-      if (CACHED) {
-        // the runs that touch a word boundary here; inter[w]: the word without its leading and trailing runs
-        const int trail = (int)__builtin_clzll(~a[w]);
-        best = (c + lead) > best ? (c + lead) : best;
-        c = trail;
-        inter[CACHED ? w : 0] = a[w] & ~word_range(0, lead) & ~word_range(64 - trail, 64);
-      } else {
-        const int inner = word_longest_run(a[w]);
-        const int cand = (c + lead) > inner ? (c + lead) : inner;
-        best = cand > best ? cand : best;
-        c = (int)__builtin_clzll(~a[w]);
-      }
+      const int inner = word_longest_run(a[w]);
+      const int cand = (c + lead) > inner ? (c + lead) : inner;
+      best = cand > best ? cand : best;
+      c = (int)__builtin_clzll(~a[w]);
     }
   }
   if (CACHED) {
@@ -1272,13 +1271,17 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
   // encoding the slice)
   const bool two = nu > 1;
   const int fb = two ? nu - 1 : 0;
-  st.nu = nu; st.lo = lo; st.hi = hi; st.occ = two ? hi - lo : 0; st.fb = fb; st.free_ = free_; st.nf = nf;
   max_empty = best;
   const int tw = (S - 1) >> 6, tb = (S - 1) & 63;
   int top_bit = 0;
 #pragma unroll
   for (int w = 0; w < W; w++) top_bit = (w == tw) ? (int)((a[w] >> tb) & 1ull) : top_bit;
   edge = (int)(a[0] & 1ull) + top_bit;
+  // free blocks: used and free blocks alternate along the row, so there is one more, as many, or one fewer of them than used
+  // blocks according to how many ends of the row are free (a row without a used slot: 0 - 1 + 2 = 1) — no second pass of
+  // block-start counts over the words
+  nf = nu - 1 + edge;
+  st.nu = nu; st.lo = lo; st.hi = hi; st.occ = two ? hi - lo : 0; st.fb = fb; st.free_ = free_; st.nf = nf;
 }
 
 // the cache word of a row, from scratch
@@ -1332,6 +1335,28 @@ __device__ __forceinline__ void row_occ_fb(const u64 (&a)[W], int S, int& occ, i
   const bool two = nu > 1;
   occ = two ? hi - lo : 0;
   fb = two ? nu - 1 : 0;
+}
+
+// x / d for several x and one d.  The compiler's float64 division (v_div_scale x 2, v_rcp_f64, four refinement FMAs, quotient,
+// remainder, v_div_fmas, v_div_fixup) spends half of its instructions on the reciprocal of the denominator; the running averages
+// of a link divide three sums by the same clock.  Same operations on the same operands as that sequence for operands that need
+// no rescaling (v_div_scale returns them unchanged unless an exponent is within 2^-/+768 of the range's ends; the clock is a
+// positive simulation time, the sums are products of ratios in [0, 1] and such times), so the quotients are bit-identical —
+// the parity suite compares every link's averages of every env with the oracle's.
+struct Recip { double d, r; };
+__device__ __forceinline__ Recip recip_of(double d) {
+  Recip k;
+  k.d = d;
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  k.r = __builtin_fma(r, e, r);
+  return k;
+}
+__device__ __forceinline__ double div_by(double x, const Recip& k) {
+  const double q = x * k.r;
+  return __builtin_fma(__builtin_fma(-k.d, q, x), k.r, q);
 }
 
 // Single-core families (RMSA, DeepRMSA, RWA): every mask of an item works on the same row, and only the first touch of
@@ -1449,19 +1474,22 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
       if (stash_env && rel_f) { stash_env[2 * link] = util; stash_env[2 * link + 1] = comp; }
       if (clock > 0) {  // the first touch of the link at this clock value
         const double time_diff = clock - last_update;
-        util = ((util * last_update) + (cur_util * time_diff)) / clock;
+        const Recip rc = recip_of(clock);
+        util = div_by((util * last_update) + (cur_util * time_diff), rc);
         if (ENV != ENV_RWA) {
-          frag = ((frag * last_update) + (cur_frag * time_diff)) / clock;
-          comp = ((comp * last_update) + (cur_comp * time_diff)) / clock;
+          frag = div_by((frag * last_update) + (cur_frag * time_diff), rc);
+          comp = div_by((comp * last_update) + (cur_comp * time_diff), rc);
         }
       }
       last_update = clock;
       // further releases of the step on this link: the time_diff == 0 form of the update (never for an A lane)
-      if (now > 0)
+      if (now > 0 && n_rest > 0) {
+        const Recip rn = recip_of(now);
         for (int k = 0; k < n_rest; k++) {
-          util = ((util * now) + 0.0) / now;
-          if (ENV != ENV_RWA) { frag = ((frag * now) + 0.0) / now; comp = ((comp * now) + 0.0) / now; }
+          util = div_by((util * now) + 0.0, rn);
+          if (ENV != ENV_RWA) { frag = div_by((frag * now) + 0.0, rn); comp = div_by((comp * now) + 0.0, rn); }
         }
+      }
       *(double2*)ls = make_double2(util, frag);
       *(double2*)(ls + 2) = make_double2(comp, last_update);
     }

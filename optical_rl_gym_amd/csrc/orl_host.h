@@ -57,6 +57,7 @@ struct orl_batch {
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_totals = nullptr;
+  int32_t* h_actions = nullptr;    // page-locked [B][4]: where orl_batch_step_async expands the caller's compact action rows
   int step_pending = 0;            // orl_batch_step_async queued a step that orl_batch_step_wait has not collected yet
   unsigned int* h_tail = nullptr;  // page-locked: where the straggler count / flag words of a run land (a pageable target is staged)
   int cache_epoch = 1;             // bumped by every call that may change slot maps outside the persistent kernel (DevParams::row_cache_key)

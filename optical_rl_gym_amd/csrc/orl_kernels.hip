@@ -723,7 +723,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   // (the env's soon list requested with its record and kept in registers through the control phase, as the 3-wave forms of
   // k_persist do — two dependent memory round trips less, but at 128 VGPRs it costs more than it saves: cfg2 86 -> 101 us
   // per launch, cfg1 the same; DeepRMSA / RMCSA spill with it.  Off.)
-  constexpr bool SOONR = false;
+#ifndef ORL_AGENT_SOONR
+#define ORL_AGENT_SOONR 0
+#endif
+  constexpr bool SOONR = ORL_AGENT_SOONR != 0;
   sp::SoonRegs soon_c;
   soon_c.dirty = 0;
   if constexpr (SOONR) {
@@ -1044,7 +1047,9 @@ struct PersistChoice { int form; size_t lds; int inner; };
 static size_t persist_window(const DevParams& VP, int state, int inner) {
   return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, state, persist_compact(VP.env_type, state), inner).total;
 }
-static PersistChoice persist_choose(const DevParams& VP) {
+// `tuned`: the choice for a specialisation library (built without machine-level LICM and with the soon list in registers in the
+// 4-wave forms, _build.py SPEC_TUNING) — for the flags such a library is built with, and at launch when one is attached
+static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
   // Measured on MI355X, env-steps/s: cfg2 65 536 envs: form 0 (global state, 4 waves) 8.3e8, form 4 (LDS
   // state, 3 waves) 1.02e9 at 11 wavefronts per CU with the inner-run cache, 1.05e9 at 12 without it — 69 MB of HBM traffic
   // and 0.85 M L2<->fabric requests per batched step against 206 MB / 2.63 M; cfg1 65 536: form 4 1.13e9, form 5 (LDS state,
@@ -1069,6 +1074,10 @@ static PersistChoice persist_choose(const DevParams& VP) {
   // records in global memory, the soon list in memory and 9 spilled VGPRs — 1.14e9: what a wavefront keeps next to itself is
   // worth more than a fourth wavefront per SIMD.  Form 6 is taken only where the 3-wave window does not fit at all.)
   if (r0 >= 16) { c.form = 5; c.inner = level(1, 16); }
+  // (round 4: a tuned instantiation of form 6 needs 128 VGPRs with the soon list in registers and no spills, and 16 wavefronts
+  // per CU are 4 096 resident = exactly two generations of a 65 536-env batch: cfg2 20-step launches 1.135e9 -> 1.190e9, 300-step
+  // runs 1.467e9 -> 1.474e9 against form 4)
+  else if (tuned && VP.env_type != ENV_RMCSA && r0 >= 10 && lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = level(3, 16); }
   else if (r0 >= 10) { c.form = 4; c.inner = level(1, 12); }
   else if (lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = level(3, 16); }
   // (global state: the 4-wave form except for RMCSA — round 3, with the 4-byte sink entries: cfg5 Germany50 32 768 envs 5.6e8 at 4
@@ -1093,20 +1102,20 @@ static PersistChoice persist_choose(const DevParams& VP) {
   c.lds = persist_window(VP, kPersistForms[c.form].lds, c.inner);
   return c;
 }
-static int persist_variant(const DevParams& VP, size_t* lds_bytes) {
-  const PersistChoice c = persist_choose(VP);
+static int persist_variant(const DevParams& VP, size_t* lds_bytes, bool tuned = false) {
+  const PersistChoice c = persist_choose(VP, tuned);
   *lds_bytes = c.lds;
   return c.form;
 }
 // the form the launcher takes for this configuration: what is in the LDS window, waves per SIMD (the key of a specialisation)
 template <int W> void persist_form(const DevParams& VP, int* lds_state, int* waves) {
-  const PersistChoice c = persist_choose(VP);
+  const PersistChoice c = persist_choose(VP, true);
   *lds_state = kPersistForms[c.form].lds;
   *waves = kPersistForms[c.form].waves;
 }
 template <int W> int persist_uses_lds(orl_batch* b) {
   size_t lds;
-  return kPersistForms[persist_variant(b->P, &lds)].lds;
+  return kPersistForms[persist_variant(b->P, &lds, b->spec_launch != nullptr)].lds;
 }
 // Workgroups per CU the form allows (LDS window, register budget).  ORL_PERSIST_WGS_PER_CU=r lowers the residency by padding
 // the LDS request (experiments).
@@ -1135,7 +1144,9 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   DevParams VP = VP0;
   VP.persist_finish = finish;
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64);
-  const PersistChoice ch = persist_choose(VP);
+  bool use_spec = b->spec_launch != nullptr;
+  if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) use_spec = false; }
+  const PersistChoice ch = persist_choose(VP, use_spec);
   const int v = ch.form;
   VP.persist_ic = ch.inner;
   VP.row_cache_key = VP.row_cache ? ((b->cache_epoch << 8) | (v << 4) | ch.inner) : 0;
@@ -1189,7 +1200,7 @@ template <int W> void agent_step(orl_batch* b, int auto_reset) {
 // wavefronts of the persistent kernel a GPU of `n_cu` CUs holds at once for this batch (LDS window and register budget)
 template <int W> int persist_resident(orl_batch* b, int n_cu) {
   size_t lds = 0;
-  const int v = persist_variant(b->P, &lds);
+  const int v = persist_variant(b->P, &lds, b->spec_launch != nullptr);
   return persist_max_per_cu(v, lds) * n_cu;
 }
 

@@ -237,6 +237,8 @@ class BatchedOpticalEnv:
         if os.environ.get("ORL_SPEC_EXTRA"):  # A/B experiments on the specialised kernels only: extra compiler flags (part of the cache key)
             flags += " " + os.environ["ORL_SPEC_EXTRA"]
         path = _build.spec_path(flags)
+        if os.environ.get("ORL_SPEC_LIB"):  # A/B: a specialisation library built elsewhere (e.g. from another commit's device code)
+            path = os.environ["ORL_SPEC_LIB"]
         if not os.path.exists(path):
             if not (mode == "1" or self.num_envs >= self.JIT_MIN_ENVS):
                 return False
@@ -355,13 +357,16 @@ class BatchedOpticalEnv:
     def step_async(self, actions, auto_reset=False, obs_out=None, fetch_info=True):
         """First half of step() (include/orl.h, orl_batch_step_async): checks the actions, queues the copies and the kernel on
         the batch's stream and returns at once.  `step_wait()` collects what `step()` would have returned."""
-        a = None
+        a, width, esz = None, 0, 0
         if actions is not None:
-            actions = np.asarray(actions)
-            if actions.ndim == 1:
-                actions = actions[:, None]
-            a = self._act_in
-            a[:, : actions.shape[1]] = actions
+            a = np.asarray(actions)
+            if a.ndim == 1:
+                a = a[:, None]
+            if a.dtype not in (np.int32, np.int64) or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a, np.int64)
+            assert a.shape[0] == self.num_envs and 1 <= a.shape[1] <= 4
+            width, esz = a.shape[1], a.dtype.itemsize
+            self._pending_actions = a  # (kept alive until the call returns: the library copies it before it does)
         obs64 = obs32 = None
         if self.obs_dim:
             obs = self._obs if obs_out is None else obs_out
@@ -371,12 +376,12 @@ class BatchedOpticalEnv:
             else:
                 assert obs.dtype == np.float64
                 obs64 = obs
-            self._pending_obs = obs
         else:
-            self._pending_obs = None
-        self._pending_info = self._info if fetch_info else None
-        self._ck(self.lib.orl_batch_step_async(self._h, _ptr(a), int(auto_reset), _ptr(obs64), _ptr(obs32), self._reward.ctypes.data,
+            obs = None
+        self._ck(self.lib.orl_batch_step_async(self._h, _ptr(a), width, esz, int(auto_reset), _ptr(obs64), _ptr(obs32), self._reward.ctypes.data,
                                                  self._done.ctypes.data, self._info.ctypes.data if fetch_info else None))
+        # (a refused call — bad action, a step still pending — leaves what step_wait() returns as it was)
+        self._pending_obs, self._pending_info = obs, (self._info if fetch_info else None)
 
     def step_wait(self):
         self._ck(self.lib.orl_batch_step_wait(self._h))

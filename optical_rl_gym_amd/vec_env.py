@@ -91,6 +91,7 @@ class OpticalVecEnv:
         self._sparse_info = "fetch_info" in inspect.signature(batch.step).parameters and hasattr(batch, "info_rows")
         self._async = hasattr(batch, "step_async") and self._sparse_info  # (the HIP batches)
         self._queued = False
+        self._infos, self._infos_set = None, ()
         self._ep_ret = np.zeros(self.num_envs)
         self._ep_len = np.zeros(self.num_envs, np.int64)
         self._t0 = time.time()
@@ -148,8 +149,15 @@ class OpticalVecEnv:
             rows = self.batch.info_rows(finished)
             info = None
         # SB3 wants one dict per env and only ever READS the ones of envs that did not finish an episode: those share one empty
-        # dict (65 536 fresh dicts per step cost ten times the step itself); an env that reports done gets a dict of its own
-        infos = [_NO_INFO] * self.num_envs
+        # read-only mapping (65 536 fresh dicts per step cost ten times the step itself); an env that reports done gets a dict of
+        # its own.  The LIST is this object's, reused from step to step (a fresh 65 536-entry list per step costs as much as
+        # the device's whole step): valid until the next step_wait(), like the arrays SB3's own VecEnvs hand out.
+        infos = self._infos
+        if infos is None:
+            infos = self._infos = [_NO_INFO] * self.num_envs
+        for i in self._infos_set:
+            infos[i] = _NO_INFO
+        self._infos_set = finished
         for n_, i in enumerate(finished):
             infos[i] = {}
             row = dict(r=float(self._ep_ret[i]), l=int(self._ep_len[i]), t=round(time.time() - self._t0, 6))

@@ -1286,6 +1286,52 @@ def test_qos_batches_match_oracle_and_run_equals_stepping():
         dev.close()
 
 
+@pytest.mark.parametrize("fam,n,kw,pol", [
+    ("RMSA", 2304, dict(load=300, mean_service_holding_time=25, episode_length=30, num_spectrum_resources=320), "SAP_FF"),
+    ("DeepRMSA", 2304, dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=1.0 / 12.0, j=1, episode_length=30), "SAP"),
+    ("RWA", 96, dict(load=450, mean_service_holding_time=25, episode_length=30, allow_rejection=True), "SAP_FF")])
+def test_step_in_two_halves_equals_step(fam, n, kw, pol):
+    """orl_batch_step_async / orl_batch_step_wait (VecEnv.step_async / step_wait): the compact action rows an agent hands over
+    (int64 and int32, 1 or 2 columns) are checked and widened by the library, everything is queued, and the results equal those
+    of the synchronous step on a twin batch — k_agent (>= 2 048 envs) and k_step; an out-of-range action is refused before
+    anything is modified, a second step before the first is collected is refused too."""
+    import optical_rl_gym_amd as orl
+    from optical_rl_gym_amd._lib import OrlError
+
+    seeds = [40 + i for i in range(n)]
+    a = orl.make(fam, topology="nsfnet_chen", num_envs=n, seeds=seeds, **kw)
+    b = orl.make(fam, topology="nsfnet_chen", num_envs=n, seeds=seeds, **kw)
+    width = 1 if fam == "DeepRMSA" else 2
+    chk = _exact(fam + " async")
+    obs32 = a.host_array((n, a.obs_dim), np.float32) if a.obs_dim else None
+    for t in range(70):
+        acts = b.policy(pol)[:, :width].copy()
+        compact = acts.astype(np.int64) if t % 2 else np.ascontiguousarray(acts, np.int32)
+        a.step_async(compact, auto_reset=True, obs_out=obs32 if (obs32 is not None and t % 3 == 0) else None, fetch_info=t % 4 != 1)
+        if t == 5:
+            with pytest.raises(OrlError):
+                a.step_async(compact, auto_reset=True)
+        o_a, r_a, d_a, i_a = a.step_wait()
+        o_b, r_b, d_b, i_b = b.step(acts, auto_reset=True)
+        chk(t, "reward", r_a, r_b); chk(t, "done", d_a, d_b)
+        if i_a is not None:
+            chk(t, "info", i_a, i_b)
+        if o_b is not None:
+            chk(t, "obs", o_a, o_b.astype(o_a.dtype))
+    before = a.counters().copy()
+    bad = np.zeros((n, width), np.int64)
+    bad[n // 2, 0] = 10 ** 6 if fam == "DeepRMSA" else 77
+    if fam != "DeepRMSA":  # (DeepRMSA takes any integer: deeprmsa_env.py:48-58)
+        with pytest.raises(IndexError):
+            a.step_async(bad, auto_reset=True)
+        chk(0, "untouched", a.counters(), before)
+    with pytest.raises(OrlError):
+        a.step_wait()  # nothing pending
+    chk(0, "counters", a.counters(), b.counters())
+    chk(0, "services", a.services(), b.services())
+    a.close(); b.close()
+
+
 def test_qos_evaluate_on_device_equals_the_harness():
     """evaluate_heuristic (utils.py:103-141) for QoSConstrainedRA on the device: the reward of an accepted service is its
     class's reward (qos_constrained_ra.py:131-136), so the kernels keep each episode's float64 reward sum in step order;
