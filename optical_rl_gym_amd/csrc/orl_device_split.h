@@ -63,6 +63,31 @@ struct Prof { long long t; };
 #define ORL_PROFR_BEGIN() do { } while (0)
 #define ORL_PROFR_END() do { } while (0)
 
+// x / d for several x and one d.  The compiler's float64 division (v_div_scale x 2, v_rcp_f64, four refinement FMAs, quotient,
+// remainder, v_div_fmas, v_div_fixup) spends half of its instructions on the reciprocal of the denominator; the running averages
+// of a link divide three sums by the same clock.  Same operations on the same operands as that sequence for operands that need
+// no rescaling (v_div_scale returns them unchanged unless an exponent is within 2^-/+768 of the range's ends; the clock is a
+// positive simulation time, the sums are products of ratios in [0, 1] and such times), so the quotients are bit-identical —
+// the parity suite compares every link's averages of every env with the oracle's.
+struct Recip { double d, r; };
+__device__ __forceinline__ Recip recip_of(double d) {
+  Recip k;
+  k.d = d;
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  k.r = __builtin_fma(r, e, r);
+  return k;
+}
+__device__ __forceinline__ double div_by(double x, const Recip& k) {
+  const double q = x * k.r;
+  return __builtin_fma(__builtin_fma(-k.d, q, x), k.r, q);
+}
+// x / d for 0 <= x, 0 < d in that range (counts of slots, blocks and links; clocks; sums of such): the same sequence without
+// the two v_div_scale, v_div_fmas' rescaling and v_div_fixup's special cases — 8 instructions instead of 14
+__device__ __forceinline__ double div_pos(double x, double d) { return div_by(x, recip_of(d)); }
+
 using g8::EnvG;
 using g8::gballot;
 using g8::gget;
@@ -522,8 +547,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         }
         const double a0 = __longlong_as_double((i64)e.scal[SC_GC_A]), td = __longlong_as_double((i64)e.scal[SC_GC_TD]);
         const double now_a = __longlong_as_double((i64)e.scal[SC_NOWA]);
-        const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
-        e.g_comp = (a0 + (cmp * td)) / now_a;
+        const double cmp = (fb > 0) ? div_pos((double)occ, (double)s_nh_prov) * div_pos((double)P.E, (double)fb) : 1.0;
+        e.g_comp = div_pos(a0 + (cmp * td), now_a);
       }
       for (int i = gl; i < 2 * P.C; i += 8) {  // this step's releases start from zero
         if (O.persistent && !M.cs_lds) atomicExch(rs + i, 0);
@@ -768,7 +793,7 @@ __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 en
     double last_update = e.g_last, time_diff = e.now - last_update;
     if (e.now > 0) {
       double cur_thr = (double)e.s_br;
-      e.g_thr = ((e.g_thr * last_update) + (cur_thr * time_diff)) / e.now;
+      e.g_thr = div_pos((e.g_thr * last_update) + (cur_thr * time_diff), e.now);
       // the compactness term needs the sums after the provision's row updates: the next step finishes
       // g_comp = (g_comp * last_update + compactness * time_diff) / now from these two stashed factors
       if (gl == 0) {
@@ -1337,28 +1362,6 @@ __device__ __forceinline__ void row_occ_fb(const u64 (&a)[W], int S, int& occ, i
   fb = two ? nu - 1 : 0;
 }
 
-// x / d for several x and one d.  The compiler's float64 division (v_div_scale x 2, v_rcp_f64, four refinement FMAs, quotient,
-// remainder, v_div_fmas, v_div_fixup) spends half of its instructions on the reciprocal of the denominator; the running averages
-// of a link divide three sums by the same clock.  Same operations on the same operands as that sequence for operands that need
-// no rescaling (v_div_scale returns them unchanged unless an exponent is within 2^-/+768 of the range's ends; the clock is a
-// positive simulation time, the sums are products of ratios in [0, 1] and such times), so the quotients are bit-identical —
-// the parity suite compares every link's averages of every env with the oracle's.
-struct Recip { double d, r; };
-__device__ __forceinline__ Recip recip_of(double d) {
-  Recip k;
-  k.d = d;
-  double r = __builtin_amdgcn_rcp(d);
-  double e = __builtin_fma(-d, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-d, r, 1.0);
-  k.r = __builtin_fma(r, e, r);
-  return k;
-}
-__device__ __forceinline__ double div_by(double x, const Recip& k) {
-  const double q = x * k.r;
-  return __builtin_fma(__builtin_fma(-k.d, q, x), k.r, q);
-}
-
 // Single-core families (RMSA, DeepRMSA, RWA): every mask of an item works on the same row, and only the first touch of
 // the link at a clock value needs the row's statistics — the provision at the provision clock and the first release at the
 // step clock (_update_link_stats, rmsa_env.py:464-543); further releases of the step see time_diff == 0, i.e.
@@ -1451,12 +1454,12 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   ORL_PROFR(5);
   // the values _update_link_stats derives from the row (rmsa_env.py:464-543)
   const int free_ = after.free_;
-  const double cur_util = (double)(S - free_) / (double)S;
+  const double cur_util = div_pos((double)(S - free_), (double)S);
   double cur_frag = 0.0, cur_comp = 0.0;
   if (ENV != ENV_RWA && free_ > 0) {
     int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
-    cur_frag = 1.0 - ((double)me / (double)free_);
-    if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
+    cur_frag = 1.0 - div_pos((double)me, (double)free_);
+    if (after.nu > 1) cur_comp = div_pos((double)(after.hi - after.lo), (double)(S - free_)) * div_pos(1.0, (double)after.nu);
     else cur_comp = 1.0;
   }
   if (ocw && role_a) *ocw = ((u32)after.occ << 16) | (u32)after.fb;  // (B reads it after the fence that ends round 0)
