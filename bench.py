@@ -280,16 +280,21 @@ def main():
     # HBM traffic and L2<->fabric requests from rocprofv3 PMC passes (tools/pmc_traffic.py, FETCH_SIZE x calibration +
     # WRITE_SIZE; TCC_EA0_RDREQ + WRREQ): used only when they were collected for exactly this build, workload, batch and
     # state — otherwise null
-    traffic = req_roof = valu = traffic_gbs = None
+    traffic = req_roof = valu = traffic_gbs = traffic_scaled = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        k = tj.get("kernels", {}).get(kernel)
+        # counters taken over launches of the SAME length as the timed ones where there are such (cfg2: ten 20-step launches for
+        # the driver's invocation), else over 128-step launches, scaled per step (then `traffic_scaled_from_steps` says so: the
+        # window fill / write-back of a launch is amortised over 128 steps there)
+        k = tj.get("kernels", {}).get("%s_steps%d" % (kernel, int(round(args.steps / max(med[2], 1)))) if med[3] else kernel) \
+            or tj.get("kernels", {}).get(kernel)
         same_state = abs(tj.get("mean_active_services", -1e9) - active_after) <= 0.05 * active_after
         if k and tj.get("workload") == args.workload and tj.get("batch") == B and same_state and \
                 tj.get("source_hash") == _build.source_hash(with_compiler=False):
             per_step = k["hbm_bytes_per_launch"] / k["steps_per_launch"]
             traffic = int(per_step * steps_per_launch)
+            traffic_scaled = None if abs(k["steps_per_launch"] - steps_per_launch) < 0.5 else k["steps_per_launch"]
             traffic_gbs = traffic / (ms_launch * 1e-3) / 1e9  # bytes that really crossed the HBM interface / launch time
             sq = k.get("sq_per_launch") or {}
             if sq.get("SQ_ACTIVE_INST_VALU"):
@@ -335,7 +340,8 @@ def main():
                     peak_measured=None if peak_meas is None else round(peak_meas, 1),
                     frac_of_measured=None if peak_meas is None else round(ach / peak_meas, 5),
                     traffic=traffic, achieved_traffic_gbs=None if traffic_gbs is None else round(traffic_gbs, 2),
-                    traffic_frac=None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 5), valu=valu,
+                    traffic_frac=None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 5),
+                    traffic_scaled_from_steps=traffic_scaled, valu=valu,
                     kernel=kernel, us_per_launch=round(ms_launch * 1e3, 2),
                     steps_per_launch=round(steps_per_launch, 2), algorithmic_bytes_per_env_step=round(alg["step"], 1),
                     algorithmic_bytes_per_launch=int(bytes_per_launch))
