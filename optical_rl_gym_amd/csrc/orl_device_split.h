@@ -396,7 +396,17 @@ __device__ __forceinline__ void svc_generate(const DevParams& P, u64* rec, u32* 
 #undef ORL_SVC_RND
     sb.pk = (u32)src | ((u32)dst << 10) | ((u32)br_idx << 20);
   }
-  if (active) sb.cnt = got << 8;
+  if (active) {
+    // not even the first service fits the window — 88 bit-rate draws rejected in a row: below 10^-26 per batch for any range of
+    // rates — would draw the same nothing again for ever: the env is flagged like one that ran out of pending-release slots
+    // (its state is no longer valid, the run reports it) and goes on with empty services
+    if (got == 0 && n_want > 0) {
+      if (gl == 0) rec[SC_FLAGS] |= ((u64)ORL_FLAG_EV_OVERFLOW << 32);
+      sb.q = 0.0; sb.ht = 0.0; sb.pk = 0u;
+      got = n_want;
+    }
+    sb.cnt = got << 8;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
