@@ -253,7 +253,8 @@ struct SvcBuf {
   int cnt;       // group-uniform: services in the batch << 8 | next one to take
 };
 __device__ __forceinline__ bool svc_empty(const SvcBuf& b) { return (b.cnt & 0xff) >= (b.cnt >> 8); }
-__device__ __forceinline__ int svc_wrap(int i) { return i >= 624 ? i - 624 : i; }
+// i mod 624 for 0 <= i < 1248 (a subtraction and an unsigned minimum: below 624 the difference wraps to a huge value)
+__device__ __forceinline__ int svc_wrap(int i) { const u32 u = (u32)i, d = u - 624u; return (int)(d < u ? d : u); }
 // bisect(cum_weights, x, 0, n - 1) of random.choices: the number of entries cum[0 .. n-2] that are <= x (cum is non-decreasing).
 // Two rounds of independent requests instead of a chain of log2(n) dependent ones: every eighth entry first (the block the
 // answer lies in), then that block's entries — Germany50's 49 entries took six dependent memory round trips per table.
