@@ -88,9 +88,6 @@ __device__ __forceinline__ double div_by(double x, const Recip& k) {
 // the two v_div_scale, v_div_fmas' rescaling and v_div_fixup's special cases — 8 instructions instead of 14
 __device__ __forceinline__ double div_pos(double x, double d) { return div_by(x, recip_of(d)); }
 
-// (release time, slot) a before (release time, slot) b — bitwise, not short-circuit: with && / || the compiler builds a branch per
-// term and exec-masked register copies per assignment; as one predicate the selections below are v_cndmask
-__device__ __forceinline__ bool ev_before(double ta, int ia, double tb, int ib) { return (ta < tb) | ((ta == tb) & (ia < ib)); }
 using g8::EnvG;
 using g8::gballot;
 using g8::gget;
@@ -531,7 +528,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       int pi = e.sr_i[0];
 #pragma unroll
       for (int k = 1; k < ORL_SOON_PER_LANE; k++)
-        { const bool b = ev_before(e.sr_t[k], e.sr_i[k], pt, pi); pt = b ? e.sr_t[k] : pt; pi = b ? e.sr_i[k] : pi; }
+        if (e.sr_t[k] < pt || (e.sr_t[k] == pt && e.sr_i[k] < pi)) { pt = e.sr_t[k]; pi = e.sr_i[k]; }
       // (t_soon == -inf: the list is stale — after a reset or the serial tail — and its entries mean nothing)
       if (pt <= e.now + P.pf_window && e.t_soon > -__builtin_inf() && (u32)pi < (u32)P.ev_cap) { pre_idx = pi; pre_info = e.ev_info[pi]; }
     }
@@ -974,7 +971,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
     for (int k = 0; k < NS; k++) {
       const bool due = st[k] <= e.now;
       ndl += due ? 1 : 0;
-      { const bool b = due & ev_before(st[k], si[k], ct, ci); ct = b ? st[k] : ct; ci = b ? si[k] : ci; ck = b ? k : ck; }
+      if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; ck = k; }
     }
     const int tot = g8_sum(ndl);
     if (tot == 0) {
@@ -1061,7 +1058,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         // exactly one partner's.
         int r = 1;
 #define ORL_RANK_STEP(OT, OI) { const double ot_ = (OT); const int oi_ = (OI); \
-                                r += ev_before(ot_, oi_, ct, ci) ? 1 : 0; \
+                                r += (ot_ < ct || (ot_ == ct && oi_ < ci)) ? 1 : 0; \
                                 if (ot_ < INF && gl == (oi_ & 7)) e.ev_time[oi_] = INF; }
         ORL_RANK_STEP(dpp_d<ORL_DPP_XOR1>(ct), dpp_i<ORL_DPP_XOR1>(ci))
         ORL_RANK_STEP(dpp_d<ORL_DPP_XOR2>(ct), dpp_i<ORL_DPP_XOR2>(ci))
@@ -1089,7 +1086,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           double bt = ct;
           int bi = ci, bl = gl;
 #define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); int ol = dpp_i<CTRL>(bl); \
-                             const bool b_ = ev_before(ot, oi, bt, bi); bt = b_ ? ot : bt; bi = b_ ? oi : bi; bl = b_ ? ol : bl; }
+                             if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; bl = ol; } }
           ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
 #undef ORL_MIN_STEP
           if (!(bt <= e.now)) break;
@@ -1104,7 +1101,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
             for (int k = 0; k < NS; k++) {
               if (k == ck) st[k] = INF;
               const bool due = st[k] <= e.now;
-              { const bool b = due & ev_before(st[k], si[k], ct, ci); ct = b ? st[k] : ct; ci = b ? si[k] : ci; nk = b ? k : nk; }
+              if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
             }
             ck = nk;
           }
@@ -1154,7 +1151,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         double bt = ct;
         int bi = ci, bl = gl;
   #define ORL_MIN_STEP(CTRL) { double ot = dpp_d<CTRL>(bt); int oi = dpp_i<CTRL>(bi); int ol = dpp_i<CTRL>(bl); \
-                               const bool b_ = ev_before(ot, oi, bt, bi); bt = b_ ? ot : bt; bi = b_ ? oi : bi; bl = b_ ? ol : bl; }
+                               if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; bl = ol; } }
         ORL_MIN_STEP(ORL_DPP_XOR1) ORL_MIN_STEP(ORL_DPP_XOR2) ORL_MIN_STEP(ORL_DPP_HALF_MIRROR)
   #undef ORL_MIN_STEP
         if (!(bt <= e.now)) break;
@@ -1171,7 +1168,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           for (int k = 0; k < NS; k++) {
             if (k == ck) st[k] = INF;
             const bool due = st[k] <= e.now;
-            { const bool b = due & ev_before(st[k], si[k], ct, ci); ct = b ? st[k] : ct; ci = b ? si[k] : ci; nk = b ? k : nk; }
+            if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; nk = k; }
           }
           ck = nk;
           if (ci != 0x7fffffff) { inf0 = (ci == pushed_idx) ? pushed_info : ((ci == pre_idx) ? pre_info : e.ev_info[ci]); rc0 = path_rec_load(P, (int)(inf0 & 0xffffffu)); }
