@@ -308,6 +308,22 @@ template <int W> __device__ __forceinline__ Row<W> row_shr_small(const Row<W>& a
   }
   return r;
 }
+// the same for 0 < st < 32 (the log-step run search of services of at most 63 slots shifts by at most 31), one v_alignbit_b32 per
+// 32-bit half instead of two 64-bit shifts and two ORs per word
+template <int W> __device__ __forceinline__ Row<W> row_shr_lt32(const Row<W>& a, int st) {
+  Row<W> r;
+  u32 d[2 * W + 1];
+#pragma unroll
+  for (int i = 0; i < W; i++) { d[2 * i] = (u32)a.w[i]; d[2 * i + 1] = (u32)(a.w[i] >> 32); }
+  d[2 * W] = 0u;
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    const u32 lo = __builtin_amdgcn_alignbit(d[2 * i + 1], d[2 * i], (u32)st);
+    const u32 hi = __builtin_amdgcn_alignbit(d[2 * i + 2], d[2 * i + 1], (u32)st);
+    r.w[i] = ((u64)hi << 32) | lo;
+  }
+  return r;
+}
 // x & ~(x << 1): one bit per run of ones (its first position)
 template <int W> __device__ __forceinline__ Row<W> row_starts(const Row<W>& a) {
   Row<W> r;
@@ -325,10 +341,36 @@ template <int W> __device__ __forceinline__ Row<W> row_runs_ge(const Row<W>& m, 
   while (have < n) {
     int st = n - have;
     st = st < have ? st : have;
-    r = row_and<W>(r, row_shr_small<W>(r, st));
+    if (st < 32) r = row_and<W>(r, row_shr_lt32<W>(r, st));  // (the usual case; a real branch: the other side is skipped)
+    else r = row_and<W>(r, row_shr_small<W>(r, st));
     have += st;
   }
   return r;
+}
+// the same, straight-line: the masks of run starts of >= 1, 2, 4, 8, 16, 32 ones, the largest power of two that still has one,
+// then five refinement steps — for the row phase, where 40-odd lanes search words with different longest runs and the two
+// data-dependent loops of word_longest_run() ran as many rounds as the lane with the longest one, under exec masks.  For x with at
+// least one zero bit (runs of at most 63: the row phase searches words without their boundary runs); checked against the loop
+// version and a bit-by-bit count on 2e7 words
+__device__ __forceinline__ int word_longest_run_flat(u64 x) {
+  const u64 r2 = x & (x >> 1), r4 = r2 & (r2 >> 2), r8 = r4 & (r4 >> 4), r16 = r8 & (r8 >> 8), r32 = r16 & (r16 >> 16);
+  int L = x ? 1 : 0;
+  u64 r = x;
+  if (r2) { L = 2; r = r2; }
+  if (r4) { L = 4; r = r4; }
+  if (r8) { L = 8; r = r8; }
+  if (r16) { L = 16; r = r16; }
+  if (r32) { L = 32; r = r32; }
+  const int p2 = L;  // the power of two found: the steps halve IT
+#pragma unroll
+  for (int k = 1; k <= 5; k++) {
+    const int st = p2 >> k;  // (0 once the steps are used up: r & r, L + 0)
+    const u64 t = r & (r >> st);
+    const bool ok = (t != 0ull) & (st > 0);
+    r = ok ? t : r;
+    L += ok ? st : 0;
+  }
+  return L;
 }
 // longest run of ones inside one 64-bit word (binary search on run length)
 __device__ __forceinline__ int word_longest_run(u64 x) {
@@ -1137,7 +1179,7 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
       int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
       Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
       Row<W> cand = row_and<W>(row_runs_ge<W>(m, n), row_mask_lo<W>(S - n));
-      if (row_any<W>(cand)) { slot = row_ctz<W>(cand); freec = row_popc<W>(m); }
+      if (row_any<W>(cand)) { slot = row_ctz<W>(cand); if (pol == POL_LLP_FF) freec = row_popc<W>(m); }
     }
     u64 fit = group_ballot<GS>(slot >= 0, lane);
     int best = fit ? (int)__builtin_ctzll(fit) : -1;

@@ -739,7 +739,11 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       // has gone back already (so that only the handful of release-related fields stays in registers through the
       // detection); those fields are written again below when the detection changed them.
       SoonRegs soon;
+#ifdef ORL_X_SKIP_REL
+      soon.dirty = 0;
+#else
       release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
+#endif
       if (!svc) g8::rng_commit_stores(e, rng, gl);  // the Mersenne-Twister words of next_service: behind the detection's loads
       ORL_PROFA(10);
       if (sink.deferred) {
@@ -1261,7 +1265,9 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
       const int lead = full ? 64 : (int)__builtin_ctzll(na), trail = full ? 64 : (int)__builtin_clzll(na);
       best = (c + lead) > best ? (c + lead) : best;
       c = full ? c + 64 : trail;
-      inter[CACHED ? w : 0] = full ? 0ull : (a[w] & ~word_range(0, lead) & ~word_range(64 - trail, 64));
+      // (a & (a + 1) drops the run of free slots at the word's low end — the carry runs through it —, the shifted all-ones
+      // mask the run at its high end: a 64-bit add, a shift and two ANDs where two word_range() masks took a dozen instructions)
+      inter[CACHED ? w : 0] = full ? 0ull : ((a[w] & (a[w] + 1ull)) & (~0ull >> trail));
     } else if (a[w] == ~0ull) {
       c += 64;
       best = c > best ? c : best;
@@ -1296,7 +1302,7 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
       for (int k = 1; k < (CACHED ? W : 1); k++) x = (w == k) ? inter[k] : x;
       // (searched whatever `best` is: an unknown entry would have to be searched in a later step, when the word has not
       // changed, and the wavefront runs as many rounds as its lane with the most words to search)
-      const int f = word_longest_run(x);  // <= 62: x has neither its lowest nor its highest bit set
+      const int f = word_longest_run_flat(x);  // <= 62: x has neither its lowest nor its highest bit set
       best = f > best ? f : best;
       cw = (cw & ~(63u << (6 * w))) | ((u32)f << (6 * w));
     }
@@ -1454,8 +1460,12 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   int max_empty = 0, edge = 0;
   u32* icw = (ENV != ENV_RWA && M.ic0) ? M.ic0 + (env - M.cenv0) * E + link : nullptr;
   if (ENV != ENV_RWA) {
+#ifdef ORL_X_SKIP_STAT  // (diagnostic: wrong results, instruction counters of the rest — tools/valu_ab.sh)
+    after.free_ = (int)(a[0] & 255ull) + 1; after.nu = 3; after.nf = 3; after.lo = 2; after.hi = 200; after.occ = 198; after.fb = 2; max_empty = 7; edge = 1;
+#else
     if (W >= 3 && W <= 5 && icw) row_stat_lane<W, (W >= 3 && W <= 5)>(a, S, after, max_empty, edge, icw, touched, !role_a);
     else row_stat_lane<W>(a, S, after, max_empty, edge);
+#endif
   } else {
     int f = 0;
 #pragma unroll
@@ -1478,7 +1488,11 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   const int n_rest = __popc(rest);
   // the running averages: round 0 every lane but the B lanes, round 1 the B lanes (their link's record has been updated and
   // stored by the A lane of the same wavefront in round 0)
+#ifdef ORL_X_SKIP_ROUND2
+  const u64 any_b = 0ull;
+#else
   const u64 any_b = __ballot(role_b);
+#endif
   for (int round = 0; round < 2; round++) {
     if (round == 1 && !any_b) break;
     if ((round == 1) == role_b) {
@@ -1486,7 +1500,11 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
       double last_update = ls23.y;
       double util = ls01.x, frag = ls01.y, comp = ls23.x;
       if (stash_env && rel_f) { stash_env[2 * link] = util; stash_env[2 * link + 1] = comp; }
+#ifdef ORL_X_SKIP_F64
+      if (false) {
+#else
       if (clock > 0) {  // the first touch of the link at this clock value
+#endif
         const double time_diff = clock - last_update;
         const Recip rc = recip_of(clock);
         util = div_by((util * last_update) + (cur_util * time_diff), rc);

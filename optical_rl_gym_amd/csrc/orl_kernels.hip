@@ -485,12 +485,18 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     asm volatile("" : "+v"(env_lo), "+v"(lane_i));
     const i64 env_i = (i64)env_lo;
     const bool valid_i = env_i < P.B;
+    // (-DORL_X_SKIP_*: diagnostic builds whose RESULTS ARE WRONG — a phase is left out so that the instruction counters of the
+    // rest can be read, tools/valu_ab.sh: the difference to the full kernel is that phase's share)
     if (SVC) {  // a group whose batch of services is used up draws the next one: as many as the launch has steps left, 8 at most
       const bool need = valid_i && sp::svc_empty(svb);
+#ifdef ORL_X_SKIP_SVC
+      if (need) { svb.q = 0.08; svb.ht = 20.0; svb.pk = 3u | (7u << 10) | (30u << 20); svb.cnt = 8 << 8; }
+#else
       if (__ballot(need) != 0ull) {
         const int left = target - step;
         sp::svc_generate<ENV>(P, sp::wm_scal(P, M, valid_i ? env_i : M.scenv0), P.mt + (valid_i ? env_i : 0) * 624, lane_i, left < 8 ? left : 8, svb, need);
       }
+#endif
     }
     ORL_PROFA(0);
     sp::CtrlOpts O;
@@ -504,8 +510,12 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     int done_i = 0;
     {
       int a[4];
+#ifdef ORL_X_SKIP_SCAN
+      a[0] = 0; a[1] = (int)(desc & 63u); a[2] = 0; a[3] = 0;
+#else
       policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
                           (int)((desc >> 48) & 0xffu), lane_i, pol, (pol == POL_PATH_FF && valid_i) ? P.path_col[env_i] : 0, a);
+#endif
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
       desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
@@ -513,7 +523,11 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
     __syncthreads();  // sink table + item list, clocks, env records
     {
+#ifdef ORL_X_SKIP_ROWS
+      const int n_items = 0;
+#else
       const int n_items = (int)*s_list_n;
+#endif
       ORL_PROFA(12);
       for (int idx = lane_i; idx < n_items; idx += 64) {
         const int code = (int)s_list[idx];

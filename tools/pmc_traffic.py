@@ -24,11 +24,19 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 STEPS_PER_LAUNCH = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 fam, topo, kw, policy = WORKLOADS[name]
 env = orl.make(fam, topology=topo, num_envs=B, seeds=[10 + i for i in range(B)], **kw)
-env.run(policy, max(1500, int(math.ceil(5 * workload_load(kw)))))
+def run(n_steps):
+    try:
+        env.run(policy, n_steps)
+    except (OverflowError, IndexError):  # diagnostic builds that leave a phase out (-DORL_X_SKIP_*): the counters are what is wanted
+        if not os.environ.get("ORL_X_IGNORE_ERRORS"):
+            raise
+
+
+run(max(1500, int(math.ceil(5 * workload_load(kw)))))
 for w in (0, 1, 0, 1):
     n = env.lib.orl_batch_debug_stream_read(env._h, w)
 for _ in range(MEASURED_LAUNCHES):
-    env.run(policy, STEPS_PER_LAUNCH)
+    run(STEPS_PER_LAUNCH)
 for _ in range(20):
     env.policy(policy, fetch=False)
 env.sync()
