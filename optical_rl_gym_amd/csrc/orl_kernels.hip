@@ -516,6 +516,16 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
                           (int)((desc >> 48) & 0xffu), lane_i, pol, (pol == POL_PATH_FF && valid_i) ? P.path_col[env_i] : 0, a);
 #endif
+#ifdef ORL_X_DUP_SCAN  // (diagnostic: the scan executed twice, second result discarded — its share of the instruction counters)
+      {
+        int a2[4];
+        int lane_j = lane_i;
+        asm volatile("" : "+v"(lane_j));
+        policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
+                            (int)((desc >> 48) & 0xffu), lane_j, pol, 0, a2);
+        asm volatile("" :: "v"(a2[0]), "v"(a2[1]));
+      }
+#endif
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
       desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
