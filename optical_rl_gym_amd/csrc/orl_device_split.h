@@ -1325,7 +1325,7 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
       best = c > best ? c : best;
     } else {
       const int lead = (int)__builtin_ctzll(~a[w]);
-      const int inner = word_longest_run(a[w]);
+      const int inner = word_longest_run_flat(a[w]);  // (a[w] has a used slot here: runs of at most 63)
       const int cand = (c + lead) > inner ? (c + lead) : inner;
       best = cand > best ? cand : best;
       c = (int)__builtin_clzll(~a[w]);
