@@ -1312,7 +1312,7 @@ def test_step_in_two_halves_equals_step(fam, n, kw, pol):
             with pytest.raises(OrlError):
                 a.step_async(compact, auto_reset=True)
         o_a, r_a, d_a, i_a = a.step_wait()
-        o_b, r_b, d_b, i_b = b.step(acts, auto_reset=True)
+        o_b, r_b, d_b, i_b = b.step_sync_abi(acts, auto_reset=True)  # orl_batch_step itself, as a C caller uses it
         chk(t, "reward", r_a, r_b); chk(t, "done", d_a, d_b)
         if i_a is not None:
             chk(t, "info", i_a, i_b)
