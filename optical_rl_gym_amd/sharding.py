@@ -141,6 +141,32 @@ class MultiDeviceBatch:
         obs = obs_out if (obs_out is not None and getattr(self, "obs_dim", 0)) else self._cat([o[0] for o in out])
         return obs, self._cat([o[1] for o in out]), self._cat([o[2] for o in out]), (self._info if fetch_info else None)
 
+    def step_async(self, actions, auto_reset=False, obs_out=None, fetch_info=True):
+        """First half of step() on every shard (`BatchedOpticalEnv.step_async`): each device gets its slice of the actions and its
+        step queued on its own stream, one shard after the other from this thread — the calls only queue work, so all devices run
+        at once without host threads — and `step_wait()` collects them.  Shards without the two halves (the oracle stand-in of the
+        CPU tests) step synchronously here."""
+        self._async_obs = obs_out
+        self._async_sync = {}
+        for r, sh in enumerate(self.shards):
+            a = self._cut(actions, r)
+            oo = None if obs_out is None else obs_out[self.bounds[r]:self.bounds[r + 1]]
+            if hasattr(sh, "step_async"):
+                sh.step_async(a, auto_reset=auto_reset, obs_out=oo, fetch_info=fetch_info)
+            else:
+                out = sh.step(a, auto_reset=auto_reset)
+                if oo is not None and out[0] is not None:
+                    oo[:] = out[0]
+                self._async_sync[r] = out
+
+    def step_wait(self):
+        out = [self._async_sync[r] if r in self._async_sync else sh.step_wait() for r, sh in enumerate(self.shards)]
+        infos = [o[3] for o in out]
+        self._info_parts = infos
+        self._info = None if any(i is None for i in infos) else self._cat(infos)
+        obs = self._async_obs if (self._async_obs is not None and getattr(self, "obs_dim", 0)) else self._cat([o[0] for o in out])
+        return obs, self._cat([o[1] for o in out]), self._cat([o[2] for o in out]), self._info
+
     def info_rows(self, indices):
         """Rows `indices` of the info arrays the last step left on the devices, in the order asked for."""
         idx = np.asarray(indices, np.int64).reshape(-1)

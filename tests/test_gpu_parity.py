@@ -1206,6 +1206,12 @@ def test_multi_device_wrapper_on_one_gpu():
         _, r1, d1, i1 = one.step(a, auto_reset=True)
         _, r2, d2, i2 = two.step(a, auto_reset=True)
         assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(i1, i2)
+    for t in range(10):  # the step in two halves: both shards queued from one thread, then collected
+        a = one.policy(policy)[:, :2].astype(np.int64)
+        two.step_async(a, auto_reset=True, fetch_info=t % 2 == 0)
+        _, r1, d1, i1 = one.step(a, auto_reset=True)
+        _, r2, d2, i2 = two.step_wait()
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and (i2 is None or np.array_equal(i1, i2))
     assert np.array_equal(one.counters(), two.counters()) and np.array_equal(one.services(), two.services())
     for e in (0, 499, 500, 999):
         assert np.array_equal(one.slots(e), two.slots(e)) and np.array_equal(one.link_stats(e), two.link_stats(e))

@@ -215,6 +215,13 @@ def test_multi_device_wrapper_equals_one_batch():
         o1, r1, d1, i1 = whole.step(a, auto_reset=True)
         o2, r2, d2, i2 = multi.step(a, auto_reset=True)
         assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(i1, i2)
+    for t in range(30):  # the step in two halves over the shards (shards without the halves step synchronously inside)
+        a = whole.policy("SAP_FF")
+        multi.step_async(a, auto_reset=True)
+        o1, r1, d1, i1 = whole.step(a, auto_reset=True)
+        o2, r2, d2, i2 = multi.step_wait()
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(i1, i2)
+        assert np.array_equal(multi.info_rows([5, 1]), i1[[5, 1]])
     whole.run("LLP_FF", 80)
     multi.run("LLP_FF", 80)
     assert np.array_equal(whole.counters(), multi.counters()) and np.array_equal(whole.services(), multi.services())
