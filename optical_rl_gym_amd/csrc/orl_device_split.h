@@ -1659,18 +1659,20 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Wmem& M,
         // the row's contribution to the compactness sums BEFORE the change, recomputed from the row itself: the
         // kernel is bound by scattered memory requests, not ALU — the cached copy the per-env kernels keep
         // (core_sums[2C + ...]) would cost a read and a write of one more line per item
-        RowStat b4;
-        int me_, ed_;
-        row_stat_lane<W>(a, S, b4, me_, ed_);
-        pk = (b4.occ << 16) | b4.fb;
+        int occ_b, fb_b;
+        row_occ_fb<W>(a, S, occ_b, fb_b);
+        pk = (occ_b << 16) | fb_b;
       }
       prev_core = core;
     }
+    {
+      const Mask2 mm = mask2(s0, n);
 #pragma unroll
-    for (int w = 0; w < W; w++) {
-      const u64 m = word_range(s0 - 64 * w, s0 + n - 64 * w);
-      a[w] = rel_k ? (a[w] | m) : (a[w] & ~m);
-      if (m) row[w] = a[w];
+      for (int w = 0; w < W; w++) {
+        const u64 m = mask2_word(mm, w);
+        a[w] = rel_k ? (a[w] | m) : (a[w] & ~m);
+        if (m) row[w] = a[w];
+      }
     }
     RowStat after;
     int max_empty = 0, edge = 0;
@@ -1697,24 +1699,26 @@ __device__ __forceinline__ void row_item_lane(const DevParams& P, const Wmem& M,
       if (first_at_clock) {  // _update_link_stats (rmsa_env.py:464-543)
         const double time_diff = clock - last_update;
         const int free_ = after.free_;
-        double cur_util = (double)(S - free_) / (double)S;
-        util = ((util * last_update) + (cur_util * time_diff)) / clock;
+        const Recip rc = recip_of(clock);  // (one reciprocal for the three quotients: see div_by)
+        double cur_util = div_pos((double)(S - free_), (double)S);
+        util = div_by((util * last_update) + (cur_util * time_diff), rc);
         if (ENV != ENV_RWA) {
           double cur_frag = 0.0, cur_comp = 0.0;
           if (free_ > 0) {
             int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
-            cur_frag = 1.0 - ((double)me / (double)free_);
-            if (after.nu > 1) cur_comp = ((double)(after.hi - after.lo) / (double)(S - free_)) * (1.0 / (double)after.nu);
+            cur_frag = 1.0 - div_pos((double)me, (double)free_);
+            if (after.nu > 1) cur_comp = div_pos((double)(after.hi - after.lo), (double)(S - free_)) * div_pos(1.0, (double)after.nu);
             else cur_comp = 1.0;
           }
-          frag = ((frag * last_update) + (cur_frag * time_diff)) / clock;
-          comp = ((comp * last_update) + (cur_comp * time_diff)) / clock;
+          frag = div_by((frag * last_update) + (cur_frag * time_diff), rc);
+          comp = div_by((comp * last_update) + (cur_comp * time_diff), rc);
         }
       } else {
         // the same link touched again at the same clock: the reference's update has last_update == now and
         // time_diff == 0, i.e. new = ((old * now) + (cur * 0.0)) / now with a finite cur
-        util = ((util * clock) + 0.0) / clock;
-        if (ENV != ENV_RWA) { frag = ((frag * clock) + 0.0) / clock; comp = ((comp * clock) + 0.0) / clock; }
+        const Recip rc = recip_of(clock);
+        util = div_by((util * clock) + 0.0, rc);
+        if (ENV != ENV_RWA) { frag = div_by((frag * clock) + 0.0, rc); comp = div_by((comp * clock) + 0.0, rc); }
       }
     }
     last_update = clock;
