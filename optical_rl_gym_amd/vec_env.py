@@ -157,18 +157,25 @@ class OpticalVecEnv:
             infos = self._infos = [_NO_INFO] * self.num_envs
         for i in self._infos_set:
             infos[i] = _NO_INFO
-        self._infos_set = finished
-        for n_, i in enumerate(finished):
-            infos[i] = {}
-            row = dict(r=float(self._ep_ret[i]), l=int(self._ep_len[i]), t=round(time.time() - self._t0, 6))
-            for k, j in zip(self.info_keywords, self._kw_idx):
-                row[k] = float(rows[n_, j] if info is None else info[i, j])
-            infos[i]["episode"] = row
+        self._infos_set = finished.tolist()
+        if len(finished):
+            # (with 50-step episodes 1 300 of 65 536 envs finish per step: everything per env is taken out of numpy in bulk first —
+            # scalar by scalar the conversions cost more than the device's step)
+            idx = finished.tolist()
+            rets, lens = self._ep_ret[finished].tolist(), self._ep_len[finished].tolist()
+            cols = [(rows[:, j] if info is None else info[finished, j]).tolist() for j in self._kw_idx]
             # the in-kernel reset is soft: the pending service (hence the observation) is unchanged by it
-            infos[i]["terminal_observation"] = None if obs is None else np.array(obs[i])
-            self.episode_log.append(row)
-            self._ep_ret[i] = 0
-            self._ep_len[i] = 0
+            term = None if obs is None else np.array(obs[finished])  # one copy; each env gets its row of it
+            t_now = round(time.time() - self._t0, 6)
+            log = self.episode_log
+            for n_, i in enumerate(idx):
+                row = {"r": rets[n_], "l": lens[n_], "t": t_now}
+                for k, col in zip(self.info_keywords, cols):
+                    row[k] = col[n_]
+                infos[i] = {"episode": row, "terminal_observation": None if term is None else term[n_]}
+                log.append(row)
+            self._ep_ret[finished] = 0
+            self._ep_len[finished] = 0
         return obs, np.array(reward), np.array(done, dtype=bool), infos
 
     def step(self, actions):
