@@ -1101,7 +1101,9 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
   // (round 4: a tuned instantiation of form 6 needs 128 VGPRs with the soon list in registers and no spills, and 16 wavefronts
   // per CU are 4 096 resident = exactly two generations of a 65 536-env batch: cfg2 20-step launches 1.135e9 -> 1.190e9, 300-step
   // runs 1.467e9 -> 1.474e9 against form 4)
-  else if (tuned && VP.env_type != ENV_RMCSA && r0 >= 10 && lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = level(3, 16); }
+  // ... for batches of more wavefronts than form 4 keeps resident (12 per CU x 256 CUs); below that no generation is cut short, and
+  // the records in LDS are a dependent round trip per step less: 4 096 envs +1.7 %, 8 192 +2.1 %, 16 384 +4.1 % for form 4
+  else if (tuned && VP.env_type != ENV_RMCSA && r0 >= 10 && lds_wgs_per_cu(g0) >= 16 && (VP.B + 7) / 8 > 12 * 256) { c.form = 6; c.inner = level(3, 16); }
   else if (r0 >= 10) { c.form = 4; c.inner = level(1, 12); }
   else if (lds_wgs_per_cu(g0) >= 16) { c.form = 6; c.inner = level(3, 16); }
   // (global state: the 4-wave form except for RMCSA — round 3, with the 4-byte sink entries: cfg5 Germany50 32 768 envs 5.6e8 at 4
