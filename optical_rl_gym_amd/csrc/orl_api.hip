@@ -370,6 +370,7 @@ static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
   q.soon_t += lo * ORL_SOON; q.soon_i += lo * ORL_SOON;
   q.svc_q += lo * 8; q.svc_ht += lo * 8; q.svc_pk += lo * 8; q.svc_cnt += lo * 8;  // (64 lanes per 8 envs; lo is a multiple of 8)
   q.row_cache += (lo / 8) * 2 * (i64)P.row_cache_words; q.row_cache_stamp += lo / 8;
+  if (q.slog) { q.slog += lo; q.log_n += lo / 8; }  // (rows of the log span the whole batch: log_stride stays)
   if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
   if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (P.S + 1));
   if (q.act2d) q.act2d += lo * P.act2d_words;
@@ -598,6 +599,20 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       rc |= dalloc(b, &P.svc_pk, n_lanes);
       rc |= dalloc(b, &P.svc_cnt, n_lanes);
       if (!rc) HIPCHK_B(hipMemset(P.svc_cnt, 0, n_lanes * sizeof(int)));  // nothing drawn ahead
+    }
+    if (b->persist && orl_persist_deferred(P.env_type)) {
+      // the statistics log of a launch: 24 bytes per env-step, two chunks' worth of steps (a wavefront that left a launch early
+      // catches up in the next one), at most 1 GiB — larger batches run shorter launches (orl_batch_run)
+      const size_t per_step = (size_t)ORL_SLOG_ROW_WORDS * 8 * B;
+      size_t cap = ((size_t)1 << 30) / per_step;
+      cap = cap > 256 ? 256 : (cap < 16 ? 16 : cap);
+      if (const char* lv = getenv("ORL_LOG_CAP")) { const int v = atoi(lv); if (v >= 2 && v <= 256) cap = (size_t)v; }  // tests
+      P.log_cap = (int)cap;
+      P.log_stride = (i64)B;
+      b->log_cap = (int)cap;
+      rc |= dalloc(b, &P.slog, (cap + 1) * (size_t)ORL_SLOG_ROW_WORDS * B);
+      rc |= dalloc(b, &P.log_n, (B + 7) / 8 + 16);
+      if (!rc) HIPCHK_B(hipMemset(P.log_n, 0, ((B + 7) / 8 + 16) * sizeof(int)));
     }
   }
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
@@ -1153,6 +1168,8 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     // leave its loop early, so longer launches leave no stragglers behind)
     int chunk = 128;
     if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
+    // (deferred statistics: a launch logs at most log_cap steps per wavefront, a straggler up to two chunks)
+    if (b->log_cap > 0 && chunk > b->log_cap / 2) chunk = b->log_cap / 2 > 0 ? b->log_cap / 2 : 1;
     // A launch occupies the GPU in rounds of `resident` wavefronts, and a last round that is not full leaves CUs idle until
     // the launch ends (cfg2: 8 192 wavefronts over 3 072 resident = 2.67 rounds, 11 % of the machine-time lost).  When the
     // rounds do not come out even, the batch runs as two halves on two streams: the tail of one half's launch overlaps the

@@ -76,6 +76,7 @@ enum {
 #endif
 #define ORL_SOON (8 * ORL_SOON_PER_LANE)
 
+#define ORL_SLOG_ROW_WORDS 3  // statistics log of the persistent kernel: words per env-step (orl_device_split.h, ctrl_d)
 struct DevParams {
   int env_type, N, E, K, H, M, S, W, C, episode_length, allow_rejection, J;
   int bit_rate_mode, br_lo, n_br, rand_n, rand_bits;
@@ -137,6 +138,12 @@ struct DevParams {
   double* svc_ht;   // holding time
   u32* svc_pk;      // source | destination << 10 | bit-rate index << 20
   int* svc_cnt;     // services in the group's batch << 8 | next one to take
+  // deferred statistics of the persistent kernel (orl_device_split.h: ctrl_d logs, k_stats replays lane-per-env after the launch):
+  // three words per env-step, [slot][word][env] so that the replay reads consecutive envs
+  u64* slog;        // [log_cap + 1][3][log_stride]; slot s = the s-th step a wavefront ran in this launch
+  int* log_n;       // [ceil(B/8)] steps the wavefront logged in this launch | (it finished the run's state itself) << 16
+  i64 log_stride;   // envs per row of the log: the whole batch, whichever view of it a launch works on
+  int log_cap;      // steps one launch can log per wavefront
   double* soon_t;   // [B][ORL_SOON] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8, ...
   u32* soon_i;      // [B][ORL_SOON] their slots in ev_time / ev_info
   i64 q_cap;

@@ -816,6 +816,227 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
   return desc_out;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Deferred statistics (round 5).  Most of what ctrl_a does per env is bookkeeping that nothing in the loop reads back: the
+// eight service / bit-rate counters, the running averages of network throughput and compactness, the done / soft-reset
+// logic on them, and the 32-word record that carries them in and out of registers every step — the same arithmetic on all
+// 8 lanes of a group, ~350 VALU instructions and 31 loads + 13 stores per wavefront-step for 8 envs.  The dynamics of an env
+// (slot maps, pending releases, clock, generator) never depend on it.  So the single-core families' persistent kernel does
+// not do it at all: ctrl_d keeps the clock, the pending service and the release queue's fields, and LOGS per env-step the
+// three words the bookkeeping needs (DevParams::slog); k_stats (orl_kernels.hip) replays the log after the launch with one
+// LANE per env — 64 envs per instruction instead of 8 — in the reference's operation order (rmsa_env.py:163-282, 439-462,
+// 545-597), leaving the record exactly as ctrl_a would have.  Log words of a step:
+//   w0  the clock after the step's next service was created (float64 bits)
+//   w1  accepted:1 | n x hops of the provision:12 | bit-rate index of the NEW service:12 | the per-core sums at the START of the
+//       step minus what the previous step's releases added — the network compactness right after the previous step's provision —
+//       (lambda_max - lambda_min) sum:17 | free blocks inside:16   (RWA instead of the sums: the action's path:4 | wavelength:10,
+//       for the actions_output marginals).  Single-core families: the core is 0.
+//   w2  what the step's releases take off the sums: n x hops:20 | bit rate:24   (stored after the release detection; w0 and w1
+//       before it, so that nothing of them is live across it)
+// Slot n of a wavefront that logged n steps carries w1's sums only: those after its last row phase.
+// ---------------------------------------------------------------------------------------------------------------
+#define ORL_SLOG_WORDS ORL_SLOG_ROW_WORDS
+__device__ __forceinline__ u64 slog_w1(bool accepted, int n_hops, int br_new, int occ, int fb) {
+  return (u64)(accepted ? 1u : 0u) | ((u64)(u32)n_hops << 1) | ((u64)(u32)br_new << 13) | ((u64)(u32)occ << 25) | ((u64)(u32)fb << 42);
+}
+__device__ __forceinline__ u64 slog_w1_rwa(bool accepted, int n_hops, int path, int slot) {
+  return (u64)(accepted ? 1u : 0u) | ((u64)(u32)n_hops << 1) | ((u64)(u32)path << 25) | ((u64)(u32)slot << 29);
+}
+__device__ __forceinline__ u64 slog_w2(int d_nh, int d_br) { return (u64)(u32)d_nh | ((u64)(u32)d_br << 20); }
+
+// the control phase of the persistent kernel without the bookkeeping (single-core families, compact sink, services drawn
+// ahead).  `esp`: the env's episode step counter, kept by the caller for the whole launch (done / observation need it);
+// `slog`: this step's log slot, at the env's column.  Returns the descriptor of the new pending service.
+template <int ENV, int W>
+__device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
+                                      const int4& av, u64 desc, SinkEntryC* s_tab, int* s_deferred, int* done_out, unsigned short* s_list,
+                                      u32* s_list_n, SoonRegs* carried, unsigned short* s_mtab, SvcBuf& svc, int& esp, u64* slog) {
+  const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
+  u64 desc_out = 0ull;
+  SinkT<true> sink;
+  sink.tally = nullptr; sink.tw = 0; sink.active = false; sink.deferred = false; sink.cnt = 0;
+  sink.list = s_list; sink.list_n = s_list_n; sink.nrel = 0;
+  if (lane == 0) *s_list_n = 0u;
+  {
+    SinkEntryC* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
+    for (int i = lane; i < 8 * P.E; i += 64) sink_entry_clear(tb[i]);
+    wave_fence();
+    sink.tab = s_tab + P.E * (int)(threadIdx.x >> 3);
+    sink.mtab = s_mtab + ORL_MTAB * (int)(threadIdx.x >> 3);
+  }
+  if (valid) {
+    u64* rec = wm_scal(P, M, env);
+    EnvG e;
+    e.scal = rec;
+    e.env = env;
+    // what the loop itself needs of the record: clock, the pending service's holding time and bit rate, the release queue
+    {
+      const u64 w_now = rec[SC_NOW], w_ht = rec[SC_HT], w_nr = rec[SC_NEXTREL], w_ts = rec[SC_TSOON];
+      const u64 w_ev = rec[SC_EV], w_hint = rec[SC_HINT];
+      const u64 f0 = rec[SC_FREE0], f1 = rec[SC_FREE1], f2 = rec[SC_FREE2], f3 = rec[SC_FREE3];
+      e.now = __longlong_as_double((i64)w_now); e.ht = __longlong_as_double((i64)w_ht);
+      e.next_rel = __longlong_as_double((i64)w_nr); e.t_soon = __longlong_as_double((i64)w_ts);
+      // (the pending service's bit rate from its descriptor: no load)
+      e.br_idx = (int)((desc >> 32) & 0xffffu);
+      e.bit_rate = (ENV == ENV_RWA) ? 0 : ((P.bit_rate_mode == 0) ? P.br_lo + e.br_idx : P.bit_rates[e.br_idx]);
+      e.ev_hwm = (int)(u32)w_ev; e.ev_cnt = (int)(w_ev >> 32);
+      e.nfree = (int)(u32)w_hint;
+      const int top = e.nfree - 1;
+      const u64 w = (top >> 2) == 0 ? f0 : (top >> 2) == 1 ? f1 : (top >> 2) == 2 ? f2 : f3;
+      e.pop_idx = (top >= 0) ? (int)((w >> (16 * (top & 3))) & 0xffffu) : -1;
+    }
+    e.flags = 0;
+    e.s_br = 0; e.s_nh = 0;  // (here: minus what this step's releases take off the sums)
+    e.ev_time = P.ev_time + env * P.ev_cap;
+    e.ev_info = P.ev_info + env * P.ev_cap;
+    e.soon_t = P.soon_t + env * ORL_SOON;
+    e.soon_i = P.soon_i + env * ORL_SOON;
+    e.sr_on = false;
+    e.rank_pairs = false;
+    if (carried) {
+      e.sr_on = true;
+      e.rank_pairs = O.rank_pairs;
+#pragma unroll
+      for (int k = 0; k < ORL_SOON_PER_LANE; k++) { e.sr_t[k] = carried->t[k]; e.sr_i[k] = carried->i[k]; }
+    }
+    int pre_idx = -1;
+    u64 pre_info = 0ull;
+    if (carried && O.prefetch) {  // (as ctrl_a: the info word of this lane's earliest list entry, if it may come due in this step)
+      double pt = e.sr_t[0];
+      int pi = e.sr_i[0];
+#pragma unroll
+      for (int k = 1; k < ORL_SOON_PER_LANE; k++)
+        if (e.sr_t[k] < pt || (e.sr_t[k] == pt && e.sr_i[k] < pi)) { pt = e.sr_t[k]; pi = e.sr_i[k]; }
+      if (pt <= e.now + P.pf_window && e.t_soon > -__builtin_inf() && (u32)pi < (u32)P.ev_cap) { pre_idx = pi; pre_info = e.ev_info[pi]; }
+    }
+    e.bm = wm_bm(P, M, env);
+    e.ls = wm_ls(P, M, env);
+    e.cs = wm_cs(P, M, env);
+    int occ_s = 0, fb_s = 0;
+    if (ENV != ENV_RWA) {
+      // the sums right after the previous step's provision (its pending network-compactness update, rmsa_env.py:439-462, is
+      // finished by the replay from them); this step's releases start from zero
+      int* rs = e.cs + 2;
+      if (!M.cs_lds) {
+        occ_s = atomicAdd(e.cs, 0) - atomicAdd(rs, 0);
+        fb_s = atomicAdd(e.cs + 1, 0) - atomicAdd(rs + 1, 0);
+        if (gl < 2) atomicExch(rs + gl, 0);
+      } else {
+        occ_s = e.cs[0] - rs[0];
+        fb_s = e.cs[1] - rs[1];
+        if (gl < 2) rs[gl] = 0;
+      }
+    }
+    int path, slot;
+    if (ENV == ENV_DEEPRMSA) { path = av.y; slot = av.z; }  // (decoded by the in-kernel scan on this slot map, policy_g)
+    else { path = av.x; slot = av.y; }
+    const int path0 = path, slot0 = slot;
+    ORL_PROFA(2);
+    const int pb = (int)(u32)desc, np_ = (int)((desc >> 48) & 0xffu);
+    bool accepted = false;
+    int n = 1, n_hops = 0;
+    int pushed_idx = -1;
+    u64 pushed_info = 0ull;
+    double pushed_t = 0.0;
+    if (path < K && slot < S && path < np_) {
+      const int pidx = pb + path;
+      if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
+      const PathRec prec = path_rec_load(P, pidx);
+      ORL_PROFA(3);
+      const int hops = path_rec_byte(prec, 0);
+      n_hops = n * hops;
+      accepted = true;
+      pushed_info = ev_pack(pidx, slot, n, 0, e.bit_rate);
+      pushed_t = e.now + e.ht;  // (arrival time + holding time: the clock stands at the pending service's arrival)
+      pushed_idx = g8::ev_push(P, e, lane, pushed_t, pushed_info, false);
+      sink_add(sink, prec, 0, slot, n, lane, true);
+      ORL_PROFA(4);
+    }
+    if (P.act2d && gl == 0) act2d_count(P, env, path0, slot0, accepted);
+    if (gl == 0) {
+      if (O.write_io) {
+        P.reward[env] = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
+        *(int4*)(P.actions + env * 4) = (ENV == ENV_DEEPRMSA) ? make_int4(av.x, 0, 0, 0) : av;
+      }
+      M.clk[2 * (env - M.clk_env0)] = e.now;  // (SC_NOWA is the replay's: every form with this control phase has the clock pair)
+    }
+    ORL_PROFA(5);
+    // the next service, drawn ahead by svc_generate: from the lane of the group that holds it
+    int br_new;
+    {
+      const int k = svc.cnt & 0xff;
+      const double q = gget(svc.q, k, lane), ht = gget(svc.ht, k, lane);
+      const u32 pk = gget(svc.pk, k, lane);
+      svc.cnt += 1;
+      e.now = e.now + q;
+      br_new = (int)(pk >> 20);
+      int bit_rate = 0;
+      if (ENV != ENV_RWA) bit_rate = (P.bit_rate_mode == 0) ? P.br_lo + br_new : P.bit_rates[br_new];
+      const int src = (int)(pk & 0x3ffu), dst = (int)((pk >> 10) & 0x3ffu);
+      const u64 npn = (u64)(u32)P.n_paths[src * P.N + dst];
+      desc_out = (u64)(u32)((src * P.N + dst) * K) | ((u64)(u32)(ENV != ENV_RWA ? br_new : 0) << 32) | (npn << 48);
+      if (gl == 0) {
+        rec[SC_NOW] = (u64)__double_as_longlong(e.now);
+        rec[SC_AT] = (u64)__double_as_longlong(e.now);
+        rec[SC_HT] = (u64)__double_as_longlong(ht);
+        rec[SC_SRC_DST] = pack2(src, dst);
+        rec[SC_BR_IDX] = pack2(bit_rate, ENV != ENV_RWA ? br_new : 0);
+        if (O.write_io) P.svc_desc[env] = desc_out;
+      }
+    }
+    if (gl < 2) {
+      const u64 w1 = (ENV == ENV_RWA) ? slog_w1_rwa(accepted, n_hops, path0, slot0) : slog_w1(accepted, n_hops, br_new, occ_s, fb_s);
+      slog[(size_t)gl * (size_t)P.log_stride] = gl == 0 ? (u64)__double_as_longlong(e.now) : w1;
+    }
+    ORL_PROFA(7);
+    // episode end (rmsa_env.py:263, 310-315: the soft reset re-counts the pending service; rwa_env.py:141: RWA counts at the decision)
+    esp += 1;
+    const bool done = (esp == P.episode_length);
+    if (done) esp = (ENV == ENV_RWA) ? 0 : 1;
+    if (gl == 0 && O.write_io) P.done[env] = done ? 1 : 0;
+    if (done_out) *done_out = done ? 1 : 0;
+    if (pushed_idx >= 0 && gl == (pushed_idx & 7)) { e.ev_time[pushed_idx] = pushed_t; e.ev_info[pushed_idx] = pushed_info; }
+    if (M.clk && gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
+    ORL_PROFA(8);
+    {
+      SoonRegs soon;
+      release_soon<ENV, W, true>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
+      ORL_PROFA(10);
+      if (sink.deferred) {
+        // (as ctrl_a) the releases stay pending; rel_serial does them in place at the start of this wavefront's next launch
+        if (gl == 0) {
+          *s_deferred = 1;
+          rec[SC_ACC] = rec[SC_ACC] | (1ull << 16);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
+          if (e.sr_on) {
+            if (soon.dirty) { e.sr_t[k] = soon.t[k]; e.sr_i[k] = soon.i[k]; }
+          } else if ((soon.dirty >> k) & 1) {
+            e.soon_t[gl + 8 * k] = soon.t[k];
+            e.soon_i[gl + 8 * k] = (u32)soon.i[k];
+          }
+        }
+      }
+      if (gl == 0) {
+        rec[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
+        rec[SC_TSOON] = (u64)__double_as_longlong(e.t_soon);
+        rec[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
+        rec[SC_HINT] = pack2(e.nfree, 0);
+        if (e.flags) rec[SC_FLAGS] = rec[SC_FLAGS] | ((u64)(u32)e.flags << 32);
+      }
+    }
+    if (gl == 2) slog[2 * (size_t)P.log_stride] = slog_w2((int)(-e.s_nh), (int)(-e.s_br));
+    if (carried) {
+#pragma unroll
+      for (int k = 0; k < ORL_SOON_PER_LANE; k++) { carried->t[k] = e.sr_t[k]; carried->i[k] = e.sr_i[k]; }
+    }
+  }
+  ORL_PROFA(11);
+  return desc_out;
+}
+
 // persistent kernel: an item of the row phase read from the sink table in place (RMCSA; the single-core families hand the
 // entry's bit word and the env's mask table to row_item_lane1)
 __device__ __forceinline__ Item item_from_sink(i64 env, int link, const SinkEntry& t) {

@@ -13,6 +13,18 @@
 #include "../../include/orl.h"
 #include "orl_device.h"
 
+// Deferred statistics of the persistent kernel (orl_device_split.h ctrl_d, orl_kernels.hip k_stats): the single-core families log
+// the per-env bookkeeping of a launch and replay it lane-per-env afterwards.  -DORL_PERSIST_DS=0 keeps it in the loop.
+#ifndef ORL_PERSIST_DS
+#define ORL_PERSIST_DS 1
+#endif
+#ifndef ORL_PERSIST_SVC
+#define ORL_PERSIST_SVC 1
+#endif
+static inline bool orl_persist_deferred(int env_type) {
+  return ORL_PERSIST_DS != 0 && ORL_PERSIST_SVC != 0 && (env_type == orl::ENV_RMSA || env_type == orl::ENV_DEEPRMSA || env_type == orl::ENV_RWA);
+}
+
 struct orl_topology {
   int device;
   int N, E, K, H, M;
@@ -60,6 +72,7 @@ struct orl_batch {
   int32_t* h_actions = nullptr;    // page-locked [B][4]: where orl_batch_step_async expands the caller's compact action rows
   int step_pending = 0;            // orl_batch_step_async queued a step that orl_batch_step_wait has not collected yet
   unsigned int* h_tail = nullptr;  // page-locked: where the straggler count / flag words of a run land (a pageable target is staged)
+  int log_cap = 0;                 // deferred statistics: steps one launch of k_persist can log per wavefront (0: no log)
   int cache_epoch = 1;             // bumped by every call that may change slot maps outside the persistent kernel (DevParams::row_cache_key)
   long long* gather_idx = nullptr;  // orl_batch_get_info_rows: row indices and gathered rows on the device, grown on demand
   double* gather_out = nullptr;

@@ -245,7 +245,9 @@ __host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_wo
   L.tally = o; o += 8 * L.tw * 4;
   // one entry per touched link and env, a second one where the step's provision meets a release (at most its hops)
   L.list = o; o += ((8 * (E + (H < E ? H : E)) * 2) + 15) & ~15;
-  L.clk = o; if (state == 0 || state == 3) o += 8 * 2 * 8;  // (records in LDS: the row phase reads the clocks from them)
+  // {provision clock, step clock} of the 8 envs for the row phase (the deferred-statistics control phase never writes SC_NOWA,
+  // which the replay owns, so the forms with the records in LDS have the pair too; the full-LDS test form reads the records)
+  L.clk = o; if (state != 2) o += 8 * 2 * 8;
   L.misc = o; o += 16;
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
   L.csw = (4 * C + 3) & ~3;  // sums + their release part, ints per env
@@ -317,17 +319,157 @@ __device__ __forceinline__ void persist_fill_window(const DevParams& P, i64 env0
   }
 }
 
+// Deferred statistics (orl_device_split.h, ctrl_d): the persistent kernel of the single-core families leaves the per-env
+// bookkeeping to k_stats below.  -DORL_PERSIST_DS=0 builds keep it in the loop (ctrl_a; A/B measurements, cross-checks).
+// (the macros and orl_persist_deferred(): orl_host.h)
+template <int ENV, int LDS> struct PersistDeferred {
+  static constexpr bool value = ORL_PERSIST_DS != 0 && ORL_PERSIST_SVC != 0 && LDS != 2 && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA || ENV == ENV_RWA);
+};
+
+// The bookkeeping of the steps a launch of k_persist ran, one LANE per env: counters, bit-rate sums, the running averages of
+// network throughput and compactness, episode ends — what ctrl_a / service_part (orl_device_split.h) do inside the step,
+// statement for statement and in the reference's order (rmsa_env.py:163-282 decision and counters, 439-462
+// _update_network_stats, 545-597 _next_service, 284-359 soft reset; rwa_env.py:101-162), from the three log words per step.
+// Leaves the record exactly as that code would: a pending network-compactness update stays pending (SC_ACC bit 1 with its
+// stashed factors) unless the wavefront finished the run's state (log_n bit 16), in which case it is finished here from the
+// sums the wavefront logged after its last row phase, as k_finish2 does.
+#define ORL_STATS_BATCH 8  // log slots requested per round trip
+template <int ENV>
+__global__ void __launch_bounds__(64) k_stats(DevParams P) {
+  const i64 env = (i64)blockIdx.x * 64 + (i64)threadIdx.x;
+  if (env >= P.B) return;
+  const int ln = P.log_n[env >> 3];
+  const int n = ln & 0xffff;
+  const bool fin = ((ln >> 16) & 1) != 0;
+  if (n == 0) return;
+  u64* s = P.scal + env * ORL_SCAL_WORDS;
+#define F64(slot) __longlong_as_double((i64)s[slot])
+  double g_thr = F64(SC_GTHR), g_comp = F64(SC_GCOMP), g_last = F64(SC_GLAST);
+  double gc_a = F64(SC_GC_A), gc_td = F64(SC_GC_TD), now_a = F64(SC_NOWA);
+#undef F64
+  i64 sp = (i64)s[SC_SP], sa = (i64)s[SC_SA], esp = (i64)s[SC_ESP], esa = (i64)s[SC_ESA];
+  i64 brq = (i64)s[SC_BRQ], brp = (i64)s[SC_BRP], ebrq = (i64)s[SC_EBRQ], ebrp = (i64)s[SC_EBRP];
+  i64 s_br = (i64)s[SC_SBR], s_nh = (i64)s[SC_SNH];
+  u64 acc = s[SC_ACC];
+  const u64 acc_keep = acc & (1ull << 16);  // (serial releases pending: set by the loop, cleared by rel_serial)
+  int id = (int)(u32)s[SC_ID_MTPOS];
+  const u64* lg = P.slog + env;
+  const size_t st = (size_t)P.log_stride;
+  // the clock the first logged step is decided at and the bit rate of the service it serves: the record has moved on to the
+  // launch's last step — the wavefront logged them when it began (header row, slot log_cap)
+  double now = __longlong_as_double((i64)lg[(size_t)(3 * P.log_cap) * st]);
+  int br_idx = (int)(u32)lg[(size_t)(3 * P.log_cap + 2) * st];
+  int bit_rate = (ENV == ENV_RWA) ? 0 : ((P.bit_rate_mode == 0) ? P.br_lo + br_idx : P.bit_rates[br_idx]);
+  bool done = false;
+  for (int t0 = 0; t0 < n; t0 += ORL_STATS_BATCH) {
+    u64 w0[ORL_STATS_BATCH], w1[ORL_STATS_BATCH], w2[ORL_STATS_BATCH];
+#pragma unroll
+    for (int k = 0; k < ORL_STATS_BATCH; k++) {
+      const int t = (t0 + k < n) ? t0 + k : n - 1;
+      w0[k] = lg[(size_t)(3 * t) * st];
+      w1[k] = lg[(size_t)(3 * t + 1) * st];
+      w2[k] = lg[(size_t)(3 * t + 2) * st];
+    }
+#pragma unroll
+    for (int k = 0; k < ORL_STATS_BATCH; k++) {
+      if (t0 + k < n) {
+        const u64 a1 = w1[k], a2 = w2[k];
+        if (ENV != ENV_RWA && ((u32)acc & 2u)) {
+          // the previous accepted step's network-compactness update, from the sums right after its provision (ctrl_a)
+          const int c0 = (int)((acc >> 32) & 31);
+          (void)c0;
+          const i64 s_nh_prov = (i64)(acc >> 37);
+          const int occ = (int)((a1 >> 25) & 0x1ffffu), fb = (int)((a1 >> 42) & 0xffffu);
+          const double cmp = (fb > 0) ? sp::div_pos((double)occ, (double)s_nh_prov) * sp::div_pos((double)P.E, (double)fb) : 1.0;
+          g_comp = sp::div_pos(gc_a + (cmp * gc_td), now_a);
+        }
+        const bool accepted = (a1 & 1ull) != 0ull;
+        const int core = 0, n_hops = (int)((a1 >> 1) & 0xfffu), br_new = (int)((a1 >> 13) & 0xfffu);
+        const int d_nh = (int)(a2 & 0xfffffu), d_br = (int)((a2 >> 20) & 0xffffffu);
+        if (accepted) {
+          s_br += bit_rate;
+          s_nh += n_hops;
+          if (ENV != ENV_RWA) {
+            brp += bit_rate;
+            ebrp += bit_rate;
+            if (P.bit_rate_mode == 1) P.br_hist[env * 2 * P.n_br + P.n_br + br_idx] += 1;
+          }
+          sa += 1;
+          esa += 1;
+        }
+        if (ENV == ENV_RWA) {
+          sp += 1; esp += 1;
+          // actions_output marginals (rwa_env.py:103): the scan's action is never out of range
+          const int path0 = (int)((a1 >> 25) & 15u), slot0 = (int)((a1 >> 29) & 1023u), rej = P.allow_rejection ? 1 : 0;
+          i64* h = P.act_hist + env * ((P.K + 1) + (P.S + 1));
+          if (path0 < P.K + rej) h[path0] += 1;
+          if (slot0 < P.S + rej) h[(P.K + 1) + slot0] += 1;
+        }
+        acc = pack2(accepted ? 1 : 0, core);
+        now_a = now;
+        if (accepted && ENV != ENV_RWA) {  // _update_network_stats (rmsa_env.py:439-462), as service_part
+          const double last_update = g_last, time_diff = now - last_update;
+          if (now > 0) {
+            const double cur_thr = (double)s_br;
+            g_thr = sp::div_pos((g_thr * last_update) + (cur_thr * time_diff), now);
+            gc_a = g_comp * last_update;
+            gc_td = time_diff;
+            acc = 3ull | ((u64)(u32)core << 32) | ((u64)s_nh << 37);
+          }
+          g_last = now;
+        }
+        // _next_service: the clock moves to the new arrival; the service is counted (RMSA / DeepRMSA)
+        now = __longlong_as_double((i64)w0[k]);
+        br_idx = (ENV != ENV_RWA) ? br_new : 0;
+        bit_rate = (ENV == ENV_RWA) ? 0 : ((P.bit_rate_mode == 0) ? P.br_lo + br_idx : P.bit_rates[br_idx]);
+        id = (int)esp;
+        if (ENV != ENV_RWA) {
+          sp += 1; esp += 1;
+          brq += bit_rate;
+          ebrq += bit_rate;
+          if (P.bit_rate_mode == 1) P.br_hist[env * 2 * P.n_br + br_idx] += 1;
+        }
+        done = (esp == (i64)P.episode_length);
+        if (done) {
+          if (P.ep_log) episode_log(P, env, esa);
+          ebrq = 0; ebrp = 0; esp = 0; esa = 0;
+          if (ENV != ENV_RWA) { esp += 1; ebrq += bit_rate; }
+        }
+        // the step's releases
+        s_br -= d_br;
+        s_nh -= d_nh;
+      }
+    }
+  }
+  if (fin && ENV != ENV_RWA && ((u32)acc & 2u)) {
+    // the run ends here: the update the last step left pending, from the sums after its row phase (k_finish2's expressions)
+    const u64 a1 = lg[(size_t)(3 * n + 1) * st];
+    const i64 s_nh_prov = (i64)(acc >> 37);
+    const int occ = (int)((a1 >> 25) & 0x1ffffu), fb = (int)((a1 >> 42) & 0xffffu);
+    const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
+    g_comp = (gc_a + (cmp * gc_td)) / now_a;
+    acc &= ~2ull;
+  }
+#define PF(slot, x) s[slot] = (u64)__double_as_longlong(x);
+  PF(SC_GTHR, g_thr) PF(SC_GCOMP, g_comp) PF(SC_GLAST, g_last) PF(SC_GC_A, gc_a) PF(SC_GC_TD, gc_td) PF(SC_NOWA, now_a)
+#undef PF
+  s[SC_SP] = (u64)sp; s[SC_SA] = (u64)sa; s[SC_ESP] = (u64)esp; s[SC_ESA] = (u64)esa;
+  s[SC_BRQ] = (u64)brq; s[SC_BRP] = (u64)brp; s[SC_EBRQ] = (u64)ebrq; s[SC_EBRP] = (u64)ebrp;
+  s[SC_SBR] = (u64)s_br; s[SC_SNH] = (u64)s_nh;
+  s[SC_ACC] = acc | acc_keep;
+  ((u32*)(s + SC_ID_MTPOS))[0] = (u32)id;
+  (void)now; (void)br_idx;
+}
+
 // LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics,
 // 3 = slot maps + per-core sums in LDS, env records in global memory
 // PF: early requests of the Mersenne-Twister window and the link statistics (more live registers: the 3-wave forms)
 // SVC: services drawn 8 steps ahead, one per lane of an env's group (sp::svc_generate)
-#ifndef ORL_PERSIST_SVC
-#define ORL_PERSIST_SVC 1
-#endif
 template <int ENV, int W, int LDS, bool PF>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
   constexpr bool SVC = ORL_PERSIST_SVC != 0;
+  constexpr bool DS = CP && PersistDeferred<ENV, LDS>::value;  // bookkeeping logged for k_stats (ctrl_d) instead of done in the loop
   const int ICL = PersistInner<ENV, W, LDS>::value ? P.persist_ic : 0;  // (the host decides: only where it costs no wavefront)
   const bool IC = ICL >= 1, OC = ICL >= 2;
   constexpr bool SR = PF;  // soon list in registers: the forms with registers to spare
@@ -361,9 +503,15 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   soon_c.dirty = 0;
   sp::SvcBuf svb;
   svb.q = 0.0; svb.ht = 0.0; svb.pk = 0u; svb.cnt = 0;
+  int esp_c = 0;        // DS: the env's episode step counter (SC_ESP; the replay keeps the record's copy)
+  u64 now0_w = 0ull;    // DS: the clock the launch starts at (logged for the replay)
 #define ORL_LOAD_CARRIED()                                                                                  \
   do {                                                                                                      \
     desc = valid ? P.svc_desc[env] : 0ull;                                                                  \
+    if (DS && valid && step < target) {                                                                     \
+      esp_c = (int)P.scal[env * ORL_SCAL_WORDS + SC_ESP];                                                   \
+      now0_w = P.scal[env * ORL_SCAL_WORDS + SC_NOW];                                                       \
+    }                                                                                                       \
     if (SVC && valid && step < target) {                                                                    \
       const size_t sl_ = (size_t)blockIdx.x * 64 + (size_t)lane;                                            \
       svb.cnt = P.svc_cnt[sl_];                                                                             \
@@ -377,7 +525,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   } while (0)
   sp::Wmem M = sp::wmem_global(P);
   constexpr bool REC = (LDS == 1 || LDS == 2);  // the env records are in the LDS window
-  if (!REC) {
+  if (LDS != 2) {
     M.clk = (double*)(orl_lds_raw + L.clk);
     M.clk_env0 = env0;
   }
@@ -475,8 +623,14 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   if (threadIdx.x == 0) s_deferred[0] = s_deferred[1] = 0;
   const int first_step = step;
   bool left_pending = false;  // the loop ended on a step whose releases are still to be done
+  if (DS && valid && step < target && (lane & 7) < 2) {
+    // header row of the log: the clock the first step is decided at, the bit-rate index of the service it serves
+    // (words 0 and 2 of that row: its word 1 is where a wavefront that logs log_cap steps leaves its last sums)
+    P.slog[(size_t)(3 * P.log_cap + 2 * (lane & 7)) * (size_t)P.log_stride + (size_t)env] = (lane & 7) == 0 ? now0_w : ((desc >> 32) & 0xffffull);
+  }
   ORL_PROF_BEGIN();
-  while (step < target) {
+  // (DS: a wavefront that caught up over more steps than a launch can log stops there and counts as unfinished)
+  while (step < target && (!DS || step - first_step < P.log_cap)) {
     __syncthreads();  // (one wavefront: an ordering point) the previous row phase's writes are done
     if (threadIdx.x == 0) s_deferred[(step + 1) & 1] = 0;
     // per-iteration opaque copies: without them the compiler hoists every per-lane address out of the loop and keeps
@@ -528,8 +682,14 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 #endif
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
-      desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
-                                    s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab, nullptr, SVC ? &svb : nullptr);
+      if constexpr (DS) {
+        u64* slog_s = P.slog + (size_t)(step - first_step) * ORL_SLOG_WORDS * (size_t)P.log_stride + (size_t)(valid_i ? env_i : 0);
+        desc = sp::ctrl_d<ENV, W>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, &s_deferred[step & 1], &done_i, s_list, s_list_n,
+                                  SR ? &soon_c : nullptr, s_mtab, svb, esp_c, slog_s);
+      } else {
+        desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
+                                      s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab, nullptr, SVC ? &svb : nullptr);
+      }
     }
     __syncthreads();  // sink table + item list, clocks, env records
     {
@@ -559,6 +719,28 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if (deferred) { left_pending = true; break; }
   }
   ORL_PROF_END();
+  const bool finished_run = P.persist_finish && step > first_step && !left_pending;
+  if (DS) {
+    // the sums after the last row phase (the replay finishes the last step's pending network-compactness update from them when
+    // the run ends here), and how many steps this wavefront logged
+    if (step > first_step) {
+      __syncthreads();
+      int tid_t = (int)threadIdx.x;
+      asm volatile("" : "+v"(tid_t));
+      const i64 env_t = env0 + (tid_t >> 3);
+      if (ENV != ENV_RWA && env_t < P.B && (tid_t & 7) == 0) {
+        int* cs = sp::wm_cs(P, M, env_t);
+        int* rs = cs + 2 * P.C;
+        int occ, fb;
+        if (!M.cs_lds) { occ = atomicAdd(cs, 0) - atomicAdd(rs, 0); fb = atomicAdd(cs + 1, 0) - atomicAdd(rs + 1, 0); }
+        else { occ = cs[0] - rs[0]; fb = cs[1] - rs[1]; }
+        P.slog[(size_t)(3 * (step - first_step) + 1) * (size_t)P.log_stride + (size_t)env_t] = sp::slog_w1(false, 0, 0, occ, fb);
+      }
+    }
+    if (threadIdx.x == 0) P.log_n[blockIdx.x] = (step - first_step) | (finished_run ? (1 << 16) : 0);
+  } else if (PersistDeferred<ENV, 0>::value && threadIdx.x == 0) {
+    P.log_n[blockIdx.x] = 0;  // (a form that keeps the bookkeeping in the loop: nothing for k_stats)
+  }
   if (P.persist_finish && step > first_step && !left_pending) {
     // the end of a run: what k_finish2 (orl_api.hip) does for every env in a launch of its own — the network-compactness update
     // the last step left pending (rmsa_env.py:439-462 with the sums right after that step's provision), the release part of
@@ -574,7 +756,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       u64* s = sp::wm_scal(P, M, env_f);
       int* cs = sp::wm_cs(P, M, env_f);
       int* rs = cs + 2 * P.C;
-      const u64 acc = s[SC_ACC];
+      const u64 acc = DS ? 0ull : s[SC_ACC];  // (DS: the replay finishes the pending update, from the sums logged above)
       if ((u32)acc & 2u) {
         const int c0 = (int)((acc >> 32) & 31);
         const i64 s_nh_prov = (i64)(acc >> 37);
@@ -1189,8 +1371,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   b->persist_spec = spec ? 1 : 0;
   if (spec) {
     b->spec_launch(&VP, gc.x, lds_a, st, pol, target, wg_step, unfinished, clear_next);
-    return;
-  }
+  } else {
 #define PER_ENV(E_)                                                                                                          \
   switch (v) {                                                                                                               \
     case 0: LAUNCH(E_, 0, 4); break;                                                                                         \
@@ -1200,9 +1381,20 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     case 6: LAUNCH(E_, 3, 4); break;                                                                                         \
     default: LAUNCH(E_, 1, 4); break;                                                                                        \
   }
-  ORL_FOR_ENV(b, PER_ENV)
+    ORL_FOR_ENV(b, PER_ENV)
 #undef PER_ENV
+  }
 #undef LAUNCH
+  // the bookkeeping of the steps this launch ran, one lane per env (deferred statistics: ctrl_d logged it), behind the launch
+  // on its stream; the forms that keep it in the loop logged nothing
+  if (orl_persist_deferred(VP.env_type) && VP.slog) {
+    dim3 gs((unsigned)((VP.B + 63) / 64));
+    switch (VP.env_type) {
+      case ENV_RMSA: hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP); break;
+      case ENV_DEEPRMSA: hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP); break;
+      default: hipLaunchKernelGGL((k_stats<ENV_RWA>), gs, blk, 0, st, VP); break;
+    }
+  }
 }
 // one host- or agent-driven step through the phases of the persistent kernel
 template <int W> void agent_step(orl_batch* b, int auto_reset) {
