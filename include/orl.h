@@ -205,6 +205,16 @@ int orl_batch_step_async(orl_batch* b, const void* actions, int action_width, in
                          double* obs_out, float* obs_f32_out, double* reward_out, uint8_t* done_out, double* info_out);
 int orl_batch_step_wait(orl_batch* b);
 
+/* A heuristic's decision and the step on it in one call: what orl_batch_policy(b, policy_id, ...) followed by
+ * orl_batch_step(b, NULL, auto_reset, ...) do — the heuristic of rmsa_env.py:747-803 / deeprmsa_env.py:135-155 / rwa_env.py:403-502 /
+ * rmcsa_env.py:882-911, then step() — with the slot scan as the first phase of the step kernel where the 8-lanes-per-env step
+ * kernel serves the batch (ONE launch per step instead of two; k_paths <= 8), else as the two launches.  For agents on the same
+ * GPU that imitate, warm-start from or are compared with a heuristic.  actions_out: [n_envs][4] int32 or NULL (the actions also
+ * stay in ORL_BUF_ACTIONS); the other outputs and the error behaviour as orl_batch_step with device-resident actions.  With no
+ * output buffer the call only queues work on the batch's stream. */
+int orl_batch_policy_step(orl_batch* b, int policy_id, int auto_reset, int32_t* actions_out, double* obs_out, double* reward_out,
+                          uint8_t* done_out, double* info_out);
+
 /* DeepRMSAEnv.observation() for the pending service (deeprmsa_env.py:60-121). */
 int orl_batch_observation(orl_batch* b, double* obs_out);
 /* The observation array the last orl_batch_step / orl_batch_observation / orl_batch_reset left on the device (ORL_BUF_OBS), cast

@@ -336,9 +336,9 @@ static void launch_step64(orl_batch* b, int auto_reset, int want_info, int fused
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
-static void launch_agent_step(orl_batch* b, int auto_reset) {
+static void launch_agent_step(orl_batch* b, int auto_reset, int pol = -1) {
   slot_maps_change(b);
-#define CALL(WW) orl_launch::agent_step<WW>(b, auto_reset)
+#define CALL(WW) orl_launch::agent_step<WW>(b, auto_reset, pol)
   ORL_DISPATCH_W(b, CALL)
 #undef CALL
 }
@@ -1021,6 +1021,35 @@ extern "C" int orl_batch_step_wait(orl_batch* b) try {
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
   return flags_to_rc(b, b->h_tail[17]);
+}
+ORL_ABI_CATCH_INT
+
+// policy + step in one call, for an agent whose action source is one of the library's heuristics (or which wants a heuristic's
+// transitions: imitation targets, baselines): where k_agent serves the batch (and k <= 8) ONE launch — the slot scan is the
+// step kernel's first phase — else k_policy followed by the step kernel.  Everything is queued on the batch's stream; with no
+// output buffer the call does not synchronise (like orl_batch_step(b, NULL, ...)).
+extern "C" int orl_batch_policy_step(orl_batch* b, int policy_id, int auto_reset, int32_t* actions_out, double* obs_out, double* reward_out,
+                                     uint8_t* done_out, double* info_out) try {
+  if (!b) return fail(ORL_E_INVALID, "null batch");
+  if (!policy_ok(b, policy_id)) return fail(ORL_E_INVALID, "policy %d is not defined for this env family", policy_id);
+  if (b->step_pending) return fail(ORL_E_INVALID, "orl_batch_policy_step: a step queued by orl_batch_step_async has not been waited for");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t B = (size_t)b->P.B;
+  if (b->agent_step && b->P.K <= 8) {
+    launch_agent_step(b, auto_reset ? 1 : 0, policy_id);
+  } else {
+    launch_policy(b, policy_id);
+    if (b->agent_step) launch_agent_step(b, auto_reset ? 1 : 0);
+    else launch_step64(b, auto_reset ? 1 : 0, 1, -1);
+  }
+  bool any = false;
+  if (actions_out) { HIPCHK(hipMemcpyAsync(actions_out, b->P.actions, B * 4 * sizeof(int), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (reward_out) { HIPCHK(hipMemcpyAsync(reward_out, b->P.reward, B * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (done_out) { HIPCHK(hipMemcpyAsync(done_out, b->P.done, B, hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (info_out) { HIPCHK(hipMemcpyAsync(info_out, b->P.info, B * b->P.n_info * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (obs_out && b->P.obs_dim) { HIPCHK(hipMemcpyAsync(obs_out, b->P.obs, B * b->P.obs_dim * sizeof(double), hipMemcpyDeviceToHost, b->stream)); any = true; }
+  if (any) return report_flags(b);  // synchronises
+  return ORL_OK;
 }
 ORL_ABI_CATCH_INT
 

@@ -948,7 +948,9 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
       accepted = true;
       pushed_info = ev_pack(pidx, slot, n, 0, e.bit_rate);
       pushed_t = e.now + e.ht;  // (arrival time + holding time: the clock stands at the pending service's arrival)
+#ifndef ORL_X_SKIP_PUSH
       pushed_idx = g8::ev_push(P, e, lane, pushed_t, pushed_info, false);
+#endif
       sink_add(sink, prec, 0, slot, n, lane, true);
       ORL_PROFA(4);
     }
@@ -1000,7 +1002,11 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     ORL_PROFA(8);
     {
       SoonRegs soon;
+#ifdef ORL_X_SKIP_REL
+      soon.dirty = 0;
+#else
       release_soon<ENV, W, true>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
+#endif
       ORL_PROFA(10);
       if (sink.deferred) {
         // (as ctrl_a) the releases stay pending; rel_serial does them in place at the start of this wavefront's next launch

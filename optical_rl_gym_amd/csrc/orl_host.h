@@ -51,7 +51,7 @@ struct orl_batch {
   // a specialisation library attached by orl_batch_load_spec: k_persist with this batch's sizes as compile-time constants
   void* spec_handle = nullptr;
   void (*spec_launch)(const orl::DevParams*, unsigned, size_t, hipStream_t, int, int, int*, unsigned int*, unsigned int*) = nullptr;
-  void (*spec_agent_launch)(const orl::DevParams*, unsigned, size_t, hipStream_t, int) = nullptr;  // k_agent of the same library
+  void (*spec_agent_launch)(const orl::DevParams*, unsigned, size_t, hipStream_t, int, int) = nullptr;  // k_agent of the same library
   int spec_lds = -1, spec_waves = -1;
   int* d_wg_step = nullptr;        // [ceil(B/8)] steps each workgroup of the persistent kernel has completed since run_base was 0
   int64_t run_base = 0;            // ... all of them, between runs (no per-run clearing of d_wg_step)
@@ -107,7 +107,7 @@ template <int W> int persist_resident(orl_batch* b, int n_cu);              // w
 template <int W> int persist_uses_lds(orl_batch* b);                       // 1: the persistent kernel keeps slot maps / link statistics in LDS
 template <int W> int prof_read(unsigned long long* out48, int reset);      // -DORL_TIMING builds: per-phase cycle sums
 template <int W> void step2(orl_batch* b, int pol);
-template <int W> void agent_step(orl_batch* b, int auto_reset);
+template <int W> void agent_step(orl_batch* b, int auto_reset, int pol);
 template <int W> void persist_form(const orl::DevParams& VP, int* lds_state, int* waves);  // the form persist() takes for this configuration                            // k_agent: one step, actions in P.actions, info / obs written                        // ORL_ALT_IMPLS: k_step_a2 ; k_rows2 ; k_rel_tail
 }  // namespace orl_launch
 

@@ -899,8 +899,12 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
 #define ORL_AGENT_WAVES 4  // waves per SIMD the register allocator leaves room for (cfg2 65 536 envs: 3 -> 114 us, 4 -> 108 us, 5 -> 141 us, 8 -> 193 us per launch)
 #endif
 // SPEC: the configuration's sizes as compile-time constants (the instantiation a specialisation library carries beside k_persist)
-template <int ENV, int W, int SPEC = 0>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGENT_WAVES, ORL_AGENT_WAVES))) k_agent(DevParams P, int auto_reset) {
+// FUSED (round 5): the action comes from one of the library's heuristics — the slot scan runs as this kernel's first phase, on
+// the same slot maps, exactly as k_persist does (policy_g; the action is then trusted: is_path_free holds by construction and
+// DeepRMSA's block walk is skipped) — instead of from a launch of k_policy in front of this one: one launch per agent step
+// instead of two (cfg2 65 536 envs: 109 us -> ~85 us), actions written to P.actions as the stand-alone scan would have.
+template <int ENV, int W, int SPEC = 0, bool FUSED = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGENT_WAVES, ORL_AGENT_WAVES))) k_agent(DevParams P, int auto_reset, int pol) {
   persist_spec_apply<SPEC>(P);
   constexpr bool CP = ENV != ENV_RMCSA;                                  // RMCSA: sink entries with a core per mask, the general row loop
   constexpr bool LINK_INFO = (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA);   // info carries network compactness and the two link averages
@@ -942,7 +946,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
       soon_c.i[k] = valid ? (int)P.soon_i[env * ORL_SOON + gl + 8 * k] : 0;
     }
   }
-  sp::ctrl_a<ENV, W, CP>(P, M, O, env, valid, lane, prof, nullptr, s_tally, s_tab, 0, s_deferred, &done_i, s_list, s_list_n, L.tw,
+  int4 av = make_int4(0, 0, 0, 0);
+  if constexpr (FUSED) {
+    const u64 desc = valid ? P.svc_desc[env] : 0ull;
+    int a[4];
+    policy_g<ENV, W, 8>(P, P.bitmap + (valid ? env : 0) * P.bm_words, valid, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
+                        (int)((desc >> 48) & 0xffu), lane, pol, (pol == POL_PATH_FF && valid) ? P.path_col[env] : 0, a);
+    av = make_int4(a[0], a[1], a[2], a[3]);
+    O.trusted = true;
+  }
+  sp::ctrl_a<ENV, W, CP>(P, M, O, env, valid, lane, prof, FUSED ? &av : nullptr, s_tally, s_tab, 0, s_deferred, &done_i, s_list, s_list_n, L.tw,
                          SOONR ? &soon_c : nullptr, s_mtab, &ic);
   if constexpr (SOONR) {
     if (valid) {
@@ -1167,8 +1180,9 @@ extern "C" void orl_spec_launch(const DevParams* VP, unsigned grid, size_t lds, 
   hipLaunchKernelGGL((k_persist<ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, 1>), dim3(grid), dim3(64), lds, st, *VP, pol, target, wg_step,
                      unfinished, clear_next);
 }
-extern "C" void orl_spec_agent_launch(const DevParams* VP, unsigned grid, size_t lds, hipStream_t st, int auto_reset) {
-  hipLaunchKernelGGL((k_agent<ORL_SPEC_ENV, ORL_W, 1>), dim3(grid), dim3(64), lds, st, *VP, auto_reset);
+extern "C" void orl_spec_agent_launch(const DevParams* VP, unsigned grid, size_t lds, hipStream_t st, int auto_reset, int pol) {
+  if (pol >= 0) hipLaunchKernelGGL((k_agent<ORL_SPEC_ENV, ORL_W, 1, true>), dim3(grid), dim3(64), lds, st, *VP, auto_reset, pol);
+  else hipLaunchKernelGGL((k_agent<ORL_SPEC_ENV, ORL_W, 1, false>), dim3(grid), dim3(64), lds, st, *VP, auto_reset, -1);
 }
 #else
 // =============================================================================================
@@ -1397,7 +1411,8 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   }
 }
 // one host- or agent-driven step through the phases of the persistent kernel
-template <int W> void agent_step(orl_batch* b, int auto_reset) {
+// pol >= 0: the heuristic's slot scan as the kernel's first phase (k_agent<..., FUSED>); -1: the actions in P.actions
+template <int W> void agent_step(orl_batch* b, int auto_reset, int pol) {
   const DevParams& VP = b->P;
   dim3 g((unsigned)((VP.B + 7) / 8)), blk(64);
   const size_t lds = (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, 0, VP.env_type != ENV_RMCSA, 0).total + (size_t)8 * VP.E * 16;
@@ -1405,11 +1420,13 @@ template <int W> void agent_step(orl_batch* b, int auto_reset) {
   bool spec = b->spec_agent_launch != nullptr;
   if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = false; }
   if (spec) {
-    b->spec_agent_launch(&VP, g.x, lds, b->stream, auto_reset);
+    b->spec_agent_launch(&VP, g.x, lds, b->stream, auto_reset, pol);
     ORL_TK(b, "k_agent");
     return;
   }
-#define PER_ENV(E_) hipLaunchKernelGGL((k_agent<E_, W>), g, blk, lds, b->stream, VP, auto_reset);
+#define PER_ENV(E_)                                                                                                 \
+  if (pol >= 0) hipLaunchKernelGGL((k_agent<E_, W, 0, true>), g, blk, lds, b->stream, VP, auto_reset, pol);         \
+  else hipLaunchKernelGGL((k_agent<E_, W, 0, false>), g, blk, lds, b->stream, VP, auto_reset, -1);
   ORL_FOR_ENV(b, PER_ENV)
 #undef PER_ENV
   ORL_TK(b, "k_agent");
@@ -1479,7 +1496,7 @@ template void persist<ORL_W>(orl_batch*, const DevParams&, hipStream_t, int, int
 template int persist_resident<ORL_W>(orl_batch*, int);
 template int persist_uses_lds<ORL_W>(orl_batch*);
 template void step2<ORL_W>(orl_batch*, int);
-template void agent_step<ORL_W>(orl_batch*, int);
+template void agent_step<ORL_W>(orl_batch*, int, int);
 template void persist_form<ORL_W>(const DevParams&, int*, int*);
 
 }  // namespace orl_launch

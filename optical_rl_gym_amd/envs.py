@@ -347,6 +347,20 @@ class BatchedOpticalEnv:
         self._ck(self.lib.orl_batch_step(self._h, _ptr(a), int(auto_reset), None, None, None, None))
         return None
 
+    def policy_step(self, policy, auto_reset=False, fetch=True, paths=None):
+        """policy(policy) and step() on its actions in one call (include/orl.h, orl_batch_policy_step): ONE launch where the
+        8-lanes-per-env step kernel serves the batch — the slot scan is its first phase.  Returns (actions, obs, reward, done,
+        info) like policy() / step(), or None with fetch=False (everything stays on the GPU; nothing is synchronised)."""
+        pid = POLICIES[policy] if isinstance(policy, str) else int(policy)
+        if paths is not None:
+            self.set_paths(paths)
+        if not fetch:
+            self._ck(self.lib.orl_batch_policy_step(self._h, pid, int(auto_reset), None, None, None, None, None))
+            return None
+        self._ck(self.lib.orl_batch_policy_step(self._h, pid, int(auto_reset), self._act.ctypes.data, _ptr(self._obs), self._reward.ctypes.data,
+                                                  self._done.ctypes.data, self._info.ctypes.data))
+        return self._act, self._obs, self._reward, self._done, self._info
+
     def step_sync_abi(self, actions, auto_reset=False):
         """The synchronous entry point `orl_batch_step` with every output, as a C caller would use it ([num_envs][4] int32 action
         rows; tests compare it with the two-halves path)."""

@@ -1587,3 +1587,53 @@ def test_row_caches_kept_between_launches_follow_every_change_of_the_slot_maps(w
     chk(0, "deferrals: slots", dev.slots_packed(), ora.slots_packed())
     chk(0, "deferrals: link stats", dev.link_stats_all(), ora.link_stats_all())
     dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,policy,n,agent", [
+    ("g2_rmsa_cfg2_sapff", "SAP_FF", 2304, None), ("g2_rmsa_cfg2_llpff", "LLP_FF", 96, "1"), ("g2_rmsa_cfg2_sapff", "SP_FF", 96, "0"),
+    ("g4_deeprmsa_j2_sap", "SAP", 2304, None), ("g4_deeprmsa_j2_sap", "SP", 64, "1"),
+    ("g5_rwa_testcfg_saplf", "SAP_LF", 96, "1"), ("g5_rwa_testcfg_llpff", "LLP_FF", 2304, None),
+    ("g6_rmcsa_7x320_sapff", "SAP_BM_FC_FF", 64, "1"), ("g7_rmsa_germany50_sapff", "SAP_FF", 64, "1")])
+def test_policy_and_step_in_one_launch_equals_policy_then_step(gname, policy, n, agent, monkeypatch):
+    """orl_batch_policy_step: the heuristic's slot scan as the first phase of the step kernel (k_agent<..., FUSED>; all four
+    families, every policy form) against policy() followed by step() on a twin batch — actions, reward, done, every info float,
+    the DeepRMSA observation per step, then counters, services and sampled slot maps; with ORL_AGENT_STEP=0 the entry point is
+    the two launches (k_policy, k_step) and must agree too."""
+    import optical_rl_gym_amd as orl
+
+    if agent is None:
+        monkeypatch.delenv("ORL_AGENT_STEP", raising=False)
+    else:
+        monkeypatch.setenv("ORL_AGENT_STEP", agent)
+    meta = load_golden(gname)["meta"]
+    kw = dict(meta["kwargs"])
+    kw.pop("seed")
+    kw["episode_length"] = 45
+    seeds = [700 + 3 * i for i in range(n)]
+    a = orl.make(meta["env"], topology=meta["topology"], num_envs=n, seeds=seeds, **kw)
+    b = orl.make(meta["env"], topology=meta["topology"], num_envs=n, seeds=seeds, **kw)
+    if agent != "0":
+        assert int(a.lib.orl_batch_debug_step_kernel(a._h)) == 2
+    chk = _exact(gname + " fused")
+    for t in range(160):
+        act_a, o_a, r_a, d_a, i_a = a.policy_step(policy, auto_reset=True)
+        act_b = b.policy(policy).copy()
+        o_b, r_b, d_b, i_b = b.step(None, auto_reset=True)
+        chk(t, "actions", act_a, act_b)
+        chk(t, "reward", r_a, r_b); chk(t, "done", d_a, d_b); chk(t, "info", i_a, i_b)
+        if o_b is not None:
+            chk(t, "obs", o_a, o_b)
+        if t == 80:  # nothing fetched: the calls only queue work
+            for _ in range(5):
+                a.policy_step(policy, auto_reset=True, fetch=False)
+                b.policy(policy, fetch=False)
+                b.step(None, auto_reset=True, fetch=False)
+    a.check(); b.check()
+    chk(0, "counters", a.counters(), b.counters())
+    chk(0, "services", a.services(), b.services())
+    for e in (0, n // 2, n - 1):
+        chk(e, "slots", a.slots(e), b.slots(e))
+        chk(e, "link_stats", a.link_stats(e), b.link_stats(e))
+        chk(e, "net_stats", a.net_stats(e), b.net_stats(e))
+    a.close(); b.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rate of the loop an agent on the same GPU drives (nothing crosses PCIe): policy(fetch=False) [stand-alone slot scan, in
-place of the agent's network] + step(None, auto_reset=True, fetch=False) for N steps, one sync at the end; and of the
-host-driven step() over PCIe.  usage: agent_loop_rate.py [workload] [batch]   (ORL_AGENT_STEP=0 -> the one-wavefront-per-env kernel)"""
+place of the agent's network] + step(None, auto_reset=True, fetch=False) for N steps, one sync at the end; the same with the
+scan fused into the step launch (policy_step); and of the host-driven step() over PCIe.  usage: agent_loop_rate.py [workload] [batch]   (ORL_AGENT_STEP=0 -> the one-wavefront-per-env kernel)"""
 import json
 import math
 import os
@@ -20,12 +20,15 @@ fam, topo, kw, policy = WORKLOADS[name]
 env = orl.make(fam, topology=topo, num_envs=B, seeds=[10 + i for i in range(B)], **kw)
 env.run(policy, max(1500, int(math.ceil(5 * workload_load(kw)))))
 out = dict(workload=name, batch=B, agent_step=os.environ.get("ORL_AGENT_STEP", "default"))
-for label, with_policy in (("step_only", False), ("policy_and_step", True)):
+for label, with_policy in (("step_only", 0), ("policy_and_step", 1), ("policy_step_fused", 2)):
     env.policy(policy, fetch=False)
     env.sync()
     n = 200
     t0 = time.perf_counter()
     for _ in range(n):
+        if with_policy == 2:  # orl_batch_policy_step: the scan as the step kernel's first phase, one launch
+            env.policy_step(policy, auto_reset=True, fetch=False)
+            continue
         if with_policy:
             env.policy(policy, fetch=False)
         env.step(None, auto_reset=True, fetch=False)
