@@ -151,7 +151,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=0, help="extra untimed steps on top of the mandatory state preparation")
-    ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="envs per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: every rank owns --batch envs (the default; BASELINE cfg5 = --gpus 8 --workload cfg5 --batch 32768); "
+                         "strong: --batch envs in total, cut into contiguous blocks of env indices over the ranks "
+                         "(optical_rl_gym_amd.sharding.shard_range) — the headline batch of 65 536 at 1/2/4/8 GPUs")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--min-timed-s", type=float, default=5.0, help="repeat the timed block until this much has been timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,8 +211,16 @@ def main():
     from optical_rl_gym_amd import _build
 
     fam, topo, kw, policy = WORKLOADS[args.workload]
-    B = args.batch
-    seeds = [10 + rank * B + i for i in range(B)]  # seed_i = 10 + global env index
+    from optical_rl_gym_amd.sharding import shard_range
+
+    if args.scaling == "strong":  # the batch is the job's: rank r owns env indices [lo, hi)
+        lo, hi = shard_range(args.batch, rank, world)
+        if hi - lo < 8:
+            raise SystemExit("bench: --scaling strong leaves rank %d with %d envs" % (rank, hi - lo))
+    else:
+        lo, hi = rank * args.batch, (rank + 1) * args.batch
+    B = hi - lo
+    seeds = [10 + i for i in range(lo, hi)]  # seed_i = 10 + global env index
     env = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, device_id=dev_index, **kw)
 
     def device_sync():
@@ -252,7 +264,7 @@ def main():
         timed += elapsed
         if len(blocks) >= 20000:
             break
-    per_rank = [dict(rank=rank, device=dev_index, env_steps_per_s=round(B * args.steps / statistics.median(own), 1))]
+    per_rank = [dict(rank=rank, device=dev_index, envs=B, env_steps_per_s=round(B * args.steps / statistics.median(own), 1))]
     if dist is not None:
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
@@ -317,27 +329,23 @@ def main():
                 rate = rps / (elapsed / args.steps)
                 req_roof = dict(bound="dram_requests", requests_per_step=int(rps), peak=RANDOM_ACCESS_PEAK, unit="requests/s",
                                 achieved=round(rate, 1), frac=round(rate / RANDOM_ACCESS_PEAK, 4))
-    # SURVEY 8(d) "report both": beside the 8 TB/s spec peak, what a plain device copy achieves on THIS GPU, measured now
-    # (read + write bytes of a 1 GiB copy, HIP events, best of 10)
-    peak_meas = None
+    # SURVEY 8(d) "report both": beside the 8 TB/s spec peak, what this GPU's HBM delivers to the library's own plain streaming
+    # kernels, measured now (orl_debug_stream_peak: 1 GiB, 16 bytes per lane, HIP events, best of 10): a read — the kernel the
+    # counter calibration uses — and a copy (read + write bytes).  `peak_measured` is the higher of the two.
+    peak_meas = peak_read = peak_copy = None
     try:
-        src_t = torch.empty(1 << 28, dtype=torch.float32, device="cuda:%d" % dev_index).fill_(1.0)
-        dst_t = torch.empty_like(src_t)
-        best = None
-        for _ in range(12):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            dst_t.copy_(src_t)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1)
-            best = ms if best is None or ms < best else best
-        peak_meas = 2.0 * src_t.numel() * 4 / (best * 1e-3) / 1e9
-        del src_t, dst_t
+        import ctypes as C_
+
+        rd, cp = C_.c_double(), C_.c_double()
+        if env.lib.orl_debug_stream_peak(dev_index, 1 << 30, 10, C_.byref(rd), C_.byref(cp)) == 0 and rd.value > 0:
+            peak_read, peak_copy = rd.value, cp.value
+            peak_meas = max(peak_read, peak_copy)
     except Exception:  # (a GPU too full for the two buffers: the spec peak alone)
         peak_meas = None
     roofline = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
                     peak_measured=None if peak_meas is None else round(peak_meas, 1),
+                    peak_measured_read=None if peak_read is None else round(peak_read, 1),
+                    peak_measured_copy=None if peak_copy is None else round(peak_copy, 1),
                     frac_of_measured=None if peak_meas is None else round(ach / peak_meas, 5),
                     traffic=traffic, achieved_traffic_gbs=None if traffic_gbs is None else round(traffic_gbs, 2),
                     traffic_frac=None if traffic_gbs is None else round(traffic_gbs / HBM_PEAK_GBS, 5),
@@ -431,9 +439,10 @@ def main():
                                                  "k_agent per step, info / reward / done written in place" % n_loop)
 
     if rank == 0:
-        total_steps = B * world * args.steps
+        total_envs = sum(p["envs"] for p in per_rank)
+        total_steps = total_envs * args.steps
         out = {
-            "metric": "env-steps/sec RMSA-v0 NSFNET batch 65536" if args.workload == "cfg2" and B == 65536
+            "metric": "env-steps/sec RMSA-v0 NSFNET batch 65536" if args.workload == "cfg2" and args.batch == 65536
                       else "env-steps/sec %s" % args.workload,
             "value": round(total_steps / elapsed, 1),
             "unit": "env-steps/s",
@@ -444,13 +453,15 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "timed_region_s": round(timed, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64 bitmaps + f64 statistics",
             "data": "synthetic",
-            "config": {"workload": "%s: %s-v0 %s, %d slots, k=%d, batch %d envs/GPU, on-device %s policy, seeds 10+i"
-                                   % (args.workload, fam, topo, env.num_spectrum_resources, env.k_paths, B, policy),
-                       "envs_per_gpu": B,
+            "config": {"workload": "%s: %s-v0 %s, %d slots, k=%d, batch %s, on-device %s policy, seeds 10+i"
+                                   % (args.workload, fam, topo, env.num_spectrum_resources, env.k_paths,
+                                      "%d envs/GPU" % B if args.scaling == "weak" else "%d envs over %d GPU(s)" % (total_envs, len(per_rank)), policy),
+                       "envs_per_gpu": B if args.scaling == "weak" else [p["envs"] for p in per_rank],
+                       "envs_total": total_envs,
                        "step_kernels": ["%s (%d launches per %d-step block)" % (kernel, launches, args.steps)]},
             "timing": {"blocks": len(blocks), "timed_region_s": round(timed, 4), "block_s_median": round(elapsed, 6),
                        "block_s_min": round(walls[0], 6), "block_s_max": round(walls[-1], 6),

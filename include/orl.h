@@ -320,6 +320,10 @@ int orl_batch_set_state(orl_batch* b, const void* in);
 /* Profiling aid: reads the whole slot-map array once with 8-B (width16 = 0) or 16-B (1) loads per lane and returns the
  * number of bytes read, so that rocprofv3's FETCH_SIZE can be calibrated on a known byte count. */
 int64_t orl_batch_debug_stream_read(orl_batch* b, int width16);
+/* Measurement aid (bench.py, roofline.peak_measured): what the HBM of GPU `device` delivers to plain streaming kernels of this
+ * library, measured now with HIP events, best of `reps` launches over `bytes` bytes (>= 1 MiB): *read_gbs — 16 bytes per lane,
+ * read only (the kernel of orl_batch_debug_stream_read); *copy_gbs — 16 bytes per lane, copied (read + write bytes counted). */
+int orl_debug_stream_peak(int device, int64_t bytes, int reps, double* read_gbs, double* copy_gbs);
 /* Specialisation: the persistent kernel with ONE configuration's sizes (topology, spectrum, traffic model, kernel form) as
  * compile-time constants — same source, same results, 5-12 % faster.  It is a small shared library of its own, built on first
  * use from csrc/orl_kernels.hip with the -D flags orl_batch_spec_flags() writes (hipcc --offload-arch=gfx950 -O3 -std=c++17

@@ -72,6 +72,7 @@ EXPORTS = {
     "orl_batch_get_active": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_flags": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_debug_stream_read": (C.c_int64, [C.c_void_p, C.c_int]),
+    "orl_debug_stream_peak": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "orl_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "orl_host_free": (C.c_int, [C.c_void_p]),
     "orl_batch_device_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),

@@ -172,6 +172,11 @@ __global__ void k_calib_read(const u64* __restrict__ src, i64 n_words, int width
   if (acc == 0x123456789abcdefull) *sink = acc;  // keep the loads alive
 }
 
+// 16-byte-per-lane copy (the read + write companion of k_calib_read for orl_debug_stream_peak)
+__global__ void k_calib_copy(const ulonglong2* __restrict__ src, ulonglong2* __restrict__ dst, i64 n16) {
+  for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n16; j += (i64)gridDim.x * blockDim.x) dst[j] = src[j];
+}
+
 // observation array -> float32 (orl_batch_get_obs_f32)
 __global__ void k_cast_f32(const double* __restrict__ src, float* __restrict__ dst, i64 n) {
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = (float)src[i];
@@ -646,7 +651,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) b->n_cu = prop.multiProcessorCount;
   }
-  HIPCHK_B(hipHostMalloc((void**)&b->h_tail, 32 * sizeof(unsigned int), hipHostMallocDefault));
+  HIPCHK_B(hipHostMalloc((void**)&b->h_tail, 32 * sizeof(unsigned int), hipHostMallocPortable));
   HIPCHK_B(hipEventCreate(&b->ev0));
   HIPCHK_B(hipEventCreate(&b->ev1));
   // everything below is ordered on the batch's own stream
@@ -771,6 +776,8 @@ extern "C" int orl_batch_reseed(orl_batch* b, const int64_t* seeds, const uint8_
   HIPCHK(hipMalloc((void**)&raw, B * 625 * sizeof(u32)));
   if (hipMalloc((void**)&dseeds, B * sizeof(long long)) != hipSuccess) { hipFree(raw); return fail(ORL_E_HIP, "hipMalloc failed"); }
   hipError_t e = hipMemcpyAsync(dseeds, seeds, B * sizeof(long long), hipMemcpyHostToDevice, b->stream);
+  // (services parked by an abandoned run were drawn from the stream that is being replaced; between completed runs none are)
+  if (e == hipSuccess && b->P.svc_cnt) e = hipMemsetAsync(b->P.svc_cnt, 0, ((B + 7) / 8) * 64 * sizeof(int), b->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_seed_mt, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, b->stream, dseeds, (i64)B, raw);
     hipLaunchKernelGGL(k_init_mt, dim3((unsigned)B), dim3(64), 624 * 4, b->stream, b->P, raw, (const unsigned char*)m.d, 1);
@@ -980,7 +987,7 @@ extern "C" int orl_batch_step_async(orl_batch* b, const void* actions, int actio
   if (actions) {
     if (action_width < 1 || action_width > 4 || (action_elem_bytes != 4 && action_elem_bytes != 8))
       return fail(ORL_E_INVALID, "actions: 1..4 columns of int32 or int64");
-    if (!b->h_actions) HIPCHK(hipHostMalloc((void**)&b->h_actions, B * 4 * sizeof(int32_t), hipHostMallocDefault));
+    if (!b->h_actions) HIPCHK(hipHostMalloc((void**)&b->h_actions, B * 4 * sizeof(int32_t), hipHostMallocPortable));
     const int64_t bad = action_elem_bytes == 4 ? stage_actions(b, (const int32_t*)actions, action_width, b->h_actions)
                                                : stage_actions(b, (const int64_t*)actions, action_width, b->h_actions);
     if (bad >= 0) {
@@ -1060,9 +1067,11 @@ extern "C" int orl_batch_check(orl_batch* b) try {
 }
 ORL_ABI_CATCH_INT
 
+// (hipHostMallocPortable: page-locked for EVERY device of the process, whichever is current — a MultiDeviceBatch hands slices of
+// one such array to the shards of several GPUs, each of which copies into its slice on its own stream)
 extern "C" int orl_host_alloc(size_t bytes, void** out) try {
   if (!out || bytes == 0) return fail(ORL_E_INVALID, "bad argument");
-  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocPortable));
   memset(*out, 0, bytes);
   return ORL_OK;
 }
@@ -1191,6 +1200,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
       b->run_base = 0;
     }
     b->wg_dirty = true;  // until this run has completed
+    b->run_abandoned = true;
     const int64_t base = b->run_base;
     // (launches of 128 steps: every launch boundary costs a wavefront its window fill / write-back and a cold first step —
     // cfg2 1.265e9 with 64-step launches, 1.295e9 with 128; with the bit-word sink a wavefront practically never has to
@@ -1257,6 +1267,7 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     have_flags = n_steps > 0;
     b->run_base = base + n_steps;  // every workgroup stands here now
     b->wg_dirty = false;
+    b->run_abandoned = false;
   } else if (time_kernels == 2) {
     for (int64_t s = 0; s < n_steps; s++) {
       HIPCHK(hipEventRecord(pool.ev[3 * s], b->stream));
@@ -1524,6 +1535,54 @@ extern "C" int64_t orl_batch_debug_stream_read(orl_batch* b, int width16) try {
 }
 ORL_ABI_CATCH_INT
 
+/* debug: what this GPU's HBM delivers to the library's own plain streaming kernels, measured now (HIP events, best of `reps`):
+ * a 16-byte-per-lane read of `bytes` bytes (k_calib_read, the kernel the counter calibration uses) and a 16-byte-per-lane copy of
+ * them (read + write bytes counted).  bench.py reports both beside the 8 TB/s spec peak (roofline.peak_measured). */
+extern "C" int orl_debug_stream_peak(int device, int64_t bytes, int reps, double* read_gbs, double* copy_gbs) try {
+  if (bytes < (1 << 20) || reps < 1 || !read_gbs || !copy_gbs) return fail(ORL_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(device));
+  const i64 n16 = bytes / 16;
+  void *a = nullptr, *c = nullptr;
+  u64* sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st = nullptr;
+  int rc = ORL_OK;
+  double best_r = 0.0, best_c = 0.0;
+  if (hipMalloc(&a, (size_t)n16 * 16) != hipSuccess || hipMalloc(&c, (size_t)n16 * 16) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess ||
+      hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipStreamCreate(&st) != hipSuccess) {
+    rc = fail(ORL_E_HIP, "orl_debug_stream_peak: allocation failed");
+  } else {
+    hipMemsetAsync(a, 1, (size_t)n16 * 16, st);
+    hipMemsetAsync(c, 2, (size_t)n16 * 16, st);
+    for (int r = 0; r < reps + 2 && rc == ORL_OK; r++) {  // (two untimed launches of each first)
+      float ms_r = 0.f, ms_c = 0.f;
+      hipEventRecord(e0, st);
+      hipLaunchKernelGGL(k_calib_read, dim3(4096), dim3(256), 0, st, (const u64*)a, n16 * 2, 1, sink);
+      hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms_r, e0, e1) != hipSuccess) { rc = fail(ORL_E_HIP, "stream read failed"); break; }
+      hipEventRecord(e0, st);
+      hipLaunchKernelGGL(k_calib_copy, dim3(4096), dim3(256), 0, st, (const ulonglong2*)a, (ulonglong2*)c, n16);
+      hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms_c, e0, e1) != hipSuccess) { rc = fail(ORL_E_HIP, "stream copy failed"); break; }
+      if (r >= 2) {
+        const double gr = (double)n16 * 16.0 / (ms_r * 1e-3) / 1e9, gc = 2.0 * (double)n16 * 16.0 / (ms_c * 1e-3) / 1e9;
+        best_r = gr > best_r ? gr : best_r;
+        best_c = gc > best_c ? gc : best_c;
+      }
+    }
+  }
+  if (st) hipStreamDestroy(st);
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  if (a) hipFree(a);
+  if (c) hipFree(c);
+  if (sink) hipFree(sink);
+  *read_gbs = best_r;
+  *copy_gbs = best_c;
+  return rc;
+}
+ORL_ABI_CATCH_INT
+
 extern "C" int orl_batch_matrix_obs_dim(const orl_batch* b) { return b ? 2 * b->P.N + b->P.C * b->P.E * b->P.S : 0; }
 
 extern "C" int orl_batch_matrix_observation(orl_batch* b, uint8_t* out) try {
@@ -1714,6 +1773,10 @@ extern "C" int orl_batch_get_state(orl_batch* b, void* out) try {
   if (!b || !out) return fail(ORL_E_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
+  // (a device-resident run that did not complete — a HIP error mid-launch — may have left services drawn ahead and envs at
+  // different step counts: not a state a snapshot can resume from exactly)
+  if (b->run_abandoned)
+    return fail(ORL_E_INVALID, "the last device-resident run did not complete: reset or restore the batch before taking a snapshot");
   unsigned char* o = (unsigned char*)out;
   for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(o, s.ptr, s.bytes, hipMemcpyDeviceToHost)); o += s.bytes; }
   return ORL_OK;
@@ -1725,6 +1788,10 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) try {
   HIPCHK(hipStreamSynchronize(b->stream));
   const unsigned char* o = (const unsigned char*)in;
   for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(s.ptr, o, s.bytes, hipMemcpyHostToDevice)); o += s.bytes; }
+  // services the persistent kernel drew ahead and parked when a run was abandoned mid-launch (a HIP error) belong to the
+  // generator state that has just been replaced: a snapshot is always taken between runs, where nothing is parked
+  if (b->P.svc_cnt) HIPCHK(hipMemset(b->P.svc_cnt, 0, (size_t)((b->P.B + 7) / 8) * 64 * sizeof(int)));
+  b->run_abandoned = false;  // (the step counters of an abandoned run are cleared by the next run: wg_dirty stays set)
   slot_maps_change(b);
   if (b->P.obs_dim) launch_obs(b, 0);
   HIPCHK(hipStreamSynchronize(b->stream));

@@ -56,6 +56,7 @@ struct orl_batch {
   int* d_wg_step = nullptr;        // [ceil(B/8)] steps each workgroup of the persistent kernel has completed since run_base was 0
   int64_t run_base = 0;            // ... all of them, between runs (no per-run clearing of d_wg_step)
   bool wg_dirty = true;            // a run did not complete (or none has run yet): clear d_wg_step and run_base first
+  bool run_abandoned = false;      // a device-resident run returned early (HIP error): services may be parked, envs at different steps
   int un_slot[2] = {0, 0};         // per half of the batch: the slot of d_unfinished its next launch counts into
   // per half p and slot s, at 8 p + 4 s: [0] straggler workgroups of a persistent launch, [1] OR of the env flag words
   // (k_finish2); a launch counts into one slot and clears the other for the launch after it (no memset between launches);

@@ -1368,7 +1368,11 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   dim3 gc((unsigned)((VP.B + 7) / 8)), blk(64);
   bool use_spec = b->spec_launch != nullptr;
   if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) use_spec = false; }
-  const PersistChoice ch = persist_choose(VP, use_spec);
+  // the form is chosen for the WHOLE batch (its wavefront count decides between the 3- and the 4-wave form, and a specialisation
+  // library is built for that choice): a run in two halves launches the same kernel on both views
+  DevParams VC = VP;
+  VC.B = b->P.B;
+  const PersistChoice ch = persist_choose(VC, use_spec);
   const int v = ch.form;
   VP.persist_ic = ch.inner;
   VP.row_cache_key = VP.row_cache ? ((b->cache_epoch << 8) | (v << 4) | ch.inner) : 0;

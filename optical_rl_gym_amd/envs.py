@@ -237,8 +237,10 @@ class BatchedOpticalEnv:
         if os.environ.get("ORL_SPEC_EXTRA"):  # A/B experiments on the specialised kernels only: extra compiler flags (part of the cache key)
             flags += " " + os.environ["ORL_SPEC_EXTRA"]
         path = _build.spec_path(flags)
+        from_cache = True
         if os.environ.get("ORL_SPEC_LIB"):  # A/B: a specialisation library built elsewhere (e.g. from another commit's device code)
             path = os.environ["ORL_SPEC_LIB"]
+            from_cache = False  # (the user's file: never deleted, whatever the library says about it)
         if not os.path.exists(path):
             if not (mode == "1" or self.num_envs >= self.JIT_MIN_ENVS):
                 return False
@@ -256,10 +258,13 @@ class BatchedOpticalEnv:
 
             warnings.warn("optical_rl_gym_amd: specialisation %s not attached (%s); the generic persistent kernel runs"
                           % (os.path.basename(path), exc))
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+            # a cache entry that cannot be opened or is not a specialisation library is dropped (it would fail again every time);
+            # one that is merely for another configuration or layout stays, and so does anything the user named
+            if from_cache and any(t in str(exc) for t in ("dlopen", "not a specialisation", "other sources")):
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
             return False
         return True
 
@@ -360,6 +365,37 @@ class BatchedOpticalEnv:
         self._ck(self.lib.orl_batch_policy_step(self._h, pid, int(auto_reset), self._act.ctypes.data, _ptr(self._obs), self._reward.ctypes.data,
                                                   self._done.ctypes.data, self._info.ctypes.data))
         return self._act, self._obs, self._reward, self._done, self._info
+
+    def action_bounds(self):
+        """Exclusive upper bound per action column (None: any integer) — the index ranges of the reference's actions_output
+        arrays that orl_batch_step checks before it modifies anything (rmsa_env.py:126-137, 167; rwa_env.py:52-58, 103;
+        rmcsa_env.py:145-153, 219; qos_constrained_ra.py:101; DeepRMSA decodes any integer, deeprmsa_env.py:48-58)."""
+        K, S, rej = self.k_paths, self.num_spectrum_resources, 1 if self.allow_rejection else 0
+        t = self.ENV_TYPE
+        if t == 0:
+            return (K + 1, S + 1)
+        if t == 2:
+            return (K + rej, S + rej)
+        if t == 3:
+            return (K + 1, len(self.modulation_formats) + 1, self.num_spatial_resources + 1, S + 1)
+        if t == 4:
+            return (K + rej,)
+        return (None,)
+
+    def validate_actions(self, actions):
+        """Raises the IndexError step() would, without touching the batch (a MultiDeviceBatch checks every shard's slice before it
+        queues a step on any of them)."""
+        if actions is None:
+            return
+        a = np.asarray(actions)
+        if a.ndim == 1:
+            a = a[:, None]
+        for c, hi in enumerate(self.action_bounds()[: a.shape[1]]):
+            if hi is None:
+                continue
+            bad = np.flatnonzero((a[:, c] < 0) | (a[:, c] >= hi))
+            if len(bad):
+                raise IndexError("action %s of env %d is outside the action space" % (tuple(int(v) for v in a[bad[0]]), int(bad[0])))
 
     def step_sync_abi(self, actions, auto_reset=False):
         """The synchronous entry point `orl_batch_step` with every output, as a C caller would use it ([num_envs][4] int32 action

@@ -119,6 +119,10 @@ class MultiDeviceBatch:
         the HIP batches — and emulated for others (the oracle stand-in of the CPU tests)."""
         import inspect
 
+        for r, sh in enumerate(self.shards):  # (refused before anything is modified on any shard, like a single batch's step)
+            if hasattr(sh, "validate_actions"):
+                sh.validate_actions(self._cut(actions, r))
+
         def one(r):
             sh = self.shards[r]
             params = inspect.signature(sh.step).parameters
@@ -141,23 +145,50 @@ class MultiDeviceBatch:
         obs = obs_out if (obs_out is not None and getattr(self, "obs_dim", 0)) else self._cat([o[0] for o in out])
         return obs, self._cat([o[1] for o in out]), self._cat([o[2] for o in out]), (self._info if fetch_info else None)
 
+    def policy_step(self, policy, auto_reset=False, fetch=True, paths=None):
+        """policy() and step() on its actions in one launch per shard (BatchedOpticalEnv.policy_step)."""
+        out = self._map(lambda r: self.shards[r].policy_step(policy, auto_reset=auto_reset, fetch=fetch, paths=self._cut(paths, r)))
+        if not fetch:
+            return None
+        return tuple(self._cat([o[k] for o in out]) for k in range(5))
+
     def step_async(self, actions, auto_reset=False, obs_out=None, fetch_info=True):
         """First half of step() on every shard (`BatchedOpticalEnv.step_async`): each device gets its slice of the actions and its
         step queued on its own stream, one shard after the other from this thread — the calls only queue work, so all devices run
         at once without host threads — and `step_wait()` collects them.  Shards without the two halves (the oracle stand-in of the
         CPU tests) step synchronously here."""
+        # every shard's slice is checked BEFORE a step is queued on any of them: an action outside the action space is refused
+        # with nothing modified anywhere (include/orl.h), not with shards 0..r-1 stepped and their steps left pending
+        for r, sh in enumerate(self.shards):
+            if hasattr(sh, "validate_actions"):
+                try:
+                    sh.validate_actions(self._cut(actions, r))
+                except IndexError as exc:
+                    raise IndexError("shard %d (envs %d..%d): %s" % (r, self.bounds[r], self.bounds[r + 1] - 1, exc)) from None
         self._async_obs = obs_out
         self._async_sync = {}
-        for r, sh in enumerate(self.shards):
-            a = self._cut(actions, r)
-            oo = None if obs_out is None else obs_out[self.bounds[r]:self.bounds[r + 1]]
-            if hasattr(sh, "step_async"):
-                sh.step_async(a, auto_reset=auto_reset, obs_out=oo, fetch_info=fetch_info)
-            else:
-                out = sh.step(a, auto_reset=auto_reset)
-                if oo is not None and out[0] is not None:
-                    oo[:] = out[0]
-                self._async_sync[r] = out
+        queued = []
+        try:
+            for r, sh in enumerate(self.shards):
+                a = self._cut(actions, r)
+                oo = None if obs_out is None else obs_out[self.bounds[r]:self.bounds[r + 1]]
+                if hasattr(sh, "step_async"):
+                    sh.step_async(a, auto_reset=auto_reset, obs_out=oo, fetch_info=fetch_info)
+                    queued.append(sh)
+                else:
+                    out = sh.step(a, auto_reset=auto_reset)
+                    if oo is not None and out[0] is not None:
+                        oo[:] = out[0]
+                    self._async_sync[r] = out
+        except Exception:
+            # (a device error on one shard: the steps already queued are collected, so that no shard is left with a pending step;
+            # the batch is no longer consistent — the earlier shards are one step ahead — and the error says so)
+            for sh in queued:
+                try:
+                    sh.step_wait()
+                except Exception:
+                    pass
+            raise
 
     def step_wait(self):
         out = [self._async_sync[r] if r in self._async_sync else sh.step_wait() for r, sh in enumerate(self.shards)]

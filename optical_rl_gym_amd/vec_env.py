@@ -54,12 +54,195 @@ def make_spaces(batch, obs_dtype=np.float64, mod=None):
     return obs, act
 
 
-# Shared by every env without episode information in a step: a READ-ONLY empty mapping (get / in / copy work like a dict's; a
-# wrapper or callback that tries to write a key into it gets a TypeError instead of leaking the key into all 65 536 envs).
-# An env that reports done gets a dict of its own.
-import types as _types
+# Shared by every env without episode information in a step: an empty dict that REFUSES writes (a wrapper or callback that tries
+# to put a key into it gets a TypeError instead of leaking the key into all 65 536 envs) and that copies / pickles as a plain
+# empty dict — copy.deepcopy(infos) and pickle, which callbacks that snapshot their locals and HerReplayBuffer do, work as on
+# the infos of SB3's own VecEnvs.  An env that reports done gets a mapping of its own.
+class _NoInfo(dict):
+    __slots__ = ()
 
-_NO_INFO = _types.MappingProxyType({})
+    def _ro(self, *a, **k):
+        raise TypeError("the info of an env without episode information is shared and read-only")
+
+    __setitem__ = __delitem__ = update = setdefault = pop = popitem = clear = __ior__ = _ro
+
+    def copy(self):
+        return {}
+
+    def __copy__(self):
+        return {}
+
+    def __deepcopy__(self, memo):
+        return {}
+
+    def __reduce__(self):
+        return (dict, ())
+
+
+_NO_INFO = _NoInfo()
+
+
+class _FinishedStep:
+    """What the envs that finished an episode in one step hand to SB3, kept as arrays: returns, lengths, info keywords, the
+    terminal observations — one device gather and a handful of numpy calls per step whatever their number."""
+    __slots__ = ("rets", "lens", "t", "keys", "cols", "term")
+
+    def __init__(self, rets, lens, t, keys, cols, term):
+        self.rets, self.lens, self.t, self.keys, self.cols, self.term = rets, lens, t, keys, cols, term
+
+    def row(self, n):
+        row = {"r": self.rets[n], "l": self.lens[n], "t": self.t}
+        for k, col in zip(self.keys, self.cols):
+            row[k] = col[n]
+        return row
+
+
+class _EpisodeInfo(dict):
+    """The info dict of an env that finished an episode — {"episode": {r, l, t, **info_keywords}, "terminal_observation": row} —
+    built when it is first looked at: SB3 reads `episode` of every finished env once (Monitor statistics) and
+    `terminal_observation` only when it bootstraps a truncated episode; 1 300 envs finish per step at cfg3's steady state and
+    building every dict up front cost 2 ms of Python per step.  Holds its step's arrays, so it stays valid for as long as it
+    is held."""
+    __slots__ = ("_src", "_n")
+
+    def __init__(self, src, n):
+        dict.__init__(self)
+        self._src, self._n = src, n
+
+    def _fill(self):
+        src = self._src
+        if src is not None:
+            self._src = None
+            n = self._n
+            dict.__setitem__(self, "episode", src.row(n))
+            dict.__setitem__(self, "terminal_observation", None if src.term is None else src.term[n])
+        return self
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self._fill(), k)
+
+    def get(self, k, default=None):
+        return dict.get(self._fill(), k, default)
+
+    def __contains__(self, k):
+        return dict.__contains__(self._fill(), k)
+
+    def __iter__(self):
+        return dict.__iter__(self._fill())
+
+    def __len__(self):
+        return dict.__len__(self._fill())
+
+    def keys(self):
+        return dict.keys(self._fill())
+
+    def items(self):
+        return dict.items(self._fill())
+
+    def values(self):
+        return dict.values(self._fill())
+
+    def __setitem__(self, k, v):
+        dict.__setitem__(self._fill(), k, v)
+
+    def __repr__(self):
+        return dict.__repr__(self._fill())
+
+    def __eq__(self, other):
+        return dict.__eq__(self._fill(), other)
+
+    __hash__ = None
+
+    def copy(self):
+        return dict(self._fill())
+
+    def __copy__(self):
+        return dict(self._fill())
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        return copy.deepcopy(dict(self._fill()), memo)
+
+    def __reduce__(self):
+        return (dict, (dict(self._fill()),))
+
+
+class EpisodeLog:
+    """Monitor-style rows (r, l, t, **info_keywords) of every finished episode, kept as numpy blocks appended once per step; reads
+    like a list of dicts (len, iteration, indexing, truth value).  Bounded: beyond `max_rows` the oldest blocks are dropped —
+    or appended to `spill_path` (a Monitor CSV, see OpticalVecEnv.save_monitor_csv) when one is set — so that a 10^9-step run
+    keeps a flat memory footprint (cfg3's steady state finishes 1 300 episodes per step)."""
+
+    def __init__(self, keys, max_rows=1 << 20, spill_path=None):
+        self.keys = tuple(keys)
+        self.max_rows = int(max_rows)
+        self.spill_path = spill_path
+        self._blocks = []  # [k, 3 + len(keys)] float64
+        self._n = 0
+        self.total = 0     # episodes ever logged (dropped or spilled ones included)
+        self._spill_header = False
+
+    def append_block(self, rets, lens, t, cols):
+        k = len(rets)
+        if not k:
+            return
+        blk = np.empty((k, 3 + len(self.keys)))
+        blk[:, 0] = rets
+        blk[:, 1] = lens
+        blk[:, 2] = t
+        for j, c in enumerate(cols):
+            blk[:, 3 + j] = c
+        self._blocks.append(blk)
+        self._n += k
+        self.total += k
+        while self._n > self.max_rows and len(self._blocks) > 1:
+            old = self._blocks.pop(0)
+            self._n -= len(old)
+            if self.spill_path:
+                self._spill(old)
+
+    def _spill(self, blk):
+        with open(self.spill_path, "a") as f:
+            for r in blk:
+                f.write(self._csv_row(r) + "\n")
+
+    def _csv_row(self, r):
+        return ",".join([str(float(r[0])), str(int(r[1])), str(float(r[2]))] + [str(float(x)) for x in r[3:]])
+
+    def _row(self, r):
+        d = {"r": float(r[0]), "l": int(r[1]), "t": float(r[2])}
+        for k, x in zip(self.keys, r[3:]):
+            d[k] = float(x)
+        return d
+
+    def __len__(self):
+        return self._n
+
+    def __bool__(self):
+        return self._n > 0
+
+    def __iter__(self):
+        for blk in list(self._blocks):
+            for r in blk:
+                yield self._row(r)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return list(self)[i]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        for blk in self._blocks:
+            if i < len(blk):
+                return self._row(blk[i])
+            i -= len(blk)
+        raise IndexError(i)
+
+    def array(self):
+        """Every kept row as one [n, 3 + len(keys)] float64 array (columns r, l, t, then the info keywords)."""
+        return np.concatenate(self._blocks) if self._blocks else np.empty((0, 3 + len(self.keys)))
 
 
 class OpticalVecEnv:
@@ -67,9 +250,10 @@ class OpticalVecEnv:
     render_mode = None
 
     def __init__(self, batch, info_keywords=("episode_service_blocking_rate", "episode_bit_rate_blocking_rate"),
-                 obs_dtype=np.float64, observation="default"):
+                 obs_dtype=np.float64, observation="default", max_logged_episodes=1 << 20, monitor_spill_path=None):
         """observation: "default" (DeepRMSA: its 1-D vector; other families: None, as their Dict observation holds live
-        objects) or "matrix" (SimpleMatrixObservation built on the device: uint8 [2N + C*E*S])."""
+        objects) or "matrix" (SimpleMatrixObservation built on the device: uint8 [2N + C*E*S]).
+        max_logged_episodes / monitor_spill_path: the bound of `episode_log` and where rows beyond it go (EpisodeLog)."""
         self.batch = batch
         self.num_envs = batch.num_envs
         self.obs_dtype = np.dtype(obs_dtype)
@@ -95,7 +279,7 @@ class OpticalVecEnv:
         self._ep_ret = np.zeros(self.num_envs)
         self._ep_len = np.zeros(self.num_envs, np.int64)
         self._t0 = time.time()
-        self.episode_log = []  # Monitor-style rows: dict(r, l, t, **info_keywords)
+        self.episode_log = EpisodeLog(self.info_keywords, max_logged_episodes, monitor_spill_path)  # Monitor-style rows
 
     # ---- VecEnv API ----
     def reset(self):
@@ -157,23 +341,19 @@ class OpticalVecEnv:
             infos = self._infos = [_NO_INFO] * self.num_envs
         for i in self._infos_set:
             infos[i] = _NO_INFO
-        self._infos_set = finished.tolist()
-        if len(finished):
-            # (with 50-step episodes 1 300 of 65 536 envs finish per step: everything per env is taken out of numpy in bulk first —
-            # scalar by scalar the conversions cost more than the device's step)
-            idx = finished.tolist()
-            rets, lens = self._ep_ret[finished].tolist(), self._ep_len[finished].tolist()
-            cols = [(rows[:, j] if info is None else info[finished, j]).tolist() for j in self._kw_idx]
+        idx = self._infos_set = finished.tolist()
+        if idx:
+            # (with 50-step episodes 1 300 of 65 536 envs finish per step: everything per env stays in numpy — one gather per
+            # quantity — and each finished env gets a small mapping that builds its dict when SB3 looks at it)
+            rets, lens = self._ep_ret[finished], self._ep_len[finished]
+            cols = [np.array(rows[:, j] if info is None else info[finished, j]) for j in self._kw_idx]
             # the in-kernel reset is soft: the pending service (hence the observation) is unchanged by it
             term = None if obs is None else np.array(obs[finished])  # one copy; each env gets its row of it
             t_now = round(time.time() - self._t0, 6)
-            log = self.episode_log
+            src = _FinishedStep(rets.tolist(), lens.tolist(), t_now, self.info_keywords, [c.tolist() for c in cols], term)
             for n_, i in enumerate(idx):
-                row = {"r": rets[n_], "l": lens[n_], "t": t_now}
-                for k, col in zip(self.info_keywords, cols):
-                    row[k] = col[n_]
-                infos[i] = {"episode": row, "terminal_observation": None if term is None else term[n_]}
-                log.append(row)
+                infos[i] = _EpisodeInfo(src, n_)
+            self.episode_log.append_block(rets, lens, t_now, cols)
             self._ep_ret[finished] = 0
             self._ep_len[finished] = 0
         return obs, np.array(reward), np.array(done, dtype=bool), infos
@@ -279,6 +459,7 @@ class OpticalVecEnv:
             f.write(",".join(cols) + "\n")
             for row in self.episode_log:
                 f.write(",".join(str(row[c]) for c in cols) + "\n")
+        # (rows beyond the log's bound went to monitor_spill_path as they were dropped, in the same column order)
 
     def info_array(self):
         """Last step's info as [num_envs, len(info_keys)] (cheaper than per-env dicts for large batches)."""

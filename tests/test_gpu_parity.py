@@ -45,6 +45,19 @@ def impl(request, monkeypatch):
     return request.param
 
 
+# Shards of a multi-device batch: both on the box's only GPU, and — wherever a box has them — on two distinct GPUs (the
+# driver's GPU box has one: that case is skipped there and runs on any multi-GPU machine).
+DEVICE_PAIRS = [pytest.param((0, 0), id="one_gpu"), pytest.param((0, 1), id="two_gpus")]
+
+
+def _need_devices(devs):
+    from optical_rl_gym_amd import _lib
+
+    n = int(_lib.lib().orl_device_count())
+    if max(devs) >= n:
+        pytest.skip("needs %d GPUs, this box has %d" % (max(devs) + 1, n))
+
+
 def _product(meta, num_envs=1, seeds=None, **extra):
     import optical_rl_gym_amd as orl
 
@@ -838,10 +851,14 @@ def test_hip_reproduces_wrapper_and_event_fixtures(name):
     env.close()
 
 
-def test_c_abi_multi_device_group_equals_one_batch():
-    """orl_multi_create / orl_multi_run (SURVEY 8e's `n_devices, device_ids` at the C ABI): three shards — all on device 0
-    here — of 50 envs run their device loops at once from three host threads and leave the state of one 50-env batch."""
+@pytest.mark.parametrize("devs", DEVICE_PAIRS)
+def test_c_abi_multi_device_group_equals_one_batch(devs):
+    """orl_multi_create / orl_multi_run (SURVEY 8e's `n_devices, device_ids` at the C ABI): three shards — on device 0, or
+    spread over two GPUs — of 50 envs run their device loops at once from three host threads and leave the state of one
+    50-env batch."""
     import ctypes as C
+
+    _need_devices(devs)
 
     import optical_rl_gym_amd as orl
     from optical_rl_gym_amd import _lib
@@ -852,8 +869,8 @@ def test_c_abi_multi_device_group_equals_one_batch():
     lib = one.lib
     m = C.c_void_p()
     sd = np.array(seeds, np.int64)
-    devs = (C.c_int * 3)(0, 0, 0)
-    _lib.check(lib.orl_multi_create(C.byref(one._cfg), C.byref(one._desc), 50, sd.ctypes.data, 3, devs, C.byref(m)), lib)
+    dev3 = (C.c_int * 3)(devs[0], devs[1], devs[0])
+    _lib.check(lib.orl_multi_create(C.byref(one._cfg), C.byref(one._desc), 50, sd.ctypes.data, 3, dev3, C.byref(m)), lib)
     assert lib.orl_multi_n_shards(m) == 3
     stats = (_lib.RunStats * 3)()
     _lib.check(lib.orl_multi_run(m, 1, 130, stats), lib)
@@ -1185,18 +1202,22 @@ def test_vecenv_on_hip_dlpack_and_monitor_file(tmp_path):
     venv.close()
 
 
-def test_multi_device_wrapper_on_one_gpu():
-    """make(..., device_ids=[0, 0]): two shards behind one batch object (here both on the only GPU of the box), each driven
-    by its own host thread and stream — same results as the single batch."""
+@pytest.mark.parametrize("devs", DEVICE_PAIRS)
+def test_multi_device_wrapper_on_one_gpu(devs):
+    """make(..., device_ids=[0, 0] / [0, 1]): two shards behind one batch object (both on the only GPU of the box, or on two
+    GPUs), each driven by its own host thread and stream — same results as the single batch; an action outside the action space
+    in the SECOND shard's slice is refused before the first shard has queued anything."""
     import optical_rl_gym_amd as orl
     from bench import WORKLOADS
+
+    _need_devices(devs)
 
     fam, topo, kw, policy = WORKLOADS["cfg2"]
     kw = dict(kw, episode_length=70)
     n = 1000
     seeds = [10 + i for i in range(n)]
     one = orl.make(fam, topology=topo, num_envs=n, seeds=seeds, **kw)
-    two = orl.make(fam, topology=topo, num_envs=n, seeds=seeds, device_ids=[0, 0], **kw)
+    two = orl.make(fam, topology=topo, num_envs=n, seeds=seeds, device_ids=list(devs), **kw)
     assert isinstance(two, orl.MultiDeviceBatch) and two.num_envs == n and [s.num_envs for s in two.shards] == [500, 500]
     one.run(policy, 150)
     two.run(policy, 150)
@@ -1212,6 +1233,24 @@ def test_multi_device_wrapper_on_one_gpu():
         _, r1, d1, i1 = one.step(a, auto_reset=True)
         _, r2, d2, i2 = two.step_wait()
         assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and (i2 is None or np.array_equal(i1, i2))
+    # a bad action in the second shard's slice: refused with nothing queued or modified on either shard, and the next step works
+    before = two.counters().copy()
+    bad = one.policy(policy)[:, :2].astype(np.int64)
+    bad[777, 0] = 77
+    for call in (two.step_async, two.step):
+        with pytest.raises(IndexError):
+            call(bad, auto_reset=True)
+    assert np.array_equal(two.counters(), before)
+    a = one.policy(policy)[:, :2].astype(np.int64)
+    two.step_async(a, auto_reset=True)
+    _, r1, d1, _ = one.step(a, auto_reset=True)
+    _, r2, d2, _ = two.step_wait()
+    assert np.array_equal(r1, r2) and np.array_equal(d1, d2)
+    # policy + step in one launch per shard
+    acts, _, r2, d2, i2 = two.policy_step(policy, auto_reset=True)
+    a1 = one.policy(policy).copy()
+    _, r1, d1, i1 = one.step(None, auto_reset=True)
+    assert np.array_equal(acts, a1) and np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(i1, i2)
     assert np.array_equal(one.counters(), two.counters()) and np.array_equal(one.services(), two.services())
     for e in (0, 499, 500, 999):
         assert np.array_equal(one.slots(e), two.slots(e)) and np.array_equal(one.link_stats(e), two.link_stats(e))
@@ -1427,13 +1466,15 @@ def test_tiny_topologies_through_every_step_form(n_nodes, chords, fam, impl, tmp
 @pytest.mark.gpu
 @pytest.mark.parametrize("fam,kw,policy", [("RMSA", dict(load=300, mean_service_holding_time=25, num_spectrum_resources=320), "SAP_FF"),
                                             ("DeepRMSA", dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=0.1, j=1), "SAP")])
-def test_vecenv_sparse_info_equals_the_whole_info_array(fam, kw, policy):
+@pytest.mark.parametrize("devs", DEVICE_PAIRS)
+def test_vecenv_sparse_info_equals_the_whole_info_array(fam, kw, policy, devs):
     """OpticalVecEnv leaves info on the device and reads the rows of the envs that finished an episode
     (orl_batch_get_info_rows): the episode rows must be the ones the whole [n_envs][info_dim] array gives — same batch, same
     seeds, stepped once through the VecEnv and once through step() with everything fetched — in both the k_agent range
     (4 096 envs) and the one-wavefront-per-env range (300 envs); the row reader is also checked against the array directly."""
     import optical_rl_gym_amd as orl
 
+    _need_devices(devs)
     for B in (300, 4096):
         seeds = [5 + i for i in range(B)]
         a = orl.make(fam, topology="nsfnet_chen", num_envs=B, seeds=seeds, episode_length=9 + (B % 7), **kw)
@@ -1442,7 +1483,7 @@ def test_vecenv_sparse_info_equals_the_whole_info_array(fam, kw, policy):
         assert venv._sparse_info
         venv.reset()
         # ... and the same through two shards behind one VecEnv (both on device 0 here): obs_out slices, per-shard info rows
-        m = orl.make(fam, topology="nsfnet_chen", num_envs=B, seeds=seeds, episode_length=9 + (B % 7), device_ids=[0, 0], **kw)
+        m = orl.make(fam, topology="nsfnet_chen", num_envs=B, seeds=seeds, episode_length=9 + (B % 7), device_ids=list(devs), **kw)
         mvenv = orl.OpticalVecEnv(m, obs_dtype=np.float32)
         assert mvenv._sparse_info and mvenv._direct_obs
         mvenv.reset()

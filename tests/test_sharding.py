@@ -95,6 +95,13 @@ def test_bench_two_ranks_on_one_device_and_refusal():
     assert p.returncode == 0, p.stderr[-2000:]
     assert out["n_gpus"] == 2 and len(out["per_rank"]) == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and all(r["env_steps_per_s"] > 0 for r in out["per_rank"])
+    assert [r["envs"] for r in out["per_rank"]] == [4096, 4096] and out["config"]["envs_total"] == 8192
+    # strong scaling: --batch is the job's; the ranks own contiguous blocks of it (here 4 104 envs -> 2 052 + 2 052)
+    p, out = _bench("--gpus", "2", "--device", "0", "--scaling", "strong", "--batch", "4104", "--steps", "20", "--no-cpu-baseline",
+                    "--min-timed-s", "0.2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["scaling"] == "strong" and [r["envs"] for r in out["per_rank"]] == [2052, 2052]
+    assert out["config"]["envs_total"] == 4104 and out["config"]["envs_per_gpu"] == [2052, 2052] and out["value"] > 0
 
 
 @pytest.mark.timeout(300)

@@ -53,6 +53,17 @@ def kernel_record(suffix, kern, last, spl, factor):
     f = mean_last("tr_f" + suffix, kern, "FETCH_SIZE", last) * 1024 * factor
     w = mean_last("tr_w" + suffix, kern, "WRITE_SIZE", last) * 1024
     rec = {"fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w)}
+    if kern.startswith("k_persist"):
+        # every launch of the persistent kernel is followed by k_stats, which replays the statistics log it wrote (deferred
+        # bookkeeping, one lane per env): its traffic belongs to the launch
+        try:
+            fs = mean_last("tr_f" + suffix, "k_stats<", "FETCH_SIZE", last) * 1024 * factor
+            ws = mean_last("tr_w" + suffix, "k_stats<", "WRITE_SIZE", last) * 1024
+            rec["k_stats_bytes_per_launch"] = int(fs + ws)
+            rec["hbm_bytes_per_launch"] = int(f + w + fs + ws)
+            f, w = f + fs, w + ws
+        except (FileNotFoundError, KeyError):
+            pass
     if spl:
         rec["steps_per_launch"] = spl
         rec["hbm_bytes_per_step"] = int((f + w) / spl)
@@ -73,6 +84,80 @@ def kernel_record(suffix, kern, last, spl, factor):
     if sq:
         rec["sq_per_launch"] = sq
     return rec
+
+
+def launches_report(name, trace_csv, bench_log):
+    """The timed blocks of a bench command inside its kernel trace.  The stats file averages over EVERY k_persist dispatch of the
+    command — the 128-step launches of the state preparation, the timed launches, half-batch launches on two streams — so the
+    dispatches are classified by what the command itself says it launched (its JSON line: blocks, launches per block): the timed
+    blocks are the LAST blocks x launches-per-block x parts dispatches of k_persist, in start order (what follows them — the
+    stand-alone scan and the host-driven loops — launches other kernels).  Per block: every dispatch's own duration, and the
+    block's span on the device (first start to last end, k_stats — the deferred bookkeeping behind every launch — included:
+    launches of two half batches overlap on two streams, so durations do not add up there).  The roofline fraction is recomputed
+    from the spans and set beside the one the command measured with HIP events."""
+    rows = [r for r in csv.DictReader(open(trace_csv)) if "k_persist" in r["Kernel_Name"] or "k_stats" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    pers = [r for r in rows if "k_persist" in r["Kernel_Name"]]
+    if not pers:
+        return None
+    out = ["rocprofv3 --kernel-trace of the bench command for %s (tools/run_profiles.sh)" % name]
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    out.append("  all %d k_persist dispatches of the command (state preparation included): mean %.1f us, median %.1f us"
+               % (len(pers), sum(map(dur, pers)) / len(pers), statistics.median(map(dur, pers))))
+    bench = None
+    try:
+        bench = json.loads([ln for ln in open(bench_log) if ln.startswith("{")][-1])
+    except Exception:
+        pass
+    if not bench:
+        out.append("  (no bench line beside the trace: timed blocks not identified)")
+        return "\n".join(out) + "\n"
+    import re
+
+    m = re.search(r"\((\d+) launches per (\d+)-step block\)", bench["config"]["step_kernels"][0])
+    launches, steps = int(m.group(1)), int(m.group(2))
+    blocks = bench["timing"]["blocks"]
+    # a run of more than one launch on a batch of more than one generation is two half batches on two streams (orl_batch_run)
+    grids = sorted({int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0)) for r in pers})
+    full = max(grids)
+    tail = pers[-1]
+    parts = 2 if (launches > 1 and int(tail.get("Grid_Size_X", tail.get("Grid_Size", full))) < full) else 1
+    per_block = launches * parts
+    timed = pers[-blocks * per_block:] if blocks * per_block <= len(pers) else []
+    if not timed:
+        out.append("  (fewer k_persist dispatches than the bench line's %d blocks x %d: timed blocks not identified)" % (blocks, per_block))
+        return "\n".join(out) + "\n"
+    t_first = int(timed[0]["Start_Timestamp"])
+    after = [r for r in rows if int(r["Start_Timestamp"]) >= t_first]
+    spans, d_p, d_s = [], [], []
+    for b in range(blocks):
+        blk = timed[b * per_block:(b + 1) * per_block]
+        lo = int(blk[0]["Start_Timestamp"])
+        hi_lim = int(timed[(b + 1) * per_block]["Start_Timestamp"]) if (b + 1) * per_block < len(timed) else None
+        mine = [r for r in after if int(r["Start_Timestamp"]) >= lo and (hi_lim is None or int(r["Start_Timestamp"]) < hi_lim)]
+        if hi_lim is None:  # the last block: its k_persist dispatches and the k_stats right behind them
+            last_end = max(int(r["End_Timestamp"]) for r in blk)
+            mine = [r for r in mine if "k_persist" in r["Kernel_Name"] or int(r["Start_Timestamp"]) <= last_end + 200000][: 2 * per_block]
+        spans.append((max(int(r["End_Timestamp"]) for r in mine) - lo) / 1e3)
+        d_p += [dur(r) for r in mine if "k_persist" in r["Kernel_Name"]]
+        d_s += [dur(r) for r in mine if "k_stats" in r["Kernel_Name"]]
+    out.append("  timed blocks: the last %d blocks x %d k_persist dispatches (%d launch(es) of <= 128 steps per %d-step block%s)"
+               % (blocks, per_block, launches, steps, ", two half batches on two streams" if parts == 2 else ""))
+    out.append("    k_persist per dispatch: median %.1f us, mean %.1f, min %.1f, max %.1f" % (statistics.median(d_p), sum(d_p) / len(d_p), min(d_p), max(d_p)))
+    if d_s:
+        out.append("    k_stats   per dispatch: median %.1f us, mean %.1f (the bookkeeping of the launch in front of it, one lane per env)"
+                   % (statistics.median(d_s), sum(d_s) / len(d_s)))
+    sp = statistics.median(spans)
+    out.append("    block span on the device (first start to last end): median %.1f us, mean %.1f, min %.1f, max %.1f"
+               % (sp, sum(spans) / len(spans), min(spans), max(spans)))
+    rf = bench["roofline"]
+    bytes_block = rf["algorithmic_bytes_per_launch"] * launches
+    frac_trace = bytes_block / (sp * 1e-6) / 1e9 / rf["peak"]
+    out.append("    roofline from the trace: %d algorithmic bytes per block / %.1f us = %.1f GB/s = %.4f of %d GB/s"
+               % (bytes_block, sp, bytes_block / (sp * 1e-6) / 1e9, frac_trace, rf["peak"]))
+    out.append("    the same command's own line (HIP events; under the profiler): frac %.4f, %.1f us per launch x %d  ->  ratio trace / events %.3f"
+               % (rf["frac"], rf["us_per_launch"], launches, frac_trace / rf["frac"] if rf["frac"] else 0.0))
+    return "\n".join(out) + "\n"
 
 
 src_hash = _build.source_hash(with_compiler=False)
@@ -118,21 +203,9 @@ for d in sorted(glob.glob(O + "/stats_*")):
         shutil.copy(st, os.path.join(P, "%s_bench_%s_kernel_stats.csv" % (tag, name)))
     tr = newest(d + "/**/*kernel_trace.csv")
     if tr:
-        # the stats file averages over EVERY k_persist dispatch of the command — the 128-step launches of the state preparation
-        # included; the timed blocks are the launches of --steps steps: their durations from the kernel trace
-        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr)) if "k_persist" in r["Kernel_Name"]]
-        if dur:
-            with open(os.path.join(P, "%s_bench_%s_launches.txt" % (tag, name)), "w") as f:
-                f.write("rocprofv3 --kernel-trace of the bench command for %s (tools/run_profiles.sh), k_persist dispatches by duration:\n" % name)
-                groups = {}
-                for x in dur:
-                    groups.setdefault(round(x / (0.15 * statistics.median(dur) + 1e-9)), []).append(x)
-                med = statistics.median(dur)
-                short = [x for x in dur if x <= 1.6 * min(dur)]
-                f.write("  all %d dispatches: mean %.1f us, median %.1f us\n" % (len(dur), sum(dur) / len(dur), med))
-                f.write("  the %d shortest-class dispatches (within 1.6x of the minimum: the timed blocks of a --steps 20 command, or the\n"
-                        "  half-batch launches of a longer one): median %.1f us, mean %.1f us, min %.1f, max %.1f\n"
-                        % (len(short), statistics.median(short), sum(short) / len(short), min(short), max(short)))
+        txt = launches_report(name, tr, os.path.join(O, "stats_%s.log" % name))
+        if txt:
+            open(os.path.join(P, "%s_bench_%s_launches.txt" % (tag, name)), "w").write(txt)
 for f in glob.glob(O + "/bench_*.json") + glob.glob(O + "/phase_*.txt") + glob.glob(O + "/agent_loop_*.json"):
     if os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(P, "%s_%s" % (tag, os.path.basename(f))))
