@@ -215,6 +215,14 @@ int orl_batch_step_wait(orl_batch* b);
 int orl_batch_policy_step(orl_batch* b, int policy_id, int auto_reset, int32_t* actions_out, double* obs_out, double* reward_out,
                           uint8_t* done_out, double* info_out);
 
+/* Which info entries the 8-lanes-per-env step kernel writes per step (RMSA / DeepRMSA; rmsa_env.py:228-264): 0 (default) = all of
+ * them; 1 = the blocking rates only (service / episode_service / bit_rate / episode_bit_rate blocking and the per-rate entries of
+ * the discrete mode) — network_compactness, network_compactness_difference, avg_link_compactness and avg_link_utilization, the
+ * last two a read of every link record of every env per step, keep whatever an earlier step wrote.  For consumers that read the
+ * rates only (SB3's Monitor with the reference's info_keywords, examples/stable_baselines3/DeepRMSA.ipynb:279-288).  The
+ * one-wavefront-per-env kernel always writes everything. */
+int orl_batch_set_info_mode(orl_batch* b, int mode);
+
 /* DeepRMSAEnv.observation() for the pending service (deeprmsa_env.py:60-121). */
 int orl_batch_observation(orl_batch* b, double* obs_out);
 /* The observation array the last orl_batch_step / orl_batch_observation / orl_batch_reset left on the device (ORL_BUF_OBS), cast

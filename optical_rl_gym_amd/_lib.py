@@ -62,6 +62,7 @@ EXPORTS = {
     "orl_batch_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "orl_batch_step_wait": (C.c_int, [C.c_void_p]),
+    "orl_batch_set_info_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "orl_batch_policy_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orl_batch_get_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_get_services": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1060,6 +1060,13 @@ extern "C" int orl_batch_policy_step(orl_batch* b, int policy_id, int auto_reset
 }
 ORL_ABI_CATCH_INT
 
+extern "C" int orl_batch_set_info_mode(orl_batch* b, int mode) try {
+  if (!b || mode < 0 || mode > 1) return fail(ORL_E_INVALID, "info mode 0 (all entries) or 1 (blocking rates only)");
+  b->P.info_mode = mode;
+  return ORL_OK;
+}
+ORL_ABI_CATCH_INT
+
 extern "C" int orl_batch_check(orl_batch* b) try {
   if (!b) return fail(ORL_E_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));

@@ -162,6 +162,9 @@ struct DevParams {
   // episode_reward (utils.py:125-131: += reward per step, from 0.0) is kept as a float64 sum in step order
   double* ep_rew;      // [B][ep_cap] or null: sum of rewards of every finished episode
   double* ep_rew_acc;  // [B] the running episode's sum
+  int info_mode;    // k_agent: 0 = every info entry of step() is written; 1 = the blocking rates only (entries 0..3 and the per-rate
+                    // ones) — the network-compactness entries and the two means over the links, a read of every link record of
+                    // every env per step, are left as they were (orl_batch_set_info_mode: SB3's Monitor reads the rates)
   // I/O (device resident; the C-ABI copies to/from host buffers)
   int* actions;            // [B][4]
   double* reward;          // [B]

@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
         if (!second) sp::row_item_lane<ENV, W>(P, M, sp::item_from_sink(env0 + iel, link, s_tab[P.E * iel + link]), prof);
       } else {
         sp::row_item_lane1<ENV, W>(P, M, env0 + iel, link, s_tab[P.E * iel + link].bits, s_mtab + ORL_MTAB * iel, second, prof, true,
-                                   LINK_INFO ? s_stash + 2 * P.E * iel : nullptr);
+                                   (LINK_INFO && P.info_mode == 0) ? s_stash + 2 * P.E * iel : nullptr);
       }
     }
   }
@@ -985,7 +985,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   u64* rec = P.scal + env * ORL_SCAL_WORDS;
   double mean_comp = 0.0, mean_util = 0.0;
   if constexpr (LINK_INFO) {
-    if (valid) {
+    if (valid && P.info_mode == 0) {
       // np.mean over the links in topology.edges() order (numpy pairwise sum, optical_rl_gym_amd/csrc/orl_device.h link_mean):
       // lane j of the group accumulates x[j], x[8 + j], ...; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); the tail one by one.
       // Every round's link indices are requested together, then the values of all of them (the loop that fetched index and
@@ -1055,7 +1055,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
         rec[SC_ACC] = acc & ~2ull;
       }
       for (int i = gl; i < 2 * P.C; i += 8) atomicExch(rs + i, 0);
-      if (LINK_INFO && gl == 0) {
+      if (LINK_INFO && gl == 0 && P.info_mode == 0) {
         double* io = P.info + env * P.n_info;
         io[4] = cur;
         io[5] = ic.prev_comp - cur;

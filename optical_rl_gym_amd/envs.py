@@ -366,6 +366,11 @@ class BatchedOpticalEnv:
                                                   self._done.ctypes.data, self._info.ctypes.data))
         return self._act, self._obs, self._reward, self._done, self._info
 
+    def set_info_mode(self, rates_only):
+        """rates_only=True: the 8-lanes-per-env step kernel writes the blocking rates of info only (include/orl.h,
+        orl_batch_set_info_mode); the compactness entries and the two link means keep whatever was written before."""
+        self._ck(self.lib.orl_batch_set_info_mode(self._h, 1 if rates_only else 0))
+
     def action_bounds(self):
         """Exclusive upper bound per action column (None: any integer) — the index ranges of the reference's actions_output
         arrays that orl_batch_step checks before it modifies anything (rmsa_env.py:126-137, 167; rwa_env.py:52-58, 103;

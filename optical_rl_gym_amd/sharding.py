@@ -106,6 +106,9 @@ class MultiDeviceBatch:
             seeds = [int(seeds) + i for i in range(self.num_envs)]
         self._map(lambda r: self.shards[r].seed(list(seeds[self.bounds[r]:self.bounds[r + 1]]), mask=self._cut(mask, r)))
 
+    def set_info_mode(self, rates_only):
+        self._map(lambda r: self.shards[r].set_info_mode(rates_only))
+
     def set_paths(self, paths):
         self._map(lambda r: self.shards[r].set_paths(self._cut(paths, r)))
 

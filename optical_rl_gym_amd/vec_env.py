@@ -15,6 +15,7 @@ stable-baselines3 itself is not a dependency: if it is importable the class regi
 For an agent on the same GPU, `device_obs()` / `device_tensors()` hand out zero-copy views (DLPack) of the batch's
 device-resident arrays; `obs_dtype=np.float32` casts observations for float32 policies.
 """
+import os
 import time
 
 import numpy as np
@@ -85,10 +86,11 @@ _NO_INFO = _NoInfo()
 class _FinishedStep:
     """What the envs that finished an episode in one step hand to SB3, kept as arrays: returns, lengths, info keywords, the
     terminal observations — one device gather and a handful of numpy calls per step whatever their number."""
-    __slots__ = ("rets", "lens", "t", "keys", "cols", "term")
+    __slots__ = ("rets", "lens", "t", "keys", "cols", "term", "pos")
 
-    def __init__(self, rets, lens, t, keys, cols, term):
+    def __init__(self, idx, rets, lens, t, keys, cols, term):
         self.rets, self.lens, self.t, self.keys, self.cols, self.term = rets, lens, t, keys, cols, term
+        self.pos = dict(zip(idx, range(len(idx))))  # env -> its row
 
     def row(self, n):
         row = {"r": self.rets[n], "l": self.lens[n], "t": self.t}
@@ -100,22 +102,28 @@ class _FinishedStep:
 class _EpisodeInfo(dict):
     """The info dict of an env that finished an episode — {"episode": {r, l, t, **info_keywords}, "terminal_observation": row} —
     built when it is first looked at: SB3 reads `episode` of every finished env once (Monitor statistics) and
-    `terminal_observation` only when it bootstraps a truncated episode; 1 300 envs finish per step at cfg3's steady state and
-    building every dict up front cost 2 ms of Python per step.  Holds its step's arrays, so it stays valid for as long as it
-    is held."""
-    __slots__ = ("_src", "_n")
+    `terminal_observation` only when it bootstraps a truncated episode; 1 300 envs finish per step at cfg3's steady state, and
+    building every dict up front cost 2 ms of Python per step, creating a fresh lazy object per finished env still 1 ms.  So
+    every env has ONE such object for the life of the VecEnv (created the first time an env finishes); a step only puts the
+    objects of the envs that finished into the infos list.  Like the list itself it is valid until the next step_wait(): looked
+    at later it shows the env's entry of the then current step, or nothing when the env did not finish in it.  copy() /
+    copy.deepcopy / pickle give an independent plain dict (what VecMonitor and the replay buffers keep)."""
+    __slots__ = ("_owner", "_i", "_serial")
 
-    def __init__(self, src, n):
+    def __init__(self, owner, i):
         dict.__init__(self)
-        self._src, self._n = src, n
+        self._owner, self._i, self._serial = owner, i, -1
 
     def _fill(self):
-        src = self._src
-        if src is not None:
-            self._src = None
-            n = self._n
-            dict.__setitem__(self, "episode", src.row(n))
-            dict.__setitem__(self, "terminal_observation", None if src.term is None else src.term[n])
+        o = self._owner
+        if self._serial != o._serial:
+            self._serial = o._serial
+            dict.clear(self)
+            src = o._fin_src
+            n = src.pos.get(self._i) if src is not None else None
+            if n is not None:
+                dict.__setitem__(self, "episode", src.row(n))
+                dict.__setitem__(self, "terminal_observation", None if src.term is None else src.term[n])
         return self
 
     def __getitem__(self, k):
@@ -265,6 +273,11 @@ class OpticalVecEnv:
             self.observation_space = _space_module().Box(low=0, high=1, shape=(dim,), dtype=np.uint8)
         self.info_keywords = tuple(k for k in info_keywords if k in batch.info_keys)
         self._kw_idx = [batch.info_keys.index(k) for k in self.info_keywords]
+        # what SB3 reads of info is the keywords of finished envs: when those are blocking rates only, the step kernel skips the
+        # compactness entries and the per-step read of every link record behind the two link means (orl_batch_set_info_mode)
+        rates = ("service_blocking_rate", "episode_service_blocking_rate", "bit_rate_blocking_rate", "episode_bit_rate_blocking_rate")
+        if hasattr(batch, "set_info_mode") and all(k in rates or k.startswith("bit_rate_blocking_") for k in self.info_keywords):
+            batch.set_info_mode(True)
         self._actions = None
         self._obs_ring, self._obs_turn = None, 0
         # (batches that take `obs_out` in step(): the HIP batches; the oracle stand-in of the CPU tests does not)
@@ -276,6 +289,8 @@ class OpticalVecEnv:
         self._async = hasattr(batch, "step_async") and self._sparse_info  # (the HIP batches)
         self._queued = False
         self._infos, self._infos_set = None, ()
+        self._info_pool, self._fin_src, self._serial = None, None, 0
+        self._timing = {} if os.environ.get("ORL_VEC_TIMING") else None
         self._ep_ret = np.zeros(self.num_envs)
         self._ep_len = np.zeros(self.num_envs, np.int64)
         self._t0 = time.time()
@@ -314,6 +329,9 @@ class OpticalVecEnv:
                     and self.obs_dtype in (np.dtype(np.float64), np.dtype(np.float32)) and self._direct_obs)
 
     def step_wait(self):
+        tm = self._timing  # (ORL_VEC_TIMING=1: seconds per section, tools/vec_env_episodes.py)
+        if tm is not None:
+            t_a = time.perf_counter()
         direct = self._direct()
         kw = dict(fetch_info=False) if self._sparse_info else {}
         if self._queued:
@@ -326,12 +344,18 @@ class OpticalVecEnv:
         else:
             obs, reward, done, info = self.batch.step(self._actions, auto_reset=True, **kw)
             obs = self._obs(obs)
+        if tm is not None:
+            t_b = time.perf_counter()
         self._ep_ret += reward
         self._ep_len += 1
         finished = np.flatnonzero(done)
+        if tm is not None:
+            t_c = time.perf_counter()
         if self._sparse_info:  # info stayed on the device: the rows of the envs that report done (row i of `rows` = finished[i])
             rows = self.batch.info_rows(finished)
             info = None
+        if tm is not None:
+            t_d = time.perf_counter()
         # SB3 wants one dict per env and only ever READS the ones of envs that did not finish an episode: those share one empty
         # read-only mapping (65 536 fresh dicts per step cost ten times the step itself); an env that reports done gets a dict of
         # its own.  The LIST is this object's, reused from step to step (a fresh 65 536-entry list per step costs as much as
@@ -342,6 +366,10 @@ class OpticalVecEnv:
         for i in self._infos_set:
             infos[i] = _NO_INFO
         idx = self._infos_set = finished.tolist()
+        self._serial += 1
+        self._fin_src = None
+        if tm is not None:
+            t_e = time.perf_counter()
         if idx:
             # (with 50-step episodes 1 300 of 65 536 envs finish per step: everything per env stays in numpy — one gather per
             # quantity — and each finished env gets a small mapping that builds its dict when SB3 looks at it)
@@ -350,13 +378,27 @@ class OpticalVecEnv:
             # the in-kernel reset is soft: the pending service (hence the observation) is unchanged by it
             term = None if obs is None else np.array(obs[finished])  # one copy; each env gets its row of it
             t_now = round(time.time() - self._t0, 6)
-            src = _FinishedStep(rets.tolist(), lens.tolist(), t_now, self.info_keywords, [c.tolist() for c in cols], term)
-            for n_, i in enumerate(idx):
-                infos[i] = _EpisodeInfo(src, n_)
+            src = self._fin_src = _FinishedStep(idx, rets.tolist(), lens.tolist(), t_now, self.info_keywords, [c.tolist() for c in cols], term)
+            if tm is not None:
+                t_f = time.perf_counter()
+                tm["gather"] = tm.get("gather", 0.0) + t_f - t_e
+            pool = self._info_pool
+            if pool is None:  # (one object per env, created the first time any env finishes)
+                pool = self._info_pool = [_EpisodeInfo(self, i) for i in range(self.num_envs)]
+            for i in idx:
+                infos[i] = pool[i]
             self.episode_log.append_block(rets, lens, t_now, cols)
             self._ep_ret[finished] = 0
             self._ep_len[finished] = 0
-        return obs, np.array(reward), np.array(done, dtype=bool), infos
+            if tm is not None:
+                tm["objects+log"] = tm.get("objects+log", 0.0) + time.perf_counter() - t_f
+        out = obs, np.array(reward), np.array(done, dtype=bool), infos
+        if tm is not None:
+            t_z = time.perf_counter()
+            for k, v in (("wait", t_b - t_a), ("returns", t_c - t_b), ("info_rows", t_d - t_c), ("clear", t_e - t_d), ("total", t_z - t_a)):
+                tm[k] = tm.get(k, 0.0) + v
+            tm["steps"] = tm.get("steps", 0) + 1
+        return out
 
     def step(self, actions):
         self.step_async(actions)

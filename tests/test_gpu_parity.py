@@ -1678,3 +1678,38 @@ def test_policy_and_step_in_one_launch_equals_policy_then_step(gname, policy, n,
         chk(e, "link_stats", a.link_stats(e), b.link_stats(e))
         chk(e, "net_stats", a.net_stats(e), b.net_stats(e))
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fam,kw,policy", [("RMSA", dict(load=300, mean_service_holding_time=25, num_spectrum_resources=320), "SAP_FF"),
+                                            ("DeepRMSA", dict(mean_service_holding_time=7.5, mean_service_inter_arrival_time=0.1, j=1), "SAP")])
+def test_info_mode_rates_only_changes_nothing_but_the_skipped_entries(fam, kw, policy):
+    """orl_batch_set_info_mode(1): the 8-lanes-per-env step kernel leaves out the compactness entries and the two link means of
+    info (what OpticalVecEnv asks for when SB3 reads blocking rates only); rewards, dones, the four blocking rates, observations
+    and the whole state stay those of the full mode."""
+    import optical_rl_gym_amd as orl
+
+    n = 2304
+    seeds = [300 + i for i in range(n)]
+    a = orl.make(fam, topology="nsfnet_chen", num_envs=n, seeds=seeds, episode_length=25, **kw)
+    b = orl.make(fam, topology="nsfnet_chen", num_envs=n, seeds=seeds, episode_length=25, **kw)
+    assert int(a.lib.orl_batch_debug_step_kernel(a._h)) == 2
+    a.set_info_mode(True)
+    chk = _exact(fam + " info mode")
+    for t in range(60):
+        act = b.policy(policy).copy()
+        o_a, r_a, d_a, i_a = a.step(act, auto_reset=True)
+        o_b, r_b, d_b, i_b = b.step(act, auto_reset=True)
+        chk(t, "reward", r_a, r_b); chk(t, "done", d_a, d_b); chk(t, "rates", i_a[:, :4], i_b[:, :4])
+        if o_b is not None:
+            chk(t, "obs", o_a, o_b)
+    a.set_info_mode(False)
+    act = b.policy(policy).copy()
+    _, _, _, i_a = a.step(act, auto_reset=True)
+    _, _, _, i_b = b.step(act, auto_reset=True)
+    chk(61, "info, full mode again", i_a, i_b)
+    chk(0, "counters", a.counters(), b.counters())
+    for e in (0, n // 2, n - 1):
+        chk(e, "link_stats", a.link_stats(e), b.link_stats(e))
+        chk(e, "net_stats", a.net_stats(e), b.net_stats(e))
+    a.close(); b.close()
