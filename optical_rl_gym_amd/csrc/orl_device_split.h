@@ -821,7 +821,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
 // eight service / bit-rate counters, the running averages of network throughput and compactness, the done / soft-reset
 // logic on them, and the 32-word record that carries them in and out of registers every step — the same arithmetic on all
 // 8 lanes of a group, ~350 VALU instructions and 31 loads + 13 stores per wavefront-step for 8 envs.  The dynamics of an env
-// (slot maps, pending releases, clock, generator) never depend on it.  So the single-core families' persistent kernel does
+// (slot maps, pending releases, clock, generator) never depend on it.  So the persistent kernel does
 // not do it at all: ctrl_d keeps the clock, the pending service and the release queue's fields, and LOGS per env-step the
 // three words the bookkeeping needs (DevParams::slog); k_stats (orl_kernels.hip) replays the log after the launch with one
 // LANE per env — 64 envs per instruction instead of 8 — in the reference's operation order (rmsa_env.py:163-282, 439-462,
@@ -830,46 +830,56 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
 //   w1  accepted:1 | n x hops of the provision:12 | bit-rate index of the NEW service:12 | the per-core sums at the START of the
 //       step minus what the previous step's releases added — the network compactness right after the previous step's provision —
 //       (lambda_max - lambda_min) sum:17 | free blocks inside:16   (RWA instead of the sums: the action's path:4 | wavelength:10,
-//       for the actions_output marginals).  Single-core families: the core is 0.
+//       for the actions_output marginals) | core of the provision:5 (RMCSA; the sums logged are those of the core the env's
+//       previous accepted provision went to)
 //   w2  what the step's releases take off the sums: n x hops:20 | bit rate:24   (stored after the release detection; w0 and w1
 //       before it, so that nothing of them is live across it)
 // Slot n of a wavefront that logged n steps carries w1's sums only: those after its last row phase.
 // ---------------------------------------------------------------------------------------------------------------
 #define ORL_SLOG_WORDS ORL_SLOG_ROW_WORDS
-__device__ __forceinline__ u64 slog_w1(bool accepted, int n_hops, int br_new, int occ, int fb) {
-  return (u64)(accepted ? 1u : 0u) | ((u64)(u32)n_hops << 1) | ((u64)(u32)br_new << 13) | ((u64)(u32)occ << 25) | ((u64)(u32)fb << 42);
+__device__ __forceinline__ u64 slog_w1(bool accepted, int n_hops, int br_new, int occ, int fb, int core = 0) {
+  return (u64)(accepted ? 1u : 0u) | ((u64)(u32)n_hops << 1) | ((u64)(u32)br_new << 13) | ((u64)(u32)occ << 25) | ((u64)(u32)fb << 42) |
+         ((u64)(u32)core << 58);
 }
 __device__ __forceinline__ u64 slog_w1_rwa(bool accepted, int n_hops, int path, int slot) {
   return (u64)(accepted ? 1u : 0u) | ((u64)(u32)n_hops << 1) | ((u64)(u32)path << 25) | ((u64)(u32)slot << 29);
 }
 __device__ __forceinline__ u64 slog_w2(int d_nh, int d_br) { return (u64)(u32)d_nh | ((u64)(u32)d_br << 20); }
 
-// the control phase of the persistent kernel without the bookkeeping (single-core families, compact sink, services drawn
-// ahead).  `esp`: the env's episode step counter, kept by the caller for the whole launch (done / observation need it);
-// `slog`: this step's log slot, at the env's column.  Returns the descriptor of the new pending service.
-template <int ENV, int W>
+// the control phase of the persistent kernel without the bookkeeping (services drawn ahead; CP: the single-core families'
+// compact sink, else RMCSA's entries with a core per mask).  `esp`: the env's episode step counter, kept by the caller for the
+// whole launch (done / observation need it); `prev_core` (RMCSA): the core of the env's last accepted provision — the sums
+// logged are that core's; `slog`: this step's log slot, at the env's column.  Returns the descriptor of the new pending service.
+template <int ENV, int W, bool CP>
 __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
-                                      const int4& av, u64 desc, SinkEntryC* s_tab, int* s_deferred, int* done_out, unsigned short* s_list,
-                                      u32* s_list_n, SoonRegs* carried, unsigned short* s_mtab, SvcBuf& svc, int& esp, u64* slog) {
-  const int K = P.K, S = P.S, rej = P.allow_rejection ? 1 : 0, gl = lane & 7;
+                                      const int4& av, u64 desc, typename SinkEntryOf<CP>::type* s_tab, u32* s_tally, int tw, int* s_deferred,
+                                      int* done_out, unsigned short* s_list, u32* s_list_n, SoonRegs* carried, unsigned short* s_mtab,
+                                      SvcBuf& svc, int& esp, int& prev_core, u64* slog) {
+  const int K = P.K, S = P.S, gl = lane & 7;
   u64 desc_out = 0ull;
-  SinkT<true> sink;
-  sink.tally = nullptr; sink.tw = 0; sink.active = false; sink.deferred = false; sink.cnt = 0;
-  sink.list = s_list; sink.list_n = s_list_n; sink.nrel = 0;
+  SinkT<CP> sink;
+  sink.tab = nullptr; sink.tally = nullptr; sink.tw = tw; sink.active = false; sink.deferred = false; sink.cnt = 0;
+  sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0;
   if (lane == 0) *s_list_n = 0u;
   {
-    SinkEntryC* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
+    typename SinkEntryOf<CP>::type* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
+    if constexpr (!CP) {
+      u32* ty = s_tally + tw * 8 * (int)(threadIdx.x >> 6);
+      for (int i = lane; i < 8 * tw; i += 64) ty[i] = 0u;
+      sink.tally = s_tally + tw * (int)(threadIdx.x >> 3);
+    } else {
+      sink.mtab = s_mtab + ORL_MTAB * (int)(threadIdx.x >> 3);
+    }
     for (int i = lane; i < 8 * P.E; i += 64) sink_entry_clear(tb[i]);
     wave_fence();
     sink.tab = s_tab + P.E * (int)(threadIdx.x >> 3);
-    sink.mtab = s_mtab + ORL_MTAB * (int)(threadIdx.x >> 3);
   }
   if (valid) {
     u64* rec = wm_scal(P, M, env);
     EnvG e;
     e.scal = rec;
     e.env = env;
-    // what the loop itself needs of the record: clock, the pending service's holding time and bit rate, the release queue
+    // what the loop itself needs of the record: clock, the pending service's holding time, the release queue
     {
       const u64 w_now = rec[SC_NOW], w_ht = rec[SC_HT], w_nr = rec[SC_NEXTREL], w_ts = rec[SC_TSOON];
       const u64 w_ev = rec[SC_EV], w_hint = rec[SC_HINT];
@@ -914,21 +924,23 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     e.cs = wm_cs(P, M, env);
     int occ_s = 0, fb_s = 0;
     if (ENV != ENV_RWA) {
-      // the sums right after the previous step's provision (its pending network-compactness update, rmsa_env.py:439-462, is
-      // finished by the replay from them); this step's releases start from zero
-      int* rs = e.cs + 2;
+      // the sums right after the previous step's provision — of the core it went to — (its pending network-compactness update,
+      // rmsa_env.py:439-462, is finished by the replay from them); this step's releases start from zero
+      int* rs = e.cs + 2 * P.C;
+      const int pc = (ENV == ENV_RMCSA) ? prev_core : 0;
       if (!M.cs_lds) {
-        occ_s = atomicAdd(e.cs, 0) - atomicAdd(rs, 0);
-        fb_s = atomicAdd(e.cs + 1, 0) - atomicAdd(rs + 1, 0);
-        if (gl < 2) atomicExch(rs + gl, 0);
+        occ_s = atomicAdd(e.cs + 2 * pc, 0) - atomicAdd(rs + 2 * pc, 0);
+        fb_s = atomicAdd(e.cs + 2 * pc + 1, 0) - atomicAdd(rs + 2 * pc + 1, 0);
+        for (int i = gl; i < 2 * P.C; i += 8) atomicExch(rs + i, 0);
       } else {
-        occ_s = e.cs[0] - rs[0];
-        fb_s = e.cs[1] - rs[1];
-        if (gl < 2) rs[gl] = 0;
+        occ_s = e.cs[2 * pc] - rs[2 * pc];
+        fb_s = e.cs[2 * pc + 1] - rs[2 * pc + 1];
+        for (int i = gl; i < 2 * P.C; i += 8) rs[i] = 0;
       }
     }
-    int path, slot;
+    int path, slot, mod = 0, core = 0;
     if (ENV == ENV_DEEPRMSA) { path = av.y; slot = av.z; }  // (decoded by the in-kernel scan on this slot map, policy_g)
+    else if (ENV == ENV_RMCSA) { path = av.x; mod = av.y; core = av.z; slot = av.w; }
     else { path = av.x; slot = av.y; }
     const int path0 = path, slot0 = slot;
     ORL_PROFA(2);
@@ -938,23 +950,38 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     int pushed_idx = -1;
     u64 pushed_info = 0ull;
     double pushed_t = 0.0;
-    if (path < K && slot < S && path < np_) {
+    const bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
+    if (in_range && path < np_) {
       const int pidx = pb + path;
-      if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
+      if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
+      else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
       const PathRec prec = path_rec_load(P, pidx);
+      bool ok = true;
+      if (ENV == ENV_RMCSA) {  // _crosstalk_is_acceptable: the two reach limits (rmcsa_env.py:341-384), as ctrl_a
+        const double len = P.path_length[pidx];
+        ok = (len < P.lmax_xt[mod]) && (len < P.lmax_snr[mod * P.n_br + e.br_idx]);
+      }
       ORL_PROFA(3);
-      const int hops = path_rec_byte(prec, 0);
-      n_hops = n * hops;
-      accepted = true;
-      pushed_info = ev_pack(pidx, slot, n, 0, e.bit_rate);
-      pushed_t = e.now + e.ht;  // (arrival time + holding time: the clock stands at the pending service's arrival)
+      if (ok) {
+        const int hops = path_rec_byte(prec, 0);
+        n_hops = n * hops;
+        accepted = true;
+        pushed_info = ev_pack(pidx, slot, n, core, e.bit_rate);
+        pushed_t = e.now + e.ht;  // (arrival time + holding time: the clock stands at the pending service's arrival)
 #ifndef ORL_X_SKIP_PUSH
-      pushed_idx = g8::ev_push(P, e, lane, pushed_t, pushed_info, false);
+        pushed_idx = g8::ev_push(P, e, lane, pushed_t, pushed_info, false);
 #endif
-      sink_add(sink, prec, 0, slot, n, lane, true);
-      ORL_PROFA(4);
+        sink_add(sink, prec, core, slot, n, lane, true);
+        if constexpr (!CP)
+          for (int h = gl; h < hops; h += 8) {
+            const int link = path_rec_byte(prec, 2 + h);
+            atomicAdd(sink.tally + (link >> 2), 1u << (8 * (link & 3)));
+          }
+        ORL_PROFA(4);
+      }
     }
-    if (P.act2d && gl == 0) act2d_count(P, env, path0, slot0, accepted);
+    if (ENV != ENV_RMCSA && P.act2d && gl == 0) act2d_count(P, env, path0, slot0, accepted);
+    if (ENV == ENV_RMCSA && P.act2d && gl == 0) act4d_count(P, env, path0, mod, core, slot0, accepted);
     if (gl == 0) {
       if (O.write_io) {
         P.reward[env] = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
@@ -987,25 +1014,27 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
       }
     }
     if (gl < 2) {
-      const u64 w1 = (ENV == ENV_RWA) ? slog_w1_rwa(accepted, n_hops, path0, slot0) : slog_w1(accepted, n_hops, br_new, occ_s, fb_s);
+      const u64 w1 = (ENV == ENV_RWA) ? slog_w1_rwa(accepted, n_hops, path0, slot0) : slog_w1(accepted, n_hops, br_new, occ_s, fb_s, core);
       slog[(size_t)gl * (size_t)P.log_stride] = gl == 0 ? (u64)__double_as_longlong(e.now) : w1;
     }
+    if (ENV == ENV_RMCSA && accepted) prev_core = core;
     ORL_PROFA(7);
-    // episode end (rmsa_env.py:263, 310-315: the soft reset re-counts the pending service; rwa_env.py:141: RWA counts at the decision)
+    // episode end (rmsa_env.py:263, 310-315: the soft reset re-counts the pending service; rwa_env.py:141, rmcsa_env.py:294: RWA
+    // and RMCSA count at the decision)
     esp += 1;
     const bool done = (esp == P.episode_length);
     if (done) esp = (ENV == ENV_RWA) ? 0 : 1;
     if (gl == 0 && O.write_io) P.done[env] = done ? 1 : 0;
     if (done_out) *done_out = done ? 1 : 0;
     if (pushed_idx >= 0 && gl == (pushed_idx & 7)) { e.ev_time[pushed_idx] = pushed_t; e.ev_info[pushed_idx] = pushed_info; }
-    if (M.clk && gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
+    if (gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
     ORL_PROFA(8);
     {
       SoonRegs soon;
 #ifdef ORL_X_SKIP_REL
       soon.dirty = 0;
 #else
-      release_soon<ENV, W, true>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
+      release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
 #endif
       ORL_PROFA(10);
       if (sink.deferred) {

@@ -13,8 +13,8 @@
 #include "../../include/orl.h"
 #include "orl_device.h"
 
-// Deferred statistics of the persistent kernel (orl_device_split.h ctrl_d, orl_kernels.hip k_stats): the single-core families log
-// the per-env bookkeeping of a launch and replay it lane-per-env afterwards.  -DORL_PERSIST_DS=0 keeps it in the loop.
+// Deferred statistics of the persistent kernel (orl_device_split.h ctrl_d, orl_kernels.hip k_stats): the per-env bookkeeping of a launch is
+// logged and replayed lane-per-env afterwards (RMSA, DeepRMSA, RWA, RMCSA).  -DORL_PERSIST_DS=0 keeps it in the loop.
 #ifndef ORL_PERSIST_DS
 #define ORL_PERSIST_DS 1
 #endif
@@ -22,7 +22,8 @@
 #define ORL_PERSIST_SVC 1
 #endif
 static inline bool orl_persist_deferred(int env_type) {
-  return ORL_PERSIST_DS != 0 && ORL_PERSIST_SVC != 0 && (env_type == orl::ENV_RMSA || env_type == orl::ENV_DEEPRMSA || env_type == orl::ENV_RWA);
+  return ORL_PERSIST_DS != 0 && ORL_PERSIST_SVC != 0 &&
+         (env_type == orl::ENV_RMSA || env_type == orl::ENV_DEEPRMSA || env_type == orl::ENV_RWA || env_type == orl::ENV_RMCSA);
 }
 
 struct orl_topology {

@@ -323,7 +323,8 @@ __device__ __forceinline__ void persist_fill_window(const DevParams& P, i64 env0
 // bookkeeping to k_stats below.  -DORL_PERSIST_DS=0 builds keep it in the loop (ctrl_a; A/B measurements, cross-checks).
 // (the macros and orl_persist_deferred(): orl_host.h)
 template <int ENV, int LDS> struct PersistDeferred {
-  static constexpr bool value = ORL_PERSIST_DS != 0 && ORL_PERSIST_SVC != 0 && LDS != 2 && (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA || ENV == ENV_RWA);
+  static constexpr bool value = ORL_PERSIST_DS != 0 && ORL_PERSIST_SVC != 0 && LDS != 2 &&
+                                (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA || ENV == ENV_RWA || ENV == ENV_RMCSA);
 };
 
 // The bookkeeping of the steps a launch of k_persist ran, one LANE per env: counters, bit-rate sums, the running averages of
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
           g_comp = sp::div_pos(gc_a + (cmp * gc_td), now_a);
         }
         const bool accepted = (a1 & 1ull) != 0ull;
-        const int core = 0, n_hops = (int)((a1 >> 1) & 0xfffu), br_new = (int)((a1 >> 13) & 0xfffu);
+        const int core = (int)((a1 >> 58) & 31u), n_hops = (int)((a1 >> 1) & 0xfffu), br_new = (int)((a1 >> 13) & 0xfffu);
         const int d_nh = (int)(a2 & 0xfffffu), d_br = (int)((a2 >> 20) & 0xffffffu);
         if (accepted) {
           s_br += bit_rate;
@@ -396,6 +397,10 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
           }
           sa += 1;
           esa += 1;
+        }
+        if (ENV == ENV_RMCSA) {  // counted at the decision — and the bit rate requested a second time (rmcsa_env.py:294-295, 730-731)
+          sp += 1; esp += 1;
+          brq += bit_rate; ebrq += bit_rate;
         }
         if (ENV == ENV_RWA) {
           sp += 1; esp += 1;
@@ -423,8 +428,8 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
         br_idx = (ENV != ENV_RWA) ? br_new : 0;
         bit_rate = (ENV == ENV_RWA) ? 0 : ((P.bit_rate_mode == 0) ? P.br_lo + br_idx : P.bit_rates[br_idx]);
         id = (int)esp;
+        if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) { sp += 1; esp += 1; }
         if (ENV != ENV_RWA) {
-          sp += 1; esp += 1;
           brq += bit_rate;
           ebrq += bit_rate;
           if (P.bit_rate_mode == 1) P.br_hist[env * 2 * P.n_br + br_idx] += 1;
@@ -469,7 +474,7 @@ template <int ENV, int W, int LDS, bool PF>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
   constexpr bool SVC = ORL_PERSIST_SVC != 0;
-  constexpr bool DS = CP && PersistDeferred<ENV, LDS>::value;  // bookkeeping logged for k_stats (ctrl_d) instead of done in the loop
+  constexpr bool DS = PersistDeferred<ENV, LDS>::value;  // bookkeeping logged for k_stats (ctrl_d) instead of done in the loop
   const int ICL = PersistInner<ENV, W, LDS>::value ? P.persist_ic : 0;  // (the host decides: only where it costs no wavefront)
   const bool IC = ICL >= 1, OC = ICL >= 2;
   constexpr bool SR = PF;  // soon list in registers: the forms with registers to spare
@@ -504,12 +509,14 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   sp::SvcBuf svb;
   svb.q = 0.0; svb.ht = 0.0; svb.pk = 0u; svb.cnt = 0;
   int esp_c = 0;        // DS: the env's episode step counter (SC_ESP; the replay keeps the record's copy)
+  int prev_core = 0;    // DS, RMCSA: the core of the env's last accepted provision (the high half of SC_ACC)
   u64 now0_w = 0ull;    // DS: the clock the launch starts at (logged for the replay)
 #define ORL_LOAD_CARRIED()                                                                                  \
   do {                                                                                                      \
     desc = valid ? P.svc_desc[env] : 0ull;                                                                  \
     if (DS && valid && step < target) {                                                                     \
       esp_c = (int)P.scal[env * ORL_SCAL_WORDS + SC_ESP];                                                   \
+      if (ENV == ENV_RMCSA) prev_core = (int)((P.scal[env * ORL_SCAL_WORDS + SC_ACC] >> 32) & 31ull);       \
       now0_w = P.scal[env * ORL_SCAL_WORDS + SC_NOW];                                                       \
     }                                                                                                       \
     if (SVC && valid && step < target) {                                                                    \
@@ -684,8 +691,8 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       ORL_PROFA(1);
       if constexpr (DS) {
         u64* slog_s = P.slog + (size_t)(step - first_step) * ORL_SLOG_WORDS * (size_t)P.log_stride + (size_t)(valid_i ? env_i : 0);
-        desc = sp::ctrl_d<ENV, W>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, &s_deferred[step & 1], &done_i, s_list, s_list_n,
-                                  SR ? &soon_c : nullptr, s_mtab, svb, esp_c, slog_s);
+        desc = sp::ctrl_d<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
+                                      s_list, s_list_n, SR ? &soon_c : nullptr, s_mtab, svb, esp_c, prev_core, slog_s);
       } else {
         desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
                                       s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab, nullptr, SVC ? &svb : nullptr);
@@ -731,9 +738,10 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       if (ENV != ENV_RWA && env_t < P.B && (tid_t & 7) == 0) {
         int* cs = sp::wm_cs(P, M, env_t);
         int* rs = cs + 2 * P.C;
+        const int pc = (ENV == ENV_RMCSA) ? prev_core : 0;  // (this lane's group is env_t's)
         int occ, fb;
-        if (!M.cs_lds) { occ = atomicAdd(cs, 0) - atomicAdd(rs, 0); fb = atomicAdd(cs + 1, 0) - atomicAdd(rs + 1, 0); }
-        else { occ = cs[0] - rs[0]; fb = cs[1] - rs[1]; }
+        if (!M.cs_lds) { occ = atomicAdd(cs + 2 * pc, 0) - atomicAdd(rs + 2 * pc, 0); fb = atomicAdd(cs + 2 * pc + 1, 0) - atomicAdd(rs + 2 * pc + 1, 0); }
+        else { occ = cs[2 * pc] - rs[2 * pc]; fb = cs[2 * pc + 1] - rs[2 * pc + 1]; }
         P.slog[(size_t)(3 * (step - first_step) + 1) * (size_t)P.log_stride + (size_t)env_t] = sp::slog_w1(false, 0, 0, occ, fb);
       }
     }
@@ -1410,6 +1418,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     switch (VP.env_type) {
       case ENV_RMSA: hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP); break;
       case ENV_DEEPRMSA: hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP); break;
+      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, 0, st, VP); break;
       default: hipLaunchKernelGGL((k_stats<ENV_RWA>), gs, blk, 0, st, VP); break;
     }
   }
