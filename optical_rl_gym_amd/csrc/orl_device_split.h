@@ -446,10 +446,12 @@ struct Wmem {
   double* clk;   // LDS [8][2] {provision clock, step clock} of the wavefront's envs, or nullptr (row phase reads SC_NOWA / SC_NOW)
   i64 clk_env0;  // first env of the wavefront (index base of clk)
   bool cs_lds;   // the sums are in the wavefront's LDS window: plain reads; else they are read through L2 where the row phase's atomics land
+  u64* mini;     // LDS [8][ORL_MINI_STRIDE]: the record words ctrl_d works on (deferred statistics, records in global memory), or nullptr
+  i64 mini_env0; // index base of mini
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.sc_stride = ORL_SCAL_WORDS; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.sc_stride = ORL_SCAL_WORDS; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false; m.mini = nullptr; m.mini_env0 = 0;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
@@ -846,11 +848,38 @@ __device__ __forceinline__ u64 slog_w1_rwa(bool accepted, int n_hops, int path, 
 }
 __device__ __forceinline__ u64 slog_w2(int d_nh, int d_br) { return (u64)(u32)d_nh | ((u64)(u32)d_br << 20); }
 
+// The six record words ctrl_d reads and writes every step — clock, the pending service's holding time, the release queue's
+// bound, horizon, window and free-slot count — live in the wavefront's LDS window for the launch where the records themselves
+// stay in global memory (Wmem::mini: 7 words per env, the seventh for the banks): six loads and nine stores per wavefront-step
+// that went through L2 in the step's dependent chain become LDS accesses or disappear (the pending service's source /
+// destination / bit rate are the descriptor's: written to the record when the launch ends, svc_words).  The free-slot stack,
+// the flags and the statistics' words stay where the record is.  448 bytes: with them cfg2's window keeps its eight LDS pieces.
+#define ORL_MINI_WORDS 6
+#define ORL_MINI_STRIDE 7
+__device__ __forceinline__ int mini_slot(int k) {  // record slot of mini word k
+  return k == 0 ? SC_NOW : k == 1 ? SC_HT : k == 2 ? SC_NEXTREL : k == 3 ? SC_TSOON : k == 4 ? SC_EV : SC_HINT;
+}
+__device__ __forceinline__ int mini_index(int slot) {
+  return slot == SC_NOW ? 0 : slot == SC_HT ? 1 : slot == SC_NEXTREL ? 2 : slot == SC_TSOON ? 3 : slot == SC_EV ? 4 : 5;
+}
+// SC_SRC_DST and SC_BR_IDX of the pending service from its descriptor (pair base, bit-rate index): once per launch
+template <int ENV> __device__ __forceinline__ void svc_words(const DevParams& P, u64 desc, u64& sd, u64& br) {
+  const int pair = (int)(u32)desc / P.K, src = pair / P.N, dst = pair - src * P.N;
+  const int br_idx = (ENV == ENV_RWA) ? 0 : (int)((desc >> 32) & 0xffffu);
+  const int bit_rate = (ENV == ENV_RWA) ? 0 : ((P.bit_rate_mode == 0) ? P.br_lo + br_idx : P.bit_rates[br_idx]);
+  sd = pack2(src, dst);
+  br = pack2(bit_rate, br_idx);
+}
+// (MINI is a template parameter: a pointer chosen at run time between the LDS window and global memory would be a flat one)
+template <bool MINI> __device__ __forceinline__ u64* mrec(const Wmem& M, u64* rec, i64 env, int slot) {
+  if constexpr (MINI) return M.mini + (env - M.mini_env0) * ORL_MINI_STRIDE + mini_index(slot);
+  else return rec + slot;
+}
 // the control phase of the persistent kernel without the bookkeeping (services drawn ahead; CP: the single-core families'
 // compact sink, else RMCSA's entries with a core per mask).  `esp`: the env's episode step counter, kept by the caller for the
 // whole launch (done / observation need it); `prev_core` (RMCSA): the core of the env's last accepted provision — the sums
 // logged are that core's; `slog`: this step's log slot, at the env's column.  Returns the descriptor of the new pending service.
-template <int ENV, int W, bool CP>
+template <int ENV, int W, bool CP, bool MINI>
 __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
                                       const int4& av, u64 desc, typename SinkEntryOf<CP>::type* s_tab, u32* s_tally, int tw, int* s_deferred,
                                       int* done_out, unsigned short* s_list, u32* s_list_n, SoonRegs* carried, unsigned short* s_mtab,
@@ -881,8 +910,8 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     e.env = env;
     // what the loop itself needs of the record: clock, the pending service's holding time, the release queue
     {
-      const u64 w_now = rec[SC_NOW], w_ht = rec[SC_HT], w_nr = rec[SC_NEXTREL], w_ts = rec[SC_TSOON];
-      const u64 w_ev = rec[SC_EV], w_hint = rec[SC_HINT];
+      const u64 w_now = *mrec<MINI>(M, rec, env, SC_NOW), w_ht = *mrec<MINI>(M, rec, env, SC_HT), w_nr = *mrec<MINI>(M, rec, env, SC_NEXTREL);
+      const u64 w_ts = *mrec<MINI>(M, rec, env, SC_TSOON), w_ev = *mrec<MINI>(M, rec, env, SC_EV), w_hint = *mrec<MINI>(M, rec, env, SC_HINT);
       const u64 f0 = rec[SC_FREE0], f1 = rec[SC_FREE1], f2 = rec[SC_FREE2], f3 = rec[SC_FREE3];
       e.now = __longlong_as_double((i64)w_now); e.ht = __longlong_as_double((i64)w_ht);
       e.next_rel = __longlong_as_double((i64)w_nr); e.t_soon = __longlong_as_double((i64)w_ts);
@@ -1005,11 +1034,13 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
       const u64 npn = (u64)(u32)P.n_paths[src * P.N + dst];
       desc_out = (u64)(u32)((src * P.N + dst) * K) | ((u64)(u32)(ENV != ENV_RWA ? br_new : 0) << 32) | (npn << 48);
       if (gl == 0) {
-        rec[SC_NOW] = (u64)__double_as_longlong(e.now);
-        rec[SC_AT] = (u64)__double_as_longlong(e.now);
-        rec[SC_HT] = (u64)__double_as_longlong(ht);
-        rec[SC_SRC_DST] = pack2(src, dst);
-        rec[SC_BR_IDX] = pack2(bit_rate, ENV != ENV_RWA ? br_new : 0);
+        *mrec<MINI>(M, rec, env, SC_NOW) = (u64)__double_as_longlong(e.now);
+        if (!MINI) rec[SC_AT] = (u64)__double_as_longlong(e.now);  // (with the words in LDS: written back with them at the end of the launch)
+        *mrec<MINI>(M, rec, env, SC_HT) = (u64)__double_as_longlong(ht);
+        if (!MINI) {  // (MINI: the caller writes them from the descriptor when the launch ends)
+          rec[SC_SRC_DST] = pack2(src, dst);
+          rec[SC_BR_IDX] = pack2(bit_rate, ENV != ENV_RWA ? br_new : 0);
+        }
         if (O.write_io) P.svc_desc[env] = desc_out;
       }
     }
@@ -1055,10 +1086,10 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
         }
       }
       if (gl == 0) {
-        rec[SC_NEXTREL] = (u64)__double_as_longlong(e.next_rel);
-        rec[SC_TSOON] = (u64)__double_as_longlong(e.t_soon);
-        rec[SC_EV] = pack2(e.ev_hwm, e.ev_cnt);
-        rec[SC_HINT] = pack2(e.nfree, 0);
+        *mrec<MINI>(M, rec, env, SC_NEXTREL) = (u64)__double_as_longlong(e.next_rel);
+        *mrec<MINI>(M, rec, env, SC_TSOON) = (u64)__double_as_longlong(e.t_soon);
+        *mrec<MINI>(M, rec, env, SC_EV) = pack2(e.ev_hwm, e.ev_cnt);
+        *mrec<MINI>(M, rec, env, SC_HINT) = pack2(e.nfree, 0);
         if (e.flags) rec[SC_FLAGS] = rec[SC_FLAGS] | ((u64)(u32)e.flags << 32);
       }
     }

@@ -154,6 +154,8 @@ __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int au
 
 template <int W>
 __device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, const u64* rec, i64 env, int lane, int terminal);
+template <int W>
+__device__ __forceinline__ void obs8_env_w(const DevParams& P, const u64* bm, u64 sd, u64 br, i64 env, int lane, int terminal);
 
 #ifdef ORL_ALT_IMPLS
 // ---- two-kernel form of the persistent kernel's phases (cross-checks, per-kernel timing): k_step_a2 ; k_rows2 ------------
@@ -229,14 +231,15 @@ __global__ void __launch_bounds__(ORL_ROWS2_THREADS) k_rows2(DevParams P, int pa
 // row phase and counts as unfinished; at the start of its next launch it releases them in place and resumes from its own
 // step count.
 struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (all multiples of 16)
-  int tab, mtab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, total;  // (ic: inner-run cache, then the occ / fb cache)
+  int tab, mtab, tally, tw, list, clk, misc, bm, ls, cs, csw, sc, ic, mini, total;  // (ic: inner-run cache, then the occ / fb cache)
 };
 // state: 0 = only the per-step tables, 1 = + slot maps, per-core sums and env records, 2 = + link statistics, 3 = slot maps and
 // per-core sums but the env records stay in global memory (the window of the 4-wave forms: cfg2 8 832 B, 16 per CU);
 // compact: the bit-word sink of the single-core families (4 bytes per link and env + a mask table per env);
 // inner: 0 = no row caches, 1 = the per-word longest-run cache of every row, 2 = + every row's contribution to the compactness
 // sums, (occ << 16) | free blocks (4 bytes per row each)
-__host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, int inner) {
+// mini: the eight record words the deferred-statistics control phase works on, for the forms whose records stay in global memory
+__host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, int inner, bool mini = false) {
   PersistLds L;
   int o = 0;
   L.tab = o; o += (8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry)) + 15) & ~15;
@@ -255,6 +258,7 @@ __host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_wo
   L.sc = o; if (state == 1 || state == 2) o += 8 * ORL_SCAL_LDS_WORDS * 8;
   L.ic = o; if (state >= 1 && inner) o += inner * ((8 * E * 4 + 15) & ~15);
   L.ls = o; if (state == 2) o += 8 * E * 32;
+  L.mini = o; if (mini && (state == 0 || state == 3)) o += (8 * ORL_MINI_STRIDE * 8 + 15) & ~15;
   L.total = o;
   return L;
 }
@@ -334,10 +338,17 @@ template <int ENV, int LDS> struct PersistDeferred {
 // Leaves the record exactly as that code would: a pending network-compactness update stays pending (SC_ACC bit 1 with its
 // stashed factors) unless the wavefront finished the run's state (log_n bit 16), in which case it is finished here from the
 // sums the wavefront logged after its last row phase, as k_finish2 does.
+#ifndef ORL_STATS_BATCH
 #define ORL_STATS_BATCH 8  // log slots requested per round trip
+#endif
+// (one lane per env, 64 envs per wavefront: spreading a batch over four times the wavefronts — 16 busy lanes each — measured
+// slower, 143 us instead of 90 us behind a 128-step launch of 65 536 envs: the replay is bound by memory requests, and a
+// request of 16 lanes carries a quarter of the bytes)
+#define ORL_STATS_LANES 64
 template <int ENV>
 __global__ void __launch_bounds__(64) k_stats(DevParams P) {
-  const i64 env = (i64)blockIdx.x * 64 + (i64)threadIdx.x;
+  if (threadIdx.x >= ORL_STATS_LANES) return;
+  const i64 env = (i64)blockIdx.x * ORL_STATS_LANES + (i64)threadIdx.x;
   if (env >= P.B) return;
   const int ln = P.log_n[env >> 3];
   const int n = ln & 0xffff;
@@ -475,10 +486,15 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
   constexpr bool SVC = ORL_PERSIST_SVC != 0;
   constexpr bool DS = PersistDeferred<ENV, LDS>::value;  // bookkeeping logged for k_stats (ctrl_d) instead of done in the loop
+#ifdef ORL_X_NOMINI  // (A/B: the control phase's record words stay in the global records)
+  constexpr bool MINI = false;
+#else
+  constexpr bool MINI = DS && (LDS == 0 || LDS == 3);    // ... and the control phase's record words in the LDS window (sp::mrec)
+#endif
   const int ICL = PersistInner<ENV, W, LDS>::value ? P.persist_ic : 0;  // (the host decides: only where it costs no wavefront)
   const bool IC = ICL >= 1, OC = ICL >= 2;
   constexpr bool SR = PF;  // soon list in registers: the forms with registers to spare
-  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, LDS, CP, ICL);
+  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, LDS, CP, ICL, PersistDeferred<ENV, 0>::value);
   typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_mtab = (unsigned short*)(orl_lds_raw + L.mtab);
@@ -635,6 +651,13 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     // (words 0 and 2 of that row: its word 1 is where a wavefront that logs log_cap steps leaves its last sums)
     P.slog[(size_t)(3 * P.log_cap + 2 * (lane & 7)) * (size_t)P.log_stride + (size_t)env] = (lane & 7) == 0 ? now0_w : ((desc >> 32) & 0xffffull);
   }
+  if (MINI) {
+    M.mini = (u64*)(orl_lds_raw + L.mini);
+    M.mini_env0 = env0;
+    if (valid && step < target && (lane & 7) < ORL_MINI_WORDS)
+      M.mini[(lane >> 3) * ORL_MINI_STRIDE + (lane & 7)] = P.scal[env * ORL_SCAL_WORDS + sp::mini_slot(lane & 7)];
+    wave_fence();
+  }
   ORL_PROF_BEGIN();
   // (DS: a wavefront that caught up over more steps than a launch can log stops there and counts as unfinished)
   while (step < target && (!DS || step - first_step < P.log_cap)) {
@@ -691,7 +714,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       ORL_PROFA(1);
       if constexpr (DS) {
         u64* slog_s = P.slog + (size_t)(step - first_step) * ORL_SLOG_WORDS * (size_t)P.log_stride + (size_t)(valid_i ? env_i : 0);
-        desc = sp::ctrl_d<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
+        desc = sp::ctrl_d<ENV, W, CP, MINI>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
                                       s_list, s_list_n, SR ? &soon_c : nullptr, s_mtab, svb, esp_c, prev_core, slog_s);
       } else {
         desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
@@ -720,7 +743,15 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     const bool deferred = s_deferred[step & 1] != 0;  // set before the barrier in front of the row phase
     if (ENV == ENV_DEEPRMSA && (O.write_io || deferred)) {  // the observation of the new pending service, from the rows as they are now
       __syncthreads();
-      if (valid_i) obs8_env<W>(P, sp::wm_bm(P, M, env_i), sp::wm_scal(P, M, env_i), env_i, lane_i, done_i);
+      if (valid_i) {
+        if (MINI) {  // (the pending service's words are the descriptor's)
+          u64 sd, br;
+          sp::svc_words<ENV>(P, desc, sd, br);
+          obs8_env_w<W>(P, sp::wm_bm(P, M, env_i), sd, br, env_i, lane_i, done_i);
+        } else {
+          obs8_env<W>(P, sp::wm_bm(P, M, env_i), sp::wm_scal(P, M, env_i), env_i, lane_i, done_i);
+        }
+      }
     }
     step++;
     if (deferred) { left_pending = true; break; }
@@ -819,6 +850,21 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     double2* gs = (double2*)(P.lstat + env0 * 4 * P.E);
     const double2* ls = (const double2*)M.ls0;
     for (int i = lane; i < nenv * 2 * P.E; i += 64) gs[i] = ls[i];
+  }
+  if (MINI && step > first_step && valid) {
+    // the record words the control phase kept in the window go back to the records (SC_AT: the pending service arrived at the clock)
+    wave_fence();
+    const int k = lane & 7;
+    if (k < ORL_MINI_WORDS) {
+      const u64 v = M.mini[(lane >> 3) * ORL_MINI_STRIDE + k];
+      P.scal[env * ORL_SCAL_WORDS + sp::mini_slot(k)] = v;
+      if (k == 0) P.scal[env * ORL_SCAL_WORDS + SC_AT] = v;
+    } else if (k == ORL_MINI_WORDS) {
+      u64 sd, br;
+      sp::svc_words<ENV>(P, desc, sd, br);
+      P.scal[env * ORL_SCAL_WORDS + SC_SRC_DST] = sd;
+      P.scal[env * ORL_SCAL_WORDS + SC_BR_IDX] = br;
+    }
   }
   if (SVC && step > first_step && valid) {
     // what the group drew ahead and did not use: nothing when the loop ran to the launch's target; a wavefront that left early
@@ -1116,14 +1162,12 @@ __global__ void __launch_bounds__(64) k_obs(DevParams P, int with_terminal) {
 // one-wavefront-per-env k_obs above staged the whole slot map in LDS and took 26.7 us per 32 768-env launch (cfg3).
 // bm: the env's slot map (global or LDS); terminal: also write the observation as `terminal_observation` (the env just
 // finished its episode: the soft reset keeps the pending service, so the values are the same; SB3 VecEnv convention)
+// (sd, br: the record's SC_SRC_DST and SC_BR_IDX words)
 template <int W>
-__device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, const u64* rec, i64 env, int lane, int terminal) {
+__device__ __forceinline__ void obs8_env_w(const DevParams& P, const u64* bm, u64 sd, u64 br, i64 env, int lane, int terminal) {
   const int gl = lane & 7;
-  const u64* s = rec;
-  u64 t = s[SC_SRC_DST];
-  const int src = (int)(u32)t, dst = (int)(t >> 32);
-  t = s[SC_BR_IDX];
-  const int bit_rate = (int)(u32)t, br_idx = (int)(t >> 32);
+  const int src = (int)(u32)sd, dst = (int)(sd >> 32);
+  const int bit_rate = (int)(u32)br, br_idx = (int)(br >> 32);
   const int N = P.N, J = P.J, S = P.S, WD = 2 * J + 3;
   double* o = P.obs + env * P.obs_dim;
   double* o2 = terminal ? P.term_obs + env * P.obs_dim : nullptr;
@@ -1164,6 +1208,10 @@ __device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, cons
       if (sp2) { sp2[2 * J] = fn; sp2[2 * J + 1] = ft; sp2[2 * J + 2] = fr; }
     }
   }
+}
+template <int W>
+__device__ __forceinline__ void obs8_env(const DevParams& P, const u64* bm, const u64* rec, i64 env, int lane, int terminal) {
+  obs8_env_w<W>(P, bm, rec[SC_SRC_DST], rec[SC_BR_IDX], env, lane, terminal);
 }
 template <int W>
 __global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
@@ -1273,7 +1321,8 @@ static int lds_wgs_per_cu(size_t lds) {
 }
 struct PersistChoice { int form; size_t lds; int inner; };
 static size_t persist_window(const DevParams& VP, int state, int inner) {
-  return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, state, persist_compact(VP.env_type, state), inner).total;
+  return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, state, persist_compact(VP.env_type, state), inner,
+                                    orl_persist_deferred(VP.env_type)).total;
 }
 // `tuned`: the choice for a specialisation library (built without machine-level LICM and with the soon list in registers in the
 // 4-wave forms, _build.py SPEC_TUNING) — for the flags such a library is built with, and at launch when one is attached
@@ -1414,7 +1463,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   // the bookkeeping of the steps this launch ran, one lane per env (deferred statistics: ctrl_d logged it), behind the launch
   // on its stream; the forms that keep it in the loop logged nothing
   if (orl_persist_deferred(VP.env_type) && VP.slog) {
-    dim3 gs((unsigned)((VP.B + 63) / 64));
+    dim3 gs((unsigned)((VP.B + ORL_STATS_LANES - 1) / ORL_STATS_LANES));
     switch (VP.env_type) {
       case ENV_RMSA: hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP); break;
       case ENV_DEEPRMSA: hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP); break;
