@@ -188,16 +188,10 @@ __device__ __forceinline__ void sink_add(SinkT<CP>& s, const PathRec& rec, int c
   if constexpr (CP) {
     const int k = prov ? 0 : ++s.nrel;  // this mask's entry of the env's table (the caller keeps nrel <= ORL_REL_MAX)
     if ((lane & 7) == 0) s.mtab[k] = (unsigned short)((u32)s0 | ((u32)n << 9));
-    for (int h = lane & 7; h < hops; h += 8) {
-      const int link = path_rec_byte(rec, 2 + h);
-      const u32 old = atomicOr(&s.tab[link].bits, 1u << k);
-      s.cnt += (old == 0u) ? 1 : 0;
-      // a new item: the row phase finds it through the list (any order: items are independent).  A link that carries the
-      // step's provision AND a release gets a second entry (bit 15) when its first release arrives: two lanes share its row
-      // work (row_item_lane1)
-      if (s.list && old <= 1u)  // (old == 1: the provision alone so far, and this is a release — the provision is added first)
-        s.list[atomicAdd(s.list_n, 1u)] = (unsigned short)((old << 15) | (((lane >> 3) & 7) << 8) | link);
-    }
+    // (no value comes back from the atomics: the item list is made from the table afterwards, sink_compact — until round 5 every
+    // hop waited for its atomic OR to learn whether a list entry was due, and for an atomic add when one was: two dependent LDS
+    // round trips per hop of every provision and release)
+    for (int h = lane & 7; h < hops; h += 8) atomicOr(&s.tab[path_rec_byte(rec, 2 + h)].bits, 1u << k);
   } else {
     const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
     for (int h = lane & 7; h < hops; h += 8) {
@@ -412,6 +406,28 @@ __device__ __forceinline__ void svc_generate(const DevParams& P, u64* rec, u32* 
     }
     sb.cnt = got << 8;
   }
+}
+
+// The work items of a step, from the compact sink table once every mask of the step is in it: one list entry (local env << 8 |
+// link) per (env, link) word that holds a bit, and a second one (bit 15) where the word holds the step's provision AND a release
+// — two lanes share that row's work (row_item_lane1).  Any order: items are independent.  All 64 lanes call: the 8 lanes of a
+// group walk their env's links 8 at a time, ballots and prefix counts place the entries.  `tab`: the wavefront's table [8][E].
+__device__ __forceinline__ void sink_compact(const SinkEntryC* tab, int E, int lane, unsigned short* list, u32* list_n) {
+  const int gl = lane & 7, el = lane >> 3;
+  u32 n = 0u;
+  for (int l0 = 0; l0 < E; l0 += 8) {
+    const int link = l0 + gl;
+    const u32 bits = (link < E) ? tab[el * E + link].bits : 0u;
+    const bool nz = bits != 0u, sh = (bits & 1u) != 0u && (bits >> 1) != 0u;
+    const u64 bnz = __ballot(nz), bsh = __ballot(sh);
+    const u32 pos = n + __builtin_amdgcn_mbcnt_hi((u32)(bnz >> 32), __builtin_amdgcn_mbcnt_lo((u32)bnz, 0u)) +
+                    __builtin_amdgcn_mbcnt_hi((u32)(bsh >> 32), __builtin_amdgcn_mbcnt_lo((u32)bsh, 0u));
+    const unsigned short code = (unsigned short)((el << 8) | link);
+    if (nz) list[pos] = code;
+    if (sh) list[pos + 1u] = (unsigned short)(code | 0x8000u);
+    n += (u32)__popcll(bnz) + (u32)__popcll(bsh);
+  }
+  if (lane == 0) *list_n = n;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -814,6 +830,12 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
   }
   ORL_PROFA(11);
   if constexpr (!CP) { if (O.emit_queue) emit_items(P, env, sink, true, lane, P.q_a, P.q_cnt_a); }
+  if constexpr (CP) {
+    if (s_list) {
+      wave_fence();
+      sink_compact(s_tab + P.E * 8 * (int)(threadIdx.x >> 6), P.E, lane, s_list, s_list_n);
+    }
+  }
   ORL_PROFA(9);
   return desc_out;
 }
@@ -1098,6 +1120,10 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
 #pragma unroll
       for (int k = 0; k < ORL_SOON_PER_LANE; k++) { carried->t[k] = e.sr_t[k]; carried->i[k] = e.sr_i[k]; }
     }
+  }
+  if constexpr (CP) {
+    wave_fence();
+    sink_compact(s_tab + P.E * 8 * (int)(threadIdx.x >> 6), P.E, lane, s_list, s_list_n);
   }
   ORL_PROFA(11);
   return desc_out;
@@ -1466,13 +1492,7 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu), br = (int)((info >> 49) & 0x7fffu);
         const int hops = path_rec_byte(rec, 0), kk = nrel0 + r;
         sink.mtab[kk] = (unsigned short)((u32)s0 | ((u32)n << 9));
-        for (int h = 0; h < hops; h++) {
-          const int link = path_rec_byte(rec, 2 + h);
-          const u32 old = atomicOr(&sink.tab[link].bits, 1u << kk);
-          sink.cnt += (old == 0u) ? 1 : 0;
-          if (sink.list && old <= 1u)  // a new item, or the first release on a link of the step's provision (second lane)
-            sink.list[atomicAdd(sink.list_n, 1u)] = (unsigned short)((old << 15) | (((lane >> 3) & 7) << 8) | link);
-        }
+        for (int h = 0; h < hops; h++) atomicOr(&sink.tab[path_rec_byte(rec, 2 + h)].bits, 1u << kk);  // (items: sink_compact)
         // the freed slot goes onto the env's free-slot stack at the place its rank gives it (g8::free_push, one by one before)
         const int fp = nfree0 + r - 1;
         if (fp < ORL_FREE_SLOTS) fs[fp] = (unsigned short)idx;
