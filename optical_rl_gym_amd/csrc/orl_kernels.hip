@@ -254,7 +254,7 @@ __host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_wo
   L.misc = o; o += 16;
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
   L.csw = (4 * C + 3) & ~3;  // sums + their release part, ints per env
-  L.cs = o; if (state >= 1) o += 8 * L.csw * 4;
+  L.cs = o; if (state >= 1 || mini) o += 8 * L.csw * 4;  // (the global-state form of the deferred-statistics kernel keeps them in LDS too)
   L.sc = o; if (state == 1 || state == 2) o += 8 * ORL_SCAL_LDS_WORDS * 8;
   L.ic = o; if (state >= 1 && inner) o += inner * ((8 * E * 4 + 15) & ~15);
   L.ls = o; if (state == 2) o += 8 * E * 32;
@@ -634,6 +634,22 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     ORL_LOAD_CARRIED();
   }
 #undef ORL_LOAD_CARRIED
+  // Global-state form (round 5): the per-core sums of the 8 envs — 16 bytes each for a single core — in the LDS window for the
+  // launch.  In global memory every work item of the row phase updated them with L2 atomics, and the control phase read them
+  // back through L2 with four RETURNING atomics per step, a global round trip in the step's dependent chain.
+  constexpr bool CS0 = (LDS == 0) && PersistDeferred<ENV, 0>::value;
+  if constexpr (CS0) {
+    M.cs0 = (int*)(orl_lds_raw + L.cs);
+    M.cenv0 = env0;
+    M.cs_lds = true;
+    M.cs_stride = L.csw;
+    if (step < target) {
+      const int q = L.csw / 4;
+      for (int i = lane; i < nenv * q; i += 64)
+        ((orl_i32x4*)M.cs0)[i] = ((const orl_i32x4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q];
+    }
+    wave_fence();
+  }
   if (LDS == 2) {
     M.ls0 = (double*)(orl_lds_raw + L.ls);
     M.senv0 = env0;
@@ -823,6 +839,12 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
     for (int o = 32; o > 0; o >>= 1) f |= (u32)__shfl_xor((int)f, o, 64);
     if ((tid_f & 63) == 0 && f) atomicOr(n_unfinished + 1, f);
+  }
+  if (CS0 && step > first_step) {
+    wave_fence();
+    const int q = L.csw / 4;
+    for (int i = lane; i < nenv * q; i += 64)
+      ((int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q] = ((const int4*)M.cs0)[i];
   }
   if (LDS >= 1 && step > first_step) {
     __syncthreads();
