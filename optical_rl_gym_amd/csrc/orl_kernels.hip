@@ -984,7 +984,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   persist_spec_apply<SPEC>(P);
   constexpr bool CP = ENV != ENV_RMCSA;                                  // RMCSA: sink entries with a core per mask, the general row loop
   constexpr bool LINK_INFO = (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA);   // info carries network compactness and the two link averages
-  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, 0, CP, 0);
+  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, 0, CP, 0, true);
   typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_mtab = (unsigned short*)(orl_lds_raw + L.mtab);
@@ -995,11 +995,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   const int lane = lane_id(), gl = lane & 7, el = lane >> 3;
   const i64 env0 = (i64)blockIdx.x * 8, env = env0 + el;
   const bool valid = env < P.B;
+  const int nenv = (int)(P.B - env0 < 8 ? P.B - env0 : 8);
   sp::Prof prof;
   sp::Wmem M = sp::wmem_global(P);
   M.clk = (double*)(orl_lds_raw + L.clk);
   M.clk_env0 = env0;
+  // the per-core sums of the 8 envs in LDS for the launch (round 5): the control phase reads them three times — compactness before
+  // the provision, the previous step's pending update, the end of the step — and in global memory every read was a RETURNING L2
+  // atomic behind the row phase's L2 atomics: three global round trips of the step's dependent chain
+  M.cs0 = (int*)(orl_lds_raw + L.cs);
+  M.cenv0 = env0;
+  M.cs_lds = true;
+  M.cs_stride = L.csw;
+  {
+    const int q = L.csw / 4;
+    for (int i = lane; i < nenv * q; i += 64)
+      ((orl_i32x4*)M.cs0)[i] = ((const orl_i32x4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q];
+  }
   if (threadIdx.x == 0) s_deferred[0] = 0;
+  wave_fence();
   sp::CtrlOpts O;
   O.persistent = true; O.write_io = true; O.trusted = false; O.emit_queue = false; O.prefetch = true; O.auto_reset = auto_reset != 0;
   O.rank_pairs = false;
@@ -1059,6 +1073,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   __syncthreads();
   const bool deferred = s_deferred[0] != 0;
   u64* rec = P.scal + env * ORL_SCAL_WORDS;
+  // the sums right after the provision = totals minus what the step's releases added; then the release part is cleared for the
+  // next step and the sums go back to global memory (before the rare in-place releases below, which work there)
+  int occ_p = 0, fb_p = 0;
+  u64 acc_p = 0ull;
+  if (ENV != ENV_RWA) {
+    if (valid) {
+      int* cs = sp::wm_cs(P, M, env);
+      int* rs = cs + 2 * P.C;
+      acc_p = rec[SC_ACC];
+      const int c0 = (int)((acc_p >> 32) & 31);
+      occ_p = cs[2 * c0] - rs[2 * c0];
+      fb_p = cs[2 * c0 + 1] - rs[2 * c0 + 1];
+      wave_fence();
+      for (int i = gl; i < 2 * P.C; i += 8) rs[i] = 0;
+    }
+    wave_fence();
+    const int q = L.csw / 4;
+    for (int i = lane; i < nenv * q; i += 64)
+      ((int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q] = ((const int4*)M.cs0)[i];
+  }
   double mean_comp = 0.0, mean_util = 0.0;
   if constexpr (LINK_INFO) {
     if (valid && P.info_mode == 0) {
@@ -1108,8 +1142,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
     }
   }
   if (deferred) {  // (a few env-steps in 10^7) releases that did not fit the item form: in place, now
+    __threadfence();
     __syncthreads();
-    if (valid) sp::rel_serial<ENV, W>(P, env, lane);
+    if (valid) {
+      sp::rel_serial<ENV, W>(P, env, lane);
+      if (ENV != ENV_RWA) {  // (what they added to the release part of the sums is not the next step's business either)
+        int* rs_g = P.core_sums + env * P.cs_words + 2 * P.C;
+        for (int i = gl; i < 2 * P.C; i += 8) rs_g[i] = 0;
+      }
+    }
     __threadfence();
     __syncthreads();
   }
@@ -1118,19 +1159,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
       // network compactness right after the provision: the totals minus what the step's releases added (row phase: L2
       // atomics), over the occupied-slot sum at provision time; the pending average of _update_network_stats
       // (rmsa_env.py:439-462) is finished with it, as k_finish2 does at the end of a device-resident run
-      int* cs = P.core_sums + env * P.cs_words;
-      int* rs = cs + 2 * P.C;
-      const u64 acc = rec[SC_ACC];
-      const int c0 = (int)((acc >> 32) & 31);
-      const int occ = atomicAdd(cs + 2 * c0, 0) - atomicAdd(rs + 2 * c0, 0), fb = atomicAdd(cs + 2 * c0 + 1, 0) - atomicAdd(rs + 2 * c0 + 1, 0);
+      const u64 acc = acc_p;
+      const int occ = occ_p, fb = fb_p;
       const double cur = (fb > 0) ? ((double)occ / (double)ic.s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
       if (gl == 0 && ((u32)acc & 2u)) {
         const double a0 = __longlong_as_double((i64)rec[SC_GC_A]), td = __longlong_as_double((i64)rec[SC_GC_TD]);
         const double now_a = __longlong_as_double((i64)rec[SC_NOWA]);
         rec[SC_GCOMP] = (u64)__double_as_longlong((a0 + (cur * td)) / now_a);
-        rec[SC_ACC] = acc & ~2ull;
+        rec[SC_ACC] = (deferred ? rec[SC_ACC] : acc) & ~2ull;  // (the in-place releases cleared their own flag in the word)
       }
-      for (int i = gl; i < 2 * P.C; i += 8) atomicExch(rs + i, 0);
       if (LINK_INFO && gl == 0 && P.info_mode == 0) {
         double* io = P.info + env * P.n_info;
         io[4] = cur;
@@ -1499,7 +1536,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
 template <int W> void agent_step(orl_batch* b, int auto_reset, int pol) {
   const DevParams& VP = b->P;
   dim3 g((unsigned)((VP.B + 7) / 8)), blk(64);
-  const size_t lds = (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, 0, VP.env_type != ENV_RMCSA, 0).total + (size_t)8 * VP.E * 16;
+  const size_t lds = (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, 0, VP.env_type != ENV_RMCSA, 0, true).total + (size_t)8 * VP.E * 16;
   // the instantiation built for this configuration, when a specialisation library is attached (ORL_PERSIST_SPEC=0: generic)
   bool spec = b->spec_agent_launch != nullptr;
   if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = false; }
