@@ -88,10 +88,10 @@ __device__ __forceinline__ double div_by(double x, const Recip& k) {
 // the two v_div_scale, v_div_fmas' rescaling and v_div_fixup's special cases — 8 instructions instead of 14
 __device__ __forceinline__ double div_pos(double x, double d) { return div_by(x, recip_of(d)); }
 
-// Diagnostic builds (results unchanged, instruction counters read by tools/valu_ab.sh): -DORL_X_DUP_<PIECE>=1 executes an
-// idempotent piece of the control phase a second time behind an opaque barrier, so that the difference of SQ_INSTS_VALU to the
-// normal build is that piece's share.  Pieces: ENVLOAD, ENVSTORE, SINKCLR, PREINFO, GCOMP, CAND, RANK.
-#define ORL_OPAQUE_I(v) asm volatile("" : "+v"(v))
+// Diagnostic builds (-DORL_DIAG plus -DORL_X_SKIP_<PHASE>, tools/valu_ab.sh): orl_diag.h holds what such a build puts in place
+// of a phase it leaves out — their RESULTS ARE WRONG, their instruction counters are what is read.  Here and in orl_kernels.hip
+// only the hook points (ORL_DIAG_*) remain; without -DORL_DIAG every one of them is the product code.
+#include "orl_diag.h"
 using g8::EnvG;
 using g8::gballot;
 using g8::gget;
@@ -528,21 +528,12 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       sink.mtab = s_mtab + ORL_MTAB * (int)(threadIdx.x >> 3);  // (entries are written before they are read: nothing to clear)
     }
     for (int i = lane; i < 8 * P.E; i += 64) sink_entry_clear(tb[i]);
-#ifdef ORL_X_DUP_SINKCLR
-    { int l2 = lane; ORL_OPAQUE_I(l2); wave_fence(); for (int i = l2; i < 8 * P.E; i += 64) sink_entry_clear(tb[i]); }
-#endif
     wave_fence();
     sink.tab = s_tab + P.E * (int)(threadIdx.x >> 3);
   }
   if (valid) {
     EnvG e;
     g8::env_load(P, e, env, wm_scal(P, M, env));
-#ifdef ORL_X_DUP_ENVLOAD
-    { int el = (int)env; ORL_OPAQUE_I(el); EnvG e2; g8::env_load(P, e2, (i64)el, wm_scal(P, M, (i64)el));
-      double a_ = e2.now + e2.at + e2.ht + e2.g_thr + e2.g_comp + e2.g_last + e2.next_rel + e2.t_soon;
-      i64 b_ = e2.sp + e2.sa + e2.esp + e2.esa + e2.brq + e2.brp + e2.ebrq + e2.ebrp + e2.s_br + e2.s_nh + e2.src + e2.dst + e2.bit_rate + e2.br_idx + e2.id + e2.mt_pos + e2.ev_hwm + e2.ev_cnt + e2.new_service + e2.flags + e2.nfree + e2.pop_idx;
-      asm volatile("" :: "v"(a_), "v"(b_)); }
-#endif
     // the Mersenne-Twister window the next service draws from: requested now, used after the provision
     if (carried) {  // persistent kernel: the soon list stays in registers from step to step
       e.sr_on = true;
@@ -560,12 +551,6 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
 #pragma unroll
       for (int k = 1; k < ORL_SOON_PER_LANE; k++)
         if (e.sr_t[k] < pt || (e.sr_t[k] == pt && e.sr_i[k] < pi)) { pt = e.sr_t[k]; pi = e.sr_i[k]; }
-#ifdef ORL_X_DUP_PREINFO
-      { int o_ = 0; ORL_OPAQUE_I(o_); double pt2 = e.sr_t[0]; int pi2 = e.sr_i[0] + o_;
-        _Pragma("unroll") for (int k = 1; k < ORL_SOON_PER_LANE; k++)
-          if (e.sr_t[k] < pt2 || (e.sr_t[k] == pt2 && e.sr_i[k] + o_ < pi2)) { pt2 = e.sr_t[k]; pi2 = e.sr_i[k] + o_; }
-        asm volatile("" :: "v"(pt2), "v"(pi2)); }
-#endif
       // (t_soon == -inf: the list is stale — after a reset or the serial tail — and its entries mean nothing)
       if (pt <= e.now + P.pf_window && e.t_soon > -__builtin_inf() && (u32)pi < (u32)P.ev_cap) { pre_idx = pi; pre_info = e.ev_info[pi]; }
     }
@@ -597,10 +582,6 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
         const double now_a = __longlong_as_double((i64)e.scal[SC_NOWA]);
         const double cmp = (fb > 0) ? div_pos((double)occ, (double)s_nh_prov) * div_pos((double)P.E, (double)fb) : 1.0;
         e.g_comp = div_pos(a0 + (cmp * td), now_a);
-#ifdef ORL_X_DUP_GCOMP
-        { int o_ = 0; ORL_OPAQUE_I(o_); const double cmp2 = (fb > 0) ? div_pos((double)(occ + o_), (double)s_nh_prov) * div_pos((double)P.E, (double)fb) : 1.0;
-          const double g2 = div_pos(a0 + (cmp2 * td), now_a); asm volatile("" :: "v"(g2)); }
-#endif
       }
       for (int i = gl; i < 2 * P.C; i += 8) {  // this step's releases start from zero
         if (O.persistent && !M.cs_lds) atomicExch(rs + i, 0);
@@ -773,9 +754,6 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
     // the pending-release slot of this step's provision (the rebuild scan of the release detection must find it in memory)
     if (pushed_idx >= 0 && gl == (pushed_idx & 7)) { e.ev_time[pushed_idx] = pushed_t; e.ev_info[pushed_idx] = pushed_info; }
     desc_out = g8::env_store(P, e, gl, O.write_io);
-#ifdef ORL_X_DUP_ENVSTORE
-    { int g2 = gl; ORL_OPAQUE_I(g2); wave_fence(); const u64 d2 = g8::env_store(P, e, g2, O.write_io); asm volatile("" :: "v"(d2)); }
-#endif
     if (M.clk && gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
     ORL_PROFA(8);
     {
@@ -783,8 +761,8 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
       // has gone back already (so that only the handful of release-related fields stays in registers through the
       // detection); those fields are written again below when the detection changed them.
       SoonRegs soon;
-#ifdef ORL_X_SKIP_REL
-      soon.dirty = 0;
+#ifdef ORL_DIAG_INSTEAD_OF_RELEASES
+      ORL_DIAG_INSTEAD_OF_RELEASES
 #else
       release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
 #endif
@@ -1019,7 +997,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
         accepted = true;
         pushed_info = ev_pack(pidx, slot, n, core, e.bit_rate);
         pushed_t = e.now + e.ht;  // (arrival time + holding time: the clock stands at the pending service's arrival)
-#ifndef ORL_X_SKIP_PUSH
+#ifndef ORL_DIAG_NO_PUSH
         pushed_idx = g8::ev_push(P, e, lane, pushed_t, pushed_info, false);
 #endif
         sink_add(sink, prec, core, slot, n, lane, true);
@@ -1084,8 +1062,8 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     ORL_PROFA(8);
     {
       SoonRegs soon;
-#ifdef ORL_X_SKIP_REL
-      soon.dirty = 0;
+#ifdef ORL_DIAG_INSTEAD_OF_RELEASES
+      ORL_DIAG_INSTEAD_OF_RELEASES
 #else
       release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
 #endif
@@ -1316,16 +1294,6 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
       ndl += due ? 1 : 0;
       if (due && (st[k] < ct || (st[k] == ct && si[k] < ci))) { ct = st[k]; ci = si[k]; ck = k; }
     }
-#ifdef ORL_X_DUP_CAND
-    { int o_ = 0; ORL_OPAQUE_I(o_); int ndl2 = 0; double ct2 = INF; int ci2 = 0x7fffffff, ck2 = 0;
-      _Pragma("unroll") for (int k = 0; k < NS; k++) {
-        const bool due = st[k] <= e.now;
-        ndl2 += due ? 1 : 0;
-        if (due && (st[k] < ct2 || (st[k] == ct2 && si[k] + o_ < ci2))) { ct2 = st[k]; ci2 = si[k] + o_; ck2 = k; }
-      }
-      const int tot2 = g8_sum(ndl2 + o_);
-      asm volatile("" :: "v"(ct2), "v"(ci2), "v"(ck2), "v"(tot2)); }
-#endif
     const int tot = g8_sum(ndl);
     if (tot == 0) {
       if (e.now < e.t_soon) break;
@@ -1425,22 +1393,6 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
           ORL_RANK_STEP(dpp_d<ORL_DPP_XOR3>(mt), dpp_i<ORL_DPP_XOR3>(mi))
         }
 #undef ORL_RANK_STEP
-#ifdef ORL_X_DUP_RANK
-        { int o_ = 0; ORL_OPAQUE_I(o_); int r2 = 1; const int ci2 = ci + o_;
-#define ORL_RANK_STEP2(OT, OI) { const double ot_ = (OT); const int oi_ = (OI); \
-                                 r2 += (ot_ < ct || (ot_ == ct && oi_ < ci2)) ? 1 : 0; \
-                                 if (ot_ < INF && gl == (oi_ & 7)) e.ev_time[oi_] = INF; }
-          ORL_RANK_STEP2(dpp_d<ORL_DPP_XOR1>(ct), dpp_i<ORL_DPP_XOR1>(ci2))
-          ORL_RANK_STEP2(dpp_d<ORL_DPP_XOR2>(ct), dpp_i<ORL_DPP_XOR2>(ci2))
-          ORL_RANK_STEP2(dpp_d<ORL_DPP_XOR3>(ct), dpp_i<ORL_DPP_XOR3>(ci2))
-          { const double mt = dpp_d<ORL_DPP_HALF_MIRROR>(ct); const int mi = dpp_i<ORL_DPP_HALF_MIRROR>(ci2);
-            ORL_RANK_STEP2(mt, mi)
-            ORL_RANK_STEP2(dpp_d<ORL_DPP_XOR1>(mt), dpp_i<ORL_DPP_XOR1>(mi))
-            ORL_RANK_STEP2(dpp_d<ORL_DPP_XOR2>(mt), dpp_i<ORL_DPP_XOR2>(mi))
-            ORL_RANK_STEP2(dpp_d<ORL_DPP_XOR3>(mt), dpp_i<ORL_DPP_XOR3>(mi)) }
-#undef ORL_RANK_STEP2
-          asm volatile("" :: "v"(r2)); }
-#endif
         n_round = tot;
         if (ndl == 1) {
           if (gl == (ci & 7)) e.ev_time[ci] = INF;
@@ -1819,8 +1771,8 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   int max_empty = 0, edge = 0;
   u32* icw = (ENV != ENV_RWA && M.ic0) ? M.ic0 + (env - M.cenv0) * E + link : nullptr;
   if (ENV != ENV_RWA) {
-#ifdef ORL_X_SKIP_STAT  // (diagnostic: wrong results, instruction counters of the rest — tools/valu_ab.sh)
-    after.free_ = (int)(a[0] & 255ull) + 1; after.nu = 3; after.nf = 3; after.lo = 2; after.hi = 200; after.occ = 198; after.fb = 2; max_empty = 7; edge = 1;
+#ifdef ORL_DIAG_INSTEAD_OF_ROW_SUMMARY
+    ORL_DIAG_INSTEAD_OF_ROW_SUMMARY
 #else
     if (W >= 3 && W <= 5 && icw) row_stat_lane<W, (W >= 3 && W <= 5)>(a, S, after, max_empty, edge, icw, touched, !role_a);
     else row_stat_lane<W>(a, S, after, max_empty, edge);
@@ -1847,7 +1799,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   const int n_rest = __popc(rest);
   // the running averages: round 0 every lane but the B lanes, round 1 the B lanes (their link's record has been updated and
   // stored by the A lane of the same wavefront in round 0)
-#ifdef ORL_X_SKIP_ROUND2
+#ifdef ORL_DIAG_NO_SECOND_ROUND
   const u64 any_b = 0ull;
 #else
   const u64 any_b = __ballot(role_b);
@@ -1859,7 +1811,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
       double last_update = ls23.y;
       double util = ls01.x, frag = ls01.y, comp = ls23.x;
       if (stash_env && rel_f) { stash_env[2 * link] = util; stash_env[2 * link + 1] = comp; }
-#ifdef ORL_X_SKIP_F64
+#ifdef ORL_DIAG_NO_F64
       if (false) {
 #else
       if (clock > 0) {  // the first touch of the link at this clock value

@@ -486,7 +486,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
   constexpr bool SVC = ORL_PERSIST_SVC != 0;
   constexpr bool DS = PersistDeferred<ENV, LDS>::value;  // bookkeeping logged for k_stats (ctrl_d) instead of done in the loop
-#ifdef ORL_X_NOMINI  // (A/B: the control phase's record words stay in the global records)
+#ifdef ORL_DIAG_NO_MINI  // (A/B: the control phase's record words stay in the global records)
   constexpr bool MINI = false;
 #else
   constexpr bool MINI = DS && (LDS == 0 || LDS == 3);    // ... and the control phase's record words in the LDS window (sp::mrec)
@@ -685,12 +685,11 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     asm volatile("" : "+v"(env_lo), "+v"(lane_i));
     const i64 env_i = (i64)env_lo;
     const bool valid_i = env_i < P.B;
-    // (-DORL_X_SKIP_*: diagnostic builds whose RESULTS ARE WRONG — a phase is left out so that the instruction counters of the
-    // rest can be read, tools/valu_ab.sh: the difference to the full kernel is that phase's share)
+    // (ORL_DIAG_*: hook points of the diagnostic builds, orl_diag.h)
     if (SVC) {  // a group whose batch of services is used up draws the next one: as many as the launch has steps left, 8 at most
       const bool need = valid_i && sp::svc_empty(svb);
-#ifdef ORL_X_SKIP_SVC
-      if (need) { svb.q = 0.08; svb.ht = 20.0; svb.pk = 3u | (7u << 10) | (30u << 20); svb.cnt = 8 << 8; }
+#ifdef ORL_DIAG_INSTEAD_OF_SERVICES
+      ORL_DIAG_INSTEAD_OF_SERVICES
 #else
       if (__ballot(need) != 0ull) {
         const int left = target - step;
@@ -710,21 +709,11 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     int done_i = 0;
     {
       int a[4];
-#ifdef ORL_X_SKIP_SCAN
-      a[0] = 0; a[1] = (int)(desc & 63u); a[2] = 0; a[3] = 0;
+#ifdef ORL_DIAG_INSTEAD_OF_SCAN
+      ORL_DIAG_INSTEAD_OF_SCAN
 #else
       policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
                           (int)((desc >> 48) & 0xffu), lane_i, pol, (pol == POL_PATH_FF && valid_i) ? P.path_col[env_i] : 0, a);
-#endif
-#ifdef ORL_X_DUP_SCAN  // (diagnostic: the scan executed twice, second result discarded — its share of the instruction counters)
-      {
-        int a2[4];
-        int lane_j = lane_i;
-        asm volatile("" : "+v"(lane_j));
-        policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
-                            (int)((desc >> 48) & 0xffu), lane_j, pol, 0, a2);
-        asm volatile("" :: "v"(a2[0]), "v"(a2[1]));
-      }
 #endif
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
@@ -739,7 +728,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
     __syncthreads();  // sink table + item list, clocks, env records
     {
-#ifdef ORL_X_SKIP_ROWS
+#ifdef ORL_DIAG_NO_ROWS
       const int n_items = 0;
 #else
       const int n_items = (int)*s_list_n;

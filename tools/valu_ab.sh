@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dynamic instruction counts of k_persist for variants of the specialised kernel (deterministic, unlike timings: the pool's
+# Dynamic instruction counts of k_persist for variants of the specialised kernel (diagnostic variants: ORL_SPEC_EXTRA="-DORL_DIAG -DORL_X_SKIP_..." , csrc/orl_diag.h) (deterministic, unlike timings: the pool's
 # run-to-run spread is +-1.3 %).  usage (GPU box): tools/valu_ab.sh <tag> "<label>|<ENV=VAL;...>|<workload> <batch>" ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1; shift
