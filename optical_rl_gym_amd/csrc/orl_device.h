@@ -1142,9 +1142,18 @@ template <int GS> __device__ __forceinline__ u64 group_ballot(bool p, int lane) 
 template <int GS> __device__ __forceinline__ int group_max(int v) { return GS == 8 ? g8_max(v) : wave_max(v); }
 template <int GS> __device__ __forceinline__ int group_get(int v, int src, int lane) { return __shfl(v, (lane & ~(GS - 1)) + src, 64); }
 
+// What the scan's winning lane knows of the chosen path, handed to a control phase that runs in the same kernel on the same
+// state (k_persist): the slots the service needs on it and the path record — reading them again after the scan was a global
+// round trip in the step's dependent chain.  Only the first `words` 8-byte words of the record (hops, modulation and the first
+// 8 x words - 2 links) are fetched from the winning lane: the caller asks for what the longest path needs.
+struct ScanHand { int n; u64 q[4]; int words; };
+template <int GS> __device__ __forceinline__ u64 group_get64(u64 v, int src, int lane) {
+  const u32 lo = (u32)__shfl((int)(u32)v, (lane & ~(GS - 1)) + src, 64), hi = (u32)__shfl((int)(u32)(v >> 32), (lane & ~(GS - 1)) + src, 64);
+  return ((u64)hi << 32) | lo;
+}
 template <int ENV, int W, int GS>
 __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool valid, int pb, int br_idx, int np_,
-                                         int lane, int pol, int pcol, int* a) {
+                                         int lane, int pol, int pcol, int* a, ScanHand* hand = nullptr) {
   const int K = P.K, S = P.S;
   const int p = lane & (GS - 1);
   a[0] = a[1] = a[2] = a[3] = 0;
@@ -1183,10 +1192,13 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     int limit = (pol == POL_SP_FF) ? 1 : np_;
     // PathOnlyFirstFitAction: only the chosen path is scanned (a choice >= k, or beyond the pair's paths, rejects)
     const bool mine = (pol == POL_PATH_FF) ? (p == pcol && pcol < K) : true;
+    PathRec rec;
+    rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
+    int n = 1;
     if (valid && p < limit && mine) {
       int pidx = pb + p;
-      PathRec rec = path_rec_load(P, pidx);
-      int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
+      rec = path_rec_load(P, pidx);
+      n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
       Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
       Row<W> cand = row_and<W>(row_runs_ge<W>(m, n), row_mask_lo<W>(S - n));
       if (row_any<W>(cand)) { slot = row_ctz<W>(cand); if (pol == POL_LLP_FF) freec = row_popc<W>(m); }
@@ -1200,6 +1212,12 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     }
     int bslot = group_get<GS>(slot, best < 0 ? 0 : best, lane);
     if (best >= 0) { a[0] = best; a[1] = bslot; }
+    if (hand) {
+      const int src = best < 0 ? 0 : best;
+      hand->n = group_get<GS>(n, src, lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++) hand->q[i] = (i < hand->words) ? group_get64<GS>(rec.q[i], src, lane) : 0ull;
+    }
   } else if (ENV == ENV_DEEPRMSA) {
     // a[0]: the action (route * j + block 0); a[1], a[2]: what DeepRMSAEnv.step decodes it to on this very slot map — the
     // route and the first slot of its first block, (k, S) when the action rejects — so that a control phase fed by this scan
@@ -1208,10 +1226,13 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     bool has = false;
     int first = -1;
     int limit = (pol == POL_SP_FF) ? 1 : np_;
+    PathRec rec;
+    rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
+    int n = 1;
     if (valid && p < limit) {
       int pidx = pb + p;
-      PathRec rec = path_rec_load(P, pidx);
-      int n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
+      rec = path_rec_load(P, pidx);
+      n = P.nslots_path[(size_t)pidx * P.n_br + br_idx];
       Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
       const Row<W> r = row_runs_ge<W>(m, n);
       has = row_any<W>(r);
@@ -1223,14 +1244,21 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     if (pol == POL_SP_FF) a[0] = (!P.allow_rejection || fit) ? 0 : K * P.J;
     else if (fit) a[0] = route * P.J;
     if ((fit >> route) & 1ull) { a[1] = route; a[2] = rslot; }
+    if (hand) {
+      hand->n = group_get<GS>(n, route, lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++) hand->q[i] = (i < hand->words) ? group_get64<GS>(rec.q[i], route, lane) : 0ull;
+    }
   } else if (ENV == ENV_RWA) {
     a[0] = K; a[1] = S;
     int slot = -1, cap = 0, hops = 0;
     int limit = (pol == POL_SP_FF) ? 1 : np_;
     const bool mine = (pol == POL_PATH_FF) ? (p == pcol && pcol < K) : true;
+    PathRec rec;
+    rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
     if (valid && p < limit && mine) {
       int pidx = pb + p;
-      PathRec rec = path_rec_load(P, pidx);
+      rec = path_rec_load(P, pidx);
       Row<W> m = path_and_rec<W>(rec, bm, P.E, S, 0);
       hops = path_rec_byte(rec, 0);
       cap = row_popc<W>(m);
@@ -1260,6 +1288,12 @@ __device__ __forceinline__ void policy_g(const DevParams& P, const u64* bm, bool
     }
     int bslot = group_get<GS>(slot, best < 0 ? 0 : best, lane);
     if (best >= 0) { a[0] = best; a[1] = bslot; }
+    if (hand) {
+      const int src = best < 0 ? 0 : best;
+      hand->n = 1;
+#pragma unroll
+      for (int i = 0; i < 4; i++) hand->q[i] = (i < hand->words) ? group_get64<GS>(rec.q[i], src, lane) : 0ull;
+    }
   } else if (ENV == ENV_RMCSA) {
     // lanes = (path, core) pairs in the reference's loop order: path-major, then core (rmcsa_env.py:889-906)
     a[0] = K; a[1] = P.M; a[2] = P.C; a[3] = S;

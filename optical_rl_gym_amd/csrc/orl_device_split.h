@@ -883,7 +883,10 @@ template <int ENV, int W, bool CP, bool MINI>
 __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
                                       const int4& av, u64 desc, typename SinkEntryOf<CP>::type* s_tab, u32* s_tally, int tw, int* s_deferred,
                                       int* done_out, unsigned short* s_list, u32* s_list_n, SoonRegs* carried, unsigned short* s_mtab,
-                                      SvcBuf& svc, int& esp, int& prev_core, u64* slog) {
+                                      SvcBuf& svc, int& esp, int& prev_core, u64* slog, const ScanHand* hand = nullptr, int pop_pre = -2) {
+  // `hand`: the chosen path's slot count and record from the scan's winning lane (single-core families); `pop_pre`: the top entry
+  // of the env's free-slot stack (-1: empty), requested by the caller before the scan (-2: not given) — with both, nothing the
+  // decision needs is fetched from global memory behind the scan
   const int K = P.K, S = P.S, gl = lane & 7;
   u64 desc_out = 0ull;
   SinkT<CP> sink;
@@ -912,7 +915,6 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     {
       const u64 w_now = *mrec<MINI>(M, rec, env, SC_NOW), w_ht = *mrec<MINI>(M, rec, env, SC_HT), w_nr = *mrec<MINI>(M, rec, env, SC_NEXTREL);
       const u64 w_ts = *mrec<MINI>(M, rec, env, SC_TSOON), w_ev = *mrec<MINI>(M, rec, env, SC_EV), w_hint = *mrec<MINI>(M, rec, env, SC_HINT);
-      const u64 f0 = rec[SC_FREE0], f1 = rec[SC_FREE1], f2 = rec[SC_FREE2], f3 = rec[SC_FREE3];
       e.now = __longlong_as_double((i64)w_now); e.ht = __longlong_as_double((i64)w_ht);
       e.next_rel = __longlong_as_double((i64)w_nr); e.t_soon = __longlong_as_double((i64)w_ts);
       // (the pending service's bit rate from its descriptor: no load)
@@ -920,9 +922,14 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
       e.bit_rate = (ENV == ENV_RWA) ? 0 : ((P.bit_rate_mode == 0) ? P.br_lo + e.br_idx : P.bit_rates[e.br_idx]);
       e.ev_hwm = (int)(u32)w_ev; e.ev_cnt = (int)(w_ev >> 32);
       e.nfree = (int)(u32)w_hint;
-      const int top = e.nfree - 1;
-      const u64 w = (top >> 2) == 0 ? f0 : (top >> 2) == 1 ? f1 : (top >> 2) == 2 ? f2 : f3;
-      e.pop_idx = (top >= 0) ? (int)((w >> (16 * (top & 3))) & 0xffffu) : -1;
+      if (pop_pre != -2) {
+        e.pop_idx = pop_pre;
+      } else {
+        const u64 f0 = rec[SC_FREE0], f1 = rec[SC_FREE1], f2 = rec[SC_FREE2], f3 = rec[SC_FREE3];
+        const int top = e.nfree - 1;
+        const u64 w = (top >> 2) == 0 ? f0 : (top >> 2) == 1 ? f1 : (top >> 2) == 2 ? f2 : f3;
+        e.pop_idx = (top >= 0) ? (int)((w >> (16 * (top & 3))) & 0xffffu) : -1;
+      }
     }
     e.flags = 0;
     e.s_br = 0; e.s_nh = 0;  // (here: minus what this step's releases take off the sums)
@@ -982,9 +989,15 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     const bool in_range = (ENV == ENV_RMCSA) ? (path < K && mod < P.M && core < P.C && slot < S) : (path < K && slot < S);
     if (in_range && path < np_) {
       const int pidx = pb + path;
-      if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
-      else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
-      const PathRec prec = path_rec_load(P, pidx);
+      PathRec prec;
+      if (ENV != ENV_RMCSA && hand) {  // (the scan's winning lane had both)
+        n = hand->n;
+        prec.q[0] = hand->q[0]; prec.q[1] = hand->q[1]; prec.q[2] = hand->q[2]; prec.q[3] = hand->q[3];
+      } else {
+        if (ENV == ENV_RMCSA) n = P.nslots[e.br_idx * P.M + mod];
+        else if (ENV != ENV_RWA) n = P.nslots_path[(size_t)pidx * P.n_br + e.br_idx];
+        prec = path_rec_load(P, pidx);
+      }
       bool ok = true;
       if (ENV == ENV_RMCSA) {  // _crosstalk_is_acceptable: the two reach limits (rmcsa_env.py:341-384), as ctrl_a
         const double len = P.path_length[pidx];

@@ -709,18 +709,37 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     int done_i = 0;
     {
       int a[4];
+      // (deferred-statistics control phase: the top of the env's free-slot stack is requested before the scan and the chosen
+      // path's slot count and record come out of it — nothing the decision needs is fetched behind the scan)
+      ScanHand hand;
+      hand.n = 1; hand.q[0] = hand.q[1] = hand.q[2] = hand.q[3] = 0ull;
+      hand.words = (P.H + 2 + 7) >> 3;
 #ifdef ORL_DIAG_INSTEAD_OF_SCAN
+      constexpr bool HAND = false;
+      int pop_pre = -2;
       ORL_DIAG_INSTEAD_OF_SCAN
 #else
+      constexpr bool HAND = DS && ENV != ENV_RMCSA;
+      int pop_pre = -2;
+      if (HAND) {
+        pop_pre = -1;
+        if (valid_i) {
+          u64* rec_i = sp::wm_scal(P, M, env_i);
+          const int nfree = (int)(u32)*sp::mrec<MINI>(M, rec_i, env_i, SC_HINT);
+          if (nfree > 0) pop_pre = (int)((const unsigned short*)(rec_i + SC_FREE0))[nfree - 1];
+        }
+      }
       policy_g<ENV, W, 8>(P, sp::wm_bm(P, M, valid_i ? env_i : M.env0), valid_i, (int)(u32)desc, (int)((desc >> 32) & 0xffffu),
-                          (int)((desc >> 48) & 0xffu), lane_i, pol, (pol == POL_PATH_FF && valid_i) ? P.path_col[env_i] : 0, a);
+                          (int)((desc >> 48) & 0xffu), lane_i, pol, (pol == POL_PATH_FF && valid_i) ? P.path_col[env_i] : 0, a,
+                          HAND ? &hand : nullptr);
 #endif
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
       if constexpr (DS) {
         u64* slog_s = P.slog + (size_t)(step - first_step) * ORL_SLOG_WORDS * (size_t)P.log_stride + (size_t)(valid_i ? env_i : 0);
         desc = sp::ctrl_d<ENV, W, CP, MINI>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
-                                      s_list, s_list_n, SR ? &soon_c : nullptr, s_mtab, svb, esp_c, prev_core, slog_s);
+                                      s_list, s_list_n, SR ? &soon_c : nullptr, s_mtab, svb, esp_c, prev_core, slog_s,
+                                      HAND ? &hand : nullptr, pop_pre);
       } else {
         desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
                                       s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab, nullptr, SVC ? &svb : nullptr);
