@@ -3,8 +3,9 @@
 envs per MI355X, on-device KSP-FF policy (BASELINE.json `metric`; SURVEY.md §8d cfg2 at B = 65 536).
 
 One "step" = one batched policy + env.step() over the whole batch, entirely on the device: the persistent kernel
-k_persist — one wavefront owns 8 envs for the whole run and alternates a control phase (slot scan + all per-env control +
-release detection -> work items) with a row phase (one lane per touched link row); K steps are ceil(K/128) launches.
+k_persist — one wavefront owns 8 envs for the whole run and alternates a control phase (slot scan + per-env control +
+release detection -> work items) with a row phase (one lane per touched link row); K steps are ceil(K/128) launches, each
+followed by k_stats, which replays the launch's per-env bookkeeping (counters, running averages) one lane per env.
 Inputs are resident in HBM before the timed region.
 
 What is timed, however the script is invoked:
@@ -293,7 +294,9 @@ def main():
     # WRITE_SIZE; TCC_EA0_RDREQ + WRREQ): used only when they were collected for exactly this build, workload, batch and
     # state — otherwise null
     traffic = req_roof = valu = traffic_gbs = traffic_scaled = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_%d.json" % (args.workload, B))  # (a batch other than the BASELINE size)
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         # counters taken over launches of the SAME length as the timed ones where there are such (cfg2: ten 20-step launches for
@@ -425,18 +428,29 @@ def main():
                     note="host-driven step(): 16 B/env of actions in, reward+done+info (%d B/env) out per step over PCIe, "
                          "synchronous, uniform-random actions (most are rejected); k_agent (RMSA / DeepRMSA from 2 048 envs) "
                          "or the one-wavefront-per-env kernel" % (8 + 1 + 8 * env.n_info))
-        # the loop an agent on the same GPU drives: actions stay in device memory, nothing is fetched, one sync at the end
+        # the loop an agent on the same GPU drives: actions stay in device memory, nothing is fetched, one sync at the end.
+        # The representative figure applies FRESH actions every step — here a heuristic's, with its slot scan as the first phase of
+        # the step kernel (orl_batch_policy_step: one launch per step); re-issuing one stale action set (most of it rejected from
+        # the second step on: no provision to apply) is the step kernel's floor, reported beside it.
         n_loop = 100
-        env.policy(policy, fetch=False)
-        env.sync()
-        l0 = time.perf_counter()
-        for _ in range(n_loop):
-            env.step(None, auto_reset=True, fetch=False)
-        env.sync()
-        ldt = time.perf_counter() - l0
+
+        def loop(call):
+            env.policy(policy, fetch=False)
+            env.sync()
+            l0 = time.perf_counter()
+            for _ in range(n_loop):
+                call()
+            env.sync()
+            return time.perf_counter() - l0
+
+        ldt = loop(lambda: env.policy_step(policy, auto_reset=True, fetch=False))
+        sdt = loop(lambda: env.step(None, auto_reset=True, fetch=False))
         host["agent_loop_zero_copy"] = dict(value=round(B * n_loop / ldt, 1), unit="env-steps/s", us_per_step=round(ldt / n_loop * 1e6, 2),
-                                            note="step(None, auto_reset=True, fetch=False) x %d on device-resident actions, one launch of "
-                                                 "k_agent per step, info / reward / done written in place" % n_loop)
+                                            note="policy_step(%s, auto_reset=True, fetch=False) x %d: fresh actions every step from the "
+                                                 "on-device heuristic, scan + step in ONE launch of k_agent per step, info / reward / done "
+                                                 "written in place" % (policy, n_loop),
+                                            stale_actions_floor=dict(value=round(B * n_loop / sdt, 1), us_per_step=round(sdt / n_loop * 1e6, 2),
+                                                                     note="step(None, ...) x %d on one stale action set (mostly rejected)" % n_loop))
 
     if rank == 0:
         total_envs = sum(p["envs"] for p in per_rank)
@@ -462,7 +476,9 @@ def main():
                                       "%d envs/GPU" % B if args.scaling == "weak" else "%d envs over %d GPU(s)" % (total_envs, len(per_rank)), policy),
                        "envs_per_gpu": B if args.scaling == "weak" else [p["envs"] for p in per_rank],
                        "envs_total": total_envs,
-                       "step_kernels": ["%s (%d launches per %d-step block)" % (kernel, launches, args.steps)]},
+                       "step_kernels": ["%s (%d launches per %d-step block)" % (kernel, launches, args.steps)] +
+                                       (["k_stats (the launch's deferred bookkeeping, one lane per env, behind every k_persist launch)"]
+                                        if persistent else [])},
             "timing": {"blocks": len(blocks), "timed_region_s": round(timed, 4), "block_s_median": round(elapsed, 6),
                        "block_s_min": round(walls[0], 6), "block_s_max": round(walls[-1], 6),
                        "state_preparation_steps": prep_steps},

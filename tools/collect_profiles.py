@@ -161,8 +161,10 @@ def launches_report(name, trace_csv, bench_log):
 
 
 src_hash = _build.source_hash(with_compiler=False)
-for wl in ("cfg2", "cfg1", "cfg3", "cfg4", "cfg5"):
-    log = os.path.join(O, "tr_f_%s.log" % wl)
+# (workload, suffix of the pass directories, output file): the BASELINE sizes, and the literal 4 096-env batches of cfg1-3
+for wl, sfx, outname in [(w, "", "traffic_%s.json" % w) for w in ("cfg2", "cfg1", "cfg3", "cfg4", "cfg5")] + \
+                        [(w, "_b4096", "traffic_%s_4096.json" % w) for w in ("cfg2", "cfg1", "cfg3")]:
+    log = os.path.join(O, "tr_f_%s%s.log" % (wl, sfx))
     if not os.path.exists(log):
         continue
     lines = [ln for ln in open(log) if ln.startswith("{")]
@@ -170,27 +172,27 @@ for wl in ("cfg2", "cfg1", "cfg3", "cfg4", "cfg5"):
         print(wl, "counter pass failed:", open(log).read()[-300:])
         continue
     run = json.loads(lines[-1])  # what tools/pmc_traffic.py printed
-    factor = run["calibration_bytes"] / (mean_last("tr_f_" + wl, "k_calib", "FETCH_SIZE", 4) * 1024)
+    factor = run["calibration_bytes"] / (mean_last("tr_f_" + wl + sfx, "k_calib", "FETCH_SIZE", 4) * 1024)
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum / SQ_* (separate passes over "
                    "tools/pmc_traffic.py): mean of the measured launches; FETCH_SIZE (KiB) x the factor measured on k_calib_read's known "
                    "byte count (MI355X_MICROARCH.md: 2.0 for wide coalesced reads); WRITE_SIZE as is",
            "workload": run["workload"], "batch": run["batch"], "mean_active_services": run["mean_active_services"],
            "source_hash": src_hash, "tag": tag, "fetch_calibration_factor": round(factor, 4), "kernels": {}}
-    out["kernels"]["k_persist"] = kernel_record("_" + wl, "k_persist<", run["measured_launches"], run["steps_per_launch"], factor)
+    out["kernels"]["k_persist"] = kernel_record("_" + wl + sfx, "k_persist<", run["measured_launches"], run["steps_per_launch"], factor)
     try:
-        out["kernels"]["k_policy"] = kernel_record("_" + wl, "void k_policy<", 20, None, factor)
+        out["kernels"]["k_policy"] = kernel_record("_" + wl + sfx, "void k_policy<", 20, None, factor)
     except (FileNotFoundError, KeyError):
         pass
     log20 = os.path.join(O, "tr_f_%s_s20.log" % wl)
-    if os.path.exists(log20):
+    if os.path.exists(log20) and not sfx:
         l20 = [ln for ln in open(log20) if ln.startswith("{")]
         if l20:
             r20 = json.loads(l20[-1])
             out["kernels"]["k_persist_steps%d" % r20["steps_per_launch"]] = kernel_record(
                 "_%s_s20" % wl, "k_persist<", r20["measured_launches"], r20["steps_per_launch"], factor)
-    json.dump(out, open(os.path.join(P, "traffic_%s.json" % wl), "w"), indent=1)
+    json.dump(out, open(os.path.join(P, outname), "w"), indent=1)
     k = out["kernels"]["k_persist"]
-    print(wl, "HBM bytes/step", k.get("hbm_bytes_per_step"), "VALU/wavefront-step",
+    print(wl + sfx, "HBM bytes/step", k.get("hbm_bytes_per_step"), "VALU/wavefront-step",
           round(k.get("sq_per_launch", {}).get("SQ_INSTS_VALU", 0) / k["steps_per_launch"] / ((run["batch"] + 7) // 8), 1))
 
 # kernel traces of the bench commands

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): bench lines, rocprofv3 kernel traces of the same commands, counter passes — for every
 # BASELINE configuration.   usage: tools/run_profiles.sh <tag> [quick]      (quick: cfg2 only)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r4}
+TAG=${1:-r5}
 QUICK=$2
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -46,6 +46,7 @@ done
 for cfg in "cfg1 4096" "cfg2 4096" "cfg3 4096"; do
   set -- $cfg
   python3 $R/bench.py --workload $1 --batch $2 --steps 200 --no-cpu-baseline --min-timed-s 1 > $O/bench_$1_$2.json 2> $O/bench_$1_$2.err
+  counters $1 $2 128 _b4096   # (BASELINE's literal batch: the lines of tools/bench_lines.sh then carry traffic / valu too)
 done
 python3 -c "
 import json, glob
