@@ -118,10 +118,12 @@ def launches_report(name, trace_csv, bench_log):
     launches, steps = int(m.group(1)), int(m.group(2))
     blocks = bench["timing"]["blocks"]
     # a run of more than one launch on a batch of more than one generation is two half batches on two streams (orl_batch_run)
-    grids = sorted({int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0)) for r in pers})
-    full = max(grids)
+    # (Grid_Size_X counts work-items: a launch over the whole batch has ceil(B / 8) wavefronts of 64)
+    envs = bench["config"].get("envs_per_gpu")
+    envs = envs[0] if isinstance(envs, list) else envs
+    full = ((int(envs) + 7) // 8) * 64
     tail = pers[-1]
-    parts = 2 if (launches > 1 and int(tail.get("Grid_Size_X", tail.get("Grid_Size", full))) < full) else 1
+    parts = 2 if int(tail.get("Grid_Size_X", full)) < full else 1
     per_block = launches * parts
     timed = pers[-blocks * per_block:] if blocks * per_block <= len(pers) else []
     if not timed:
