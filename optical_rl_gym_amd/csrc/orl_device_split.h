@@ -462,12 +462,14 @@ struct Wmem {
   double* clk;   // LDS [8][2] {provision clock, step clock} of the wavefront's envs, or nullptr (row phase reads SC_NOWA / SC_NOW)
   i64 clk_env0;  // first env of the wavefront (index base of clk)
   bool cs_lds;   // the sums are in the wavefront's LDS window: plain reads; else they are read through L2 where the row phase's atomics land
+  u32* ocg;      // GLOBAL [8][E]: the same words as oc0 where they do not fit the LDS window (the wavefront's level-2 area of
+                 // DevParams::row_cache, live during the launch), or nullptr; indexed with cenv0
   u64* mini;     // LDS [8][ORL_MINI_STRIDE]: the record words ctrl_d works on (deferred statistics, records in global memory), or nullptr
   i64 mini_env0; // index base of mini
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.sc_stride = ORL_SCAL_WORDS; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false; m.mini = nullptr; m.mini_env0 = 0;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.sc_stride = ORL_SCAL_WORDS; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false; m.ocg = nullptr; m.mini = nullptr; m.mini_env0 = 0;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
@@ -1738,6 +1740,11 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   // lane reads it in round 1 below, after the A lane's store
   double2 ls01 = make_double2(0.0, 0.0), ls23 = make_double2(0.0, 0.0);
   if (early_ls && !role_b) { ls01 = *(const double2*)ls; ls23 = *(const double2*)(ls + 2); }
+  // the row's contribution to the compactness sums as the previous step left it, where the launch keeps those words in GLOBAL
+  // memory (Wmem::ocg: no room in the LDS window): requested with the link's record; a B lane needs none (see the sums below)
+  u32* ocg = (ENV != ENV_RWA && !M.oc0 && M.ocg) ? M.ocg + (env - M.cenv0) * E + link : nullptr;
+  u32 ocg_v = 0u;
+  if (ocg && !role_b) ocg_v = *ocg;
   u64 a[W];
 #pragma unroll
   for (int w = 0; w < W; w++) a[w] = row[w];
@@ -1764,7 +1771,8 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   u32* ocw = (ENV != ENV_RWA && M.oc0) ? M.oc0 + (env - M.cenv0) * E + link : nullptr;
   int occ0 = 0, fb0 = 0;
   if (ENV != ENV_RWA) {
-    if (!ocw) row_occ_fb<W>(a, S, occ0, fb0);
+    if (ocg) { }  // (unpacked where it is used, behind the summary: touching it here would wait for the load in front of it)
+    else if (!ocw) row_occ_fb<W>(a, S, occ0, fb0);
     else if (!role_b) { const u32 c = *ocw; occ0 = (int)(c >> 16); fb0 = (int)(c & 0xffffu); }
   }
   const bool rel_f = first != 0;  // the evaluated mask is a release
@@ -1873,19 +1881,29 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
     }
   }
   if (ENV != ENV_RWA) {
-    // this lane's part of the row's contribution to the compactness sums; releases also go into rel_sums
-    const int d_occ = occL - occ0, d_fb = fbL - fb0;
-    if (d_occ) atomicAdd(cs, d_occ);
-    if (d_fb) atomicAdd(cs + 1, d_fb);
-    if (rel_f) {
-      if (d_occ) atomicAdd(rs, d_occ);
-      if (d_fb) atomicAdd(rs + 1, d_fb);
+    if (ocg) { occ0 = (int)(ocg_v >> 16); fb0 = (int)(ocg_v & 0xffffu); }
+    if (ocg && shared) {
+      // the two lanes of a link that carries provision and release, without handing the after-provision value from A to B: the
+      // sums are integer atomics, so A takes the row's old contribution out of the totals and its after-provision one out of
+      // the release part, and B puts the final one into both — totals += final - before, release part += final - after provision
+      if (role_a) { atomicAdd(cs, -occ0); atomicAdd(cs + 1, -fb0); atomicAdd(rs, -after.occ); atomicAdd(rs + 1, -after.fb); }
+      else { atomicAdd(cs, occL); atomicAdd(cs + 1, fbL); atomicAdd(rs, occL); atomicAdd(rs + 1, fbL); }
+    } else {
+      // this lane's part of the row's contribution to the compactness sums; releases also go into rel_sums
+      const int d_occ = occL - occ0, d_fb = fbL - fb0;
+      if (d_occ) atomicAdd(cs, d_occ);
+      if (d_fb) atomicAdd(cs + 1, d_fb);
+      if (rel_f) {
+        if (d_occ) atomicAdd(rs, d_occ);
+        if (d_fb) atomicAdd(rs + 1, d_fb);
+      }
     }
   }
   if (!role_a) {
 #pragma unroll
     for (int w = 0; w < W; w++) row[w] = a[w];
     if (ocw) *ocw = ((u32)occL << 16) | (u32)fbL;
+    if (ocg) *ocg = ((u32)occL << 16) | (u32)fbL;
   }
   ORL_PROFR(7);
 }

@@ -13,6 +13,7 @@
 //   -DORL_DIAG -DORL_X_SKIP_ROUND2  no second round for the B lanes of the row phase
 //   -DORL_DIAG -DORL_X_SKIP_F64     no float64 running averages
 //   -DORL_DIAG -DORL_X_NOMINI       (correct results) the control phase's record words stay in the global records
+//   -DORL_DIAG -DORL_X_NOOCG        (correct results) cache level 1 recomputes a row's contribution to the compactness sums
 #pragma once
 #ifdef ORL_DIAG
 #ifdef ORL_X_SKIP_SVC
@@ -43,5 +44,8 @@
 #endif
 #ifdef ORL_X_NOMINI
 #define ORL_DIAG_NO_MINI 1
+#endif
+#ifdef ORL_X_NOOCG
+#define ORL_DIAG_NO_OCG 1
 #endif
 #endif  // ORL_DIAG

@@ -604,19 +604,28 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
           for (int i = lane; i < nenv * P.E; i += 64) M.ic0[i] = sp::row_inner_cache<W>(M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W);
         }
       }
-      if (OC) {  // what every row contributes to the compactness sums, as the launch finds it (kept exact by the row phase)
-        M.oc0 = (u32*)(orl_lds_raw + L.ic + ((8 * P.E * 4 + 15) & ~15));
-        if (step < target && !cache_stored)
-          for (int i = lane; i < nenv * P.E; i += 64) {
-            const u64* row = M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W;
-            u64 a[W];
+      // what every row contributes to the compactness sums, as the launch finds it (kept exact by the row phase): in the LDS
+      // window at cache level 2; at level 1 — no room for them there — the wavefront's level-2 words of DevParams::row_cache are
+      // used in place, in global memory (round 5: a load and a store of 4 bytes per work item beside its link record instead of
+      // ~90 instructions recomputing the value from the five words of the row)
+#ifdef ORL_DIAG_NO_OCG
+      const bool OCG = false;
+#else
+      const bool OCG = !OC && P.row_cache_key != 0;
+#endif
+      if (OC) M.oc0 = (u32*)(orl_lds_raw + L.ic + ((8 * P.E * 4 + 15) & ~15));
+      if (OCG) M.ocg = P.row_cache + (size_t)blockIdx.x * 2 * P.row_cache_words + P.row_cache_words;
+      if ((OC || OCG) && step < target && !cache_stored)
+        for (int i = lane; i < nenv * P.E; i += 64) {
+          const u64* row = M.bm0 + (size_t)(i / P.E) * P.bm_words + (size_t)(i % P.E) * W;
+          u64 a[W];
 #pragma unroll
-            for (int w = 0; w < W; w++) a[w] = row[w];
-            int occ, fb;
-            sp::row_occ_fb<W>(a, P.S, occ, fb);
-            M.oc0[i] = ((u32)occ << 16) | (u32)fb;
-          }
-      }
+          for (int w = 0; w < W; w++) a[w] = row[w];
+          int occ, fb;
+          sp::row_occ_fb<W>(a, P.S, occ, fb);
+          if (OC) M.oc0[i] = ((u32)occ << 16) | (u32)fb;
+          else M.ocg[i] = ((u32)occ << 16) | (u32)fb;
+        }
     }
   }
   if (LDS == 0) {

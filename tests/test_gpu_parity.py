@@ -512,6 +512,10 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
         pick = (0, batch // 2, batch - 1)
         out[v] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy()] + \
                  [env.slots(i).copy() for i in pick] + [env.link_stats(i).copy() for i in pick] + [env.net_stats(i).copy() for i in pick]
+        # one host step on top: its info holds what no read-back shows — the per-rate request / provision histograms of the
+        # discrete mode, RWA's action marginals — as the device loop (and the replay of its statistics log) left them
+        _, r_h, d_h, i_h = env.step(env.policy(policy).copy(), auto_reset=True)
+        out[v] += [np.array(r_h), np.array(d_h), np.array(i_h)]
         env.close()
     chk = _exact(fam + "/" + topo)
     for v in IMPLS[1:]:
