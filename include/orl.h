@@ -337,10 +337,14 @@ int orl_debug_stream_peak(int device, int64_t bytes, int reps, double* read_gbs,
  * use from csrc/orl_kernels.hip with the -D flags orl_batch_spec_flags() writes (hipcc --offload-arch=gfx950 -O3 -std=c++17
  * -ffp-contract=off -fPIC <flags> -shared; optical_rl_gym_amd/_build.py build_spec caches it under build/spec/ keyed by the
  * flags and the source hash) and attached with orl_batch_load_spec(), which compares every field with the batch and refuses
- * a mismatch.  orl_spec_flags_for() gives the same flags without a device (pre-building).  Both return the string length, 0
- * when the configuration does not run the persistent kernel.  ORL_PERSIST_SPEC=0 in the environment keeps the generic kernel. */
+ * a mismatch.  orl_spec_flags_for() gives the same flags without a device (pre-building) for a large batch,
+ * orl_spec_flags_for_batch() for a batch of n_envs: the kernel form is part of the flags, and batches of at most 8 192 envs of the
+ * single-core families take the two-wavefront form (a control and a row wavefront per 8 envs).  All return the
+ * string length, 0 when the configuration does not run the persistent kernel.  ORL_PERSIST_SPEC=0 in the environment keeps the
+ * generic kernel. */
 int orl_batch_spec_flags(orl_batch* b, char* buf, int capacity);
 int orl_spec_flags_for(const orl_env_config* cfg, const orl_topology_desc* topo, char* buf, int capacity);
+int orl_spec_flags_for_batch(const orl_env_config* cfg, const orl_topology_desc* topo, int64_t n_envs, char* buf, int capacity);
 int orl_batch_load_spec(orl_batch* b, const char* so_path);
 /* Whether the last orl_batch_run used the attached specialisation (1) or the generic persistent kernel (0); -1 = another
  * step form. */

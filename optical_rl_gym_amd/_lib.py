@@ -98,6 +98,7 @@ EXPORTS = {
     "orl_batch_get_net_stats_all": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orl_batch_spec_flags": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "orl_spec_flags_for": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(TopologyDesc), C.c_char_p, C.c_int]),
+    "orl_spec_flags_for_batch": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(TopologyDesc), C.c_int64, C.c_char_p, C.c_int]),
     "orl_batch_load_spec": (C.c_int, [C.c_void_p, C.c_char_p]),
     "orl_multi_create": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(TopologyDesc), C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                    C.POINTER(C.c_void_p)]),

@@ -1621,11 +1621,11 @@ static int spec_flags(const DevParams& P, int wt, char* buf, int capacity) {
   int lds = 0, waves = 0;
   persist_form_of(P, wt, &lds, &waves);
   const int n = snprintf(buf, (size_t)capacity,
-                         "-DORL_SPEC_ONLY -DORL_W=%d -DORL_SPEC_ENV=%d -DORL_SPEC_LDS=%d -DORL_SPEC_WAVES=%d -DORL_SPEC_N=%d -DORL_SPEC_E=%d "
+                         "-DORL_SPEC_ONLY -DORL_W=%d -DORL_SPEC_ENV=%d -DORL_SPEC_LDS=%d -DORL_SPEC_WAVES=%d -DORL_SPEC_RW=%d -DORL_SPEC_N=%d -DORL_SPEC_E=%d "
                          "-DORL_SPEC_K=%d -DORL_SPEC_H=%d -DORL_SPEC_M=%d -DORL_SPEC_S=%d -DORL_SPEC_C=%d -DORL_SPEC_J=%d -DORL_SPEC_BRMODE=%d "
                          "-DORL_SPEC_BRLO=%d -DORL_SPEC_NBR=%d -DORL_SPEC_RANDN=%d -DORL_SPEC_RANDBITS=%d -DORL_SPEC_EVCAP=%d "
                          "-DORL_SPEC_BMWORDS=%d -DORL_SPEC_CSWORDS=%d -DORL_SPEC_OBSDIM=%d -DORL_SPEC_NINFO=%d",
-                         wt, P.env_type, lds, waves, P.N, P.E, P.K, P.H, P.M, P.S, P.C, P.J, P.bit_rate_mode, P.br_lo, P.n_br, P.rand_n,
+                         wt, P.env_type, lds, waves & 15, waves >> 4, P.N, P.E, P.K, P.H, P.M, P.S, P.C, P.J, P.bit_rate_mode, P.br_lo, P.n_br, P.rand_n,
                          P.rand_bits, P.ev_cap, P.bm_words, P.cs_words, P.obs_dim, P.n_info);
   return (n > 0 && n < capacity) ? n : 0;
 }
@@ -1636,14 +1636,17 @@ extern "C" int orl_batch_spec_flags(orl_batch* b, char* buf, int capacity) try {
   return spec_flags(b->P, b->wt, buf, capacity);
 }
 catch (...) { return 0; }
-extern "C" int orl_spec_flags_for(const orl_env_config* cfg, const orl_topology_desc* topo, char* buf, int capacity) try {
-  if (!cfg || !topo || !buf || capacity < 1) return 0;
+extern "C" int orl_spec_flags_for(const orl_env_config* cfg, const orl_topology_desc* topo, char* buf, int capacity) {
+  return orl_spec_flags_for_batch(cfg, topo, (int64_t)1 << 20, buf, capacity);
+}
+extern "C" int orl_spec_flags_for_batch(const orl_env_config* cfg, const orl_topology_desc* topo, int64_t n_envs, char* buf, int capacity) try {
+  if (!cfg || !topo || !buf || capacity < 1 || n_envs < 1) return 0;
   buf[0] = 0;
   if (cfg->struct_size != sizeof(orl_env_config) || cfg->env_type < 0 || cfg->env_type > ORL_ENV_QOS || !(cfg->lambda_arrival > 0) || !(cfg->lambda_holding > 0)) return 0;
   DevParams P;
   memset(&P, 0, sizeof P);
   int wt = 1;
-  derive_sizes(cfg, topo->n_nodes, topo->n_links, topo->k_paths, topo->max_hops, topo->n_modulations, 1 << 20, P, &wt);
+  derive_sizes(cfg, topo->n_nodes, topo->n_links, topo->k_paths, topo->max_hops, topo->n_modulations, n_envs, P, &wt);
   if (!pipeline_applies(cfg, P)) return 0;
   return spec_flags(P, wt, buf, capacity);
 }

@@ -154,6 +154,28 @@ struct SinkEntryC {
 };
 #define ORL_REL_MAX 31
 #define ORL_MTAB 32  // masks per env in the table
+struct Mask2 { u64 lo, hi; int w0; };
+__device__ __forceinline__ Mask2 mask2(int s0, int n) {
+  Mask2 m;
+  const int b = s0 & 63;
+  const u64 ones = (1ull << n) - 1ull;
+  m.w0 = s0 >> 6;
+  m.lo = ones << b;
+  m.hi = (b + n > 64) ? (ones >> (64 - b)) : 0ull;  // (b + n > 64 implies b >= 2: the shift is in range)
+  return m;
+}
+__device__ __forceinline__ u64 mask2_word(const Mask2& m, int w) { return (w == m.w0) ? m.lo : ((w == m.w0 + 1) ? m.hi : 0ull); }
+// (the two-wavefront form: the control wavefront changes the slot maps itself, in the LDS window — no value comes back)
+__device__ __forceinline__ void row_apply_mask(u64* row, int s0, int n, bool provision) {
+  const Mask2 m = mask2(s0, n);
+  if (provision) {
+    __hip_atomic_fetch_and(row + m.w0, ~m.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (m.hi) __hip_atomic_fetch_and(row + m.w0 + 1, ~m.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    __hip_atomic_fetch_or(row + m.w0, m.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (m.hi) __hip_atomic_fetch_or(row + m.w0 + 1, m.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
 template <bool CP> struct SinkEntryOf { typedef SinkEntry type; };
 template <> struct SinkEntryOf<true> { typedef SinkEntryC type; };
 template <bool CP> struct SinkT {
@@ -165,6 +187,8 @@ template <bool CP> struct SinkT {
   int tw;
   unsigned short* mtab;  // CP: LDS, this env's mask table (ORL_MTAB entries)
   int nrel;              // CP: releases of this step appended so far (group-uniform)
+  u64* rows;             // CP, two-wavefront form: the env's slot map (LDS) — masks are applied as they are appended; else nullptr
+  int roww;              // ... and its words per row
   bool active;     // item mode decided: the releases of this step fit the item form
   bool deferred;   // they do not: nothing has been touched, k_rel_tail releases them in place
   int cnt;         // links this LANE has opened an item for
@@ -191,7 +215,11 @@ __device__ __forceinline__ void sink_add(SinkT<CP>& s, const PathRec& rec, int c
     // (no value comes back from the atomics: the item list is made from the table afterwards, sink_compact — until round 5 every
     // hop waited for its atomic OR to learn whether a list entry was due, and for an atomic add when one was: two dependent LDS
     // round trips per hop of every provision and release)
-    for (int h = lane & 7; h < hops; h += 8) atomicOr(&s.tab[path_rec_byte(rec, 2 + h)].bits, 1u << k);
+    for (int h = lane & 7; h < hops; h += 8) {
+      const int link = path_rec_byte(rec, 2 + h);
+      atomicOr(&s.tab[link].bits, 1u << k);
+      if (s.rows) row_apply_mask(s.rows + (size_t)link * s.roww, s0, n, prov);
+    }
   } else {
     const u64 m = (u64)(u32)s0 | ((u64)(u32)n << 9);
     for (int h = lane & 7; h < hops; h += 8) {
@@ -518,7 +546,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
   rec.q[0] = rec.q[1] = rec.q[2] = rec.q[3] = 0;
   SinkT<CP> sink;
   sink.tab = nullptr; sink.tally = nullptr; sink.tw = tw; sink.active = false; sink.deferred = false; sink.cnt = 0;
-  sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0;
+  sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0; sink.rows = nullptr; sink.roww = 0;
   if (s_list_n && lane == 0) *s_list_n = 0u;
   {  // every wavefront clears the tables of its own 8 envs: no workgroup barrier
     typename SinkEntryOf<CP>::type* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
@@ -881,11 +909,20 @@ template <bool MINI> __device__ __forceinline__ u64* mrec(const Wmem& M, u64* re
 // compact sink, else RMCSA's entries with a core per mask).  `esp`: the env's episode step counter, kept by the caller for the
 // whole launch (done / observation need it); `prev_core` (RMCSA): the core of the env's last accepted provision — the sums
 // logged are that core's; `slog`: this step's log slot, at the env's column.  Returns the descriptor of the new pending service.
-template <int ENV, int W, bool CP, bool MINI>
+// RW (the two-wavefront form, k_persist): this wavefront applies the masks to the slot maps itself as it appends them (LDS
+// atomics without a return value) and hands the row wavefront only the statistics; `rw_sync` are the pair's counters — [1] steps
+// whose items the row wavefront has read (sink table, mask table, clocks and rows: they may be overwritten), [2] steps whose
+// statistics are complete (the sums) — and `rw_k` the number of steps handed over so far.
+__device__ __forceinline__ void rw_wait_for(const u32* p, u32 want) {
+  while ((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int ENV, int W, bool CP, bool MINI, bool RW = false>
 __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
                                       const int4& av, u64 desc, typename SinkEntryOf<CP>::type* s_tab, u32* s_tally, int tw, int* s_deferred,
                                       int* done_out, unsigned short* s_list, u32* s_list_n, SoonRegs* carried, unsigned short* s_mtab,
-                                      SvcBuf& svc, int& esp, int& prev_core, u64* slog, const ScanHand* hand = nullptr, int pop_pre = -2) {
+                                      SvcBuf& svc, int& esp, int& prev_core, u64* slog, const ScanHand* hand = nullptr, int pop_pre = -2,
+                                      const u32* rw_sync = nullptr, u32 rw_k = 0u) {
   // `hand`: the chosen path's slot count and record from the scan's winning lane (single-core families); `pop_pre`: the top entry
   // of the env's free-slot stack (-1: empty), requested by the caller before the scan (-2: not given) — with both, nothing the
   // decision needs is fetched from global memory behind the scan
@@ -893,7 +930,8 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
   u64 desc_out = 0ull;
   SinkT<CP> sink;
   sink.tab = nullptr; sink.tally = nullptr; sink.tw = tw; sink.active = false; sink.deferred = false; sink.cnt = 0;
-  sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0;
+  sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0; sink.rows = nullptr; sink.roww = 0;
+  if constexpr (RW) { rw_wait_for(rw_sync + 1, rw_k); ORL_PROFA(14); }  // (the row wavefront has read the previous step's tables and rows)
   if (lane == 0) *s_list_n = 0u;
   {
     typename SinkEntryOf<CP>::type* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
@@ -960,22 +998,27 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     e.bm = wm_bm(P, M, env);
     e.ls = wm_ls(P, M, env);
     e.cs = wm_cs(P, M, env);
+    if constexpr (RW && CP) { sink.rows = e.bm; sink.roww = W; }
     int occ_s = 0, fb_s = 0;
-    if (ENV != ENV_RWA) {
-      // the sums right after the previous step's provision — of the core it went to — (its pending network-compactness update,
-      // rmsa_env.py:439-462, is finished by the replay from them); this step's releases start from zero
-      int* rs = e.cs + 2 * P.C;
-      const int pc = (ENV == ENV_RMCSA) ? prev_core : 0;
-      if (!M.cs_lds) {
-        occ_s = atomicAdd(e.cs + 2 * pc, 0) - atomicAdd(rs + 2 * pc, 0);
-        fb_s = atomicAdd(e.cs + 2 * pc + 1, 0) - atomicAdd(rs + 2 * pc + 1, 0);
-        for (int i = gl; i < 2 * P.C; i += 8) atomicExch(rs + i, 0);
-      } else {
-        occ_s = e.cs[2 * pc] - rs[2 * pc];
-        fb_s = e.cs[2 * pc + 1] - rs[2 * pc + 1];
-        for (int i = gl; i < 2 * P.C; i += 8) rs[i] = 0;
+    const int pc_s = (ENV == ENV_RMCSA) ? prev_core : 0;
+    auto read_sums = [&]() {
+      if (ENV != ENV_RWA) {
+        // the sums right after the previous step's provision — of the core it went to — (its pending network-compactness update,
+        // rmsa_env.py:439-462, is finished by the replay from them); this step's releases start from zero
+        int* rs = e.cs + 2 * P.C;
+        const int pc = pc_s;
+        if (!M.cs_lds) {
+          occ_s = atomicAdd(e.cs + 2 * pc, 0) - atomicAdd(rs + 2 * pc, 0);
+          fb_s = atomicAdd(e.cs + 2 * pc + 1, 0) - atomicAdd(rs + 2 * pc + 1, 0);
+          for (int i = gl; i < 2 * P.C; i += 8) atomicExch(rs + i, 0);
+        } else {
+          occ_s = e.cs[2 * pc] - rs[2 * pc];
+          fb_s = e.cs[2 * pc + 1] - rs[2 * pc + 1];
+          for (int i = gl; i < 2 * P.C; i += 8) rs[i] = 0;
+        }
       }
-    }
+    };
+    if constexpr (!RW) read_sums();  // (RW: at the end of the phase, when the row wavefront has long finished the previous step)
     int path, slot, mod = 0, core = 0;
     if (ENV == ENV_DEEPRMSA) { path = av.y; slot = av.z; }  // (decoded by the in-kernel scan on this slot map, policy_g)
     else if (ENV == ENV_RMCSA) { path = av.x; mod = av.y; core = av.z; slot = av.w; }
@@ -1059,9 +1102,13 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
         if (O.write_io) P.svc_desc[env] = desc_out;
       }
     }
-    if (gl < 2) {
-      const u64 w1 = (ENV == ENV_RWA) ? slog_w1_rwa(accepted, n_hops, path0, slot0) : slog_w1(accepted, n_hops, br_new, occ_s, fb_s, core);
-      slog[(size_t)gl * (size_t)P.log_stride] = gl == 0 ? (u64)__double_as_longlong(e.now) : w1;
+    if constexpr (!RW) {
+      if (gl < 2) {
+        const u64 w1 = (ENV == ENV_RWA) ? slog_w1_rwa(accepted, n_hops, path0, slot0) : slog_w1(accepted, n_hops, br_new, occ_s, fb_s, core);
+        slog[(size_t)gl * (size_t)P.log_stride] = gl == 0 ? (u64)__double_as_longlong(e.now) : w1;
+      }
+    } else if (gl == 0) {
+      slog[0] = (u64)__double_as_longlong(e.now);
     }
     if (ENV == ENV_RMCSA && accepted) prev_core = core;
     ORL_PROFA(7);
@@ -1109,6 +1156,13 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
       }
     }
     if (gl == 2) slog[2 * (size_t)P.log_stride] = slog_w2((int)(-e.s_nh), (int)(-e.s_br));
+    if constexpr (RW) {
+      rw_wait_for(rw_sync + 2, rw_k);
+      ORL_PROFA(15);
+      read_sums();
+      if (gl == 1)
+        slog[(size_t)P.log_stride] = (ENV == ENV_RWA) ? slog_w1_rwa(accepted, n_hops, path0, slot0) : slog_w1(accepted, n_hops, br_new, occ_s, fb_s, core);
+    }
     if (carried) {
 #pragma unroll
       for (int k = 0; k < ORL_SOON_PER_LANE; k++) { carried->t[k] = e.sr_t[k]; carried->i[k] = e.sr_i[k]; }
@@ -1459,7 +1513,11 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu), br = (int)((info >> 49) & 0x7fffu);
         const int hops = path_rec_byte(rec, 0), kk = nrel0 + r;
         sink.mtab[kk] = (unsigned short)((u32)s0 | ((u32)n << 9));
-        for (int h = 0; h < hops; h++) atomicOr(&sink.tab[path_rec_byte(rec, 2 + h)].bits, 1u << kk);  // (items: sink_compact)
+        for (int h = 0; h < hops; h++) {
+          const int link = path_rec_byte(rec, 2 + h);
+          atomicOr(&sink.tab[link].bits, 1u << kk);  // (items: sink_compact)
+          if (sink.rows) row_apply_mask(sink.rows + (size_t)link * sink.roww, s0, n, false);
+        }
         // the freed slot goes onto the env's free-slot stack at the place its rank gives it (g8::free_push, one by one before)
         const int fp = nfree0 + r - 1;
         if (fp < ORL_FREE_SLOTS) fs[fp] = (unsigned short)idx;
@@ -1673,18 +1731,6 @@ __device__ __forceinline__ u32 mask_words(int s0, int n) { return (1u << (s0 >> 
 // The slots [s0, s0 + n), 1 <= n <= 63, as bits of the (at most two) 64-slot words they lie in: word s0 >> 6 gets `lo`, the
 // next one `hi`.  word_range() per word of the row — two clamps, two 64-bit shifts and half a dozen selects, times W words,
 // times two or three masks per item — was a tenth of the persistent kernel's instruction stream.
-struct Mask2 { u64 lo, hi; int w0; };
-__device__ __forceinline__ Mask2 mask2(int s0, int n) {
-  Mask2 m;
-  const int b = s0 & 63;
-  const u64 ones = (1ull << n) - 1ull;
-  m.w0 = s0 >> 6;
-  m.lo = ones << b;
-  m.hi = (b + n > 64) ? (ones >> (64 - b)) : 0ull;  // (b + n > 64 implies b >= 2: the shift is in range)
-  return m;
-}
-__device__ __forceinline__ u64 mask2_word(const Mask2& m, int w) { return (w == m.w0) ? m.lo : ((w == m.w0 + 1) ? m.hi : 0ull); }
-
 // the part of the row summary the compactness sums need: used blocks, lambda_min, lambda_max
 template <int W>
 __device__ __forceinline__ void row_occ_fb(const u64 (&a)[W], int S, int& occ, int& fb) {
@@ -1716,10 +1762,14 @@ __device__ __forceinline__ void row_occ_fb(const u64 (&a)[W], int S, int& occ, i
 // stored — does the update at the step clock, the further releases and the row store.  Everything else (`whole`) is one lane.
 // The compactness sums change by (summary after the provision - before) and (final - after the provision), the latter
 // also into rel_sums.
-template <int ENV, int W>
+// EARLY (the two-wavefront form of the persistent kernel, persist_row_wave): the control wavefront has already applied every
+// mask to the row; this function only derives the statistics, from the row states it reconstructs, and stores no slot map.
+// `sig` (LDS, when given) is set to `sig_val` once the row, the mask table and the clocks have been read: the control wavefront
+// may overwrite them from there on.
+template <int ENV, int W, bool EARLY = false>
 __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M, const i64 env, const int link, const u32 bits,
                                                const unsigned short* mtab, int second, Prof& prof, bool early_ls = false,
-                                               double* stash_env = nullptr) {
+                                               double* stash_env = nullptr, u32* sig = nullptr, u32 sig_val = 0u) {
   // `stash_env` (k_agent; LDS, [E][2] of this env): where a lane whose evaluated mask is a release leaves the link's
   // utilization and compactness as they were BEFORE its update, i.e. after the step's provision — what info's link averages use
   // `bits`: the (env, link) word of the compact sink — bit 0 the step's provision, bit k its k-th release; `mtab`: the env's
@@ -1749,13 +1799,48 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
 #pragma unroll
   for (int w = 0; w < W; w++) a[w] = row[w];
   ORL_PROFR(3);
+  // EARLY: the row read above is the FINAL one.  A provision takes slots that were free and a release frees slots that were
+  // taken, so taking the masks of the word back in reverse order gives the row as the step found it; from there on the function
+  // works as it does on a row it changes itself.  Everything it needs of the tables is read here.
+  u64 fin[EARLY ? W : 1];
+  u32 later_e = 0u, mw0_e = 0u, mwf_e = 0u;
+  if constexpr (EARLY) {
+    u32 rest_e = bits & (bits - 1u);
+    int first_e = (int)__builtin_ctz(bits);
+    if (role_b) { first_e = (int)__builtin_ctz(rest_e); rest_e &= rest_e - 1u; }
+    if (role_a) rest_e = 0u;
+#pragma unroll
+    for (int w = 0; w < W; w++) fin[w] = a[w];
+    // (in reverse: the releases first, the provision last — a service released in the step it was provisioned in has the same
+    // mask twice, and its slots were free before the step)
+    for (u32 r = bits & ~1u; r; r &= r - 1u) {
+      const int k = (int)__builtin_ctz(r);
+      const u32 mw = mtab[k];
+      const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
+      if (k == first_e) mwf_e = mw;
+      if ((rest_e >> k) & 1u) later_e |= mask_words(s0, n);
+      const Mask2 mm = mask2(s0, n);
+#pragma unroll
+      for (int w = 0; w < W; w++) a[w] &= ~mask2_word(mm, w);
+    }
+    if (bits & 1u) {
+      mw0_e = mtab[0];
+      if (first_e == 0) mwf_e = mw0_e;
+      const Mask2 mm = mask2((int)(mw0_e & 0x1ff), (int)(mw0_e >> 9));
+#pragma unroll
+      for (int w = 0; w < W; w++) a[w] |= mask2_word(mm, w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (LDS executes a wavefront's instructions in order)
+    if (sig) __hip_atomic_store(sig, sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ORL_PROFR(9);
+  }
   // the masks of this lane, in table (= bit) order: `first` is the one whose statistics it evaluates — B: the first release
   // (after applying the provision, entry 0), else the lowest entry — and `rest` the further releases of the step (none for A)
   u32 rest = bits & (bits - 1u);
   int first = (int)__builtin_ctz(bits);
   u32 touched = 0u;  // words of the row this lane changes before it summarises it (row_stat_lane's cache)
   if (role_b) {
-    const u32 mw = mtab[0];
+    const u32 mw = EARLY ? mw0_e : (u32)mtab[0];
     const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
     touched = mask_words(s0, n);
     const Mask2 mm = mask2(s0, n);
@@ -1777,7 +1862,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   }
   const bool rel_f = first != 0;  // the evaluated mask is a release
   {
-    const u32 mw = mtab[first];
+    const u32 mw = EARLY ? mwf_e : (u32)mtab[first];
     const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
     touched |= mask_words(s0, n);
     const Mask2 mm = mask2(s0, n);
@@ -1864,13 +1949,19 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
   int occL = after.occ, fbL = after.fb;
   if (rest) {  // the masks of the further releases, then what the row contributes in the end
     u32 later = 0u;
-    for (u32 r = rest; r; r &= r - 1u) {
-      const u32 mw = mtab[__builtin_ctz(r)];
-      const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
-      later |= mask_words(s0, n);
-      const Mask2 mm = mask2(s0, n);
+    if constexpr (EARLY) {
+      later = later_e;
 #pragma unroll
-      for (int w = 0; w < W; w++) a[w] |= mask2_word(mm, w);
+      for (int w = 0; w < W; w++) a[w] = fin[w];
+    } else {
+      for (u32 r = rest; r; r &= r - 1u) {
+        const u32 mw = mtab[__builtin_ctz(r)];
+        const int s0 = (int)(mw & 0x1ff), n = (int)(mw >> 9);
+        later |= mask_words(s0, n);
+        const Mask2 mm = mask2(s0, n);
+#pragma unroll
+        for (int w = 0; w < W; w++) a[w] |= mask2_word(mm, w);
+      }
     }
     if (ENV != ENV_RWA) row_occ_fb<W>(a, S, occL, fbL);
     if (icw) {  // the cache word describes the row before these masks: their words become unknown
@@ -1900,8 +1991,10 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
     }
   }
   if (!role_a) {
+    if constexpr (!EARLY) {
 #pragma unroll
-    for (int w = 0; w < W; w++) row[w] = a[w];
+      for (int w = 0; w < W; w++) row[w] = a[w];
+    }
     if (ocw) *ocw = ((u32)occL << 16) | (u32)fbL;
     if (ocg) *ocg = ((u32)occL << 16) | (u32)fbL;
   }

@@ -48,4 +48,7 @@
 #ifdef ORL_X_NOOCG
 #define ORL_DIAG_NO_OCG 1
 #endif
+#ifdef ORL_X_WAVESYNC
+#define ORL_DIAG_WAVE_SYNC 1
+#endif
 #endif  // ORL_DIAG

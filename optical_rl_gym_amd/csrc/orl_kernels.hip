@@ -481,9 +481,95 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
 // 3 = slot maps + per-core sums in LDS, env records in global memory
 // PF: early requests of the Mersenne-Twister window and the link statistics (more live registers: the 3-wave forms)
 // SVC: services drawn 8 steps ahead, one per lane of an env's group (sp::svc_generate)
-template <int ENV, int W, int LDS, bool PF>
+// ---- the two-wavefront form (RW; round 5, small batches) -----------------------------------------------------------------------
+// A batch of a few thousand envs leaves most SIMDs idle, and a lone wavefront's step is a chain of dependent latencies: the row
+// phase is a quarter of the chain, and nothing it computes — summaries, running averages, sums — feeds the next decision;
+// only the slot maps do.  In this form a workgroup is a PAIR of wavefronts sharing the LDS window.  The control wavefront runs
+// everything but the row phase and changes the slot maps itself, as it appends a mask to the sink (sp::row_apply_mask: LDS
+// atomics without a return value); the row wavefront waits for a step's item list, reads the rows — final already — takes the
+// step's masks back to get the states the statistics are defined on (row_item_lane1<EARLY>) and does the statistics while the
+// control wavefront is in its next step.  The control wavefront waits twice per step, normally for nothing: before it clears the
+// tables, for the row wavefront to have read them; before it logs the sums, for the previous step's statistics.  Single-core
+// families, slot maps in the LDS window (everything the two wavefronts share is in LDS).  Four words behind the window: [0]
+// steps whose items are listed, [1] steps whose tables and rows have been read, [2] steps whose statistics are complete, [3] the
+// control wavefront has left its loop.
+__device__ __forceinline__ u32 rw_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (Everything the pair shares is in LDS, and a CU's LDS executes a wavefront's instructions in the order they were issued: data
+// written before a counter is visible before it.  The fences are therefore wavefront-scope — compiler ordering only: a
+// workgroup-scope release would also wait for every global store the wavefront has in flight, log words and event records that
+// nobody in the pair reads, a global round trip in the step's chain.)
+__device__ __forceinline__ void rw_wait(const u32* p, u32 want) {
+  while ((u32)__builtin_amdgcn_readfirstlane((int)rw_load(p)) < want) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void rw_signal(u32* p, u32 v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int ENV, int W, int LDS>
+__device__ __forceinline__ void persist_row_wave(const DevParams& P, const PersistLds& L, int ICL, u32* sync) {
+  static_assert(LDS == 1 || LDS == 3, "the two-wavefront form shares the slot maps through the LDS window");
+  const int lane = lane_id();
+  const i64 env0 = (i64)blockIdx.x * 8;
+  const sp::SinkEntryC* s_tab = (const sp::SinkEntryC*)(orl_lds_raw + L.tab);
+  const unsigned short* s_mtab = (const unsigned short*)(orl_lds_raw + L.mtab);
+  const unsigned short* s_list = (const unsigned short*)(orl_lds_raw + L.list);
+  const u32* s_list_n = (const u32*)(orl_lds_raw + L.misc + 8);
+  sp::Wmem M = sp::wmem_global(P);
+  M.clk = (double*)(orl_lds_raw + L.clk);
+  M.clk_env0 = env0;
+  M.bm0 = (u64*)(orl_lds_raw + L.bm);
+  M.env0 = env0;
+  M.cs0 = (int*)(orl_lds_raw + L.cs);
+  M.cenv0 = env0;
+  M.cs_lds = true;
+  M.cs_stride = L.csw;
+  if (ICL >= 1) M.ic0 = (u32*)(orl_lds_raw + L.ic);
+  if (ICL >= 2) M.oc0 = (u32*)(orl_lds_raw + L.ic + ((8 * P.E * 4 + 15) & ~15));
+  else if (ICL == 1 && P.row_cache_key != 0) M.ocg = P.row_cache + (size_t)blockIdx.x * 2 * P.row_cache_words + P.row_cache_words;
+  sp::Prof prof;
+  ORL_PROF_BEGIN();
+  u32 k = 0u;
+  for (;;) {
+    const u32 gone = (u32)__builtin_amdgcn_readfirstlane((int)rw_load(sync + 3));
+    const u32 listed = (u32)__builtin_amdgcn_readfirstlane((int)rw_load(sync + 0));
+    if (listed <= k) {
+      if (gone) break;
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ORL_PROFR(8);  // (idle)
+    k++;
+    const int n_items = __builtin_amdgcn_readfirstlane((int)*s_list_n);
+    for (int base = 0; base < n_items; base += 64) {
+      const int idx = base + lane;
+      if (idx < n_items) {
+        const int code = (int)s_list[idx];
+        const int el = (code >> 8) & 7, link = code & 0xff, second = code >> 15;
+        sp::row_item_lane1<ENV, W, true>(P, M, env0 + el, link, s_tab[P.E * el + link].bits, s_mtab + ORL_MTAB * el, second, prof, true, nullptr,
+                                         (base + 64 >= n_items) ? sync + 1 : nullptr, k);
+      }
+    }
+    if (n_items == 0) rw_signal(sync + 1, k, lane);
+    rw_signal(sync + 2, k, lane);
+    ORL_PROFR(10);
+  }
+  ORL_PROF_END();
+}
+
+// RW: the two-wavefront form above (128 threads per workgroup)
+template <int ENV, int W, int LDS, bool PF, bool RW = false>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
+  static_assert(!RW || (CP && (LDS == 1 || LDS == 3)), "two-wavefront form: single-core families, slot maps in LDS");
+// (one wavefront per workgroup: a barrier is an ordering point of the wavefront; the control wavefront of a pair must not wait at
+// one for the row wavefront, which is in its own loop)
+#ifdef ORL_DIAG_WAVE_SYNC  // (A/B: the one-wavefront forms with wavefront-scope ordering points as well)
+#define ORL_SYNC() do { wave_fence(); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define ORL_SYNC() do { if constexpr (RW) { wave_fence(); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); } while (0)
+#endif
   constexpr bool SVC = ORL_PERSIST_SVC != 0;
   constexpr bool DS = PersistDeferred<ENV, LDS>::value;  // bookkeeping logged for k_stats (ctrl_d) instead of done in the loop
 #ifdef ORL_DIAG_NO_MINI  // (A/B: the control phase's record words stay in the global records)
@@ -501,6 +587,16 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
   int* s_deferred = (int*)(orl_lds_raw + L.misc);  // [2], alternating by step
   u32* s_list_n = (u32*)(orl_lds_raw + L.misc + 8);
+  u32* rw_sync = (u32*)(orl_lds_raw + L.total);  // (RW: four words behind the window)
+  u32 rw_k = 0u;                                  // (RW: steps of this launch whose items have been listed)
+  if constexpr (RW) {
+    if (threadIdx.x < 4) rw_sync[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x >= 64) {
+      persist_row_wave<ENV, W, LDS>(P, L, ICL, rw_sync);
+      return;
+    }
+  }
   const int lane = lane_id();
   const i64 env0 = (i64)blockIdx.x * 8;
   const i64 env = env0 + (threadIdx.x >> 3);
@@ -584,7 +680,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
         }
       }
       __threadfence();
-      __syncthreads();
+      ORL_SYNC();
       if (step < target) ORL_FILL_WINDOW();
       ORL_LOAD_CARRIED();
     }
@@ -593,7 +689,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       M.ic0 = (u32*)(orl_lds_raw + L.ic);
       const u32* g_cache = P.row_cache + (size_t)blockIdx.x * 2 * P.row_cache_words;
       if (step < target) {
-        __syncthreads();  // the rows are in LDS
+        ORL_SYNC();  // the rows are in LDS
         if (cache_stored) {  // (both levels with one batch of requests)
           for (int i = lane; i < nenv * P.E; i += 64) {
             const u32 a = g_cache[i], c = OC ? g_cache[P.row_cache_words + i] : 0u;
@@ -638,7 +734,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
         }
       }
       __threadfence();
-      __syncthreads();
+      ORL_SYNC();
     }
     ORL_LOAD_CARRIED();
   }
@@ -686,7 +782,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   ORL_PROF_BEGIN();
   // (DS: a wavefront that caught up over more steps than a launch can log stops there and counts as unfinished)
   while (step < target && (!DS || step - first_step < P.log_cap)) {
-    __syncthreads();  // (one wavefront: an ordering point) the previous row phase's writes are done
+    ORL_SYNC();  // (one wavefront: an ordering point) the previous row phase's writes are done
     if (threadIdx.x == 0) s_deferred[(step + 1) & 1] = 0;
     // per-iteration opaque copies: without them the compiler hoists every per-lane address out of the loop and keeps
     // them all live across both phases
@@ -746,16 +842,20 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       ORL_PROFA(1);
       if constexpr (DS) {
         u64* slog_s = P.slog + (size_t)(step - first_step) * ORL_SLOG_WORDS * (size_t)P.log_stride + (size_t)(valid_i ? env_i : 0);
-        desc = sp::ctrl_d<ENV, W, CP, MINI>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
-                                      s_list, s_list_n, SR ? &soon_c : nullptr, s_mtab, svb, esp_c, prev_core, slog_s,
-                                      HAND ? &hand : nullptr, pop_pre);
+        desc = sp::ctrl_d<ENV, W, CP, MINI, RW>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
+                                          s_list, s_list_n, SR ? &soon_c : nullptr, s_mtab, svb, esp_c, prev_core, slog_s,
+                                          HAND ? &hand : nullptr, pop_pre, rw_sync, rw_k);
       } else {
         desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
                                       s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab, nullptr, SVC ? &svb : nullptr);
       }
     }
-    __syncthreads();  // sink table + item list, clocks, env records
-    {
+    ORL_SYNC();  // sink table + item list, clocks, env records
+    if constexpr (RW) {  // the row wavefront takes the items (the slot maps are up to date: ctrl_d applied the masks); this one goes on
+      rw_k++;
+      rw_signal(rw_sync + 0, rw_k, lane_i);
+      ORL_PROFA(12);
+    } else {
 #ifdef ORL_DIAG_NO_ROWS
       const int n_items = 0;
 #else
@@ -775,7 +875,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
     const bool deferred = s_deferred[step & 1] != 0;  // set before the barrier in front of the row phase
     if (ENV == ENV_DEEPRMSA && (O.write_io || deferred)) {  // the observation of the new pending service, from the rows as they are now
-      __syncthreads();
+      ORL_SYNC();
       if (valid_i) {
         if (MINI) {  // (the pending service's words are the descriptor's)
           u64 sd, br;
@@ -790,12 +890,16 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if (deferred) { left_pending = true; break; }
   }
   ORL_PROF_END();
+  if constexpr (RW) {
+    rw_wait(rw_sync + 2, rw_k);
+    rw_signal(rw_sync + 3, 1u, lane);
+  }
   const bool finished_run = P.persist_finish && step > first_step && !left_pending;
   if (DS) {
     // the sums after the last row phase (the replay finishes the last step's pending network-compactness update from them when
     // the run ends here), and how many steps this wavefront logged
     if (step > first_step) {
-      __syncthreads();
+      ORL_SYNC();
       int tid_t = (int)threadIdx.x;
       asm volatile("" : "+v"(tid_t));
       const i64 env_t = env0 + (tid_t >> 3);
@@ -817,7 +921,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     // the end of a run: what k_finish2 (orl_api.hip) does for every env in a launch of its own — the network-compactness update
     // the last step left pending (rmsa_env.py:439-462 with the sums right after that step's provision), the release part of
     // the sums cleared, the env's flag word reported — on the records and sums where this wavefront has them
-    __syncthreads();  // the last row phase is done
+    ORL_SYNC();  // the last row phase is done
     u32 f = 0u;
     // (the env index recomputed from the thread index behind an opaque copy: kept live across the step loop for this block it
     // cost the 128-VGPR forms a spilled register)
@@ -864,7 +968,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       ((int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q] = ((const int4*)M.cs0)[i];
   }
   if (LDS >= 1 && step > first_step) {
-    __syncthreads();
+    ORL_SYNC();
     ulonglong2* g = (ulonglong2*)(P.bitmap + env0 * P.bm_words);
     const ulonglong2* l = (const ulonglong2*)M.bm0;
     for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) g[i] = l[i];
@@ -929,6 +1033,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if (step < target || left_pending) atomicAdd(n_unfinished, 1u);  // (pending releases: the next launch starts with them)
   }
 }
+#undef ORL_SYNC
 // Register budgets: WAVES waves/SIMD -> 512 / WAVES VGPRs.  Global state: 4 (128 VGPRs) for NSFNET-sized RMSA / RWA /
 // DeepRMSA, 3 (168, no spills) for the heavier RMCSA and Germany50 steps.  LDS state: the LDS window decides the residency
 // (orl_launch::persist), the kernel is built for 2 or 3.
@@ -943,7 +1048,10 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 // generic kernels only.
 struct PersistSpec { int env, W, lds, waves, N, E, K, H, M, S, C, J, bit_rate_mode, br_lo, n_br, rand_n, rand_bits, ev_cap, bm_words, cs_words, obs_dim, n_info; };
 #ifdef ORL_SPEC_ONLY
-static constexpr PersistSpec kPersistSpec = {ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, ORL_SPEC_N, ORL_SPEC_E, ORL_SPEC_K, ORL_SPEC_H,
+#ifndef ORL_SPEC_RW
+#define ORL_SPEC_RW 0  // 1: the two-wavefront form (small batches)
+#endif
+static constexpr PersistSpec kPersistSpec = {ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES + 16 * ORL_SPEC_RW, ORL_SPEC_N, ORL_SPEC_E, ORL_SPEC_K, ORL_SPEC_H,
                                              ORL_SPEC_M, ORL_SPEC_S, ORL_SPEC_C, ORL_SPEC_J, ORL_SPEC_BRMODE, ORL_SPEC_BRLO, ORL_SPEC_NBR,
                                              ORL_SPEC_RANDN, ORL_SPEC_RANDBITS, ORL_SPEC_EVCAP, ORL_SPEC_BMWORDS, ORL_SPEC_CSWORDS,
                                              ORL_SPEC_OBSDIM, ORL_SPEC_NINFO};
@@ -959,8 +1067,8 @@ template <int SPEC> __device__ __forceinline__ void persist_spec_apply(DevParams
   }
 }
 
-template <int ENV, int W, int LDS, int WAVES, int SPEC = 0>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+template <int ENV, int W, int LDS, int WAVES, int SPEC = 0, bool RW = false>
+__global__ void __launch_bounds__(RW ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32* clear_next) {
   // the counters the NEXT launch of this half of the batch uses (it starts after this one has ended)
   if (blockIdx.x == 0 && threadIdx.x == 0) { clear_next[0] = 0u; clear_next[1] = 0u; }
@@ -968,7 +1076,7 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
   #ifndef ORL_PF_WAVES
 #define ORL_PF_WAVES 3  // forms of at most this many waves per SIMD keep the soon list in registers and request early
 #endif
-  persist_body<ENV, W, LDS, (WAVES <= ORL_PF_WAVES)>(P, pol, target, wg_step, n_unfinished);
+  persist_body<ENV, W, LDS, (WAVES <= ORL_PF_WAVES), RW>(P, pol, target, wg_step, n_unfinished);
 }
 
 
@@ -1308,9 +1416,26 @@ extern "C" void orl_spec_describe(int* out /*[22]*/) {
 extern "C" void orl_spec_launch(const DevParams* VP, unsigned grid, size_t lds, hipStream_t st, int pol, int target, int* wg_step,
                                 unsigned int* unfinished, unsigned int* clear_next) {
   if (lds > 48 * 1024)
-    hipFuncSetAttribute((const void*)k_persist<ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_persist<ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, 1>), dim3(grid), dim3(64), lds, st, *VP, pol, target, wg_step,
-                     unfinished, clear_next);
+    hipFuncSetAttribute((const void*)k_persist<ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, 1, ORL_SPEC_RW != 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_persist<ORL_SPEC_ENV, ORL_W, ORL_SPEC_LDS, ORL_SPEC_WAVES, 1, ORL_SPEC_RW != 0>), dim3(grid), dim3(ORL_SPEC_RW ? 128 : 64), lds, st, *VP, pol,
+                     target, wg_step, unfinished, clear_next);
+}
+// (diagnostic builds, -DORL_TIMING: the per-phase cycle sums of this library's kernel — tools/pair_prof.py)
+extern "C" int orl_spec_prof(unsigned long long* out48, int reset) {
+  for (int k = 0; k < ORL_PROF_SLOTS; k++) out48[k] = 0;
+#ifdef ORL_TIMING
+  std::vector<unsigned long long> h((size_t)ORL_PROF_WAVES * ORL_PROF_SLOTS);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(sp::g_prof), h.size() * 8) != hipSuccess) return -1;
+  for (size_t w = 0; w < ORL_PROF_WAVES; w++)
+    for (int k = 0; k < ORL_PROF_SLOTS; k++) out48[k] += h[w * ORL_PROF_SLOTS + k];
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sp::g_prof), h.data(), h.size() * 8) != hipSuccess) return -1;
+  }
+#else
+  (void)reset;
+#endif
+  return 0;
 }
 extern "C" void orl_spec_agent_launch(const DevParams* VP, unsigned grid, size_t lds, hipStream_t st, int auto_reset, int pol) {
   if (pol >= 0) hipLaunchKernelGGL((k_agent<ORL_SPEC_ENV, ORL_W, 1, true>), dim3(grid), dim3(64), lds, st, *VP, auto_reset, pol);
@@ -1395,7 +1520,7 @@ static int lds_wgs_per_cu(size_t lds) {
   const size_t alloc = (lds + 1279) / 1280 * 1280;
   return (int)((size_t)(160 * 1024) / alloc);
 }
-struct PersistChoice { int form; size_t lds; int inner; };
+struct PersistChoice { int form; size_t lds; int inner; int rw; };
 static size_t persist_window(const DevParams& VP, int state, int inner) {
   return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, state, persist_compact(VP.env_type, state), inner,
                                     orl_persist_deferred(VP.env_type)).total;
@@ -1454,7 +1579,16 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
     const int v = atoi(e);
     c.inner = (v >= 0 && v <= 2 && persist_inner(VP.env_type, ORL_W, kPersistForms[c.form].lds)) ? v : 0;
   }
-  c.lds = persist_window(VP, kPersistForms[c.form].lds, c.inner);
+  // The two-wavefront form (k_persist<..., RW>, specialisation libraries only): batches of so few wavefronts that every pair has
+  // two SIMDs of its own — 1 024 workgroups on 256 CUs.  LDS is no constraint there: both row caches, and 16 bytes for the pair's
+  // four counters.  ORL_PERSIST_RW=0/1: A/B measurements and cross-checks at any batch size.
+  c.rw = 0;
+  if (tuned && VP.env_type != ENV_RMCSA && kPersistForms[c.form].lds == 1) {
+    c.rw = (VP.B + 7) / 8 <= 1024 ? 1 : 0;
+    if (const char* e = getenv("ORL_PERSIST_RW")) c.rw = atoi(e) != 0 ? 1 : 0;
+  }
+  if (c.rw && !getenv("ORL_PERSIST_INNER")) c.inner = can_inner ? 2 : 0;
+  c.lds = persist_window(VP, kPersistForms[c.form].lds, c.inner) + (c.rw ? 16 : 0);
   return c;
 }
 static int persist_variant(const DevParams& VP, size_t* lds_bytes, bool tuned = false) {
@@ -1466,7 +1600,7 @@ static int persist_variant(const DevParams& VP, size_t* lds_bytes, bool tuned = 
 template <int W> void persist_form(const DevParams& VP, int* lds_state, int* waves) {
   const PersistChoice c = persist_choose(VP, true);
   *lds_state = kPersistForms[c.form].lds;
-  *waves = kPersistForms[c.form].waves;
+  *waves = kPersistForms[c.form].waves + 16 * c.rw;  // (bit 4: the two-wavefront form)
 }
 template <int W> int persist_uses_lds(orl_batch* b) {
   size_t lds;
@@ -1517,7 +1651,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     hipLaunchKernelGGL((k_persist<E_, W, LDS_, WV_>), gc, blk, lds_a, st, VP, pol, target, wg_step, unfinished, clear_next); \
   } while (0)
   // an instantiation built for this very configuration (orl_batch_load_spec)?  (ORL_PERSIST_SPEC=0: the generic kernel)
-  bool spec = b->spec_launch != nullptr && b->spec_lds == kPersistForms[v].lds && b->spec_waves == kPersistForms[v].waves;
+  bool spec = b->spec_launch != nullptr && b->spec_lds == kPersistForms[v].lds && b->spec_waves == kPersistForms[v].waves + 16 * ch.rw;
   if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = false; }
   b->persist_spec = spec ? 1 : 0;
   if (spec) {

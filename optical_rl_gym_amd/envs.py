@@ -269,13 +269,14 @@ class BatchedOpticalEnv:
         return True
 
     @classmethod
-    def spec_flags(cls, **kwargs):
-        """The -D flags of this configuration's specialisation, computed without a device (pre-building, __graft_entry__.build)."""
+    def spec_flags(cls, batch=1 << 20, **kwargs):
+        """The -D flags of this configuration's specialisation for a batch of `batch` envs (the kernel form depends on it),
+        computed without a device (pre-building, __graft_entry__.build)."""
         self = cls.__new__(cls)
         self._derive_only = True
         self.__init__(num_envs=1, **kwargs)
         buf = C.create_string_buffer(1024)
-        n = self.lib.orl_spec_flags_for(C.byref(self._cfg), C.byref(self._desc), buf, len(buf))
+        n = self.lib.orl_spec_flags_for_batch(C.byref(self._cfg), C.byref(self._desc), int(batch), buf, len(buf))
         return buf.value.decode() if n > 0 else None
 
     def _ck(self, rc):
