@@ -1653,7 +1653,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   // an instantiation built for this very configuration (orl_batch_load_spec)?  (ORL_PERSIST_SPEC=0: the generic kernel)
   bool spec = b->spec_launch != nullptr && b->spec_lds == kPersistForms[v].lds && b->spec_waves == kPersistForms[v].waves + 16 * ch.rw;
   if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = false; }
-  b->persist_spec = spec ? 1 : 0;
+  b->persist_spec = spec ? (ch.rw ? 2 : 1) : 0;  // (debug query: 2 = the two-wavefront form)
   if (spec) {
     b->spec_launch(&VP, gc.x, lds_a, st, pol, target, wg_step, unfinished, clear_next);
   } else {

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 # one-wavefront-per-env kernel (k_step).  The small parity cases run against every implementation by forcing it (the
 # variables are read when a batch is created): "wave64" = k_step for everything, "persist" = the default, "split2" = the
 # phases of the persistent kernel as two separate launches (liborlgpu_alt.so, the -DORL_ALT_IMPLS build).
-IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds", "agent8"]
+IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds", "agent8", "persist_pair"]
 IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             # the persistent kernel in the form the library picks, with all state in global memory, and with slot maps +
@@ -26,9 +26,16 @@ IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT=
             # the batch size — the library takes it from 2 048 envs — for all four families (RMSA, DeepRMSA, RWA, RMCSA: every
             # g* / w* / h* fixture of theirs replays through it); device-resident runs as "persist"
             "agent8": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None,
-                           ORL_AGENT_STEP="1")}
+                           ORL_AGENT_STEP="1"),
+            # the two-wavefront form of the persistent kernel (a control and a row wavefront per 8 envs; the library takes it for
+            # batches of at most 8 192 envs of the single-core families) at every batch size: it exists in specialisation libraries
+            # only, so one is built for every configuration (RMCSA: the one-wavefront kernel, specialised)
+            "persist_pair": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="4", ORL_PERSIST_INNER=None,
+                                 ORL_PERSIST_RW="1", ORL_JIT_SPEC="1")}
 for _name, _env in IMPL_ENV.items():
     _env.setdefault("ORL_AGENT_STEP", None)
+    _env.setdefault("ORL_PERSIST_RW", None)
+    _env.setdefault("ORL_JIT_SPEC", None)
 
 
 def force_impl(monkeypatch, name):
@@ -43,6 +50,18 @@ def force_impl(monkeypatch, name):
 def impl(request, monkeypatch):
     force_impl(monkeypatch, request.param)
     return request.param
+
+
+# (tests that only take host-driven steps: the forms of the device-resident loop that differ in nothing else are left out)
+@pytest.fixture(params=[v for v in IMPLS if v != "persist_pair"])
+def impl_host(request, monkeypatch):
+    force_impl(monkeypatch, request.param)
+    return request.param
+
+
+def _ran_pair_form(env):
+    """The last device-resident run of `env` was launches of the two-wavefront kernel (debug query: 2)."""
+    return int(env.lib.orl_batch_debug_persist_spec(env._h)) == 2
 
 
 # Shards of a multi-device batch: both on the box's only GPU, and — wherever a box has them — on two distinct GPUs (the
@@ -80,7 +99,7 @@ def _exact(name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_hip_reproduces_reference_trace(name, impl):
+def test_hip_reproduces_reference_trace(name, impl_host):
     g = load_golden(name)
     env = _product(g["meta"])
     replay(env, g, _exact(name))
@@ -103,7 +122,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("gname,policy,batch,steps", CASES)
-def test_hip_matches_oracle_on_batches(gname, policy, batch, steps, impl):
+def test_hip_matches_oracle_on_batches(gname, policy, batch, steps, impl_host):
     from oracle.oracle import OracleBatch
 
     meta = load_golden(gname)["meta"]
@@ -147,6 +166,7 @@ def test_device_resident_run_matches_stepwise(impl):
     a = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=128, seeds=seeds)
     b = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=128, seeds=seeds)
     a.run("SAP_FF", 200)
+    assert _ran_pair_form(a) == (impl == "persist_pair")
     for _ in range(200):
         b.step(b.policy("SAP_FF"), auto_reset=True)
     chk = _exact("run")
@@ -286,6 +306,8 @@ def test_split_pipeline_equals_wavefront_pipeline_on_every_env(workload, batch, 
         env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
         env.run(policy, steps // 2)  # two calls: the pipeline finishes its pending update between them
         env.run(policy, steps - steps // 2)
+        if name == "persist_pair":
+            assert _ran_pair_form(env) == (fam != "RMCSA")
         pick = [0, 1, batch // 3, batch - 1]
         if env.obs_dim:  # the observation the run left in the device buffer is the one a fresh evaluation gives
             in_loop = env.device_tensor("obs").cpu().numpy().copy()
@@ -373,7 +395,9 @@ def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkey
             assert env.specialised
             env.run(policy, 130)
             env.run(policy, 70)
-            assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == (1 if spec_env is None else 0)
+            # (1: the specialised kernel, 2: its two-wavefront form — batches of at most 8 192 envs of the single-core families)
+            pair = fam != "RMCSA" and workload != "cfg5"
+            assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == ((2 if pair else 1) if spec_env is None else 0)
             out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.slots(9).copy(),
                          env.link_stats(9).copy(), env.net_stats(9).copy()]
             if env.obs_dim:
@@ -509,6 +533,8 @@ def test_corner_configurations_agree_across_step_implementations(fam, topo, poli
         env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
         env.run(policy, 130)
         env.run(policy, 170)
+        if v == "persist_pair":
+            assert _ran_pair_form(env) == (fam != "RMCSA")
         pick = (0, batch // 2, batch - 1)
         out[v] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy()] + \
                  [env.slots(i).copy() for i in pick] + [env.link_stats(i).copy() for i in pick] + [env.net_stats(i).copy() for i in pick]
@@ -659,7 +685,7 @@ def test_agent_in_the_loop_at_full_size(workload, B):
     dev.close()
 
 
-def test_terminal_observation_on_device(impl):
+def test_terminal_observation_on_device(impl_host):
     """DeepRMSA: the env that reports done gets its observation also as terminal_observation (device array)."""
     meta = load_golden("g4_deeprmsa_j2_sap")["meta"]
     kw = dict(meta["kwargs"])
@@ -1426,6 +1452,8 @@ def test_tiny_topologies_through_every_step_form(n_nodes, chords, fam, impl, tmp
     from optical_rl_gym_amd.topology_io import build_topology, save_topology
     from oracle.oracle import OracleBatch
 
+    if impl == "persist_pair" and (n_nodes, chords) != (6, 2):
+        pytest.skip("the two-wavefront form needs a specialisation library per configuration: one ring")
     links = [(i + 1, (i + 1) % n_nodes + 1, 400 + 150 * i) for i in range(n_nodes)]
     links += [(1 + c, 1 + (c + 2) % n_nodes, 900 + 100 * c) for c in range(chords)]
     raw = tmp_path / "ring.txt"
@@ -1457,6 +1485,7 @@ def test_tiny_topologies_through_every_step_form(n_nodes, chords, fam, impl, tmp
             chk(t, "obs", dev.observation(), ora.observation())
     dev.run(policy, 150)
     ora.run(policy, 150)
+    assert _ran_pair_form(dev) == (impl == "persist_pair")
     chk(0, "counters", dev.counters(), ora.counters())
     chk(0, "services", dev.services(), ora.services())
     for i in range(B):

@@ -41,7 +41,7 @@ out = np.zeros(48, np.uint64)
 assert spec.orl_spec_prof(out.ctypes.data, 1) == 0
 st = env.run(policy, steps)
 assert spec.orl_spec_prof(out.ctypes.data, 1) == 0
-assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == 1
+assert int(env.lib.orl_batch_debug_persist_spec(env._h)) in (1, 2)
 waves = (B + 7) // 8
 per = out.astype(np.float64) / (waves * steps)
 print("%s B=%d RW=%s: %d steps in %.2f ms (%.1f us/step, timing build); cycles per workgroup-step:" %
