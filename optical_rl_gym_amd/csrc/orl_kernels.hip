@@ -1563,6 +1563,16 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
   // (global state: the 4-wave form except for RMCSA — round 3, with the 4-byte sink entries: cfg5 Germany50 32 768 envs 5.6e8 at 4
   // waves per SIMD, 5.2e8 at 3; cfg4 RMCSA 5.0e8 / 5.3e8)
   else { c.form = (VP.env_type == ENV_RMCSA) ? 1 : 0; c.inner = 0; }
+  // Small batches (round 5): at most 1 024 workgroups are at most 4 per CU, so the window only has to fit four times — form 4
+  // (everything in LDS, 3 waves per SIMD: soon list in registers) for every single-core configuration whose window fits a
+  // workgroup's 64 KiB, in its two-wavefront form (below).  4 096 envs, form 4 as a pair against the form chosen above alone:
+  // cfg2 +16 %, cfg3 +7 %, cfg1 +2 %, cfg5 (Germany50, global state above) +19 %.
+  const i64 n_wg = (VP.B + 7) / 8;
+  bool small_pair = false;
+  if (tuned && VP.env_type != ENV_RMCSA && n_wg <= 1024) {
+    const size_t w = persist_window(VP, 1, can_inner ? 2 : 0) + 16;
+    if (w <= 64 * 1024 && lds_wgs_per_cu(w) >= (int)((n_wg + 255) / 256)) { c.form = 4; small_pair = true; }
+  }
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
     const int f = atoi(e);
     bool built = f >= 0 && f < kNumPersistForms;
@@ -1584,7 +1594,7 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
   // four counters.  ORL_PERSIST_RW=0/1: A/B measurements and cross-checks at any batch size.
   c.rw = 0;
   if (tuned && VP.env_type != ENV_RMCSA && kPersistForms[c.form].lds == 1) {
-    c.rw = (VP.B + 7) / 8 <= 1024 ? 1 : 0;
+    c.rw = small_pair ? 1 : 0;
     if (const char* e = getenv("ORL_PERSIST_RW")) c.rw = atoi(e) != 0 ? 1 : 0;
   }
   if (c.rw && !getenv("ORL_PERSIST_INNER")) c.inner = can_inner ? 2 : 0;
