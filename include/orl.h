@@ -338,7 +338,7 @@ int orl_debug_stream_peak(int device, int64_t bytes, int reps, double* read_gbs,
  * -ffp-contract=off -fPIC <flags> -shared; optical_rl_gym_amd/_build.py build_spec caches it under build/spec/ keyed by the
  * flags and the source hash) and attached with orl_batch_load_spec(), which compares every field with the batch and refuses
  * a mismatch.  orl_spec_flags_for() gives the same flags without a device (pre-building) for a large batch,
- * orl_spec_flags_for_batch() for a batch of n_envs: the kernel form is part of the flags, and batches of at most 8 192 envs of the
+ * orl_spec_flags_for_batch() for a batch of n_envs: the kernel form is part of the flags, and batches of at most 12 288 envs of the
  * single-core families take the two-wavefront form (a control and a row wavefront per 8 envs).  All return the
  * string length, 0 when the configuration does not run the persistent kernel.  ORL_PERSIST_SPEC=0 in the environment keeps the
  * generic kernel. */

@@ -1563,13 +1563,14 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
   // (global state: the 4-wave form except for RMCSA — round 3, with the 4-byte sink entries: cfg5 Germany50 32 768 envs 5.6e8 at 4
   // waves per SIMD, 5.2e8 at 3; cfg4 RMCSA 5.0e8 / 5.3e8)
   else { c.form = (VP.env_type == ENV_RMCSA) ? 1 : 0; c.inner = 0; }
-  // Small batches (round 5): at most 1 024 workgroups are at most 4 per CU, so the window only has to fit four times — form 4
+  // Small batches (round 5): at most 1 536 workgroups — 6 pairs per CU, all resident at 3 waves per SIMD — need the window to fit
+  // at most six times — form 4
   // (everything in LDS, 3 waves per SIMD: soon list in registers) for every single-core configuration whose window fits a
   // workgroup's 64 KiB, in its two-wavefront form (below).  4 096 envs, form 4 as a pair against the form chosen above alone:
   // cfg2 +16 %, cfg3 +7 %, cfg1 +2 %, cfg5 (Germany50, global state above) +19 %.
   const i64 n_wg = (VP.B + 7) / 8;
   bool small_pair = false;
-  if (tuned && VP.env_type != ENV_RMCSA && n_wg <= 1024) {
+  if (tuned && VP.env_type != ENV_RMCSA && n_wg <= 1536) {
     const size_t w = persist_window(VP, 1, can_inner ? 2 : 0) + 16;
     if (w <= 64 * 1024 && lds_wgs_per_cu(w) >= (int)((n_wg + 255) / 256)) { c.form = 4; small_pair = true; }
   }
@@ -1589,9 +1590,10 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
     const int v = atoi(e);
     c.inner = (v >= 0 && v <= 2 && persist_inner(VP.env_type, ORL_W, kPersistForms[c.form].lds)) ? v : 0;
   }
-  // The two-wavefront form (k_persist<..., RW>, specialisation libraries only): batches of so few wavefronts that every pair has
-  // two SIMDs of its own — 1 024 workgroups on 256 CUs.  LDS is no constraint there: both row caches, and 16 bytes for the pair's
-  // four counters.  ORL_PERSIST_RW=0/1: A/B measurements and cross-checks at any batch size.
+  // The two-wavefront form (k_persist<..., RW>, specialisation libraries only): batches whose pairs are all resident at once
+  // (measured: +20 % at 10 240 and 12 288 envs of cfg2, -20 % at 14 336, where a second generation starts).  LDS is no constraint
+  // there: both row caches, and 16 bytes for the pair's four counters.  ORL_PERSIST_RW=0/1: A/B measurements and cross-checks at
+  // any batch size.
   c.rw = 0;
   if (tuned && VP.env_type != ENV_RMCSA && kPersistForms[c.form].lds == 1) {
     c.rw = small_pair ? 1 : 0;

@@ -28,7 +28,7 @@ IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT=
             "agent8": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None,
                            ORL_AGENT_STEP="1"),
             # the two-wavefront form of the persistent kernel (a control and a row wavefront per 8 envs; the library takes it for
-            # batches of at most 8 192 envs of the single-core families) at every batch size: it exists in specialisation libraries
+            # batches of at most 12 288 envs of the single-core families) at every batch size: it exists in specialisation libraries
             # only, so one is built for every configuration (RMCSA: the one-wavefront kernel, specialised)
             "persist_pair": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="4", ORL_PERSIST_INNER=None,
                                  ORL_PERSIST_RW="1", ORL_JIT_SPEC="1")}
@@ -166,7 +166,7 @@ def test_device_resident_run_matches_stepwise(impl):
     a = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=128, seeds=seeds)
     b = _product(dict(meta, kwargs=dict(kw, seed=0)), num_envs=128, seeds=seeds)
     a.run("SAP_FF", 200)
-    assert _ran_pair_form(a) == (impl == "persist_pair")
+    assert _ran_pair_form(a) or impl != "persist_pair"  # (the library's own choice for a small batch when a specialisation is cached)
     for _ in range(200):
         b.step(b.policy("SAP_FF"), auto_reset=True)
     chk = _exact("run")
@@ -395,8 +395,8 @@ def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkey
             assert env.specialised
             env.run(policy, 130)
             env.run(policy, 70)
-            # (1: the specialised kernel, 2: its two-wavefront form — batches of at most 8 192 envs of the single-core families)
-            pair = fam != "RMCSA" and workload != "cfg5"
+            # (1: the specialised kernel, 2: its two-wavefront form — batches of at most 12 288 envs of the single-core families)
+            pair = fam != "RMCSA"
             assert int(env.lib.orl_batch_debug_persist_spec(env._h)) == ((2 if pair else 1) if spec_env is None else 0)
             out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.slots(9).copy(),
                          env.link_stats(9).copy(), env.net_stats(9).copy()]
@@ -1485,7 +1485,7 @@ def test_tiny_topologies_through_every_step_form(n_nodes, chords, fam, impl, tmp
             chk(t, "obs", dev.observation(), ora.observation())
     dev.run(policy, 150)
     ora.run(policy, 150)
-    assert _ran_pair_form(dev) == (impl == "persist_pair")
+    assert _ran_pair_form(dev) or impl != "persist_pair"
     chk(0, "counters", dev.counters(), ora.counters())
     chk(0, "services", dev.services(), ora.services())
     for i in range(B):
