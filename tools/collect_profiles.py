@@ -121,8 +121,9 @@ def launches_report(name, trace_csv, bench_log):
     # (Grid_Size_X counts work-items: a launch over the whole batch has ceil(B / 8) wavefronts of 64)
     envs = bench["config"].get("envs_per_gpu")
     envs = envs[0] if isinstance(envs, list) else envs
-    full = ((int(envs) + 7) // 8) * 64
     tail = pers[-1]
+    # (the two-wavefront form of small batches: workgroups of 128)
+    full = ((int(envs) + 7) // 8) * int(tail.get("Workgroup_Size_X", 64) or 64)
     parts = 2 if int(tail.get("Grid_Size_X", full)) < full else 1
     per_block = launches * parts
     timed = pers[-blocks * per_block:] if blocks * per_block <= len(pers) else []
