@@ -493,6 +493,19 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
 // families, slot maps in the LDS window (everything the two wavefronts share is in LDS).  Four words behind the window: [0]
 // steps whose items are listed, [1] steps whose tables and rows have been read, [2] steps whose statistics are complete, [3] the
 // control wavefront has left its loop.
+// Behind the four counters, two channels of four words each — [4..7] the batch asked for a step ahead, [8..11] one asked for on
+// the spot: batches asked for, batches drawn, services wanted in the batch asked for, which groups draw (bit per env) — then
+// the two staging areas, one slot per lane of the control wavefront (ORL_RW_STAGE_BYTES).
+// The service look-ahead (sp::svc_generate: a window of Mersenne-Twister words, two logarithms, three table searches for 8 services
+// per env at once, every 8th step) is 9 % of the control wavefront's chain and open-loop like the row statistics: the control
+// wavefront asks for the next batch when its own holds ONE more service, behind a step that was not cut short — so at any exit
+// it holds either services of its own and nothing is on order, or none and the batch on order replaces them — and finds the batch
+// in LDS a step later.  A group that is out of phase with the others (its window of generator words once held fewer services than
+// asked for) and runs dry while their batch is on order gets one on the spot, into the second staging area.  Only the row
+// wavefront touches the generator's state.
+#define ORL_RW_SYNC_WORDS 12
+#define ORL_RW_STAGE_BYTES (2 * 64 * 24)  // two batches: the one asked for a step ahead, and one asked for on the spot
+#define ORL_RW_EXTRA_BYTES (ORL_RW_SYNC_WORDS * 4 + ORL_RW_STAGE_BYTES)
 __device__ __forceinline__ u32 rw_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // (Everything the pair shares is in LDS, and a CU's LDS executes a wavefront's instructions in the order they were issued: data
 // written before a counter is visible before it.  The fences are therefore wavefront-scope — compiler ordering only: a
@@ -527,12 +540,44 @@ __device__ __forceinline__ void persist_row_wave(const DevParams& P, const Persi
   if (ICL >= 1) M.ic0 = (u32*)(orl_lds_raw + L.ic);
   if (ICL >= 2) M.oc0 = (u32*)(orl_lds_raw + L.ic + ((8 * P.E * 4 + 15) & ~15));
   else if (ICL == 1 && P.row_cache_key != 0) M.ocg = P.row_cache + (size_t)blockIdx.x * 2 * P.row_cache_words + P.row_cache_words;
+  if (LDS == 1) {  // (the env records are in the window: the generator's position is a word of them)
+    M.sc0 = (u64*)(orl_lds_raw + L.sc);
+    M.scenv0 = env0;
+    M.sc_stride = ORL_SCAL_LDS_WORDS;
+  }
   sp::Prof prof;
   ORL_PROF_BEGIN();
-  u32 k = 0u;
+  u32 k = 0u, drawn0 = 0u, drawn1 = 0u;
   for (;;) {
     const u32 gone = (u32)__builtin_amdgcn_readfirstlane((int)rw_load(sync + 3));
+    const u32 asked0 = (u32)__builtin_amdgcn_readfirstlane((int)rw_load(sync + 4));
+    const u32 asked1 = (u32)__builtin_amdgcn_readfirstlane((int)rw_load(sync + 8));
     const u32 listed = (u32)__builtin_amdgcn_readfirstlane((int)rw_load(sync + 0));
+    // a batch of services for the control wavefront: one it is waiting for at once, one for its next step when there are no
+    // statistics to do
+    if (asked1 > drawn1 || (listed <= k && asked0 > drawn0)) {
+      {
+        const int ch = (asked1 > drawn1) ? 1 : 0;
+        u32* chan = sync + 4 + 4 * ch;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n_want = __builtin_amdgcn_readfirstlane((int)rw_load(chan + 2));
+        const u32 groups = (u32)__builtin_amdgcn_readfirstlane((int)rw_load(chan + 3));
+        double* stg_q = (double*)((char*)(sync + ORL_RW_SYNC_WORDS) + ch * (ORL_RW_STAGE_BYTES / 2));
+        double* stg_ht = stg_q + 64;
+        u32* stg_pk = (u32*)(stg_ht + 64);
+        int* stg_cnt = (int*)(stg_pk + 64);
+        const i64 env = env0 + (lane >> 3);
+        const bool active = env < P.B && ((groups >> (lane >> 3)) & 1u) != 0u;
+        sp::SvcBuf sb;
+        sb.q = 0.0; sb.ht = 0.0; sb.pk = 0u; sb.cnt = 0;
+        sp::svc_generate<ENV>(P, sp::wm_scal(P, M, active ? env : M.scenv0), P.mt + (active ? env : 0) * 624, lane, n_want, sb, active);
+        stg_q[lane] = sb.q; stg_ht[lane] = sb.ht; stg_pk[lane] = sb.pk; stg_cnt[lane] = sb.cnt;
+        if (ch) drawn1++; else drawn0++;
+        rw_signal(chan + 1, ch ? drawn1 : drawn0, lane);
+        ORL_PROFR(11);
+        continue;
+      }
+    }
     if (listed <= k) {
       if (gone) break;
       __builtin_amdgcn_s_sleep(2);
@@ -587,10 +632,27 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
   int* s_deferred = (int*)(orl_lds_raw + L.misc);  // [2], alternating by step
   u32* s_list_n = (u32*)(orl_lds_raw + L.misc + 8);
-  u32* rw_sync = (u32*)(orl_lds_raw + L.total);  // (RW: four words behind the window)
+  u32* rw_sync = (u32*)(orl_lds_raw + L.total);  // (RW: the pair's counters behind the window, then the staged batch of services)
   u32 rw_k = 0u;                                  // (RW: steps of this launch whose items have been listed)
+  u32 rw_asked0 = 0u, rw_asked1 = 0u;             // (RW: batches of services asked of the row wavefront so far, per channel)
+  u32 rw_early = 0u, rw_early_groups = 0u;        // (RW: the number of the batch asked for a step ahead and not yet taken, 0: none; its groups)
+  // (area 0: the batch asked for a step ahead; area 1: one asked for on the spot)
+#define ORL_RW_TAKE(AREA, LANE)                                                                                           \
+  do {                                                                                                                   \
+    const double* q_ = (const double*)((const char*)(rw_sync + ORL_RW_SYNC_WORDS) + (AREA) * (ORL_RW_STAGE_BYTES / 2));    \
+    svb.q = q_[LANE]; svb.ht = q_[64 + (LANE)]; svb.pk = ((const u32*)(q_ + 128))[LANE]; svb.cnt = ((const int*)(q_ + 128))[64 + (LANE)]; \
+  } while (0)
+#define ORL_RW_ASK(AREA, BALLOT, NWANT, LANE)                                                                             \
+  do {                                                                                                                   \
+    u32 groups_ = 0u;                                                                                                    \
+    for (int g_ = 0; g_ < 8; g_++) groups_ |= (u32)(((BALLOT) >> (8 * g_)) & 1ull) << g_;                               \
+    if ((LANE) == 0) { rw_sync[6 + 4 * (AREA)] = (u32)(NWANT); rw_sync[7 + 4 * (AREA)] = groups_; }                       \
+    if ((AREA) == 0) { rw_asked0++; rw_early = rw_asked0; rw_early_groups = groups_; }                                   \
+    else rw_asked1++;                                                                                                    \
+    rw_signal(rw_sync + 4 + 4 * (AREA), (AREA) ? rw_asked1 : rw_asked0, (LANE));                                         \
+  } while (0)
   if constexpr (RW) {
-    if (threadIdx.x < 4) rw_sync[threadIdx.x] = 0u;
+    if (threadIdx.x < ORL_RW_SYNC_WORDS) rw_sync[threadIdx.x] = 0u;
     __syncthreads();
     if (threadIdx.x >= 64) {
       persist_row_wave<ENV, W, LDS>(P, L, ICL, rw_sync);
@@ -798,7 +860,26 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 #else
       if (__ballot(need) != 0ull) {
         const int left = target - step;
-        sp::svc_generate<ENV>(P, sp::wm_scal(P, M, valid_i ? env_i : M.scenv0), P.mt + (valid_i ? env_i : 0) * 624, lane_i, left < 8 ? left : 8, svb, need);
+        if constexpr (RW) {
+          // the batch the row wavefront drew while this one was in its previous step (asked for below), or — the first step of a
+          // launch, groups out of phase — one asked for now
+          bool want = need;
+          const bool early_mine = ((rw_early_groups >> (lane_i >> 3)) & 1u) != 0u;
+          if (rw_early != 0u && __ballot(want && early_mine) != 0ull) {  // (its groups run dry together: all of them take it now)
+            rw_wait(rw_sync + 5, rw_early);
+            if (want && early_mine) { ORL_RW_TAKE(0, lane_i); want = false; }
+            rw_early = 0u;
+            rw_early_groups = 0u;
+          }
+          if (__ballot(want) != 0ull) {  // the first step of a launch, or a group out of phase with the others: on the spot
+            ORL_RW_ASK(1, __ballot(want), (left < 8 ? left : 8), lane_i);
+            rw_wait(rw_sync + 9, rw_asked1);
+            if (want) ORL_RW_TAKE(1, lane_i);
+          }
+          wave_fence();  // (the slots are read before a later request can overwrite them)
+        } else {
+          sp::svc_generate<ENV>(P, sp::wm_scal(P, M, valid_i ? env_i : M.scenv0), P.mt + (valid_i ? env_i : 0) * 624, lane_i, left < 8 ? left : 8, svb, need);
+        }
       }
 #endif
     }
@@ -854,6 +935,17 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if constexpr (RW) {  // the row wavefront takes the items (the slot maps are up to date: ctrl_d applied the masks); this one goes on
       rw_k++;
       rw_signal(rw_sync + 0, rw_k, lane_i);
+      if constexpr (SVC) {
+        // the next batch of services, asked for when this one holds one more: the next step — certain to run: this one was not cut
+        // short and the launch has room — takes it, the one after finds the new batch drawn
+        const bool one_left = valid_i && ((svb.cnt & 0xff) + 1 == (svb.cnt >> 8));
+        const int lim = DS ? first_step + P.log_cap : target;
+        const int after = target - step - 2;  // steps of the run left once the last service of this batch is taken
+        if (s_deferred[step & 1] == 0 && step + 1 < (lim < target ? lim : target) && after >= 1 && rw_early == 0u) {
+          const u64 bw = __ballot(one_left);
+          if (bw != 0ull) ORL_RW_ASK(0, bw, (after < 8 ? after : 8), lane_i);
+        }
+      }
       ORL_PROFA(12);
     } else {
 #ifdef ORL_DIAG_NO_ROWS
@@ -892,6 +984,10 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   ORL_PROF_END();
   if constexpr (RW) {
     rw_wait(rw_sync + 2, rw_k);
+    if (SVC && rw_early != 0u) {  // a batch on order: its groups' own are used up (see above); parked below like any other
+      rw_wait(rw_sync + 5, rw_early);
+      if (valid && ((rw_early_groups >> (lane >> 3)) & 1u) != 0u) ORL_RW_TAKE(0, lane);
+    }
     rw_signal(rw_sync + 3, 1u, lane);
   }
   const bool finished_run = P.persist_finish && step > first_step && !left_pending;
@@ -1034,6 +1130,8 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   }
 }
 #undef ORL_SYNC
+#undef ORL_RW_TAKE
+#undef ORL_RW_ASK
 // Register budgets: WAVES waves/SIMD -> 512 / WAVES VGPRs.  Global state: 4 (128 VGPRs) for NSFNET-sized RMSA / RWA /
 // DeepRMSA, 3 (168, no spills) for the heavier RMCSA and Germany50 steps.  LDS state: the LDS window decides the residency
 // (orl_launch::persist), the kernel is built for 2 or 3.
@@ -1571,7 +1669,7 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
   const i64 n_wg = (VP.B + 7) / 8;
   bool small_pair = false;
   if (tuned && VP.env_type != ENV_RMCSA && n_wg <= 1536) {
-    const size_t w = persist_window(VP, 1, can_inner ? 2 : 0) + 16;
+    const size_t w = persist_window(VP, 1, can_inner ? 2 : 0) + ORL_RW_EXTRA_BYTES;
     if (w <= 64 * 1024 && lds_wgs_per_cu(w) >= (int)((n_wg + 255) / 256)) { c.form = 4; small_pair = true; }
   }
   if (const char* e = getenv("ORL_PERSIST_VARIANT")) {  // A/B measurements and cross-checks
@@ -1592,7 +1690,7 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
   }
   // The two-wavefront form (k_persist<..., RW>, specialisation libraries only): batches whose pairs are all resident at once
   // (measured: +20 % at 10 240 and 12 288 envs of cfg2, -20 % at 14 336, where a second generation starts).  LDS is no constraint
-  // there: both row caches, and 16 bytes for the pair's four counters.  ORL_PERSIST_RW=0/1: A/B measurements and cross-checks at
+  // there: both row caches, and ORL_RW_EXTRA_BYTES for the pair's counters and the staged batch of services.  ORL_PERSIST_RW=0/1: A/B measurements and cross-checks at
   // any batch size.
   c.rw = 0;
   if (tuned && VP.env_type != ENV_RMCSA && kPersistForms[c.form].lds == 1) {
@@ -1600,7 +1698,7 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
     if (const char* e = getenv("ORL_PERSIST_RW")) c.rw = atoi(e) != 0 ? 1 : 0;
   }
   if (c.rw && !getenv("ORL_PERSIST_INNER")) c.inner = can_inner ? 2 : 0;
-  c.lds = persist_window(VP, kPersistForms[c.form].lds, c.inner) + (c.rw ? 16 : 0);
+  c.lds = persist_window(VP, kPersistForms[c.form].lds, c.inner) + (c.rw ? ORL_RW_EXTRA_BYTES : 0);
   return c;
 }
 static int persist_variant(const DevParams& VP, size_t* lds_bytes, bool tuned = false) {
