@@ -932,7 +932,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
   sink.tab = nullptr; sink.tally = nullptr; sink.tw = tw; sink.active = false; sink.deferred = false; sink.cnt = 0;
   sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0; sink.rows = nullptr; sink.roww = 0;
   if constexpr (RW) { rw_wait_for(rw_sync + 1, rw_k); ORL_PROFA(14); }  // (the row wavefront has read the previous step's tables and rows)
-  if (lane == 0) *s_list_n = 0u;
+  if (!RW && lane == 0) *s_list_n = 0u;  // (RW: the list is the row wavefront's)
   {
     typename SinkEntryOf<CP>::type* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
     if constexpr (!CP) {
@@ -1168,7 +1168,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
       for (int k = 0; k < ORL_SOON_PER_LANE; k++) { carried->t[k] = e.sr_t[k]; carried->i[k] = e.sr_i[k]; }
     }
   }
-  if constexpr (CP) {
+  if constexpr (CP && !RW) {  // (RW: the row wavefront makes its list from the table itself)
     wave_fence();
     sink_compact(s_tab + P.E * 8 * (int)(threadIdx.x >> 6), P.E, lane, s_list, s_list_n);
   }

@@ -526,8 +526,8 @@ __device__ __forceinline__ void persist_row_wave(const DevParams& P, const Persi
   const i64 env0 = (i64)blockIdx.x * 8;
   const sp::SinkEntryC* s_tab = (const sp::SinkEntryC*)(orl_lds_raw + L.tab);
   const unsigned short* s_mtab = (const unsigned short*)(orl_lds_raw + L.mtab);
-  const unsigned short* s_list = (const unsigned short*)(orl_lds_raw + L.list);
-  const u32* s_list_n = (const u32*)(orl_lds_raw + L.misc + 8);
+  unsigned short* s_list = (unsigned short*)(orl_lds_raw + L.list);
+  u32* s_list_n = (u32*)(orl_lds_raw + L.misc + 8);
   sp::Wmem M = sp::wmem_global(P);
   M.clk = (double*)(orl_lds_raw + L.clk);
   M.clk_env0 = env0;
@@ -586,6 +586,9 @@ __device__ __forceinline__ void persist_row_wave(const DevParams& P, const Persi
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     ORL_PROFR(8);  // (idle)
     k++;
+    // the step's work items, from the sink table the control wavefront filled (its own ctrl_d skips this in the pair form)
+    sp::sink_compact(s_tab, P.E, lane, s_list, s_list_n);
+    wave_fence();
     const int n_items = __builtin_amdgcn_readfirstlane((int)*s_list_n);
     for (int base = 0; base < n_items; base += 64) {
       const int idx = base + lane;

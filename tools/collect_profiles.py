@@ -211,7 +211,7 @@ for d in sorted(glob.glob(O + "/stats_*")):
         txt = launches_report(name, tr, os.path.join(O, "stats_%s.log" % name))
         if txt:
             open(os.path.join(P, "%s_bench_%s_launches.txt" % (tag, name)), "w").write(txt)
-for f in glob.glob(O + "/bench_*.json") + glob.glob(O + "/phase_*.txt") + glob.glob(O + "/agent_loop_*.json"):
+for f in glob.glob(O + "/bench_*.json") + glob.glob(O + "/phase_*.txt") + glob.glob(O + "/agent_loop_*.json") + glob.glob(O + "/pair_*.txt"):
     if os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(P, "%s_%s" % (tag, os.path.basename(f))))
 passes = sorted(d for d in glob.glob(O + "/*") if os.path.isdir(d) and os.path.basename(d).split("_")[0] in ("sq1", "sq2", "sq3", "ea", "tr"))

@@ -25,8 +25,9 @@ NAMES = {0: "loop head", 1: "slot scan (policy_g)", 2: "record words, action dec
          20: "rel: soon-list loads", 21: "rel: rebuild scan", 22: "rel: candidate info + path record", 23: "rel: release loop",
          24: "rel: next_rel", 35: "row: record + clocks + row load", 36: "row: masks", 37: "row: after-summary",
          38: "row: f64 statistics", 39: "row: sums + stores"}
-NAMES.update({12: "item list + signal", 14: "PAIR control: waits for the rows", 15: "PAIR control: waits for the statistics",
-              40: "PAIR row wavefront: idle", 41: "PAIR row: early row store + signal", 42: "PAIR row: end of step"})
+NAMES.update({12: "item list + signal", 14: "PAIR control: waits for the tables to be read", 15: "PAIR control: waits for the statistics",
+              40: "PAIR row wavefront: idle", 41: "PAIR row: rows read, masks taken back, signal", 42: "PAIR row: end of step",
+              43: "PAIR row: service look-ahead for the control wavefront"})
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 256

@@ -57,4 +57,7 @@ for f in sorted(glob.glob('$O/bench_cfg*_*.json')):
 "
 fi
 python3 $R/tools/phase_prof.py cfg2 65536 256 > $O/phase_cfg2.txt 2>&1
+# ---- small batches: the two-wavefront form against the one-wavefront form (state, rate), and where the pair's cycles go ----------
+for n in 2048 4096 8192 12288; do python3 $R/tools/pair_check.py cfg2 cfg3 cfg1 cfg5 --envs $n --reps 3 2>&1 | grep -v amdgpu.ids; done > $O/pair_check.txt
+for rw in 1 0; do ORL_PERSIST_RW=$rw python3 $R/tools/pair_prof.py cfg2 4096 256 2>&1 | grep -v amdgpu.ids; done > $O/pair_prof_cfg2_4096.txt
 ls $O | head -80
