@@ -293,6 +293,13 @@ def main():
     # HBM traffic and L2<->fabric requests from rocprofv3 PMC passes (tools/pmc_traffic.py, FETCH_SIZE x calibration +
     # WRITE_SIZE; TCC_EA0_RDREQ + WRREQ): used only when they were collected for exactly this build, workload, batch and
     # state — otherwise null
+    # which instantiation of the persistent kernel the timed launches were (debug query of the library)
+    kernel_form = None
+    if persistent:
+        kernel_form = {0: "generic", 1: "specialised for this configuration (one wavefront per 8 envs)",
+                       2: "specialised for this configuration, two-wavefront form (a control and a row wavefront per 8 envs: batches of at "
+                          "most 12 288 envs; per-wavefront-step counter figures are per 8-env workgroup)"}.get(
+                              int(env.lib.orl_batch_debug_persist_spec(env._h)))
     traffic = req_roof = valu = traffic_gbs = traffic_scaled = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s_%d.json" % (args.workload, B))  # (a batch other than the BASELINE size)
     if not os.path.exists(tpath):
@@ -478,7 +485,8 @@ def main():
                        "envs_total": total_envs,
                        "step_kernels": ["%s (%d launches per %d-step block)" % (kernel, launches, args.steps)] +
                                        (["k_stats (the launch's deferred bookkeeping, one lane per env, behind every k_persist launch)"]
-                                        if persistent else [])},
+                                        if persistent else []),
+                       "kernel_form": kernel_form},
             "timing": {"blocks": len(blocks), "timed_region_s": round(timed, 4), "block_s_median": round(elapsed, 6),
                        "block_s_min": round(walls[0], 6), "block_s_max": round(walls[-1], 6),
                        "state_preparation_steps": prep_steps},
