@@ -363,6 +363,40 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         assert out["two"]["serial"] > 100 and out["two2"]["serial"] > 0 and out["persist"]["serial"] > 100
 
 
+@pytest.mark.parametrize("workload", ["cfg3", "cfg1", "cfg5"])
+def test_pair_form_early_exits_parked_and_ordered_services(workload, monkeypatch):
+    """The two-wavefront form of small batches with the item form limited to one release per step: wavefronts leave their launches
+    early thousands of times — the batch of services on order with the row wavefront is taken over at the exit and parked, groups
+    whose batches ran out of phase ask on the spot — and every env must still equal the one-wavefront-per-env kernel (cfg2 is in
+    the serial-tail test above; tools/stress_early_exit.py runs the same at 12 288 envs and with two releases per step)."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    fam, topo, kw, policy = WORKLOADS[workload]
+    kw = dict(kw, episode_length=70)
+    batch = 4096
+    seeds = [5 + 11 * i for i in range(batch)]
+    out = {}
+    for name, masks in (("wave64", None), ("persist", "1")):
+        force_impl(monkeypatch, name)
+        if masks:
+            monkeypatch.setenv("ORL_ITEM_MASKS", masks)
+            monkeypatch.setenv("ORL_JIT_SPEC", "1")
+        else:
+            monkeypatch.delenv("ORL_ITEM_MASKS", raising=False)
+        env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+        for chunk in (130, 97, 173):
+            env.run(policy, chunk)
+        if name == "persist":
+            assert _ran_pair_form(env) and int(env.lib.orl_batch_debug_serial_count(env._h)) > 10000
+        out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy(),
+                     env.net_stats_all().copy(), env.link_stats_all().copy(), env.slots_packed().copy()]
+        env.close()
+    chk = _exact(workload + " pair form, early exits")
+    for k, (x, y) in enumerate(zip(out["persist"], out["wave64"])):
+        chk(k, "item", x, y)
+
+
 def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkeypatch):
     """Any configuration gets the persistent kernel with ITS sizes as compile-time constants: a small library built on first
     use from the flags the main library writes for the batch (orl_batch_spec_flags -> _build.build_spec -> orl_batch_load_spec),
