@@ -533,8 +533,12 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
     // (k_agent) wherever they apply and the batch is large enough to fill the GPU with 8 envs per wavefront: cfg2 65 536 envs
     // 305 us per step in k_step (one wavefront per env), ~90 us in k_agent.  ORL_AGENT_STEP=1 forces it for any batch size
     // (parity tests), 0 disables it.
-    const bool fits = b->persist && P.E <= 128;
-    b->agent_step = fits && n_envs >= 2048;
+    // (QoSConstrainedRA, which no persistent kernel serves, has its own 8-lanes-per-env step kernel, k_agent_qos: its releases
+    // are found by 8 lanes scanning the env's release times where k_step has 64, a longer chain per step that pays once the
+    // batch fills the GPU — 65 536 envs 120 against 225 us per step, 32 768: 77 / 109, 16 384: 65 / 66, 4 096: 47 / 33)
+    const char* impl64 = getenv("ORL_STEP_IMPL");
+    const bool fits = (b->persist && P.E <= 128) || (qos && P.K <= 8 && !(impl64 && atoi(impl64) == 64));
+    b->agent_step = fits && n_envs >= (qos ? 20480 : 2048);
     if (const char* av = getenv("ORL_AGENT_STEP")) b->agent_step = fits && atoi(av) != 0;
   }
 

@@ -211,8 +211,36 @@ __device__ __forceinline__ double net_compactness(const DevParams& P, const EnvG
   return 1.0;
 }
 
+// QoSConstrainedRA: one spectrum counter per link instead of a slot map, every service takes one unit
+// (qos_constrained_ra.py:381-392 is_path_free, :287-300 / :318-333 provision and release with the link's utilization average);
+// the hops of the path over the 8 lanes of the group — what qos_path_free / qos_path_apply (orl_device.h) do with 64 lanes
+__device__ __forceinline__ bool qos_path_free(const DevParams& P, const EnvG& e, int lane, const PathRec& rec) {
+  const int hops = path_rec_byte(rec, 0);
+  bool busy = false;
+  for (int h = lane & 7; h < hops; h += 8) busy = busy || (i64)e.bm[path_rec_byte(rec, 2 + h)] < 1;
+  return P.S >= 1 && gballot(busy, lane) == 0u;
+}
+__device__ __forceinline__ int qos_path_apply(const DevParams& P, EnvG& e, int lane, const PathRec& rec, bool release) {
+  const int hops = path_rec_byte(rec, 0);
+  for (int h = lane & 7; h < hops; h += 8) {
+    const int link = path_rec_byte(rec, 2 + h);
+    const i64 avail = (i64)e.bm[link] + (release ? 1 : -1);
+    e.bm[link] = (u64)avail;
+    const double last_update = e.ls[4 * link + 3];
+    const double time_diff = e.now - last_update;
+    if (e.now > 0) {
+      const double cur_util = (double)((i64)P.S - avail) / (double)P.S;
+      e.ls[4 * link] = ((e.ls[4 * link] * last_update) + (cur_util * time_diff)) / e.now;
+    }
+    e.ls[4 * link + 3] = e.now;
+  }
+  wave_fence();
+  return hops;
+}
+
 template <int ENV, int W>
 __device__ __forceinline__ int path_apply(const DevParams& P, EnvG& e, int lane, int pidx, int core, int s0, int n, bool release) {
+  if (ENV == ENV_QOS) return qos_path_apply(P, e, lane, path_rec_load(P, pidx), release);
   const PathRec rec = path_rec_load(P, pidx);
   const int hops = path_rec_byte(rec, 0), w = lane & 7;
   const int E = P.E, S = P.S;
@@ -453,7 +481,11 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
   int src = rng_choice(e, r, lane, P.cum_src, P.N);
   int dst = rng_choice(e, r, lane, P.cum_dst + src * P.N, P.N);
   int bit_rate = 0, br_idx = 0;
-  if (ENV != ENV_RWA) {
+  if (ENV == ENV_QOS) {  // the service class (qos_constrained_ra.py:262-265) rides in the bit-rate fields
+    br_idx = rng_choice(e, r, lane, P.cum_class, P.n_classes);
+    bit_rate = br_idx;
+  }
+  if (ENV != ENV_RWA && ENV != ENV_QOS) {
     if (P.bit_rate_mode == 0) {
       u32 v = rng_u32(e, r, lane) >> (32 - P.rand_bits);
       while ((int)v >= P.rand_n) v = rng_u32(e, r, lane) >> (32 - P.rand_bits);
@@ -469,7 +501,7 @@ __device__ __forceinline__ void next_service(const DevParams& P, EnvG& e, int la
   e.src = src; e.dst = dst; e.at = at; e.ht = ht; e.bit_rate = bit_rate; e.br_idx = br_idx;
   e.new_service = 1;
   if (ENV == ENV_RMSA || ENV == ENV_DEEPRMSA) { e.sp += 1; e.esp += 1; }
-  if (ENV != ENV_RWA) {
+  if (ENV != ENV_RWA && ENV != ENV_QOS) {
     e.brq += bit_rate;
     e.ebrq += bit_rate;
     if (P.bit_rate_mode == 1 && gl == 0) P.br_hist[e.env * 2 * P.n_br + br_idx] += 1;

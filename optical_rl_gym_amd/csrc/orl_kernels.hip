@@ -1189,8 +1189,8 @@ k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32
 // network-compactness update is finished in the same launch, and releases that do not fit the item form are done in place
 // right away, so that every launch leaves final state.  All four families, both bit-rate modes (the discrete mode's per-rate
 // blocking entries and their spread, io[8..], are written by the control phase; tests: the g9 discrete-bit-rate fixtures under
-// the forced `agent8` form); the one-wavefront-per-env kernel k_step serves batches below 2 048 envs, reseeded batches and
-// QoSConstrainedRA (305 us per 65 536 cfg2 envs against ~84 us here).  RWA's info carries the action probabilities (written
+// the forced `agent8` form); the one-wavefront-per-env kernel k_step serves batches below 2 048 envs and reseeded batches
+// (305 us per 65 536 cfg2 envs against ~84 us here); QoSConstrainedRA has k_agent_qos below.  RWA's info carries the action probabilities (written
 // beside the histogram update of the control phase), RMCSA's the four blocking rates.
 // info (rmsa_env.py:234-264): the four blocking rates from the counters before the next service is counted (control
 // phase); network_compactness after the provision = (totals - what this step's releases added) over the occupied-slot sum at
@@ -1505,6 +1505,73 @@ __global__ void __launch_bounds__(256) k_obs8(DevParams P, int with_terminal) {
   obs8_env<W>(P, P.bitmap + env * P.bm_words, P.scal + env * ORL_SCAL_WORDS, env, lane_id(), with_terminal && P.done[env]);
 }
 
+// ---- QoSConstrainedRA for an agent in the loop: 8 lanes per env (round 5) --------------------------------------------------------
+// QoSConstrainedRA.step (qos_constrained_ra.py:100-157) with the layout of k_agent — 8 envs per wavefront, all state in global
+// memory — for batches of at least 20 480 envs (k_step, one wavefront per env, served every batch size until round 5; it stays for
+// the smaller ones, where its 64 lanes find an env's due releases in one round trip, and is the other implementation in the
+// parity tests).  The env has per-link spectrum counters instead of slot maps
+// and no row statistics beyond a utilization average per link, so there is no row phase: the hops of a path are spread over the
+// group's 8 lanes (g8::qos_path_free / qos_path_apply), releases are done in place (g8::release_due), the next service comes from
+// the 8-lane generator helpers (g8::next_service draws the service class into the bit-rate fields).
+#ifndef ORL_SPEC_ONLY
+template <int W>  // (this file is compiled once per row width: the env's rows are one word — instantiated for W == 1 only)
+__global__ void __launch_bounds__(64) k_agent_qos(DevParams P, int auto_reset) {
+  const int lane = lane_id(), gl = lane & 7;
+  const i64 env = (i64)blockIdx.x * 8 + (lane >> 3);
+  if (env >= P.B) return;  // (whole groups: the helpers exchange values within a group only)
+  g8::EnvG e;
+  g8::env_load(P, e, env);
+  g8::RngG rng;
+  g8::rng_fill(e, rng, gl);
+  e.t_soon = -__builtin_inf();  // (no soon list is kept for this family: ev_push must not try to maintain one)
+  const int K = P.K, rej = P.allow_rejection ? 1 : 0;
+  int a = P.actions[env * 4];
+  const bool badq = a < 0 || a >= K + rej;  // actions_output[action] += 1 raises IndexError
+  if (badq) { e.flags |= ORL_FLAG_BAD_ACTION; a = K; }
+  const int clazz = e.bit_rate, np_ = P.n_paths[e.src * P.N + e.dst];
+  bool accepted = false;
+  if (!badq && ((clazz == 0 && a == 0) || (clazz != 0 && a < np_))) {
+    const int pidx = (e.src * P.N + e.dst) * K + a;
+    const PathRec prec = path_rec_load(P, pidx);
+    if (g8::qos_path_free(P, e, lane, prec)) {
+      g8::qos_path_apply(P, e, lane, prec, false);
+      e.sa += 1;
+      e.esa += 1;
+      accepted = true;
+      g8::ev_push(P, e, lane, e.at + e.ht, ev_pack(pidx, 0, 1, 0, 0));
+    }
+  }
+  e.sp += 1;
+  e.esp += 1;
+  const double rew = accepted ? P.class_reward[clazz] : 0.0;
+  if (gl == 0) {
+    double* info = P.info + env * P.n_info;
+    info[0] = (double)(e.sp - e.sa) / (double)e.sp;
+    info[1] = (double)(e.esp - e.esa) / (double)e.esp;
+  }
+  e.new_service = 0;
+  g8::next_service<ENV_QOS, 1>(P, e, lane, rng);
+  g8::rng_commit_stores(e, rng, gl);
+  g8::release_due<ENV_QOS, 1>(P, e, lane);  // (qos_constrained_ra.py:245-251: every service that left before the new arrival)
+  const bool doneq = (e.esp == (i64)P.episode_length);
+  if (P.ep_log && P.ep_rew && gl == 0) {
+    const double acc = P.ep_rew_acc[env] + rew;
+    if (doneq) {
+      const int idx = P.ep_count[env];
+      if (idx < P.ep_cap) P.ep_rew[env * P.ep_cap + idx] = acc;
+    }
+    P.ep_rew_acc[env] = doneq ? 0.0 : acc;
+  }
+  if (doneq && P.ep_log && gl == 0) episode_log(P, env, e.esa);
+  if (doneq && auto_reset) { e.ebrq = 0; e.ebrp = 0; e.esp = 0; e.esa = 0; }  // (soft reset: this family counts at the decision)
+  if (gl == 0) {
+    P.reward[env] = rew;
+    P.done[env] = doneq ? 1 : 0;
+  }
+  g8::env_store(P, e, gl);
+}
+#endif
+
 #ifdef ORL_SPEC_ONLY
 // ---- the whole of a specialisation library: one instantiation and its launch entry ----------------------------------------
 extern "C" int orl_spec_struct_bytes(void) { return (int)sizeof(DevParams); }
@@ -1800,6 +1867,14 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
 template <int W> void agent_step(orl_batch* b, int auto_reset, int pol) {
   const DevParams& VP = b->P;
   dim3 g((unsigned)((VP.B + 7) / 8)), blk(64);
+  if (VP.env_type == ENV_QOS) {  // (no slot maps, no row phase: a kernel of its own; a heuristic's scan is a launch in front of it)
+    if constexpr (W == 1) {
+      if (pol >= 0) policy<W>(b, pol);
+      hipLaunchKernelGGL((k_agent_qos<W>), g, blk, 0, b->stream, VP, auto_reset);
+      ORL_TK(b, "k_agent_qos");
+    }
+    return;
+  }
   const size_t lds = (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, 0, VP.env_type != ENV_RMCSA, 0, true).total + (size_t)8 * VP.E * 16;
   // the instantiation built for this configuration, when a specialisation library is attached (ORL_PERSIST_SPEC=0: generic)
   bool spec = b->spec_agent_launch != nullptr;

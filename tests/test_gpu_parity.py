@@ -1348,18 +1348,32 @@ def test_facade_queries_and_wrappers_on_hip():
     env.close()
 
 
+# QoSConstrainedRA's host- / agent-driven step: one wavefront per env (k_step; what the library takes below 2 048 envs) and 8 lanes
+# per env (k_agent_qos, forced here for any batch size)
+@pytest.fixture(params=["wave64", "agent8"])
+def qos_impl(request, monkeypatch):
+    monkeypatch.setenv("ORL_AGENT_STEP", "1" if request.param == "agent8" else "0")
+    return request.param
+
+
+def _qos_step_kernel_is(env, impl):
+    """The library's debug query: 2 = host-driven steps go through the 8-lanes-per-env kernel, 0 = one wavefront per env."""
+    return int(env.lib.orl_batch_debug_step_kernel(env._h)) == (2 if impl == "agent8" else 0)
+
+
 @pytest.mark.parametrize("name", golden_names("q"))
-def test_hip_reproduces_qos_fixtures(name):
+def test_hip_reproduces_qos_fixtures(name, qos_impl):
     """QoSConstrainedRA (qos_constrained_ra.py) on the device against fixtures captured from the reference with its
     constructor repaired at import time: three heuristics and a stored action stream, three service classes."""
     g = load_golden(name)
     env = _product(g["meta"])
+    assert _qos_step_kernel_is(env, qos_impl)
     replay_q(env, g, _exact(name))
     assert not env.flags().any()
     env.close()
 
 
-def test_qos_batches_match_oracle_and_run_equals_stepping():
+def test_qos_batches_match_oracle_and_run_equals_stepping(qos_impl):
     import optical_rl_gym_amd as orl
     from oracle.oracle import OracleBatch
 
@@ -1371,6 +1385,7 @@ def test_qos_batches_match_oracle_and_run_equals_stepping():
     for policy in ("SP_FF", "SAP_FF", "LLP_FF"):
         ora = OracleBatch("QoSConstrainedRA", "nsfnet_chen", seeds, **kw)
         dev = orl.make("QoSConstrainedRA-v0", topology="nsfnet_chen", num_envs=n, seeds=seeds, **kw)
+        assert _qos_step_kernel_is(dev, qos_impl)
         dev.run(policy, 160)
         ora.run(policy, 160)
         for t in range(120):
@@ -1393,6 +1408,40 @@ def test_qos_batches_match_oracle_and_run_equals_stepping():
         with pytest.raises(IndexError):
             dev.step(np.full((n, 1), 6))
         dev.close()
+
+
+def test_qos_large_batches_take_the_8_lane_kernel(monkeypatch):
+    """From 20 480 envs the library steps QoSConstrainedRA through k_agent_qos by itself; every env must end where the
+    one-wavefront-per-env kernel leaves it (agent-driven steps on device-resident actions, a device run in the middle)."""
+    import optical_rl_gym_amd as orl
+
+    kw = dict(load=300, mean_service_holding_time=25, episode_length=35, num_spectrum_resources=48, num_service_classes=3,
+              classes_arrival_probabilities=[0.2, 0.5, 0.3], classes_reward=[4.0, 2.0, 1.0], allow_rejection=True)
+    n = 24576
+    seeds = [9 + 5 * i for i in range(n)]
+    out = {}
+    for name, knob in (("default", None), ("wave64", "0")):
+        if knob is None:
+            monkeypatch.delenv("ORL_AGENT_STEP", raising=False)
+        else:
+            monkeypatch.setenv("ORL_AGENT_STEP", knob)
+        env = orl.make("QoSConstrainedRA-v0", topology="nsfnet_chen", num_envs=n, seeds=seeds, **kw)
+        assert int(env.lib.orl_batch_debug_step_kernel(env._h)) == (2 if knob is None else 0)
+        rew = np.zeros(n)
+        for phase in range(2):
+            for _ in range(60):
+                env.policy("SAP_FF", fetch=False)
+                env.step(None, auto_reset=True, fetch=False)
+                env.sync()  # (the batch steps on its own stream)
+                rew += env.device_tensor("reward").cpu().numpy()
+            if phase == 0:
+                env.run("LLP_FF", 40)
+        out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy(), env.link_stats_all().copy(),
+                     np.stack([env.spectrum(i) for i in (0, n // 2, n - 1)]), rew]
+        env.close()
+    chk = _exact("qos 8-lane kernel")
+    for k, (x, y) in enumerate(zip(out["default"], out["wave64"])):
+        chk(k, "item", x, y)
 
 
 @pytest.mark.parametrize("fam,n,kw,pol", [
@@ -1441,7 +1490,7 @@ def test_step_in_two_halves_equals_step(fam, n, kw, pol):
     a.close(); b.close()
 
 
-def test_qos_evaluate_on_device_equals_the_harness():
+def test_qos_evaluate_on_device_equals_the_harness(qos_impl):
     """evaluate_heuristic (utils.py:103-141) for QoSConstrainedRA on the device: the reward of an accepted service is its
     class's reward (qos_constrained_ra.py:131-136), so the kernels keep each episode's float64 reward sum in step order;
     against the harness's accounting played on the oracle (reset, steps until done, += reward), with rewards that do not sum
