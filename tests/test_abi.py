@@ -110,3 +110,36 @@ def test_alt_library_exports_the_same_abi():
 
     assert _lib.lib("default").orl_build_has_alt() == 0
     assert _lib.lib("alt").orl_build_has_alt() == 1
+
+
+def test_specialisation_flags_carry_the_kernel_form_for_the_batch_size(monkeypatch):
+    """orl_spec_flags_for_batch (no device needed): the form of the persistent kernel is part of a specialisation's flags —
+    batches of at most 12 288 envs of the single-core families get the two-wavefront form (-DORL_SPEC_RW=1) with everything in
+    LDS at 3 waves per SIMD, large batches one wavefront per 8 envs; RMCSA never; QoSConstrainedRA has no persistent kernel."""
+    import re
+
+    from bench import WORKLOADS
+    from optical_rl_gym_amd import envs
+
+    for k in ("ORL_PERSIST_RW", "ORL_PERSIST_VARIANT", "ORL_PERSIST_INNER", "ORL_STEP_IMPL", "ORL_PERSIST"):
+        monkeypatch.delenv(k, raising=False)
+
+    def fields(name, batch):
+        fam, topo, kw, _ = WORKLOADS[name]
+        flags = envs.ENV_CLASSES[fam].spec_flags(batch=batch, topology=topo, **kw)
+        return {k: int(v) for k, v in re.findall(r"-DORL_SPEC_(RW|LDS|WAVES)=(\d+)", flags)}
+
+    for name in ("cfg1", "cfg2", "cfg3", "cfg5"):
+        small, large = fields(name, 4096), fields(name, 1 << 20)
+        assert small == dict(RW=1, LDS=1, WAVES=3), (name, small)
+        assert large["RW"] == 0, (name, large)
+        assert fields(name, 12288)["RW"] == (1 if name != "cfg5" else 0)  # (Germany50's window fits a CU four times, not six)
+        assert fields(name, 12296)["RW"] == 0
+    assert fields("cfg4", 4096)["RW"] == 0
+    monkeypatch.setenv("ORL_PERSIST_RW", "0")
+    assert fields("cfg2", 4096)["RW"] == 0
+    monkeypatch.delenv("ORL_PERSIST_RW")
+    qos = envs.ENV_CLASSES["QoSConstrainedRA"].spec_flags(batch=4096, topology="nsfnet_chen", num_spectrum_resources=32,
+                                                          num_service_classes=2, classes_arrival_probabilities=[0.5, 0.5],
+                                                          classes_reward=[2.0, 1.0])
+    assert qos is None
