@@ -346,11 +346,11 @@ int orl_batch_spec_flags(orl_batch* b, char* buf, int capacity);
 int orl_spec_flags_for(const orl_env_config* cfg, const orl_topology_desc* topo, char* buf, int capacity);
 int orl_spec_flags_for_batch(const orl_env_config* cfg, const orl_topology_desc* topo, int64_t n_envs, char* buf, int capacity);
 int orl_batch_load_spec(orl_batch* b, const char* so_path);
-/* Whether the last orl_batch_run used the attached specialisation (1) or the generic persistent kernel (0); -1 = another
- * step form. */
+/* Whether the last orl_batch_run used the attached specialisation — 1: one wavefront per 8 envs, 2: its two-wavefront form (a control
+ * and a row wavefront per 8 envs: batches of at most 12 288 envs) — or the generic persistent kernel (0); -1 = another step form. */
 int orl_batch_debug_persist_spec(orl_batch* b);
 /* Which kernel orl_batch_step launches for this batch: 2 = k_agent (8 lanes per env, the persistent kernel's phases for one
- * step), 0 = k_step (one wavefront per env). */
+ * step; QoSConstrainedRA: k_agent_qos, from 20 480 envs), 0 = k_step (one wavefront per env). */
 int orl_batch_debug_step_kernel(orl_batch* b);
 /* Statistics: env-steps whose releases took the serial tail (more than 8 of one step meeting on one link). */
 int64_t orl_batch_debug_serial_count(orl_batch* b);
