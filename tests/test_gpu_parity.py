@@ -397,6 +397,42 @@ def test_pair_form_early_exits_parked_and_ordered_services(workload, monkeypatch
         chk(k, "item", x, y)
 
 
+@pytest.mark.parametrize("workload,batch", [("cfg2", 4096), ("cfg2", 20000), ("cfg3", 4096), ("cfg5", 2048)])
+def test_short_statistics_log_and_early_exits(workload, batch, monkeypatch):
+    """The statistics log of a launch shortened to 12 steps (ORL_LOG_CAP; launches are then 6 steps long) and the item form limited
+    to one release per step: wavefronts that left early catch up over more steps than a launch can log, stop at the end of the log
+    and count as unfinished — with the batch of services the row wavefront of a pair has on order, and with services parked, at
+    every kind of exit.  Every env against the one-wavefront-per-env kernel (4 096 / 2 048 envs: the two-wavefront form; 20 000:
+    one wavefront per 8 envs)."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    fam, topo, kw, policy = WORKLOADS[workload]
+    kw = dict(kw, episode_length=70)
+    seeds = [5 + 11 * i for i in range(batch)]
+    out = {}
+    for name in ("wave64", "persist"):
+        force_impl(monkeypatch, name)
+        if name == "persist":
+            monkeypatch.setenv("ORL_ITEM_MASKS", "1")
+            monkeypatch.setenv("ORL_LOG_CAP", "12")
+            monkeypatch.setenv("ORL_JIT_SPEC", "1")
+        else:
+            monkeypatch.delenv("ORL_ITEM_MASKS", raising=False)
+            monkeypatch.delenv("ORL_LOG_CAP", raising=False)
+        env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+        for chunk in (83, 7, 110):
+            env.run(policy, chunk)
+        if name == "persist":
+            assert _ran_pair_form(env) == (batch <= 12288)
+        out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy(),
+                     env.net_stats_all().copy(), env.link_stats_all().copy(), env.slots_packed().copy()]
+        env.close()
+    chk = _exact("%s %d, short log" % (workload, batch))
+    for k, (x, y) in enumerate(zip(out["persist"], out["wave64"])):
+        chk(k, "item", x, y)
+
+
 def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkeypatch):
     """Any configuration gets the persistent kernel with ITS sizes as compile-time constants: a small library built on first
     use from the flags the main library writes for the batch (orl_batch_spec_flags -> _build.build_spec -> orl_batch_load_spec),
