@@ -117,6 +117,7 @@ struct DevParams {
   u32* q_cnt_a;     // [ceil(B/8)] items each control wavefront put into its region
   int q_wave;       // item slots per wavefront region
   int persist_ic;   // persistent kernel: keep the per-row cache of inner free runs in LDS (set per launch by the host)
+  int persist_evl;  // two-wavefront form: the 8 envs' pending release times in LDS behind the pair's areas (set per launch by the host)
   int persist_finish;  // this launch ends a run: every wavefront that reaches the target finishes its envs' pending
                        // network-compactness update and reports their flags itself (what k_finish2 does in a launch of its own)
   // the row caches of the persistent kernel travel with the state from launch to launch instead of being rebuilt from the

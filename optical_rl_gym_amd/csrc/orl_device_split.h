@@ -492,12 +492,13 @@ struct Wmem {
   bool cs_lds;   // the sums are in the wavefront's LDS window: plain reads; else they are read through L2 where the row phase's atomics land
   u32* ocg;      // GLOBAL [8][E]: the same words as oc0 where they do not fit the LDS window (the wavefront's level-2 area of
                  // DevParams::row_cache, live during the launch), or nullptr; indexed with cenv0
+  double* evl0;  // LDS [8][ev_cap]: the pending release times of the wavefront's envs (small batches, two-wavefront form), or nullptr
   u64* mini;     // LDS [8][ORL_MINI_STRIDE]: the record words ctrl_d works on (deferred statistics, records in global memory), or nullptr
   i64 mini_env0; // index base of mini
 };
 __device__ __forceinline__ Wmem wmem_global(const DevParams& P) {
   Wmem m;
-  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.sc_stride = ORL_SCAL_WORDS; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false; m.ocg = nullptr; m.mini = nullptr; m.mini_env0 = 0;
+  m.bm0 = P.bitmap; m.ls0 = P.lstat; m.cs0 = P.core_sums; m.env0 = 0; m.senv0 = 0; m.cenv0 = 0; m.sc0 = P.scal; m.scenv0 = 0; m.sc_stride = ORL_SCAL_WORDS; m.cs_stride = P.cs_words; m.ic0 = nullptr; m.oc0 = nullptr; m.clk = nullptr; m.clk_env0 = 0; m.cs_lds = false; m.ocg = nullptr; m.mini = nullptr; m.mini_env0 = 0; m.evl0 = nullptr;
   return m;
 }
 __device__ __forceinline__ u64* wm_bm(const DevParams& P, const Wmem& m, i64 env) { return m.bm0 + (env - m.env0) * P.bm_words; }
@@ -973,7 +974,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     }
     e.flags = 0;
     e.s_br = 0; e.s_nh = 0;  // (here: minus what this step's releases take off the sums)
-    e.ev_time = P.ev_time + env * P.ev_cap;
+    e.ev_time = M.evl0 ? M.evl0 + (env - M.env0) * P.ev_cap : P.ev_time + env * P.ev_cap;
     e.ev_info = P.ev_info + env * P.ev_cap;
     e.soon_t = P.soon_t + env * ORL_SOON;
     e.soon_i = P.soon_i + env * ORL_SOON;

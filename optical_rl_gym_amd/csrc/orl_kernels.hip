@@ -844,6 +844,26 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       M.mini[(lane >> 3) * ORL_MINI_STRIDE + (lane & 7)] = P.scal[env * ORL_SCAL_WORDS + sp::mini_slot(lane & 7)];
     wave_fence();
   }
+  // Small batches (the two-wavefront form, when the host found room: persist_evl): the pending release times of the 8 envs in LDS
+  // for the launch — the rebuild scan of the release detection walks them in five dependent rounds, global round trips of
+  // 1 000-2 000 cycles each on a GPU this empty
+  const bool EVL = RW && P.persist_evl != 0;
+  double* s_ev = (double*)(orl_lds_raw + L.total + ORL_RW_EXTRA_BYTES);
+  if (EVL) {
+    if (step < target) {
+      const double* g = P.ev_time + env0 * P.ev_cap;
+      const int n = nenv * P.ev_cap;
+      for (int base = 0; base < n; base += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = base + 64 * k + lane; v[k] = (i < n) ? g[i] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = base + 64 * k + lane; if (i < n) s_ev[i] = v[k]; }
+      }
+      wave_fence();
+    }
+    M.evl0 = s_ev;
+  }
   ORL_PROF_BEGIN();
   // (DS: a wavefront that caught up over more steps than a launch can log stops there and counts as unfinished)
   while (step < target && (!DS || step - first_step < P.log_cap)) {
@@ -1059,6 +1079,12 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
     for (int o = 32; o > 0; o >>= 1) f |= (u32)__shfl_xor((int)f, o, 64);
     if ((tid_f & 63) == 0 && f) atomicOr(n_unfinished + 1, f);
+  }
+  if (EVL && step > first_step) {  // (the release times go back)
+    wave_fence();
+    double* g = P.ev_time + env0 * P.ev_cap;
+    const int n = nenv * P.ev_cap;
+    for (int i = lane; i < n; i += 64) g[i] = s_ev[i];
   }
   if (CS0 && step > first_step) {
     wave_fence();
@@ -1688,7 +1714,7 @@ static int lds_wgs_per_cu(size_t lds) {
   const size_t alloc = (lds + 1279) / 1280 * 1280;
   return (int)((size_t)(160 * 1024) / alloc);
 }
-struct PersistChoice { int form; size_t lds; int inner; int rw; };
+struct PersistChoice { int form; size_t lds; int inner; int rw; int evl; };
 static size_t persist_window(const DevParams& VP, int state, int inner) {
   return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, state, persist_compact(VP.env_type, state), inner,
                                     orl_persist_deferred(VP.env_type)).total;
@@ -1769,6 +1795,15 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
   }
   if (c.rw && !getenv("ORL_PERSIST_INNER")) c.inner = can_inner ? 2 : 0;
   c.lds = persist_window(VP, kPersistForms[c.form].lds, c.inner) + (c.rw ? ORL_RW_EXTRA_BYTES : 0);
+  // ... and, where it still fits a workgroup's 64 KiB and the batch's workgroups a CU, the 8 envs' pending release times (cfg2:
+  // 36 KiB: two workgroups per CU, batches of at most 4 096 envs)
+  c.evl = 0;
+  if (c.rw) {
+    const size_t w = c.lds + (size_t)8 * VP.ev_cap * 8;
+    if (w <= 64 * 1024 && lds_wgs_per_cu(w) >= (int)(((VP.B + 7) / 8 + 255) / 256)) c.evl = 1;
+    if (const char* e = getenv("ORL_PERSIST_EVL")) c.evl = (atoi(e) != 0 && w <= 64 * 1024) ? 1 : 0;
+    if (c.evl) c.lds = w;
+  }
   return c;
 }
 static int persist_variant(const DevParams& VP, size_t* lds_bytes, bool tuned = false) {
@@ -1822,6 +1857,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   const PersistChoice ch = persist_choose(VC, use_spec);
   const int v = ch.form;
   VP.persist_ic = ch.inner;
+  VP.persist_evl = ch.evl;
   VP.row_cache_key = VP.row_cache ? ((b->cache_epoch << 8) | (v << 4) | ch.inner) : 0;
   if (const char* e = getenv("ORL_ROW_CACHE_KEEP")) { if (atoi(e) == 0) VP.row_cache_key = 0; }  // A/B: rebuild at every launch
   size_t lds_a = persist_tuned_lds(v, ch.lds);
