@@ -349,6 +349,10 @@ int orl_batch_load_spec(orl_batch* b, const char* so_path);
 /* Whether the last orl_batch_run used the attached specialisation — 1: one wavefront per 8 envs, 2: its two-wavefront form (a control
  * and a row wavefront per 8 envs: batches of at most 12 288 envs) — or the generic persistent kernel (0); -1 = another step form. */
 int orl_batch_debug_persist_spec(orl_batch* b);
+/* The form of the persistent kernel the last orl_batch_run launched (what lives in its LDS window / how the row statistics are
+ * done): 0-6 the forms with the row phase in the loop, 7 / 8 the rows-deferred forms (round 6: the loop logs events,
+ * k_rowstats replays the link statistics after the launch); -1 = no device-resident run through the persistent kernel yet. */
+int orl_batch_debug_persist_form(orl_batch* b);
 /* Which kernel orl_batch_step launches for this batch: 2 = k_agent (8 lanes per env, the persistent kernel's phases for one
  * step; QoSConstrainedRA: k_agent_qos, from 20 480 envs), 0 = k_step (one wavefront per env). */
 int orl_batch_debug_step_kernel(orl_batch* b);

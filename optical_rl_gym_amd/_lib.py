@@ -79,6 +79,7 @@ EXPORTS = {
     "orl_batch_device_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "orl_batch_debug_serial_count": (C.c_int64, [C.c_void_p]),
     "orl_batch_debug_persist_spec": (C.c_int, [C.c_void_p]),
+    "orl_batch_debug_persist_form": (C.c_int, [C.c_void_p]),
     "orl_batch_debug_step_kernel": (C.c_int, [C.c_void_p]),
     "orl_build_has_alt": (C.c_int, []),
     "orl_batch_debug_prof": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

@@ -189,6 +189,12 @@ __global__ void k_gather_rows(const double* __restrict__ src, const long long* _
 }
 
 // sums of services_processed / services_accepted over the batch (two atomics per wave)
+// orl_batch_set_info_mode(1): the info columns the 8-lanes-per-env step kernel stops writing (network compactness, its difference,
+// the two link means: entries 4..7 of RMSA / DeepRMSA) read NaN from here on instead of the last values written in mode 0
+__global__ void k_info_nan(DevParams P) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i < P.B * 4) P.info[(i >> 2) * P.n_info + 4 + (i & 3)] = __longlong_as_double(0x7ff8000000000000ll);
+}
 __global__ void k_totals(DevParams P, unsigned long long* out) {
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   i64 sp = 0, sa = 0;
@@ -376,6 +382,7 @@ static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
   q.svc_q += lo * 8; q.svc_ht += lo * 8; q.svc_pk += lo * 8; q.svc_cnt += lo * 8;  // (64 lanes per 8 envs; lo is a multiple of 8)
   q.row_cache += (lo / 8) * 2 * (i64)P.row_cache_words; q.row_cache_stamp += lo / 8;
   if (q.slog) { q.slog += lo; q.log_n += lo / 8; }  // (rows of the log span the whole batch: log_stride stays)
+  if (q.elog) { q.elog += lo * (i64)P.elog_cap; q.elog_n += lo; }
   if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
   if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (P.S + 1));
   if (q.act2d) q.act2d += lo * P.act2d_words;
@@ -609,20 +616,8 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
       rc |= dalloc(b, &P.svc_cnt, n_lanes);
       if (!rc) HIPCHK_B(hipMemset(P.svc_cnt, 0, n_lanes * sizeof(int)));  // nothing drawn ahead
     }
-    if (b->persist && orl_persist_deferred(P.env_type)) {
-      // the statistics log of a launch: 24 bytes per env-step, two chunks' worth of steps (a wavefront that left a launch early
-      // catches up in the next one), at most 1 GiB — larger batches run shorter launches (orl_batch_run)
-      const size_t per_step = (size_t)ORL_SLOG_ROW_WORDS * 8 * B;
-      size_t cap = ((size_t)1 << 30) / per_step;
-      cap = cap > 256 ? 256 : (cap < 16 ? 16 : cap);
-      if (const char* lv = getenv("ORL_LOG_CAP")) { const int v = atoi(lv); if (v >= 2 && v <= 256) cap = (size_t)v; }  // tests
-      P.log_cap = (int)cap;
-      P.log_stride = (i64)B;
-      b->log_cap = (int)cap;
-      rc |= dalloc(b, &P.slog, (cap + 1) * (size_t)ORL_SLOG_ROW_WORDS * B);
-      rc |= dalloc(b, &P.log_n, (B + 7) / 8 + 16);
-      if (!rc) HIPCHK_B(hipMemset(P.log_n, 0, ((B + 7) / 8 + 16) * sizeof(int)));
-    }
+    // (the statistics log and the event log of the persistent kernel's launches are allocated by the first device-resident run,
+    // for the launch length it uses: ensure_logs)
   }
   rc |= dalloc(b, &P.bitmap, B * P.bm_words);
   rc |= dalloc(b, &P.ev_time, B * P.ev_cap);
@@ -753,6 +748,9 @@ extern "C" int orl_batch_reset(orl_batch* b, int full, const uint8_t* env_mask) 
   if (b->P.obs_dim) launch_obs(b, 0);
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipGetLastError());
+  // (a full reset of every env leaves nothing of an abandoned run behind: k_reset dropped the parked services of the envs it
+  // reset, the step counters start over with the next run)
+  if (full && !env_mask) { b->run_abandoned = false; b->wg_dirty = true; }
   return ORL_OK;
 }
 ORL_ABI_CATCH_INT
@@ -1066,6 +1064,10 @@ ORL_ABI_CATCH_INT
 
 extern "C" int orl_batch_set_info_mode(orl_batch* b, int mode) try {
   if (!b || mode < 0 || mode > 1) return fail(ORL_E_INVALID, "info mode 0 (all entries) or 1 (blocking rates only)");
+  if (mode == 1 && b->P.info_mode == 0 && (b->P.env_type == ENV_RMSA || b->P.env_type == ENV_DEEPRMSA) && b->P.n_info >= 8) {
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_info_nan, dim3((unsigned)((b->P.B * 4 + 255) / 256)), dim3(256), 0, b->stream, b->P);
+  }
   b->P.info_mode = mode;
   return ORL_OK;
 }
@@ -1173,6 +1175,66 @@ extern "C" int orl_batch_get_info_rows(orl_batch* b, const int64_t* env_index, i
 }
 ORL_ABI_CATCH_INT
 
+// The logs of a launch of the persistent kernel (deferred statistics: 24 bytes per env-step, DevParams::slog; rows-deferred forms:
+// 16 bytes per provision / release, DevParams::elog), allocated by the first device-resident run and sized for the launches that
+// run makes — `chunk` steps each, a wavefront that left a launch early catching up over at most two chunks — instead of the 256
+// steps' worth every batch used to get at creation (404 MB per 65 536-env batch whether it ever ran a device loop or not).  Each
+// log stays below 1 GiB: larger batches run shorter launches.  A later run with longer launches replaces them.
+template <typename T> static void dfree(orl_batch* b, T** p) {
+  if (!*p) return;
+  for (size_t i = 0; i < b->allocs.size(); i++)
+    if (b->allocs[i] == (void*)*p) { b->allocs.erase(b->allocs.begin() + (long)i); break; }
+  hipFree(*p);
+  *p = nullptr;
+}
+static int ensure_logs(orl_batch* b, int64_t n_steps, int* chunk_io) {
+  DevParams& P = b->P;
+  if (!b->persist || !orl_persist_deferred(P.env_type)) return ORL_OK;
+  const size_t B = (size_t)P.B;
+  int chunk = *chunk_io;
+  size_t want = (n_steps <= chunk) ? (size_t)(n_steps > 0 ? n_steps : 1) : (size_t)2 * chunk;
+  const size_t per_step = (size_t)ORL_SLOG_ROW_WORDS * 8 * B;
+  size_t most = ((size_t)1 << 30) / per_step;
+  most = most > 256 ? 256 : (most < 2 ? 2 : most);
+  if (want > most) want = most;
+  if (want < 2) want = 2;
+  if (const char* lv = getenv("ORL_LOG_CAP")) { const int v = atoi(lv); if (v >= 2 && v <= 256) want = (size_t)v; }  // tests
+  if ((size_t)b->log_cap < want) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
+    dfree(b, &P.slog);
+    dfree(b, &P.elog);
+    int rc = dalloc(b, &P.slog, (want + 1) * (size_t)ORL_SLOG_ROW_WORDS * B);
+    if (rc) return rc;
+    if (!P.log_n) {
+      rc = dalloc(b, &P.log_n, (B + 7) / 8 + 16);
+      if (rc) return rc;
+      HIPCHK(hipMemset(P.log_n, 0, ((B + 7) / 8 + 16) * sizeof(int)));
+    }
+    P.log_cap = (int)want;
+    P.log_stride = (i64)B;
+    b->log_cap = (int)want;
+    // events: a step logs its provision and its releases, two per step on average; a wavefront whose envs' logs cannot take
+    // another step stops early like one that used up the statistics log
+    if (P.env_type != ENV_RMCSA && P.E <= 64) {
+      size_t ecap = 3 * want + 40, emost = ((size_t)1 << 30) / (16 * B);
+      if (emost < 80) emost = 80;
+      if (ecap > emost) ecap = emost;
+      rc = dalloc(b, &P.elog, ecap * B);
+      if (rc) return rc;
+      if (!P.elog_n) {
+        rc = dalloc(b, &P.elog_n, B + 16);
+        if (rc) return rc;
+      }
+      P.elog_cap = (int)ecap;
+    }
+  }
+  // (a launch logs at most log_cap steps per wavefront, a straggler up to two chunks)
+  if (n_steps > b->log_cap && chunk > b->log_cap / 2) chunk = b->log_cap / 2 > 0 ? b->log_cap / 2 : 1;
+  *chunk_io = chunk;
+  return ORL_OK;
+}
+
 // events created for one call, destroyed on every exit path
 struct EventPool {
   std::vector<hipEvent_t> ev;
@@ -1218,8 +1280,8 @@ extern "C" int orl_batch_run(orl_batch* b, int policy_id, int64_t n_steps, int t
     // leave its loop early, so longer launches leave no stragglers behind)
     int chunk = 128;
     if (const char* cv = getenv("ORL_PERSIST_CHUNK")) { int v = atoi(cv); if (v >= 1) chunk = v; }
-    // (deferred statistics: a launch logs at most log_cap steps per wavefront, a straggler up to two chunks)
-    if (b->log_cap > 0 && chunk > b->log_cap / 2) chunk = b->log_cap / 2 > 0 ? b->log_cap / 2 : 1;
+    // (deferred statistics: the logs a launch writes, allocated on first use; a launch logs at most log_cap steps per wavefront)
+    { const int lrc = ensure_logs(b, n_steps, &chunk); if (lrc) return lrc; }
     // A launch occupies the GPU in rounds of `resident` wavefronts, and a last round that is not full leaves CUs idle until
     // the launch ends (cfg2: 8 192 wavefronts over 3 072 resident = 2.67 rounds, 11 % of the machine-time lost).  When the
     // rounds do not come out even, the batch runs as two halves on two streams: the tail of one half's launch overlaps the
@@ -1831,6 +1893,11 @@ ORL_ABI_CATCH_INT
 extern "C" int orl_batch_debug_persist_spec(orl_batch* b) try {
   if (!b) return -1;
   return b->persist ? b->persist_spec : -1;
+}
+ORL_ABI_CATCH_INT
+extern "C" int orl_batch_debug_persist_form(orl_batch* b) try {
+  if (!b) return -1;
+  return b->persist ? b->persist_form_last : -1;
 }
 ORL_ABI_CATCH_INT
 extern "C" int orl_batch_debug_step_kernel(orl_batch* b) try {

@@ -145,6 +145,13 @@ struct DevParams {
   int* log_n;       // [ceil(B/8)] steps the wavefront logged in this launch | (it finished the run's state itself) << 16
   i64 log_stride;   // envs per row of the log: the whole batch, whichever view of it a launch works on
   int log_cap;      // steps one launch can log per wavefront
+  // rows-deferred form of the persistent kernel (round 6; orl_device_split.h ctrl_d<..., RD>, orl_kernels.hip k_rowstats): the loop
+  // changes the slot maps itself and logs one 16-byte event per provision / release — {first slot:9 | slots:6 | step of the
+  // launch:9 | provision:1, bit mask of the links of the path} — in the order the reference applies them; the per-link statistics
+  // and the compactness sums are replayed from them after the launch, one lane per link ROW
+  ulonglong2* elog; // [B][elog_cap]
+  int* elog_n;      // [B] events the env logged in this launch
+  int elog_cap;     // events per env and launch
   double* soon_t;   // [B][ORL_SOON] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8, ...
   u32* soon_i;      // [B][ORL_SOON] their slots in ev_time / ev_info
   i64 q_cap;

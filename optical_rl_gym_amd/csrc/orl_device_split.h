@@ -178,8 +178,16 @@ __device__ __forceinline__ void row_apply_mask(u64* row, int s0, int n, bool pro
 }
 template <bool CP> struct SinkEntryOf { typedef SinkEntry type; };
 template <> struct SinkEntryOf<true> { typedef SinkEntryC type; };
-template <bool CP> struct SinkT {
+// RD (rows deferred, round 6): no table at all — the control phase changes the slot maps itself (as in the two-wavefront form)
+// and appends one 16-byte EVENT per provision / release to the env's log of the launch (DevParams::elog): what k_rowstats replays
+// the per-link statistics and the compactness sums from, one lane per link row
+#define ORL_EV_META(S0, N, T, PROV) ((u64)(u32)(S0) | ((u64)(u32)(N) << 9) | ((u64)(u32)(T) << 15) | ((u64)((PROV) ? 1u : 0u) << 24))
+template <bool CP, bool RD = false> struct SinkT {
   typedef typename SinkEntryOf<CP>::type Entry;
+  ulonglong2* ev;  // RD: the env's event log of this launch
+  int ev_at;       // RD: index of this step's first event (its provision, if it has one)
+  int ev_rel0;     // RD: index of this step's first release event
+  int ev_t;        // RD: the step's number within the launch
   unsigned short* list;  // LDS (persistent kernel, else nullptr): the wavefront's open table entries, (local env << 8) | link ...
   u32* list_n;           // ... and their number, zeroed at the start of the step
   Entry* tab;      // LDS, E entries of this env, mask count zeroed
@@ -206,10 +214,23 @@ __device__ __forceinline__ int sink_entry_add(SinkEntry* t, u64 m, int core, boo
   return j | (int)((crn >> 44) & 1) << 8;
 }
 // lane h of the group appends the mask to the item of hop h's link (the links of one path are distinct)
-template <bool CP>
-__device__ __forceinline__ void sink_add(SinkT<CP>& s, const PathRec& rec, int core, int s0, int n, int lane, bool prov = false) {
+template <bool CP, bool RD>
+__device__ __forceinline__ void sink_add(SinkT<CP, RD>& s, const PathRec& rec, int core, int s0, int n, int lane, bool prov = false) {
   const int hops = path_rec_byte(rec, 0);
-  if constexpr (CP) {
+  if constexpr (RD) {
+    // (the step's provision: the hops over the group's lanes, their link bits ORed over the group; the releases of a step are
+    // logged by their holder lanes, release_soon)
+    u32 lm0 = 0u, lm1 = 0u;
+    for (int h = lane & 7; h < hops; h += 8) {
+      const int link = path_rec_byte(rec, 2 + h);
+      row_apply_mask(s.rows + (size_t)link * s.roww, s0, n, prov);
+      if (link < 32) lm0 |= 1u << link; else lm1 |= 1u << (link - 32);
+    }
+    lm0 |= (u32)dpp_i<ORL_DPP_XOR1>((int)lm0); lm1 |= (u32)dpp_i<ORL_DPP_XOR1>((int)lm1);
+    lm0 |= (u32)dpp_i<ORL_DPP_XOR2>((int)lm0); lm1 |= (u32)dpp_i<ORL_DPP_XOR2>((int)lm1);
+    lm0 |= (u32)dpp_i<ORL_DPP_HALF_MIRROR>((int)lm0); lm1 |= (u32)dpp_i<ORL_DPP_HALF_MIRROR>((int)lm1);
+    if ((lane & 7) == 0) s.ev[s.ev_at] = make_ulonglong2(ORL_EV_META(s0, n, s.ev_t, prov), (u64)lm0 | ((u64)lm1 << 32));
+  } else if constexpr (CP) {
     const int k = prov ? 0 : ++s.nrel;  // this mask's entry of the env's table (the caller keeps nrel <= ORL_REL_MAX)
     if ((lane & 7) == 0) s.mtab[k] = (unsigned short)((u32)s0 | ((u32)n << 9));
     // (no value comes back from the atomics: the item list is made from the table afterwards, sink_compact — until round 5 every
@@ -515,8 +536,8 @@ struct CtrlOpts {
   bool auto_reset;  // an env that reports done is soft-reset right away (the device-resident loop, SB3's VecEnv); k_agent: the caller's choice
   bool rank_pairs;  // (soon list in registers) rank the due releases all-pairs over DPP: needs the 168-VGPR budget
 };
-template <int ENV, int W, bool CP>
-__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
+template <int ENV, int W, bool CP, bool RD = false>
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP, RD>& sink, SoonRegs& out, Prof& prof,
                                              int extra = 0, int pushed_idx = -1, u64 pushed_info = 0ull, int pre_idx = -1,
                                              u64 pre_info = 0ull);
 
@@ -918,23 +939,29 @@ __device__ __forceinline__ void rw_wait_for(const u32* p, u32 want) {
   while ((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <int ENV, int W, bool CP, bool MINI, bool RW = false>
+// RD (rows deferred, round 6): as RW, this phase changes the slot maps itself — but there is no row phase at all in the loop: every
+// provision and release is logged as an event (SinkT<CP, true>, DevParams::elog; `ecur`: the env's event count so far in this
+// launch, `t_log`: the step's number within the launch) and k_rowstats replays the link statistics and the compactness sums after
+// the launch; the sums fields of log word w1 are left zero here and filled in by that kernel before k_stats reads them.
+template <int ENV, int W, bool CP, bool MINI, bool RW = false, bool RD = false>
 __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const CtrlOpts& O, i64 env, bool valid, int lane, Prof& prof,
                                       const int4& av, u64 desc, typename SinkEntryOf<CP>::type* s_tab, u32* s_tally, int tw, int* s_deferred,
                                       int* done_out, unsigned short* s_list, u32* s_list_n, SoonRegs* carried, unsigned short* s_mtab,
                                       SvcBuf& svc, int& esp, int& prev_core, u64* slog, const ScanHand* hand = nullptr, int pop_pre = -2,
-                                      const u32* rw_sync = nullptr, u32 rw_k = 0u) {
+                                      const u32* rw_sync = nullptr, u32 rw_k = 0u, int* ecur = nullptr, int t_log = 0) {
+  static_assert(!RD || (CP && !RW), "rows deferred: single-core families, one wavefront per 8 envs");
   // `hand`: the chosen path's slot count and record from the scan's winning lane (single-core families); `pop_pre`: the top entry
   // of the env's free-slot stack (-1: empty), requested by the caller before the scan (-2: not given) — with both, nothing the
   // decision needs is fetched from global memory behind the scan
   const int K = P.K, S = P.S, gl = lane & 7;
   u64 desc_out = 0ull;
-  SinkT<CP> sink;
+  SinkT<CP, RD> sink;
   sink.tab = nullptr; sink.tally = nullptr; sink.tw = tw; sink.active = false; sink.deferred = false; sink.cnt = 0;
   sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0; sink.rows = nullptr; sink.roww = 0;
+  sink.ev = nullptr; sink.ev_at = 0; sink.ev_rel0 = 0; sink.ev_t = t_log;
   if constexpr (RW) { rw_wait_for(rw_sync + 1, rw_k); ORL_PROFA(14); }  // (the row wavefront has read the previous step's tables and rows)
-  if (!RW && lane == 0) *s_list_n = 0u;  // (RW: the list is the row wavefront's)
-  {
+  if (!RW && !RD && lane == 0) *s_list_n = 0u;  // (RW: the list is the row wavefront's)
+  if constexpr (!RD) {
     typename SinkEntryOf<CP>::type* tb = s_tab + P.E * 8 * (int)(threadIdx.x >> 6);
     if constexpr (!CP) {
       u32* ty = s_tally + tw * 8 * (int)(threadIdx.x >> 6);
@@ -999,11 +1026,12 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     e.bm = wm_bm(P, M, env);
     e.ls = wm_ls(P, M, env);
     e.cs = wm_cs(P, M, env);
-    if constexpr (RW && CP) { sink.rows = e.bm; sink.roww = W; }
+    if constexpr ((RW || RD) && CP) { sink.rows = e.bm; sink.roww = W; }
+    if constexpr (RD) { sink.ev = P.elog + env * (i64)P.elog_cap; sink.ev_at = *ecur; sink.ev_rel0 = *ecur; }
     int occ_s = 0, fb_s = 0;
     const int pc_s = (ENV == ENV_RMCSA) ? prev_core : 0;
     auto read_sums = [&]() {
-      if (ENV != ENV_RWA) {
+      if (ENV != ENV_RWA && !RD) {
         // the sums right after the previous step's provision — of the core it went to — (its pending network-compactness update,
         // rmsa_env.py:439-462, is finished by the replay from them); this step's releases start from zero
         int* rs = e.cs + 2 * P.C;
@@ -1054,6 +1082,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
         const int hops = path_rec_byte(prec, 0);
         n_hops = n * hops;
         accepted = true;
+        if constexpr (RD) sink.ev_rel0 = sink.ev_at + 1;
         pushed_info = ev_pack(pidx, slot, n, core, e.bit_rate);
         pushed_t = e.now + e.ht;  // (arrival time + holding time: the clock stands at the pending service's arrival)
 #ifndef ORL_DIAG_NO_PUSH
@@ -1075,7 +1104,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
         P.reward[env] = accepted ? 1.0 : (ENV == ENV_DEEPRMSA ? -1.0 : 0.0);
         *(int4*)(P.actions + env * 4) = (ENV == ENV_DEEPRMSA) ? make_int4(av.x, 0, 0, 0) : av;
       }
-      M.clk[2 * (env - M.clk_env0)] = e.now;  // (SC_NOWA is the replay's: every form with this control phase has the clock pair)
+      if constexpr (!RD) M.clk[2 * (env - M.clk_env0)] = e.now;  // (SC_NOWA is the replay's: every form with this control phase has the clock pair)
     }
     ORL_PROFA(5);
     // the next service, drawn ahead by svc_generate: from the lane of the group that holds it
@@ -1121,15 +1150,16 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     if (gl == 0 && O.write_io) P.done[env] = done ? 1 : 0;
     if (done_out) *done_out = done ? 1 : 0;
     if (pushed_idx >= 0 && gl == (pushed_idx & 7)) { e.ev_time[pushed_idx] = pushed_t; e.ev_info[pushed_idx] = pushed_info; }
-    if (gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now;
+    if constexpr (!RD) { if (gl == 0) M.clk[2 * (env - M.clk_env0) + 1] = e.now; }
     ORL_PROFA(8);
     {
       SoonRegs soon;
 #ifdef ORL_DIAG_INSTEAD_OF_RELEASES
       ORL_DIAG_INSTEAD_OF_RELEASES
 #else
-      release_soon<ENV, W, CP>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
+      release_soon<ENV, W, CP, RD>(P, e, lane, sink, soon, prof, accepted ? 1 : 0, pushed_idx, pushed_info, pre_idx, pre_info);
 #endif
+      if constexpr (RD) *ecur = sink.ev_rel0 + sink.nrel;
       ORL_PROFA(10);
       if (sink.deferred) {
         // (as ctrl_a) the releases stay pending; rel_serial does them in place at the start of this wavefront's next launch
@@ -1169,7 +1199,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
       for (int k = 0; k < ORL_SOON_PER_LANE; k++) { carried->t[k] = e.sr_t[k]; carried->i[k] = e.sr_i[k]; }
     }
   }
-  if constexpr (CP && !RW) {  // (RW: the row wavefront makes its list from the table itself)
+  if constexpr (CP && !RW && !RD) {  // (RW: the row wavefront makes its list from the table itself)
     wave_fence();
     sink_compact(s_tab + P.E * 8 * (int)(threadIdx.x >> 6), P.E, lane, s_list, s_list_n);
   }
@@ -1253,11 +1283,11 @@ __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 en
 // only when the clock passes t_soon the list is rebuilt from a full scan.  Pushes keep the invariant (g8::ev_push).
 // ---------------------------------------------------------------------------------------------------------------
 // The list is returned in registers: the caller writes it back (when dirty) after everything that still loads.
-template <int ENV, int W, bool CP>
+template <int ENV, int W, bool CP, bool RD>
 // `pre_idx / pre_info`: a release slot of this LANE's list whose info word the caller requested at the start of the step.
 // `extra`: masks this step already put on links (its provision, two-kernel pipeline); `pushed_idx / pushed_info`: the
 // release slot the same kernel has just written — its info word is taken from registers, not re-read through memory.
-__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP>& sink, SoonRegs& out, Prof& prof,
+__device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int lane, SinkT<CP, RD>& sink, SoonRegs& out, Prof& prof,
                                              int extra, int pushed_idx, u64 pushed_info, int pre_idx, u64 pre_info) {
   constexpr int NS = ORL_SOON_PER_LANE;
   out.dirty = 0;
@@ -1513,11 +1543,22 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
         const PathRec rec = path_rec_load(P, (int)(info & 0xffffffu));
         const int s0 = (int)((info >> 24) & 0xfffu), n = (int)((info >> 36) & 0xffu), br = (int)((info >> 49) & 0x7fffu);
         const int hops = path_rec_byte(rec, 0), kk = nrel0 + r;
+        if constexpr (RD) {
+          // rows deferred: the holder lane frees the slots itself and logs the release as the step's kk-th event behind the provision
+          u64 lm = 0ull;
+          for (int h = 0; h < hops; h++) {
+            const int link = path_rec_byte(rec, 2 + h);
+            row_apply_mask(sink.rows + (size_t)link * sink.roww, s0, n, false);
+            lm |= 1ull << link;
+          }
+          sink.ev[sink.ev_rel0 + kk - 1] = make_ulonglong2(ORL_EV_META(s0, n, sink.ev_t, false), lm);
+        } else {
         sink.mtab[kk] = (unsigned short)((u32)s0 | ((u32)n << 9));
         for (int h = 0; h < hops; h++) {
           const int link = path_rec_byte(rec, 2 + h);
           atomicOr(&sink.tab[link].bits, 1u << kk);  // (items: sink_compact)
           if (sink.rows) row_apply_mask(sink.rows + (size_t)link * sink.roww, s0, n, false);
+        }
         }
         // the freed slot goes onto the env's free-slot stack at the place its rank gives it (g8::free_push, one by one before)
         const int fp = nfree0 + r - 1;

@@ -49,6 +49,7 @@ struct orl_batch {
   int two_kernel = 0;    // ORL_ALT_IMPLS builds, ORL_STEP_IMPL=2 ORL_PERSIST=0: the phases of k_persist as separate launches
   int64_t persist_launches = 0;
   int persist_spec = 0;            // 1: the last launch of k_persist used the instantiation built for this configuration
+  int persist_form_last = -1;      // the form (index into kPersistForms) of the last launch of k_persist
   // a specialisation library attached by orl_batch_load_spec: k_persist with this batch's sizes as compile-time constants
   void* spec_handle = nullptr;
   void (*spec_launch)(const orl::DevParams*, unsigned, size_t, hipStream_t, int, int, int*, unsigned int*, unsigned int*) = nullptr;

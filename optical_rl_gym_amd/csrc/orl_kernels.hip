@@ -239,24 +239,27 @@ struct PersistLds {  // byte offsets into the workgroup's dynamic LDS window (al
 // inner: 0 = no row caches, 1 = the per-word longest-run cache of every row, 2 = + every row's contribution to the compactness
 // sums, (occ << 16) | free blocks (4 bytes per row each)
 // mini: the eight record words the deferred-statistics control phase works on, for the forms whose records stay in global memory
-__host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, int inner, bool mini = false) {
+// rd: the rows-deferred form (round 6) — no row phase in the loop, hence no sink table, mask table, item list, clock pairs, row
+// caches or per-core sums: the window is the slot maps, the record words the control phase works on, and 16 bytes
+__host__ __device__ inline PersistLds persist_lds_layout(int E, int H, int bm_words, int C, int state, bool compact, int inner, bool mini = false,
+                                                         bool rd = false) {
   PersistLds L;
   int o = 0;
-  L.tab = o; o += (8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry)) + 15) & ~15;
-  L.mtab = o; if (compact) o += 8 * ORL_MTAB * 2;
+  L.tab = o; if (!rd) o += (8 * E * (int)(compact ? sizeof(sp::SinkEntryC) : sizeof(sp::SinkEntry)) + 15) & ~15;
+  L.mtab = o; if (compact && !rd) o += 8 * ORL_MTAB * 2;
   L.tw = compact ? 0 : (E + 3) >> 2;
   L.tally = o; o += 8 * L.tw * 4;
   // one entry per touched link and env, a second one where the step's provision meets a release (at most its hops)
-  L.list = o; o += ((8 * (E + (H < E ? H : E)) * 2) + 15) & ~15;
+  L.list = o; if (!rd) o += ((8 * (E + (H < E ? H : E)) * 2) + 15) & ~15;
   // {provision clock, step clock} of the 8 envs for the row phase (the deferred-statistics control phase never writes SC_NOWA,
   // which the replay owns, so the forms with the records in LDS have the pair too; the full-LDS test form reads the records)
-  L.clk = o; if (state != 2) o += 8 * 2 * 8;
+  L.clk = o; if (state != 2 && !rd) o += 8 * 2 * 8;
   L.misc = o; o += 16;
   L.bm = o; if (state >= 1) o += 8 * bm_words * 8;
   L.csw = (4 * C + 3) & ~3;  // sums + their release part, ints per env
-  L.cs = o; if (state >= 1 || mini) o += 8 * L.csw * 4;  // (the global-state form of the deferred-statistics kernel keeps them in LDS too)
+  L.cs = o; if ((state >= 1 || mini) && !rd) o += 8 * L.csw * 4;  // (the global-state form of the deferred-statistics kernel keeps them in LDS too)
   L.sc = o; if (state == 1 || state == 2) o += 8 * ORL_SCAL_LDS_WORDS * 8;
-  L.ic = o; if (state >= 1 && inner) o += inner * ((8 * E * 4 + 15) & ~15);
+  L.ic = o; if (state >= 1 && inner && !rd) o += inner * ((8 * E * 4 + 15) & ~15);
   L.ls = o; if (state == 2) o += 8 * E * 32;
   L.mini = o; if (mini && (state == 0 || state == 3)) o += (8 * ORL_MINI_STRIDE * 8 + 15) & ~15;
   L.total = o;
@@ -477,6 +480,188 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
   (void)now; (void)br_idx;
 }
 
+// ---- rows-deferred form: the replay of the row statistics (round 6) ----------------------------------------------------------
+// In the rows-deferred forms of k_persist the loop is slot scan + control phase only: the control phase changes the slot maps
+// itself and logs one event per provision / release (sp::ctrl_d<..., RD>).  Nothing the row phase computed feeds a decision —
+// the per-link running averages of _update_link_stats (rmsa_env.py:464-543; rwa_env.py:365-383) and the integer sums behind
+// _get_network_compactness (rmsa_env.py:699-744) are state the loop only ever wrote.  This kernel replays them after the launch
+// with one LANE per link ROW: the lane reads its row as the launch left it, takes the masks of the launch's events that touch its
+// link back (a provision clears free slots, a release sets taken ones: both are XORs, in any order) to get the row as the launch
+// found it, then walks ITS events in order — mask, row summary, float64 update at the event's clock, exactly the expressions
+// of sp::row_item_lane1 — with the link's 32-byte record, the row, its inner-run cache and its contribution to the sums in
+// registers for the whole launch: full lanes, no provision / release lane pairs, no sink tables, one read and one write of
+// the link record per launch instead of per touch.  Which events touch the lane's link is found once (first pass, a bit per
+// event in LDS) so that the second pass runs the heavy body once per lane and touch with no event scan in between.
+// The sums: every touch adds (occupied-range delta << 16) + free-block delta to the (step, provision | release) cell of its env
+// in LDS; afterwards one lane per env turns them into the sums right after each step's provision — what the control phase used
+// to log into word w1 of the statistics log — and ORs them into that word for k_stats, writes the slot behind the last step
+// (k_stats finishes the run's last pending update from it) and leaves DevParams::core_sums as the in-loop row phase would have.
+// A workgroup owns G = 256 / E whole envs (all rows of an env in one workgroup: the sums need no global atomics).
+#define ORL_ROWSTATS_THREADS 256
+template <int ENV, int W>
+__global__ void __launch_bounds__(ORL_ROWSTATS_THREADS) k_rowstats(DevParams P, int G, int nw /* 32-event words of touch bits per lane */) {
+  constexpr bool RWA = ENV == ENV_RWA;
+  const int E = P.E, S = P.S, cap = P.log_cap;
+  const int tid = (int)threadIdx.x;
+  int* s_delta = (int*)orl_lds_raw;                                  // [(cap + 1)][2][G]
+  u32* s_tb = (u32*)(orl_lds_raw + (((size_t)(cap + 1) * 2 * G * 4 + 15) & ~(size_t)15));  // [nw][256]
+  const int ge = tid / E, link = tid - ge * E;
+  const i64 env = (i64)blockIdx.x * G + ge;
+  const bool rowlane = ge < G && env < P.B;
+  if (!RWA)
+    for (int i = tid; i < (cap + 1) * 2 * G; i += ORL_ROWSTATS_THREADS) s_delta[i] = 0;
+  __syncthreads();
+  int n_ev = 0;
+  if (rowlane) {
+    const int ns = P.log_n[env >> 3] & 0xffff;
+    n_ev = ns ? P.elog_n[env] : 0;
+  }
+  if (n_ev > 0) {
+    const ulonglong2* ev = P.elog + env * (i64)P.elog_cap;
+    u64* row = P.bitmap + env * P.bm_words + (size_t)link * W;
+    u64 a[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) a[w] = row[w];
+    // pass 1: which events touch this link (bit per event, 32 per LDS word), and the row as the launch found it
+    int ntouch = 0;
+    for (int j0 = 0; j0 < n_ev; j0 += 32) {
+      u32 bits = 0u;
+      for (int j1 = 0; j1 < 32 && j0 + j1 < n_ev; j1 += 8) {
+        ulonglong2 e8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e8[k] = ev[(j0 + j1 + k < n_ev) ? j0 + j1 + k : n_ev - 1];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (j0 + j1 + k < n_ev && ((e8[k].y >> link) & 1ull)) {
+            bits |= 1u << (j1 + k);
+            const sp::Mask2 mm = sp::mask2((int)(e8[k].x & 0x1ffu), (int)((e8[k].x >> 9) & 63u));
+#pragma unroll
+            for (int w = 0; w < W; w++) a[w] ^= sp::mask2_word(mm, w);
+          }
+        }
+      }
+      s_tb[(j0 >> 5) * ORL_ROWSTATS_THREADS + tid] = bits;
+      ntouch += __popc(bits);
+    }
+    if (ntouch > 0) {
+      double* ls = P.lstat + env * 4 * E + 4 * link;
+      const double2 ls01 = *(const double2*)ls, ls23 = *(const double2*)(ls + 2);
+      double util = ls01.x, frag = ls01.y, comp = ls23.x, last_update = ls23.y;
+      const u64* lg = P.slog + env;
+      const size_t lst = (size_t)P.log_stride;
+      int occ0 = 0, fb0 = 0;
+      if (!RWA) sp::row_occ_fb<W>(a, S, occ0, fb0);
+      u32 cw = 0u;  // inner-run cache of the row: nothing known yet
+#pragma unroll
+      for (int w = 0; w < (W <= 5 ? W : 0); w++) cw |= 63u << (6 * w);
+      const int nwords = (n_ev + 31) >> 5;
+      int wi = 0;
+      u32 word = s_tb[tid];
+      for (;;) {
+        while (word == 0u && wi + 1 < nwords) { wi++; word = s_tb[wi * ORL_ROWSTATS_THREADS + tid]; }
+        if (word == 0u) break;
+        const int j = 32 * wi + (int)__builtin_ctz(word);
+        word &= word - 1u;
+        const u64 meta = ev[j].x;
+        const int s0 = (int)(meta & 0x1ffu), n = (int)((meta >> 9) & 63u), t = (int)((meta >> 15) & 0x1ffu);
+        const bool prov = ((meta >> 24) & 1ull) != 0ull;
+        // the clock of the event: a provision happens at the clock its step was decided at (the previous step's new clock, or
+        // the launch's header row), a release at the step's new clock (log word w0)
+        const int ct = prov ? t - 1 : t;
+        const double clock = __longlong_as_double((i64)lg[(size_t)(ct < 0 ? 3 * cap : 3 * ct) * lst]);
+        const sp::Mask2 mm = sp::mask2(s0, n);
+#pragma unroll
+        for (int w = 0; w < W; w++) a[w] ^= sp::mask2_word(mm, w);
+        RowStat after;
+        int max_empty = 0, edge = 0;
+        if (!RWA) {
+          if (W >= 3 && W <= 5) sp::row_stat_lane<W, (W >= 3 && W <= 5)>(a, S, after, max_empty, edge, &cw, sp::mask_words(s0, n), true);
+          else sp::row_stat_lane<W>(a, S, after, max_empty, edge);
+        } else {
+          int f = 0;
+#pragma unroll
+          for (int w = 0; w < W; w++) f += __popcll(a[w]);
+          after.free_ = f;
+        }
+        // the values _update_link_stats derives from the row (rmsa_env.py:464-543), as sp::row_item_lane1
+        const int free_ = after.free_;
+        const double cur_util = sp::div_pos((double)(S - free_), (double)S);
+        double cur_frag = 0.0, cur_comp = 0.0;
+        if (!RWA && free_ > 0) {
+          const int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
+          cur_frag = 1.0 - sp::div_pos((double)me, (double)free_);
+          if (after.nu > 1) cur_comp = sp::div_pos((double)(after.hi - after.lo), (double)(S - free_)) * sp::div_pos(1.0, (double)after.nu);
+          else cur_comp = 1.0;
+        }
+        if (clock > 0) {
+          // (a link touched again at the same clock: time_diff == 0, i.e. new = ((old * now) + (cur * 0.0)) / now with a finite
+          // cur >= 0 — the reference's own expression, and what the in-loop row phase computes for the further releases of a step)
+          const double time_diff = clock - last_update;
+          const sp::Recip rc = sp::recip_of(clock);
+          util = sp::div_by((util * last_update) + (cur_util * time_diff), rc);
+          if (!RWA) {
+            frag = sp::div_by((frag * last_update) + (cur_frag * time_diff), rc);
+            comp = sp::div_by((comp * last_update) + (cur_comp * time_diff), rc);
+          }
+        }
+        last_update = clock;
+        if (!RWA) {
+          const int d = ((after.occ - occ0) << 16) + (after.fb - fb0);
+          occ0 = after.occ; fb0 = after.fb;
+          if (d) atomicAdd(&s_delta[(2 * t + (prov ? 0 : 1)) * G + ge], d);
+        }
+      }
+      *(double2*)ls = make_double2(util, frag);
+      *(double2*)(ls + 2) = make_double2(comp, last_update);
+    }
+  }
+  if (RWA) return;
+  __syncthreads();
+  // the sums right after each step's provision, per env: prefix over the steps (LDS), then all threads OR them into the log
+  if (tid < G) {
+    const i64 env_s = (i64)blockIdx.x * G + tid;
+    const int ln = env_s < P.B ? P.log_n[env_s >> 3] : 0;
+    const int ns = ln & 0xffff;
+    if (ns > 0) {
+      int* cs = P.core_sums + env_s * P.cs_words;
+      int t_occ = cs[0], t_fb = cs[1];
+      int s_occ = t_occ - cs[2 * P.C], s_fb = t_fb - cs[2 * P.C + 1];  // (what the previous launch's last releases added is not part of it)
+      int dr = 0;
+      for (int t = 0; t < ns; t++) {
+        const int dp = s_delta[(2 * t) * G + tid];
+        dr = s_delta[(2 * t + 1) * G + tid];
+        s_delta[(2 * t) * G + tid] = s_occ;
+        s_delta[(2 * t + 1) * G + tid] = s_fb;
+        const int dp_fb = (int)(short)(dp & 0xffff), dr_fb = (int)(short)(dr & 0xffff);
+        t_occ += (dp - dp_fb) >> 16; t_fb += dp_fb;
+        s_occ = t_occ; s_fb = t_fb;
+        t_occ += (dr - dr_fb) >> 16; t_fb += dr_fb;
+      }
+      s_delta[(2 * ns) * G + tid] = s_occ;
+      s_delta[(2 * ns + 1) * G + tid] = s_fb;
+      // core_sums as the in-loop row phase leaves them: the totals, and what the last step's releases added (cleared when the
+      // wavefront finished the run's state: DevParams::persist_finish)
+      const int dr_fb = (int)(short)(dr & 0xffff);
+      const bool fin = ((ln >> 16) & 1) != 0;
+      cs[0] = t_occ; cs[1] = t_fb;
+      cs[2 * P.C] = fin ? 0 : (dr - dr_fb) >> 16;
+      cs[2 * P.C + 1] = fin ? 0 : dr_fb;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < (cap + 1) * G; i += ORL_ROWSTATS_THREADS) {
+    const int t = i / G, g = i - t * G;
+    const i64 env_s = (i64)blockIdx.x * G + g;
+    if (env_s >= P.B) continue;
+    const int ns = P.log_n[env_s >> 3] & 0xffff;
+    if (ns == 0 || t > ns) continue;
+    u64* w1 = P.slog + (size_t)(3 * t + 1) * (size_t)P.log_stride + (size_t)env_s;
+    const u64 sums = ((u64)(u32)s_delta[(2 * t) * G + g] << 25) | ((u64)(u32)s_delta[(2 * t + 1) * G + g] << 42);
+    if (t < ns) *w1 = *w1 | sums;
+    else *w1 = sums;  // (the slot behind the last step carries the sums only: sp::slog_w1(false, 0, 0, occ, fb))
+  }
+}
+
 // LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics,
 // 3 = slot maps + per-core sums in LDS, env records in global memory
 // PF: early requests of the Mersenne-Twister window and the link statistics (more live registers: the 3-wave forms)
@@ -607,9 +792,14 @@ __device__ __forceinline__ void persist_row_wave(const DevParams& P, const Persi
 }
 
 // RW: the two-wavefront form above (128 threads per workgroup)
-template <int ENV, int W, int LDS, bool PF, bool RW = false>
+// LDS_ 4 / 5: the rows-deferred forms (round 6) — the window of state 3 / 1 without everything the row phase needed; the loop is
+// slot scan + ctrl_d<..., RD> (which changes the slot maps itself and logs events), k_rowstats replays the rest after the launch
+template <int ENV, int W, int LDS_, bool PF, bool RW = false>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
+  constexpr bool RD = (LDS_ == 4 || LDS_ == 5);
+  constexpr int LDS = (LDS_ == 4) ? 3 : ((LDS_ == 5) ? 1 : LDS_);
   constexpr bool CP = PersistCompact<ENV, LDS>::value;
+  static_assert(!RD || (CP && !RW), "rows deferred: single-core families, one wavefront per 8 envs");
   static_assert(!RW || (CP && (LDS == 1 || LDS == 3)), "two-wavefront form: single-core families, slot maps in LDS");
 // (one wavefront per workgroup: a barrier is an ordering point of the wavefront; the control wavefront of a pair must not wait at
 // one for the row wavefront, which is in its own loop)
@@ -625,10 +815,10 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 #else
   constexpr bool MINI = DS && (LDS == 0 || LDS == 3);    // ... and the control phase's record words in the LDS window (sp::mrec)
 #endif
-  const int ICL = PersistInner<ENV, W, LDS>::value ? P.persist_ic : 0;  // (the host decides: only where it costs no wavefront)
+  const int ICL = (PersistInner<ENV, W, LDS>::value && !RD) ? P.persist_ic : 0;  // (the host decides: only where it costs no wavefront)
   const bool IC = ICL >= 1, OC = ICL >= 2;
   constexpr bool SR = PF;  // soon list in registers: the forms with registers to spare
-  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, LDS, CP, ICL, PersistDeferred<ENV, 0>::value);
+  const PersistLds L = persist_lds_layout(P.E, P.H, P.bm_words, P.C, LDS, CP, ICL, PersistDeferred<ENV, 0>::value, RD);
   typename sp::SinkEntryOf<CP>::type* s_tab = (typename sp::SinkEntryOf<CP>::type*)(orl_lds_raw + L.tab);
   u32* s_tally = (u32*)(orl_lds_raw + L.tally);
   unsigned short* s_mtab = (unsigned short*)(orl_lds_raw + L.mtab);
@@ -687,6 +877,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   svb.q = 0.0; svb.ht = 0.0; svb.pk = 0u; svb.cnt = 0;
   int esp_c = 0;        // DS: the env's episode step counter (SC_ESP; the replay keeps the record's copy)
   int prev_core = 0;    // DS, RMCSA: the core of the env's last accepted provision (the high half of SC_ACC)
+  int ecur = 0;         // RD: events this lane's env has logged in this launch
   u64 now0_w = 0ull;    // DS: the clock the launch starts at (logged for the replay)
 #define ORL_LOAD_CARRIED()                                                                                  \
   do {                                                                                                      \
@@ -709,7 +900,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   } while (0)
   sp::Wmem M = sp::wmem_global(P);
   constexpr bool REC = (LDS == 1 || LDS == 2);  // the env records are in the LDS window
-  if (LDS != 2) {
+  if (LDS != 2 && !RD) {
     M.clk = (double*)(orl_lds_raw + L.clk);
     M.clk_env0 = env0;
   }
@@ -725,7 +916,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       M.scenv0 = env0;
       M.sc_stride = ORL_SCAL_LDS_WORDS;
     }
-#define ORL_FILL_WINDOW() persist_fill_window<REC>(P, env0, nenv, lane, orl_lds_raw + L.bm, orl_lds_raw + L.sc, orl_lds_raw + L.cs, L.csw / 4)
+#define ORL_FILL_WINDOW() persist_fill_window<REC>(P, env0, nenv, lane, orl_lds_raw + L.bm, orl_lds_raw + L.sc, orl_lds_raw + L.cs, RD ? 0 : L.csw / 4)
     if (step < target) ORL_FILL_WINDOW();
     ORL_LOAD_CARRIED();
     // the row caches this wavefront left with the state at the end of its previous launch are still good when nothing but the
@@ -807,7 +998,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   // Global-state form (round 5): the per-core sums of the 8 envs — 16 bytes each for a single core — in the LDS window for the
   // launch.  In global memory every work item of the row phase updated them with L2 atomics, and the control phase read them
   // back through L2 with four RETURNING atomics per step, a global round trip in the step's dependent chain.
-  constexpr bool CS0 = (LDS == 0) && PersistDeferred<ENV, 0>::value;
+  constexpr bool CS0 = (LDS == 0) && PersistDeferred<ENV, 0>::value && !RD;
   if constexpr (CS0) {
     M.cs0 = (int*)(orl_lds_raw + L.cs);
     M.cenv0 = env0;
@@ -946,9 +1137,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       ORL_PROFA(1);
       if constexpr (DS) {
         u64* slog_s = P.slog + (size_t)(step - first_step) * ORL_SLOG_WORDS * (size_t)P.log_stride + (size_t)(valid_i ? env_i : 0);
-        desc = sp::ctrl_d<ENV, W, CP, MINI, RW>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
-                                          s_list, s_list_n, SR ? &soon_c : nullptr, s_mtab, svb, esp_c, prev_core, slog_s,
-                                          HAND ? &hand : nullptr, pop_pre, rw_sync, rw_k);
+        desc = sp::ctrl_d<ENV, W, CP, MINI, RW, RD>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
+                                              s_list, s_list_n, SR ? &soon_c : nullptr, s_mtab, svb, esp_c, prev_core, slog_s,
+                                              HAND ? &hand : nullptr, pop_pre, rw_sync, rw_k, &ecur, step - first_step);
       } else {
         desc = sp::ctrl_a<ENV, W, CP>(P, M, O, env_i, valid_i, lane_i, prof, &av, s_tally, s_tab, 0, &s_deferred[step & 1], &done_i,
                                       s_list, s_list_n, L.tw, SR ? &soon_c : nullptr, s_mtab, nullptr, SVC ? &svb : nullptr);
@@ -970,7 +1161,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
         }
       }
       ORL_PROFA(12);
-    } else {
+    } else if constexpr (!RD) {
 #ifdef ORL_DIAG_NO_ROWS
       const int n_items = 0;
 #else
@@ -1003,6 +1194,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     }
     step++;
     if (deferred) { left_pending = true; break; }
+    // (RD: an env whose event log could not take another step's provision and releases: the wavefront stops here and counts as
+    // unfinished, like one that has used up the statistics log)
+    if constexpr (RD) { if (__ballot(valid_i && ecur + 1 + P.rel_limit > P.elog_cap) != 0ull) break; }
   }
   ORL_PROF_END();
   if constexpr (RW) {
@@ -1022,7 +1216,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       int tid_t = (int)threadIdx.x;
       asm volatile("" : "+v"(tid_t));
       const i64 env_t = env0 + (tid_t >> 3);
-      if (ENV != ENV_RWA && env_t < P.B && (tid_t & 7) == 0) {
+      if (ENV != ENV_RWA && !RD && env_t < P.B && (tid_t & 7) == 0) {  // (RD: k_rowstats writes them)
         int* cs = sp::wm_cs(P, M, env_t);
         int* rs = cs + 2 * P.C;
         const int pc = (ENV == ENV_RMCSA) ? prev_core : 0;  // (this lane's group is env_t's)
@@ -1033,6 +1227,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       }
     }
     if (threadIdx.x == 0) P.log_n[blockIdx.x] = (step - first_step) | (finished_run ? (1 << 16) : 0);
+    if (RD && valid && (lane & 7) == 0) P.elog_n[env] = ecur;
   } else if (PersistDeferred<ENV, 0>::value && threadIdx.x == 0) {
     P.log_n[blockIdx.x] = 0;  // (a form that keeps the bookkeeping in the loop: nothing for k_stats)
   }
@@ -1069,9 +1264,11 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
         s[SC_GCOMP] = (u64)__double_as_longlong((a0 + (cmp * td)) / now_a);
         s[SC_ACC] = acc & ~2ull;
       }
-      for (int i = 0; i < 2 * P.C; i++) {
-        if (!M.cs_lds) atomicExch(rs + i, 0);
-        else rs[i] = 0;
+      if constexpr (!RD) {  // (RD: the sums are k_rowstats' — it clears the release part when the run ends here)
+        for (int i = 0; i < 2 * P.C; i++) {
+          if (!M.cs_lds) atomicExch(rs + i, 0);
+          else rs[i] = 0;
+        }
       }
       const u64 v = s[SC_FLAGS];
       f = (u32)(v >> 32);
@@ -1097,9 +1294,11 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     ulonglong2* g = (ulonglong2*)(P.bitmap + env0 * P.bm_words);
     const ulonglong2* l = (const ulonglong2*)M.bm0;
     for (int i = lane; i < nenv * (P.bm_words / 2); i += 64) g[i] = l[i];
-    const int q = L.csw / 4;
-    for (int i = lane; i < nenv * q; i += 64)
-      ((int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q] = ((const int4*)M.cs0)[i];
+    if constexpr (!RD) {  // (RD: the sums are k_rowstats')
+      const int q = L.csw / 4;
+      for (int i = lane; i < nenv * q; i += 64)
+        ((int4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q] = ((const int4*)M.cs0)[i];
+    }
     if (IC && P.row_cache_key != 0) {  // the row caches go with the state; the stamp says under which key they were written
       u32* g_cache = P.row_cache + (size_t)blockIdx.x * 2 * P.row_cache_words;
       for (int i = lane; i < nenv * P.E; i += 64) {
@@ -1707,8 +1906,10 @@ template <int W> void obs(orl_batch* b, int with_terminal) {
 // measured on MI355X: 12 workgroups share a CU's 160 KiB up to 12 800 B each, 11 up to 14 080, 16 up to 10 240 —
 // hipOccupancyMaxActiveBlocksPerMultiprocessor says 12 up to 13 648).
 struct PersistForm { int lds, waves; };
-static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}, {3, 4}};
-constexpr int kNumPersistForms = 7;
+// (round 6: 7 and 8 are the rows-deferred forms — state 4 / 5 = the window of state 3 / 1 without the row phase's tables)
+static const PersistForm kPersistForms[] = {{0, 4}, {0, 3}, {2, 2}, {2, 3}, {1, 3}, {1, 4}, {3, 4}, {4, 4}, {5, 4}};
+constexpr int kNumPersistForms = 9;
+static inline bool persist_rd_state(int state) { return state == 4 || state == 5; }
 static int lds_wgs_per_cu(size_t lds) {
   if (lds == 0) return 1 << 20;
   const size_t alloc = (lds + 1279) / 1280 * 1280;
@@ -1716,8 +1917,15 @@ static int lds_wgs_per_cu(size_t lds) {
 }
 struct PersistChoice { int form; size_t lds; int inner; int rw; int evl; };
 static size_t persist_window(const DevParams& VP, int state, int inner) {
-  return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, state, persist_compact(VP.env_type, state), inner,
-                                    orl_persist_deferred(VP.env_type)).total;
+  const bool rd = persist_rd_state(state);
+  const int base = state == 4 ? 3 : (state == 5 ? 1 : state);
+  return (size_t)persist_lds_layout(VP.E, VP.H, VP.bm_words, VP.C, base, persist_compact(VP.env_type, base), rd ? 0 : inner,
+                                    orl_persist_deferred(VP.env_type), rd).total;
+}
+// the rows-deferred forms: single-core families with the statistics deferred, a bit per link in a 64-bit event word, services of
+// at most 63 slots in a 9-bit first slot (the compact sink's own limits), and an event log to write to
+static bool persist_rd_possible(const DevParams& VP) {
+  return orl_persist_deferred(VP.env_type) && VP.env_type != ENV_RMCSA && VP.E <= 64 && VP.S <= 512;
 }
 // `tuned`: the choice for a specialisation library (built without machine-level LICM and with the soon list in registers in the
 // 4-wave forms, _build.py SPEC_TUNING) — for the flags such a library is built with, and at launch when one is attached
@@ -1774,15 +1982,16 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
 #ifndef ORL_ALT_IMPLS
     built = built && f != 2 && f != 3;
 #endif
+    if (f >= 7) built = built && persist_rd_possible(VP);
     if (built && persist_window(VP, kPersistForms[f].lds, 0) <= 64 * 1024 && f != c.form) {
       c.form = f;
       const int st = kPersistForms[f].lds;
-      c.inner = (st >= 1 && persist_inner(VP.env_type, ORL_W, st)) ? level(st, 4 * kPersistForms[f].waves) : 0;
+      c.inner = (st >= 1 && st <= 3 && persist_inner(VP.env_type, ORL_W, st)) ? level(st, 4 * kPersistForms[f].waves) : 0;
     }
   }
   if (const char* e = getenv("ORL_PERSIST_INNER")) {  // A/B and cross-checks: 0 = no row caches, 1 = inner runs, 2 = + occ / free blocks
     const int v = atoi(e);
-    c.inner = (v >= 0 && v <= 2 && persist_inner(VP.env_type, ORL_W, kPersistForms[c.form].lds)) ? v : 0;
+    c.inner = (v >= 0 && v <= 2 && !persist_rd_state(kPersistForms[c.form].lds) && persist_inner(VP.env_type, ORL_W, kPersistForms[c.form].lds)) ? v : 0;
   }
   // The two-wavefront form (k_persist<..., RW>, specialisation libraries only): batches whose pairs are all resident at once
   // (measured: +20 % at 10 240 and 12 288 envs of cfg2, -20 % at 14 336, where a second generation starts).  LDS is no constraint
@@ -1870,6 +2079,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   bool spec = b->spec_launch != nullptr && b->spec_lds == kPersistForms[v].lds && b->spec_waves == kPersistForms[v].waves + 16 * ch.rw;
   if (const char* e = getenv("ORL_PERSIST_SPEC")) { if (atoi(e) == 0) spec = false; }
   b->persist_spec = spec ? (ch.rw ? 2 : 1) : 0;  // (debug query: 2 = the two-wavefront form)
+  b->persist_form_last = v;
   if (spec) {
     b->spec_launch(&VP, gc.x, lds_a, st, pol, target, wg_step, unfinished, clear_next);
   } else {
@@ -1880,12 +2090,37 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     ORL_FULL_LDS_CASES(E_)                                                                                                   \
     case 4: LAUNCH(E_, 1, 3); break;                                                                                         \
     case 6: LAUNCH(E_, 3, 4); break;                                                                                         \
+    case 7: if constexpr (E_ != ENV_RMCSA) LAUNCH(E_, 4, 4); break;                                                          \
+    case 8: if constexpr (E_ != ENV_RMCSA) LAUNCH(E_, 5, 4); break;                                                          \
     default: LAUNCH(E_, 1, 4); break;                                                                                        \
   }
     ORL_FOR_ENV(b, PER_ENV)
 #undef PER_ENV
   }
 #undef LAUNCH
+  // rows-deferred forms: the link statistics and the compactness sums of the launch's events, one lane per link row, behind the
+  // launch on its stream and in front of k_stats (which reads the sums it puts into the statistics log)
+  if (persist_rd_state(kPersistForms[v].lds)) {
+    // (this form writes slot maps without keeping the other forms' row caches: a stamp they left must not match again)
+    if (++b->cache_epoch >= (1 << 22)) {
+      if (b->P.row_cache_stamp) hipMemsetAsync(b->P.row_cache_stamp, 0, (size_t)((b->P.B + 7) / 8) * sizeof(int), st);
+      b->cache_epoch = 1;
+    }
+    const int G = ORL_ROWSTATS_THREADS / VP.E, nw = (VP.elog_cap + 31) / 32;
+    const size_t lds_r = (((size_t)(VP.log_cap + 1) * 2 * G * 4 + 15) & ~(size_t)15) + (size_t)nw * ORL_ROWSTATS_THREADS * 4;
+    dim3 gr((unsigned)((VP.B + G - 1) / G)), br(ORL_ROWSTATS_THREADS);
+#define ROWSTATS(E_)                                                                                                                    \
+  do {                                                                                                                                 \
+    if (lds_r > 48 * 1024) hipFuncSetAttribute((const void*)k_rowstats<E_, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r); \
+    hipLaunchKernelGGL((k_rowstats<E_, W>), gr, br, lds_r, st, VP, G, nw);                                                             \
+  } while (0)
+    switch (VP.env_type) {
+      case ENV_RMSA: ROWSTATS(ENV_RMSA); break;
+      case ENV_DEEPRMSA: ROWSTATS(ENV_DEEPRMSA); break;
+      default: ROWSTATS(ENV_RWA); break;
+    }
+#undef ROWSTATS
+  }
   // the bookkeeping of the steps this launch ran, one lane per env (deferred statistics: ctrl_d logged it), behind the launch
   // on its stream; the forms that keep it in the loop logged nothing
   if (orl_persist_deferred(VP.env_type) && VP.slog) {

@@ -107,7 +107,8 @@ class MultiDeviceBatch:
         self._map(lambda r: self.shards[r].seed(list(seeds[self.bounds[r]:self.bounds[r + 1]]), mask=self._cut(mask, r)))
 
     def set_info_mode(self, rates_only):
-        self._map(lambda r: self.shards[r].set_info_mode(rates_only))
+        # (shards without the switch — the oracle stand-in of the CPU tests — always write every entry)
+        self._map(lambda r: self.shards[r].set_info_mode(rates_only) if hasattr(self.shards[r], "set_info_mode") else None)
 
     def set_paths(self, paths):
         self._map(lambda r: self.shards[r].set_paths(self._cut(paths, r)))

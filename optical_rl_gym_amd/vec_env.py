@@ -258,10 +258,15 @@ class OpticalVecEnv:
     render_mode = None
 
     def __init__(self, batch, info_keywords=("episode_service_blocking_rate", "episode_bit_rate_blocking_rate"),
-                 obs_dtype=np.float64, observation="default", max_logged_episodes=1 << 20, monitor_spill_path=None):
+                 obs_dtype=np.float64, observation="default", max_logged_episodes=1 << 20, monitor_spill_path=None,
+                 rates_only_info=False):
         """observation: "default" (DeepRMSA: its 1-D vector; other families: None, as their Dict observation holds live
         objects) or "matrix" (SimpleMatrixObservation built on the device: uint8 [2N + C*E*S]).
-        max_logged_episodes / monitor_spill_path: the bound of `episode_log` and where rows beyond it go (EpisodeLog)."""
+        max_logged_episodes / monitor_spill_path: the bound of `episode_log` and where rows beyond it go (EpisodeLog).
+        rates_only_info (opt-in; the reference's step() always fills every info entry, rmsa_env.py:228-264): when the info
+        keywords are blocking rates only, the step kernel may skip the compactness entries and the two link means — then
+        `info_array()` / `device_tensors()["info"]` hold NaN in those columns instead of stale values, and close() puts the
+        batch back into the full mode."""
         self.batch = batch
         self.num_envs = batch.num_envs
         self.obs_dtype = np.dtype(obs_dtype)
@@ -276,7 +281,9 @@ class OpticalVecEnv:
         # what SB3 reads of info is the keywords of finished envs: when those are blocking rates only, the step kernel skips the
         # compactness entries and the per-step read of every link record behind the two link means (orl_batch_set_info_mode)
         rates = ("service_blocking_rate", "episode_service_blocking_rate", "bit_rate_blocking_rate", "episode_bit_rate_blocking_rate")
-        if hasattr(batch, "set_info_mode") and all(k in rates or k.startswith("bit_rate_blocking_") for k in self.info_keywords):
+        self._rates_only = bool(rates_only_info and hasattr(batch, "set_info_mode")
+                                and all(k in rates or k.startswith("bit_rate_blocking_") for k in self.info_keywords))
+        if self._rates_only:
             batch.set_info_mode(True)
         self._actions = None
         self._obs_ring, self._obs_turn = None, 0
@@ -405,6 +412,12 @@ class OpticalVecEnv:
         return self.step_wait()
 
     def close(self):
+        if self._rates_only:  # (the batch object is the caller's: it goes back as it came)
+            self._rates_only = False
+            try:
+                self.batch.set_info_mode(False)
+            except Exception:
+                pass
         self.batch.close()
 
     def _indices(self, indices):

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 # one-wavefront-per-env kernel (k_step).  The small parity cases run against every implementation by forcing it (the
 # variables are read when a batch is created): "wave64" = k_step for everything, "persist" = the default, "split2" = the
 # phases of the persistent kernel as two separate launches (liborlgpu_alt.so, the -DORL_ALT_IMPLS build).
-IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds", "agent8", "persist_pair"]
+IMPLS = ["wave64", "split2", "persist", "persist_global", "persist_lds", "agent8", "persist_pair", "persist_rd"]
 IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             "split2": dict(ORL_STEP_IMPL="2", ORL_PERSIST="0", ORL_LIB_VARIANT="alt", ORL_PERSIST_VARIANT=None, ORL_PERSIST_INNER=None),
             # the persistent kernel in the form the library picks, with all state in global memory, and with slot maps +
@@ -31,7 +31,12 @@ IMPL_ENV = {"wave64": dict(ORL_STEP_IMPL="64", ORL_PERSIST="0", ORL_LIB_VARIANT=
             # batches of at most 12 288 envs of the single-core families) at every batch size: it exists in specialisation libraries
             # only, so one is built for every configuration (RMCSA: the one-wavefront kernel, specialised)
             "persist_pair": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="4", ORL_PERSIST_INNER=None,
-                                 ORL_PERSIST_RW="1", ORL_JIT_SPEC="1")}
+                                 ORL_PERSIST_RW="1", ORL_JIT_SPEC="1"),
+            # the rows-deferred form (round 6): the loop is slot scan + control phase, which changes the slot maps itself and logs an
+            # event per provision / release; k_rowstats replays link statistics and compactness sums after every launch, one lane per
+            # link row (single-core families with at most 64 links; elsewhere the library's own choice runs)
+            "persist_rd": dict(ORL_STEP_IMPL="2", ORL_PERSIST="1", ORL_LIB_VARIANT="default", ORL_PERSIST_VARIANT="7", ORL_PERSIST_INNER=None,
+                               ORL_PERSIST_RW="0")}
 for _name, _env in IMPL_ENV.items():
     _env.setdefault("ORL_AGENT_STEP", None)
     _env.setdefault("ORL_PERSIST_RW", None)
@@ -53,7 +58,7 @@ def impl(request, monkeypatch):
 
 
 # (tests that only take host-driven steps: the forms of the device-resident loop that differ in nothing else are left out)
-@pytest.fixture(params=[v for v in IMPLS if v != "persist_pair"])
+@pytest.fixture(params=[v for v in IMPLS if v not in ("persist_pair", "persist_rd")])
 def impl_host(request, monkeypatch):
     force_impl(monkeypatch, request.param)
     return request.param
