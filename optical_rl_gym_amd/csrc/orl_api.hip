@@ -382,7 +382,7 @@ static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
   q.svc_q += lo * 8; q.svc_ht += lo * 8; q.svc_pk += lo * 8; q.svc_cnt += lo * 8;  // (64 lanes per 8 envs; lo is a multiple of 8)
   q.row_cache += (lo / 8) * 2 * (i64)P.row_cache_words; q.row_cache_stamp += lo / 8;
   if (q.slog) { q.slog += lo; q.log_n += lo / 8; }  // (rows of the log span the whole batch: log_stride stays)
-  if (q.elog) { q.elog += lo * (i64)P.elog_cap; q.elog_n += lo; }
+  if (q.elog) { q.elog += lo * (i64)(2 * P.elog_cap); q.elog_n += lo; q.bitmap0 += lo * P.bm_words; q.ssum += lo; }
   if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
   if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (P.S + 1));
   if (q.act2d) q.act2d += lo * P.act2d_words;
@@ -1204,6 +1204,7 @@ static int ensure_logs(orl_batch* b, int64_t n_steps, int* chunk_io) {
     if (b->stream2) HIPCHK(hipStreamSynchronize(b->stream2));
     dfree(b, &P.slog);
     dfree(b, &P.elog);
+    dfree(b, &P.ssum);
     int rc = dalloc(b, &P.slog, (want + 1) * (size_t)ORL_SLOG_ROW_WORDS * B);
     if (rc) return rc;
     if (!P.log_n) {
@@ -1217,15 +1218,19 @@ static int ensure_logs(orl_batch* b, int64_t n_steps, int* chunk_io) {
     // events: a step logs its provision and its releases, two per step on average; a wavefront whose envs' logs cannot take
     // another step stops early like one that used up the statistics log
     if (P.env_type != ENV_RMCSA && P.E <= 64) {
-      size_t ecap = 3 * want + 40, emost = ((size_t)1 << 30) / (16 * B);
+      size_t ecap = 3 * want + 40, emost = ((size_t)1 << 30) / (32 * B);
       if (emost < 80) emost = 80;
       if (ecap > emost) ecap = emost;
-      rc = dalloc(b, &P.elog, ecap * B);
+      rc = dalloc(b, &P.elog, 2 * ecap * B);
       if (rc) return rc;
       if (!P.elog_n) {
         rc = dalloc(b, &P.elog_n, B + 16);
         if (rc) return rc;
+        rc = dalloc(b, &P.bitmap0, B * P.bm_words);
+        if (rc) return rc;
       }
+      rc = dalloc(b, &P.ssum, (want + 1) * B);
+      if (rc) return rc;
       P.elog_cap = (int)ecap;
     }
   }

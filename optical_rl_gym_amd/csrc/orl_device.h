@@ -146,12 +146,16 @@ struct DevParams {
   i64 log_stride;   // envs per row of the log: the whole batch, whichever view of it a launch works on
   int log_cap;      // steps one launch can log per wavefront
   // rows-deferred form of the persistent kernel (round 6; orl_device_split.h ctrl_d<..., RD>, orl_kernels.hip k_rowstats): the loop
-  // changes the slot maps itself and logs one 16-byte event per provision / release — {first slot:9 | slots:6 | step of the
-  // launch:9 | provision:1, bit mask of the links of the path} — in the order the reference applies them; the per-link statistics
-  // and the compactness sums are replayed from them after the launch, one lane per link ROW
-  ulonglong2* elog; // [B][elog_cap]
+  // changes the slot maps itself and logs one 32-byte event per provision / release — {first slot:9 | slots:6 | step of the
+  // launch:9 | provision:1, bit mask of the links of the path}, {clock of the event, 0} — in the order the reference applies
+  // them; the per-link statistics and the compactness sums are replayed from them after the launch, one lane per link ROW
+  ulonglong2* elog; // [B][elog_cap][2]
   int* elog_n;      // [B] events the env logged in this launch
   int elog_cap;     // events per env and launch
+  u64* bitmap0;     // [B][bm_words] the slot maps as the launch found them (written when a wavefront fills its window): where the
+                    // replay starts from
+  u32* ssum;        // [log_cap + 1][log_stride] what the replay hands k_stats: the compactness sums right after each step's provision,
+                    // (occupied range sum << 16) | free blocks inside — the fields the in-loop forms put into log word w1
   double* soon_t;   // [B][ORL_SOON] release times of the soon list (+inf = free slot); lane l of the env's group owns l, l+8, ...
   u32* soon_i;      // [B][ORL_SOON] their slots in ev_time / ev_info
   i64 q_cap;

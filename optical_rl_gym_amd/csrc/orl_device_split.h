@@ -184,7 +184,8 @@ template <> struct SinkEntryOf<true> { typedef SinkEntryC type; };
 #define ORL_EV_META(S0, N, T, PROV) ((u64)(u32)(S0) | ((u64)(u32)(N) << 9) | ((u64)(u32)(T) << 15) | ((u64)((PROV) ? 1u : 0u) << 24))
 template <bool CP, bool RD = false> struct SinkT {
   typedef typename SinkEntryOf<CP>::type Entry;
-  ulonglong2* ev;  // RD: the env's event log of this launch
+  ulonglong2* ev;  // RD: the env's event log of this launch, two 16-byte halves per event: {meta, link bits}, {clock, 0}
+  double ev_clock; // RD: the clock the step was decided at (its provision's clock)
   int ev_at;       // RD: index of this step's first event (its provision, if it has one)
   int ev_rel0;     // RD: index of this step's first release event
   int ev_t;        // RD: the step's number within the launch
@@ -229,7 +230,10 @@ __device__ __forceinline__ void sink_add(SinkT<CP, RD>& s, const PathRec& rec, i
     lm0 |= (u32)dpp_i<ORL_DPP_XOR1>((int)lm0); lm1 |= (u32)dpp_i<ORL_DPP_XOR1>((int)lm1);
     lm0 |= (u32)dpp_i<ORL_DPP_XOR2>((int)lm0); lm1 |= (u32)dpp_i<ORL_DPP_XOR2>((int)lm1);
     lm0 |= (u32)dpp_i<ORL_DPP_HALF_MIRROR>((int)lm0); lm1 |= (u32)dpp_i<ORL_DPP_HALF_MIRROR>((int)lm1);
-    if ((lane & 7) == 0) s.ev[s.ev_at] = make_ulonglong2(ORL_EV_META(s0, n, s.ev_t, prov), (u64)lm0 | ((u64)lm1 << 32));
+    if ((lane & 7) == 0) {
+      s.ev[2 * s.ev_at] = make_ulonglong2(ORL_EV_META(s0, n, s.ev_t, prov), (u64)lm0 | ((u64)lm1 << 32));
+      s.ev[2 * s.ev_at + 1] = make_ulonglong2((u64)__double_as_longlong(s.ev_clock), 0ull);
+    }
   } else if constexpr (CP) {
     const int k = prov ? 0 : ++s.nrel;  // this mask's entry of the env's table (the caller keeps nrel <= ORL_REL_MAX)
     if ((lane & 7) == 0) s.mtab[k] = (unsigned short)((u32)s0 | ((u32)n << 9));
@@ -886,6 +890,7 @@ __device__ __forceinline__ u64 ctrl_a(const DevParams& P, const Wmem& M, const C
 //       (lambda_max - lambda_min) sum:17 | free blocks inside:16   (RWA instead of the sums: the action's path:4 | wavelength:10,
 //       for the actions_output marginals) | core of the provision:5 (RMCSA; the sums logged are those of the core the env's
 //       previous accepted provision went to)
+//   (rows-deferred forms: the sums fields of w1 stay zero — k_rowstats hands them to k_stats through DevParams::ssum)
 //   w2  what the step's releases take off the sums: n x hops:20 | bit rate:24   (stored after the release detection; w0 and w1
 //       before it, so that nothing of them is live across it)
 // Slot n of a wavefront that logged n steps carries w1's sums only: those after its last row phase.
@@ -958,7 +963,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
   SinkT<CP, RD> sink;
   sink.tab = nullptr; sink.tally = nullptr; sink.tw = tw; sink.active = false; sink.deferred = false; sink.cnt = 0;
   sink.list = s_list; sink.list_n = s_list_n; sink.mtab = nullptr; sink.nrel = 0; sink.rows = nullptr; sink.roww = 0;
-  sink.ev = nullptr; sink.ev_at = 0; sink.ev_rel0 = 0; sink.ev_t = t_log;
+  sink.ev = nullptr; sink.ev_at = 0; sink.ev_rel0 = 0; sink.ev_t = t_log; sink.ev_clock = 0.0;
   if constexpr (RW) { rw_wait_for(rw_sync + 1, rw_k); ORL_PROFA(14); }  // (the row wavefront has read the previous step's tables and rows)
   if (!RW && !RD && lane == 0) *s_list_n = 0u;  // (RW: the list is the row wavefront's)
   if constexpr (!RD) {
@@ -1027,7 +1032,7 @@ __device__ __forceinline__ u64 ctrl_d(const DevParams& P, const Wmem& M, const C
     e.ls = wm_ls(P, M, env);
     e.cs = wm_cs(P, M, env);
     if constexpr ((RW || RD) && CP) { sink.rows = e.bm; sink.roww = W; }
-    if constexpr (RD) { sink.ev = P.elog + env * (i64)P.elog_cap; sink.ev_at = *ecur; sink.ev_rel0 = *ecur; }
+    if constexpr (RD) { sink.ev = P.elog + env * (i64)(2 * P.elog_cap); sink.ev_at = *ecur; sink.ev_rel0 = *ecur; sink.ev_clock = e.now; }
     int occ_s = 0, fb_s = 0;
     const int pc_s = (ENV == ENV_RMCSA) ? prev_core : 0;
     auto read_sums = [&]() {
@@ -1551,7 +1556,8 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
             row_apply_mask(sink.rows + (size_t)link * sink.roww, s0, n, false);
             lm |= 1ull << link;
           }
-          sink.ev[sink.ev_rel0 + kk - 1] = make_ulonglong2(ORL_EV_META(s0, n, sink.ev_t, false), lm);
+          sink.ev[2 * (sink.ev_rel0 + kk - 1)] = make_ulonglong2(ORL_EV_META(s0, n, sink.ev_t, false), lm);
+          sink.ev[2 * (sink.ev_rel0 + kk - 1) + 1] = make_ulonglong2((u64)__double_as_longlong(e.now), 0ull);  // (a release happens at the step's new clock)
         } else {
         sink.mtab[kk] = (unsigned short)((u32)s0 | ((u32)n << 9));
         for (int h = 0; h < hops; h++) {

@@ -277,10 +277,12 @@ static inline bool persist_inner(int env_type, int W, int state) { return state 
 // launch 15 % slower per step than a 300-step run.
 typedef unsigned long long orl_u64x2 __attribute__((ext_vector_type(2)));  // (a native vector: selects stay in registers)
 typedef int orl_i32x4 __attribute__((ext_vector_type(4)));
-template <bool REC>
+// SNAP (rows-deferred forms): the slot maps also go to DevParams::bitmap0 as they are read — the state the replay starts from
+template <bool REC, bool SNAP = false>
 __device__ __forceinline__ void persist_fill_window(const DevParams& P, i64 env0, int nenv, int lane, void* l_bm_, void* l_rec_, void* l_cs_,
                                                     int q /* 16-byte pieces of the sums per env */) {
   const orl_u64x2* g = (const orl_u64x2*)(P.bitmap + env0 * P.bm_words);
+  orl_u64x2* g0 = SNAP ? (orl_u64x2*)(P.bitmap0 + env0 * P.bm_words) : nullptr;
   const orl_u64x2* gr = (const orl_u64x2*)(P.scal + env0 * ORL_SCAL_WORDS);
   orl_u64x2* l_bm = (orl_u64x2*)l_bm_;
   orl_u64x2* l_rec = (orl_u64x2*)l_rec_;
@@ -313,6 +315,16 @@ __device__ __forceinline__ void persist_fill_window(const DevParams& P, i64 env0
     if (i0 + 320 < n_bm) l_bm[i0 + 320] = b5;
     if (i0 + 384 < n_bm) l_bm[i0 + 384] = b6;
     if (i0 + 448 < n_bm) l_bm[i0 + 448] = b7;
+    if constexpr (SNAP) {
+      if (i0 < n_bm) g0[i0] = b0;
+      if (i0 + 64 < n_bm) g0[i0 + 64] = b1;
+      if (i0 + 128 < n_bm) g0[i0 + 128] = b2;
+      if (i0 + 192 < n_bm) g0[i0 + 192] = b3;
+      if (i0 + 256 < n_bm) g0[i0 + 256] = b4;
+      if (i0 + 320 < n_bm) g0[i0 + 320] = b5;
+      if (i0 + 384 < n_bm) g0[i0 + 384] = b6;
+      if (i0 + 448 < n_bm) g0[i0 + 448] = b7;
+    }
     if (base == 0) {
       if (REC) {
         // (16 pieces of 16 bytes per record, records ORL_SCAL_LDS_WORDS apart)
@@ -348,8 +360,9 @@ template <int ENV, int LDS> struct PersistDeferred {
 // slower, 143 us instead of 90 us behind a 128-step launch of 65 536 envs: the replay is bound by memory requests, and a
 // request of 16 lanes carries a quarter of the bytes)
 #define ORL_STATS_LANES 64
+// rd: the launch ran a rows-deferred form — the compactness sums come from DevParams::ssum (k_rowstats), (occ << 16) | fb per step
 template <int ENV>
-__global__ void __launch_bounds__(64) k_stats(DevParams P) {
+__global__ void __launch_bounds__(64) k_stats(DevParams P, int rd) {
   if (threadIdx.x >= ORL_STATS_LANES) return;
   const i64 env = (i64)blockIdx.x * ORL_STATS_LANES + (i64)threadIdx.x;
   if (env >= P.B) return;
@@ -378,12 +391,14 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
   bool done = false;
   for (int t0 = 0; t0 < n; t0 += ORL_STATS_BATCH) {
     u64 w0[ORL_STATS_BATCH], w1[ORL_STATS_BATCH], w2[ORL_STATS_BATCH];
+    u32 w3[ORL_STATS_BATCH];
 #pragma unroll
     for (int k = 0; k < ORL_STATS_BATCH; k++) {
       const int t = (t0 + k < n) ? t0 + k : n - 1;
       w0[k] = lg[(size_t)(3 * t) * st];
       w1[k] = lg[(size_t)(3 * t + 1) * st];
       w2[k] = lg[(size_t)(3 * t + 2) * st];
+      w3[k] = (rd && ENV != ENV_RWA) ? P.ssum[(size_t)t * st + (size_t)env] : 0u;
     }
 #pragma unroll
     for (int k = 0; k < ORL_STATS_BATCH; k++) {
@@ -394,7 +409,7 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
           const int c0 = (int)((acc >> 32) & 31);
           (void)c0;
           const i64 s_nh_prov = (i64)(acc >> 37);
-          const int occ = (int)((a1 >> 25) & 0x1ffffu), fb = (int)((a1 >> 42) & 0xffffu);
+          const int occ = rd ? (int)(w3[k] >> 16) : (int)((a1 >> 25) & 0x1ffffu), fb = rd ? (int)(w3[k] & 0xffffu) : (int)((a1 >> 42) & 0xffffu);
           const double cmp = (fb > 0) ? sp::div_pos((double)occ, (double)s_nh_prov) * sp::div_pos((double)P.E, (double)fb) : 1.0;
           g_comp = sp::div_pos(gc_a + (cmp * gc_td), now_a);
         }
@@ -462,9 +477,10 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
   }
   if (fin && ENV != ENV_RWA && ((u32)acc & 2u)) {
     // the run ends here: the update the last step left pending, from the sums after its row phase (k_finish2's expressions)
-    const u64 a1 = lg[(size_t)(3 * n + 1) * st];
+    const u64 a1 = rd ? 0ull : lg[(size_t)(3 * n + 1) * st];
+    const u32 a3 = rd ? P.ssum[(size_t)n * st + (size_t)env] : 0u;
     const i64 s_nh_prov = (i64)(acc >> 37);
-    const int occ = (int)((a1 >> 25) & 0x1ffffu), fb = (int)((a1 >> 42) & 0xffffu);
+    const int occ = rd ? (int)(a3 >> 16) : (int)((a1 >> 25) & 0x1ffffu), fb = rd ? (int)(a3 & 0xffffu) : (int)((a1 >> 42) & 0xffffu);
     const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
     g_comp = (gc_a + (cmp * gc_td)) / now_a;
     acc &= ~2ull;
@@ -485,93 +501,196 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
 // itself and logs one event per provision / release (sp::ctrl_d<..., RD>).  Nothing the row phase computed feeds a decision —
 // the per-link running averages of _update_link_stats (rmsa_env.py:464-543; rwa_env.py:365-383) and the integer sums behind
 // _get_network_compactness (rmsa_env.py:699-744) are state the loop only ever wrote.  This kernel replays them after the launch
-// with one LANE per link ROW: the lane reads its row as the launch left it, takes the masks of the launch's events that touch its
-// link back (a provision clears free slots, a release sets taken ones: both are XORs, in any order) to get the row as the launch
-// found it, then walks ITS events in order — mask, row summary, float64 update at the event's clock, exactly the expressions
-// of sp::row_item_lane1 — with the link's 32-byte record, the row, its inner-run cache and its contribution to the sums in
-// registers for the whole launch: full lanes, no provision / release lane pairs, no sink tables, one read and one write of
-// the link record per launch instead of per touch.  Which events touch the lane's link is found once (first pass, a bit per
-// event in LDS) so that the second pass runs the heavy body once per lane and touch with no event scan in between.
-// The sums: every touch adds (occupied-range delta << 16) + free-block delta to the (step, provision | release) cell of its env
-// in LDS; afterwards one lane per env turns them into the sums right after each step's provision — what the control phase used
-// to log into word w1 of the statistics log — and ORs them into that word for k_stats, writes the slot behind the last step
-// (k_stats finishes the run's last pending update from it) and leaves DevParams::core_sums as the in-loop row phase would have.
-// A workgroup owns G = 256 / E whole envs (all rows of an env in one workgroup: the sums need no global atomics).
+// with one LANE per link ROW: the lane starts from the row as the launch found it (DevParams::bitmap0, written when the wavefront
+// filled its window) and walks the events that touch its link in order — mask, row summary, float64 update at the event's clock:
+// the expressions of sp::row_item_lane1 — with the row, the link's 32-byte record, the row's inner-run cache and its contribution
+// to the sums in registers for the whole launch: no provision / release lane pairs, no sink tables, one read and one write of
+// the link record per launch instead of per touch.
+// A workgroup owns G whole envs and works through their events in WINDOWS of 128 events per env:
+//   A  all threads: the window's events into LDS (step, slots, clock: a provision happens at the clock its step was decided at —
+//      the previous step's new clock, or the launch's header row — a release at the step's new clock, log word w0) and, per event
+//      and link of its path, a bit into the touch words of that link's row (LDS atomics: ~2.4 per event instead of a test per
+//      event and row)
+//   B  (first window) the rows sorted by their number of touches, heaviest first: lanes of one wavefront then run about the same
+//      number of rounds — with rows in link order a wavefront ran as many rounds as its busiest row, at 4.4 touches per row on
+//      average and ~11 at most in a 20-step launch (lanes busy 45 %)
+//   C  every lane walks the touches of ITS row: everything it needs comes from LDS
+//   D  one lane per env walks the window's events in order and turns the touches' deltas (LDS atomics, a cell per event) into the
+//      sums right after each step's provision — what the in-loop forms log into word w1 — stored to DevParams::ssum for k_stats;
+//      when the launch's events are done it leaves DevParams::core_sums as the in-loop row phase would have.
 #define ORL_ROWSTATS_THREADS 256
+#ifdef ORL_RS_PROF  // diagnostic builds: shader-clock cycles per phase of k_rowstats, summed over wavefronts (tools/rs_prof.py)
+#define ORL_RSP_WAVES 32768
+__device__ unsigned long long g_rs_prof[ORL_RSP_WAVES * 16];  // (a slot per wavefront: atomics on shared counters perturb what is measured)
+#define ORL_RSP_SLOT(k) g_rs_prof[((size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % ORL_RSP_WAVES)) * 16 + (k)]
+#define ORL_RSP(k) do { const long long n_ = clock64(); if ((threadIdx.x & 63) == 0) ORL_RSP_SLOT(k) += (unsigned long long)(n_ - rsp_t); rsp_t = n_; } while (0)
+#define ORL_RSP_CNT(k, v) do { if ((threadIdx.x & 63) == 0) ORL_RSP_SLOT(k) += (unsigned long long)(v); } while (0)
+#else
+#define ORL_RSP(k) do { } while (0)
+#define ORL_RSP_CNT(k, v) do { } while (0)
+#endif
+#define ORL_RS_WIN 64   // events per env and window (a 20-step launch logs ~40 per env: one window)
+#define ORL_RS_GMAX 16  // envs per workgroup at most
+#ifndef ORL_RS_WAVES
+#define ORL_RS_WAVES 5  // waves per SIMD the register allocator leaves room for
+#endif
+struct RowstatsLds { int bits, meta, clk, delta, hist, perm, nev, total; };
+__host__ __device__ inline RowstatsLds rowstats_lds_layout(int G) {
+  RowstatsLds L;
+  int o = 0;
+  L.clk = o; o += G * ORL_RS_WIN * 8;
+  L.bits = o; o += (ORL_RS_WIN / 32) * ORL_ROWSTATS_THREADS * 4;
+  L.meta = o; o += G * ORL_RS_WIN * 4;
+  L.delta = o; o += G * ORL_RS_WIN * 4;
+  L.hist = o; o += 2 * 16 * 4;
+  L.perm = o; o += ORL_ROWSTATS_THREADS * 2;
+  L.nev = o; o += ORL_RS_GMAX * 4;
+  L.total = (o + 15) & ~15;
+  return L;
+}
 template <int ENV, int W>
-__global__ void __launch_bounds__(ORL_ROWSTATS_THREADS) k_rowstats(DevParams P, int G, int nw /* 32-event words of touch bits per lane */) {
+__global__ void __launch_bounds__(ORL_ROWSTATS_THREADS) __attribute__((amdgpu_waves_per_eu(ORL_RS_WAVES, ORL_RS_WAVES)))
+k_rowstats(DevParams P, int G) {
   constexpr bool RWA = ENV == ENV_RWA;
-  const int E = P.E, S = P.S, cap = P.log_cap;
+  constexpr int NWORD = ORL_RS_WIN / 32;
+  const int E = P.E, S = P.S;
   const int tid = (int)threadIdx.x;
-  int* s_delta = (int*)orl_lds_raw;                                  // [(cap + 1)][2][G]
-  u32* s_tb = (u32*)(orl_lds_raw + (((size_t)(cap + 1) * 2 * G * 4 + 15) & ~(size_t)15));  // [nw][256]
-  const int ge = tid / E, link = tid - ge * E;
-  const i64 env = (i64)blockIdx.x * G + ge;
-  const bool rowlane = ge < G && env < P.B;
-  if (!RWA)
-    for (int i = tid; i < (cap + 1) * 2 * G; i += ORL_ROWSTATS_THREADS) s_delta[i] = 0;
-  __syncthreads();
-  int n_ev = 0;
-  if (rowlane) {
-    const int ns = P.log_n[env >> 3] & 0xffff;
-    n_ev = ns ? P.elog_n[env] : 0;
+  const RowstatsLds L = rowstats_lds_layout(G);
+  u32* s_bits = (u32*)(orl_lds_raw + L.bits);      // [NWORD][256]: touch bits of row r, word w at [w][r]
+  double* s_clk = (double*)(orl_lds_raw + L.clk);  // [G][WIN]
+  u32* s_meta = (u32*)(orl_lds_raw + L.meta);      // [G][WIN]
+  int* s_delta = (int*)(orl_lds_raw + L.delta);    // [G][WIN]
+  int* s_hist = (int*)(orl_lds_raw + L.hist);      // [16] rows per touch count (15 = that many or more), [16] cursors
+  unsigned short* s_perm = (unsigned short*)(orl_lds_raw + L.perm);
+  int* s_nev = (int*)(orl_lds_raw + L.nev);
+  const i64 envb = (i64)blockIdx.x * G;
+#ifdef ORL_RS_PROF
+  long long rsp_t = clock64();
+#endif
+  // the env scan of phase D (lanes tid < G): running totals, the sums pending for the step after the last event's, that step
+  int sc_occ = 0, sc_fb = 0, sp_occ = 0, sp_fb = 0, sc_t = -1, sc_ns = 0;
+  bool sc_fin = false, sc_on = false;
+  if (tid < ORL_RS_GMAX) {
+    int n = 0;
+    if (tid < G && envb + tid < P.B) {
+      const int ln = P.log_n[(envb + tid) >> 3];
+      sc_ns = ln & 0xffff;
+      sc_fin = ((ln >> 16) & 1) != 0;
+      n = sc_ns ? P.elog_n[envb + tid] : 0;
+      sc_on = !RWA && sc_ns > 0;
+      if (sc_on) {
+        const int* cs = P.core_sums + (envb + tid) * P.cs_words;
+        sc_occ = cs[0]; sc_fb = cs[1];
+        sp_occ = sc_occ - cs[2 * P.C]; sp_fb = sc_fb - cs[2 * P.C + 1];  // (what the previous launch's last releases added is not part of it)
+      }
+    }
+    s_nev[tid] = n;
   }
-  if (n_ev > 0) {
-    const ulonglong2* ev = P.elog + env * (i64)P.elog_cap;
-    u64* row = P.bitmap + env * P.bm_words + (size_t)link * W;
-    u64 a[W];
+  if (tid >= 32 && tid < 64) s_hist[tid - 32] = 0;
+  __syncthreads();
+  int nev_max = s_nev[tid & (ORL_RS_GMAX - 1)];
 #pragma unroll
-    for (int w = 0; w < W; w++) a[w] = row[w];
-    // pass 1: which events touch this link (bit per event, 32 per LDS word), and the row as the launch found it
-    int ntouch = 0;
-    for (int j0 = 0; j0 < n_ev; j0 += 32) {
-      u32 bits = 0u;
-      for (int j1 = 0; j1 < 32 && j0 + j1 < n_ev; j1 += 8) {
-        ulonglong2 e8[8];
+  for (int o = 1; o < ORL_RS_GMAX; o <<= 1) { const int t_ = __shfl_xor(nev_max, o, 64); nev_max = t_ > nev_max ? t_ : nev_max; }
+  // this lane's row (assigned after the first window's sort) and its state
+  int r = tid, g_r = 0, link = 0;
+  bool have = false, touched_any = false;
+  u64 a[W];
 #pragma unroll
-        for (int k = 0; k < 8; k++) e8[k] = ev[(j0 + j1 + k < n_ev) ? j0 + j1 + k : n_ev - 1];
+  for (int w = 0; w < W; w++) a[w] = 0ull;
+  double util = 0.0, frag = 0.0, comp = 0.0, last_update = 0.0;
+  int occ0 = 0, fb0 = 0;
+  u32 cw = 0u;
+  double* ls = nullptr;
+  ORL_RSP(0);
+  for (int j0 = 0; j0 < nev_max; j0 += ORL_RS_WIN) {
+    // ---- A: the window's events ------------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          if (j0 + j1 + k < n_ev && ((e8[k].y >> link) & 1ull)) {
-            bits |= 1u << (j1 + k);
-            const sp::Mask2 mm = sp::mask2((int)(e8[k].x & 0x1ffu), (int)((e8[k].x >> 9) & 63u));
+    for (int w = 0; w < NWORD; w++) s_bits[w * ORL_ROWSTATS_THREADS + tid] = 0u;
+    // (the cells of a window: G x the smallest power of two that holds its events)
+    const int nwin = nev_max - j0 < ORL_RS_WIN ? nev_max - j0 : ORL_RS_WIN;
+    const int sh = nwin <= 8 ? 3 : (nwin <= 16 ? 4 : (nwin <= 32 ? 5 : 6));
+    ulonglong2 ea[(ORL_RS_GMAX * ORL_RS_WIN + ORL_ROWSTATS_THREADS - 1) / ORL_ROWSTATS_THREADS], eb[(ORL_RS_GMAX * ORL_RS_WIN + ORL_ROWSTATS_THREADS - 1) / ORL_ROWSTATS_THREADS];
 #pragma unroll
-            for (int w = 0; w < W; w++) a[w] ^= sp::mask2_word(mm, w);
-          }
+    for (int q = 0; q < (ORL_RS_GMAX * ORL_RS_WIN + ORL_ROWSTATS_THREADS - 1) / ORL_ROWSTATS_THREADS; q++) {  // (every request of the window first)
+      const int i = tid + q * ORL_ROWSTATS_THREADS, g = i >> sh, k = i & ((1 << sh) - 1);
+      ea[q] = make_ulonglong2(0ull, 0ull); eb[q] = ea[q];
+      if (g < G && j0 + k < s_nev[g]) {
+        const ulonglong2* ev = P.elog + ((envb + g) * (i64)P.elog_cap + (j0 + k)) * 2;
+        ea[q] = ev[0]; eb[q] = ev[1];
+      }
+    }
+    __syncthreads();  // (the touch words are clear)
+#pragma unroll
+    for (int q = 0; q < (ORL_RS_GMAX * ORL_RS_WIN + ORL_ROWSTATS_THREADS - 1) / ORL_ROWSTATS_THREADS; q++) {
+      const int i = tid + q * ORL_ROWSTATS_THREADS, g = i >> sh, k = i & ((1 << sh) - 1);
+      if (g < G) {
+        const int c = g * ORL_RS_WIN + k;
+        s_delta[c] = 0;
+        if (j0 + k < s_nev[g]) {
+          s_clk[c] = __longlong_as_double((i64)eb[q].x);
+          s_meta[c] = (u32)ea[q].x;
+          const u32 bit = 1u << (k & 31);
+          u32* bw = s_bits + (k >> 5) * ORL_ROWSTATS_THREADS + g * E;
+          for (u64 lm = ea[q].y; lm; lm &= lm - 1ull) atomicOr(bw + (int)__builtin_ctzll(lm), bit);
         }
       }
-      s_tb[(j0 >> 5) * ORL_ROWSTATS_THREADS + tid] = bits;
-      ntouch += __popc(bits);
     }
-    if (ntouch > 0) {
-      double* ls = P.lstat + env * 4 * E + 4 * link;
-      const double2 ls01 = *(const double2*)ls, ls23 = *(const double2*)(ls + 2);
-      double util = ls01.x, frag = ls01.y, comp = ls23.x, last_update = ls23.y;
-      const u64* lg = P.slog + env;
-      const size_t lst = (size_t)P.log_stride;
-      int occ0 = 0, fb0 = 0;
-      if (!RWA) sp::row_occ_fb<W>(a, S, occ0, fb0);
-      u32 cw = 0u;  // inner-run cache of the row: nothing known yet
+    ORL_RSP(1);
+    __syncthreads();
+    ORL_RSP(2);
+    // ---- B: rows sorted by touches (first window), then each lane fetches its row ---------------------------------------------------
+    if (j0 == 0) {
+      int cnt = 0;
 #pragma unroll
-      for (int w = 0; w < (W <= 5 ? W : 0); w++) cw |= 63u << (6 * w);
-      const int nwords = (n_ev + 31) >> 5;
+      for (int w = 0; w < NWORD; w++) cnt += __popc(s_bits[w * ORL_ROWSTATS_THREADS + tid]);
+      const int bin = 15 - (cnt < 15 ? cnt : 15);  // (heaviest first)
+      atomicAdd(&s_hist[bin], 1);
+      __syncthreads();
+      int base = 0;
+#pragma unroll
+      for (int b = 0; b < 15; b++) base += (b < bin) ? s_hist[b] : 0;
+      s_perm[base + atomicAdd(&s_hist[16 + bin], 1)] = (unsigned short)tid;
+      __syncthreads();
+      // (which quarter of the sorted rows a wavefront takes rotates with the workgroup: wavefront w of every workgroup runs on the
+      // same SIMD of its CU, and the heaviest quarter everywhere on SIMD 0 left the other three SIMDs half idle)
+      r = (int)s_perm[(((tid >> 6) + (int)blockIdx.x) & 3) * 64 + (tid & 63)];
+      g_r = r / E;
+      link = r - g_r * E;
+      have = g_r < G && s_nev[g_r] > 0;
+      if (have) {
+        const i64 env = envb + g_r;
+        const u64* row = P.bitmap0 + env * P.bm_words + (size_t)link * W;
+#pragma unroll
+        for (int w = 0; w < W; w++) a[w] = row[w];
+        ls = P.lstat + env * 4 * E + 4 * link;
+        const double2 ls01 = *(const double2*)ls, ls23 = *(const double2*)(ls + 2);
+        util = ls01.x; frag = ls01.y; comp = ls23.x; last_update = ls23.y;
+        if (!RWA) sp::row_occ_fb<W>(a, S, occ0, fb0);
+#pragma unroll
+        for (int w = 0; w < (W <= 5 ? W : 0); w++) cw |= 63u << (6 * w);  // inner-run cache of the row: nothing known yet
+      }
+    }
+    ORL_RSP(3);
+    int rounds_ = 0;
+    // ---- C: this lane's touches of the window ---------------------------------------------------------------------------------------
+    if (have) {
+      const double* clk_g = s_clk + g_r * ORL_RS_WIN;
+      const u32* meta_g = s_meta + g_r * ORL_RS_WIN;
       int wi = 0;
-      u32 word = s_tb[tid];
+      u32 word = s_bits[r];
       for (;;) {
-        while (word == 0u && wi + 1 < nwords) { wi++; word = s_tb[wi * ORL_ROWSTATS_THREADS + tid]; }
+        while (word == 0u && wi + 1 < NWORD) { wi++; word = s_bits[wi * ORL_ROWSTATS_THREADS + r]; }
         if (word == 0u) break;
-        const int j = 32 * wi + (int)__builtin_ctz(word);
+        const int k = 32 * wi + (int)__builtin_ctz(word);
         word &= word - 1u;
-        const u64 meta = ev[j].x;
-        const int s0 = (int)(meta & 0x1ffu), n = (int)((meta >> 9) & 63u), t = (int)((meta >> 15) & 0x1ffu);
-        const bool prov = ((meta >> 24) & 1ull) != 0ull;
-        // the clock of the event: a provision happens at the clock its step was decided at (the previous step's new clock, or
-        // the launch's header row), a release at the step's new clock (log word w0)
-        const int ct = prov ? t - 1 : t;
-        const double clock = __longlong_as_double((i64)lg[(size_t)(ct < 0 ? 3 * cap : 3 * ct) * lst]);
+        touched_any = true;
+        rounds_++;
+        const u32 meta = meta_g[k];
+        const double clock = clk_g[k];
+        const int s0 = (int)(meta & 0x1ffu), n = (int)((meta >> 9) & 63u);
         const sp::Mask2 mm = sp::mask2(s0, n);
 #pragma unroll
-        for (int w = 0; w < W; w++) a[w] ^= sp::mask2_word(mm, w);
+        for (int w = 0; w < W; w++) a[w] ^= sp::mask2_word(mm, w);  // (a provision clears free slots, a release sets taken ones)
         RowStat after;
         int max_empty = 0, edge = 0;
         if (!RWA) {
@@ -608,57 +727,63 @@ __global__ void __launch_bounds__(ORL_ROWSTATS_THREADS) k_rowstats(DevParams P, 
         if (!RWA) {
           const int d = ((after.occ - occ0) << 16) + (after.fb - fb0);
           occ0 = after.occ; fb0 = after.fb;
-          if (d) atomicAdd(&s_delta[(2 * t + (prov ? 0 : 1)) * G + ge], d);
+          if (d) atomicAdd(&s_delta[g_r * ORL_RS_WIN + k], d);
         }
       }
-      *(double2*)ls = make_double2(util, frag);
-      *(double2*)(ls + 2) = make_double2(comp, last_update);
     }
-  }
-  if (RWA) return;
-  __syncthreads();
-  // the sums right after each step's provision, per env: prefix over the steps (LDS), then all threads OR them into the log
-  if (tid < G) {
-    const i64 env_s = (i64)blockIdx.x * G + tid;
-    const int ln = env_s < P.B ? P.log_n[env_s >> 3] : 0;
-    const int ns = ln & 0xffff;
-    if (ns > 0) {
-      int* cs = P.core_sums + env_s * P.cs_words;
-      int t_occ = cs[0], t_fb = cs[1];
-      int s_occ = t_occ - cs[2 * P.C], s_fb = t_fb - cs[2 * P.C + 1];  // (what the previous launch's last releases added is not part of it)
-      int dr = 0;
-      for (int t = 0; t < ns; t++) {
-        const int dp = s_delta[(2 * t) * G + tid];
-        dr = s_delta[(2 * t + 1) * G + tid];
-        s_delta[(2 * t) * G + tid] = s_occ;
-        s_delta[(2 * t + 1) * G + tid] = s_fb;
-        const int dp_fb = (int)(short)(dp & 0xffff), dr_fb = (int)(short)(dr & 0xffff);
-        t_occ += (dp - dp_fb) >> 16; t_fb += dp_fb;
-        s_occ = t_occ; s_fb = t_fb;
-        t_occ += (dr - dr_fb) >> 16; t_fb += dr_fb;
+    ORL_RSP(4);
+#ifdef ORL_RS_PROF
+    { int mx = rounds_, sm = rounds_;
+      for (int o = 32; o > 0; o >>= 1) { const int t_ = __shfl_xor(mx, o, 64); mx = t_ > mx ? t_ : mx; sm += __shfl_xor(sm, o, 64); }
+      ORL_RSP_CNT(8, mx); ORL_RSP_CNT(9, sm); ORL_RSP_CNT(10, 1); }
+#endif
+    (void)rounds_;
+    __syncthreads();
+    ORL_RSP(5);
+    // ---- D: the sums after each step's provision, one lane per env ------------------------------------------------------------------
+    if (sc_on) {
+      const int nk = s_nev[tid] - j0 < ORL_RS_WIN ? s_nev[tid] - j0 : ORL_RS_WIN;
+      u32* out = P.ssum + (size_t)(envb + tid);
+      const size_t st = (size_t)P.log_stride;
+      for (int k = 0; k < nk; k++) {
+        const u32 meta = s_meta[tid * ORL_RS_WIN + k];
+        const int t = (int)((meta >> 15) & 0x1ffu);
+        if (t != sc_t) {
+          // the step before is complete: its pending sums are those of step sc_t + 1; steps without events in between see the totals
+          out[(size_t)(sc_t + 1) * st] = ((u32)sp_occ << 16) | (u32)sp_fb;
+          for (int s2 = sc_t + 2; s2 <= t; s2++) out[(size_t)s2 * st] = ((u32)sc_occ << 16) | (u32)sc_fb;
+          sc_t = t;
+          sp_occ = sc_occ; sp_fb = sc_fb;
+        }
+        const int d = s_delta[tid * ORL_RS_WIN + k];
+        const int d_fb = (int)(short)(d & 0xffff);
+        sc_occ += (d - d_fb) >> 16; sc_fb += d_fb;
+        if ((meta >> 24) & 1u) { sp_occ = sc_occ; sp_fb = sc_fb; }  // (right after the provision)
       }
-      s_delta[(2 * ns) * G + tid] = s_occ;
-      s_delta[(2 * ns + 1) * G + tid] = s_fb;
-      // core_sums as the in-loop row phase leaves them: the totals, and what the last step's releases added (cleared when the
-      // wavefront finished the run's state: DevParams::persist_finish)
-      const int dr_fb = (int)(short)(dr & 0xffff);
-      const bool fin = ((ln >> 16) & 1) != 0;
-      cs[0] = t_occ; cs[1] = t_fb;
-      cs[2 * P.C] = fin ? 0 : (dr - dr_fb) >> 16;
-      cs[2 * P.C + 1] = fin ? 0 : dr_fb;
     }
+    ORL_RSP(6);
+    if (j0 + ORL_RS_WIN < nev_max) __syncthreads();  // (the next window overwrites the tables)
+    ORL_RSP(7);
   }
-  __syncthreads();
-  for (int i = tid; i < (cap + 1) * G; i += ORL_ROWSTATS_THREADS) {
-    const int t = i / G, g = i - t * G;
-    const i64 env_s = (i64)blockIdx.x * G + g;
-    if (env_s >= P.B) continue;
-    const int ns = P.log_n[env_s >> 3] & 0xffff;
-    if (ns == 0 || t > ns) continue;
-    u64* w1 = P.slog + (size_t)(3 * t + 1) * (size_t)P.log_stride + (size_t)env_s;
-    const u64 sums = ((u64)(u32)s_delta[(2 * t) * G + g] << 25) | ((u64)(u32)s_delta[(2 * t + 1) * G + g] << 42);
-    if (t < ns) *w1 = *w1 | sums;
-    else *w1 = sums;  // (the slot behind the last step carries the sums only: sp::slog_w1(false, 0, 0, occ, fb))
+  if (have && touched_any) {
+    *(double2*)ls = make_double2(util, frag);
+    *(double2*)(ls + 2) = make_double2(comp, last_update);
+  }
+  if (sc_on) {
+    // the steps behind the last event, the slot behind the last step (k_stats finishes the run's last pending update from it), and
+    // core_sums as the in-loop row phase leaves them: the totals, and what the last step's releases added (cleared when the
+    // wavefront finished the run's state: DevParams::persist_finish)
+    u32* out = P.ssum + (size_t)(envb + tid);
+    const size_t st = (size_t)P.log_stride;
+    out[(size_t)(sc_t + 1) * st] = ((u32)sp_occ << 16) | (u32)sp_fb;
+    for (int s2 = sc_t + 2; s2 <= sc_ns; s2++) out[(size_t)s2 * st] = ((u32)sc_occ << 16) | (u32)sc_fb;
+    // (the sums of slot ns: after the last step's provision — the pending ones when that step had events, else the totals)
+    const bool last_had = sc_t == sc_ns - 1;
+    const int e_occ = last_had ? sp_occ : sc_occ, e_fb = last_had ? sp_fb : sc_fb;
+    int* cs = P.core_sums + (envb + tid) * P.cs_words;
+    cs[0] = sc_occ; cs[1] = sc_fb;
+    cs[2 * P.C] = sc_fin ? 0 : sc_occ - e_occ;
+    cs[2 * P.C + 1] = sc_fin ? 0 : sc_fb - e_fb;
   }
 }
 
@@ -916,7 +1041,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       M.scenv0 = env0;
       M.sc_stride = ORL_SCAL_LDS_WORDS;
     }
-#define ORL_FILL_WINDOW() persist_fill_window<REC>(P, env0, nenv, lane, orl_lds_raw + L.bm, orl_lds_raw + L.sc, orl_lds_raw + L.cs, RD ? 0 : L.csw / 4)
+#define ORL_FILL_WINDOW() persist_fill_window<REC, RD>(P, env0, nenv, lane, orl_lds_raw + L.bm, orl_lds_raw + L.sc, orl_lds_raw + L.cs, RD ? 0 : L.csw / 4)
     if (step < target) ORL_FILL_WINDOW();
     ORL_LOAD_CARRIED();
     // the row caches this wavefront left with the state at the end of its previous launch are still good when nothing but the
@@ -1393,8 +1518,15 @@ template <int SPEC> __device__ __forceinline__ void persist_spec_apply(DevParams
   }
 }
 
+// ORL_PERSIST_VGPR (specialisation libraries of the rows-deferred forms, experiments): an explicit register budget below the one
+// the waves-per-SIMD figure gives — 4 x 104 leave room for a wavefront of k_rowstats (96) beside the four of this kernel
+#ifdef ORL_PERSIST_VGPR
+#define ORL_PERSIST_VGPR_ATTR __attribute__((amdgpu_num_vgpr(ORL_PERSIST_VGPR)))
+#else
+#define ORL_PERSIST_VGPR_ATTR
+#endif
 template <int ENV, int W, int LDS, int WAVES, int SPEC = 0, bool RW = false>
-__global__ void __launch_bounds__(RW ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+__global__ void __launch_bounds__(RW ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) ORL_PERSIST_VGPR_ATTR
 k_persist(DevParams P, int pol, int target, int* wg_step, u32* n_unfinished, u32* clear_next) {
   // the counters the NEXT launch of this half of the batch uses (it starts after this one has ended)
   if (blockIdx.x == 0 && threadIdx.x == 0) { clear_next[0] = 0u; clear_next[1] = 0u; }
@@ -1797,6 +1929,19 @@ __global__ void __launch_bounds__(64) k_agent_qos(DevParams P, int auto_reset) {
 }
 #endif
 
+#if defined(ORL_RS_PROF) && !defined(ORL_SPEC_ONLY)
+#if ORL_W == 5
+extern "C" int orl_debug_rs_prof(unsigned long long* out16, int reset) {
+  std::vector<unsigned long long> h((size_t)ORL_RSP_WAVES * 16);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_rs_prof), h.size() * 8) != hipSuccess) return -1;
+  for (int k = 0; k < 16; k++) out16[k] = 0;
+  for (size_t w = 0; w < ORL_RSP_WAVES; w++)
+    for (int k = 0; k < 16; k++) out16[k] += h[w * 16 + k];
+  if (reset) { std::fill(h.begin(), h.end(), 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), h.data(), h.size() * 8) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+#endif
 #ifdef ORL_SPEC_ONLY
 // ---- the whole of a specialisation library: one instantiation and its launch entry ----------------------------------------
 extern "C" int orl_spec_struct_bytes(void) { return (int)sizeof(DevParams); }
@@ -2106,13 +2251,14 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
       if (b->P.row_cache_stamp) hipMemsetAsync(b->P.row_cache_stamp, 0, (size_t)((b->P.B + 7) / 8) * sizeof(int), st);
       b->cache_epoch = 1;
     }
-    const int G = ORL_ROWSTATS_THREADS / VP.E, nw = (VP.elog_cap + 31) / 32;
-    const size_t lds_r = (((size_t)(VP.log_cap + 1) * 2 * G * 4 + 15) & ~(size_t)15) + (size_t)nw * ORL_ROWSTATS_THREADS * 4;
+    int G = ORL_ROWSTATS_THREADS / VP.E;
+    G = G > ORL_RS_GMAX ? ORL_RS_GMAX : G;
+    const size_t lds_r = (size_t)rowstats_lds_layout(G).total;
     dim3 gr((unsigned)((VP.B + G - 1) / G)), br(ORL_ROWSTATS_THREADS);
 #define ROWSTATS(E_)                                                                                                                    \
   do {                                                                                                                                 \
     if (lds_r > 48 * 1024) hipFuncSetAttribute((const void*)k_rowstats<E_, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r); \
-    hipLaunchKernelGGL((k_rowstats<E_, W>), gr, br, lds_r, st, VP, G, nw);                                                             \
+    hipLaunchKernelGGL((k_rowstats<E_, W>), gr, br, lds_r, st, VP, G);                                                             \
   } while (0)
     switch (VP.env_type) {
       case ENV_RMSA: ROWSTATS(ENV_RMSA); break;
@@ -2125,11 +2271,12 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   // on its stream; the forms that keep it in the loop logged nothing
   if (orl_persist_deferred(VP.env_type) && VP.slog) {
     dim3 gs((unsigned)((VP.B + ORL_STATS_LANES - 1) / ORL_STATS_LANES));
+    const int rd = persist_rd_state(kPersistForms[v].lds) ? 1 : 0;
     switch (VP.env_type) {
-      case ENV_RMSA: hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP); break;
-      case ENV_DEEPRMSA: hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP); break;
-      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, 0, st, VP); break;
-      default: hipLaunchKernelGGL((k_stats<ENV_RWA>), gs, blk, 0, st, VP); break;
+      case ENV_RMSA: hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP, rd); break;
+      case ENV_DEEPRMSA: hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP, rd); break;
+      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, 0, st, VP, rd); break;
+      default: hipLaunchKernelGGL((k_stats<ENV_RWA>), gs, blk, 0, st, VP, rd); break;
     }
   }
 }
