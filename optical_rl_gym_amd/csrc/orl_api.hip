@@ -382,7 +382,8 @@ static DevParams env_view(const DevParams& P, i64 lo, i64 cnt, int part) {
   q.svc_q += lo * 8; q.svc_ht += lo * 8; q.svc_pk += lo * 8; q.svc_cnt += lo * 8;  // (64 lanes per 8 envs; lo is a multiple of 8)
   q.row_cache += (lo / 8) * 2 * (i64)P.row_cache_words; q.row_cache_stamp += lo / 8;
   if (q.slog) { q.slog += lo; q.log_n += lo / 8; }  // (rows of the log span the whole batch: log_stride stays)
-  if (q.elog) { q.elog += lo * (i64)(2 * P.elog_cap); q.elog_n += lo; q.bitmap0 += lo * P.bm_words; q.ssum += lo; }
+  if (q.elog) { q.elog += lo * (i64)(2 * P.elog_cap); q.elog_n += lo; q.bitmap0 += lo * P.bm_words; }
+  if (q.ssum) q.ssum += lo;
   if (q.br_hist) q.br_hist += lo * 2 * P.n_br;
   if (q.act_hist) q.act_hist += lo * ((P.K + 1) + (P.S + 1));
   if (q.act2d) q.act2d += lo * P.act2d_words;
@@ -1229,10 +1230,11 @@ static int ensure_logs(orl_batch* b, int64_t n_steps, int* chunk_io) {
         rc = dalloc(b, &P.bitmap0, B * P.bm_words);
         if (rc) return rc;
       }
-      rc = dalloc(b, &P.ssum, (want + 1) * B);
-      if (rc) return rc;
       P.elog_cap = (int)ecap;
     }
+    // (allocated for every family: k_stats names it in an expression the compiler may evaluate on both sides of a select)
+    rc = dalloc(b, &P.ssum, (want + 1) * B);
+    if (rc) return rc;
   }
   // (a launch logs at most log_cap steps per wavefront, a straggler up to two chunks)
   if (n_steps > b->log_cap && chunk > b->log_cap / 2) chunk = b->log_cap / 2 > 0 ? b->log_cap / 2 : 1;

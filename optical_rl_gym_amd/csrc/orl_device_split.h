@@ -940,9 +940,20 @@ template <bool MINI> __device__ __forceinline__ u64* mrec(const Wmem& M, u64* re
 // atomics without a return value) and hands the row wavefront only the statistics; `rw_sync` are the pair's counters — [1] steps
 // whose items the row wavefront has read (sink table, mask table, clocks and rows: they may be overwritten), [2] steps whose
 // statistics are complete (the sums) — and `rw_k` the number of steps handed over so far.
+// The hand-over between the two wavefronts of the pair form goes through LDS only: release / acquire at workgroup scope restricted to
+// the LOCAL address space (clang's address-space MMRA on the fence builtin) — on gfx950 an s_waitcnt lgkmcnt(0) before the counter's
+// store, and none of the vmcnt wait a full workgroup-scope release would add for global stores nobody in the pair reads.
+#ifdef ORL_RW_FENCE_OLD  // (A/B: round 5's wavefront-scope fences)
+__device__ __forceinline__ void rw_release_lds() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+__device__ __forceinline__ void rw_acquire_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+#else
+__device__ __forceinline__ void rw_release_lds() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+__device__ __forceinline__ void rw_acquire_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+#endif
 __device__ __forceinline__ void rw_wait_for(const u32* p, u32 want) {
   while ((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  rw_acquire_lds();
+  ORL_DIAG_JITTER();
 }
 // RD (rows deferred, round 6): as RW, this phase changes the slot maps itself — but there is no row phase at all in the loop: every
 // provision and release is logged as an event (SinkT<CP, true>, DevParams::elog; `ecur`: the env's event count so far in this
@@ -1758,6 +1769,90 @@ __device__ __forceinline__ void row_stat_lane(const u64 (&a)[W], int S, RowStat&
   st.nu = nu; st.lo = lo; st.hi = hi; st.occ = two ? hi - lo : 0; st.fb = fb; st.free_ = free_; st.nf = nf;
 }
 
+// ---- incremental row summary (round 6: the replay kernel k_rowstats) ----------------------------------------------------------
+// A lane that owns a link row for a whole launch need not summarise its W words again at every touch: a provision takes n slots out
+// of ONE free run, a release merges the freed slots with the free runs on either side, and everything _update_link_stats reads of
+// the row (rmsa_env.py:464-543: free slots, used blocks, first / last used slot, longest free run) follows from the two free-run
+// lengths next to the mask — found with a count-leading / count-trailing on a 64-slot window on either side — except when a
+// provision splits the row's longest free run (then that one figure is searched again).  ~120 instructions per touch instead of
+// ~330 for the five-word summary with its inner-run cache; same integers, checked on every env against the in-loop row phase.
+struct RowInc { int free_, nu, lo, hi, me; };  // free slots; used blocks; first used slot (1 << 20: none); last used slot + 1 (0: none); longest free run
+template <int W> __device__ __forceinline__ u64 row_word(const u64 (&a)[W], int w) {  // word w of the row, 0 outside it
+  u64 x = 0ull;
+#pragma unroll
+  for (int k = 0; k < W; k++) x = (w == k) ? a[k] : x;
+  return x;
+}
+// free slots directly below slot p (p - 1, p - 2, ...) / from slot p upwards; slots outside the row count as taken (the bits above
+// the last slot of a row are zero)
+template <int W> __device__ __forceinline__ int row_run_below(const u64 (&a)[W], int p) {
+  int len = 0;
+  for (int q = p; q > 0; q -= 64) {
+    const int wq = q >> 6, b = q & 63;
+    const u64 hi = row_word<W>(a, wq), lo = row_word<W>(a, wq - 1);
+    const u64 x = (b == 0) ? lo : ((hi << (64 - b)) | (lo >> b));  // slots [q - 64, q): bit 63 = slot q - 1
+    const int c = (x == ~0ull) ? 64 : (int)__builtin_clzll(~x);
+    len += c;
+    if (c < 64) break;
+  }
+  return len;
+}
+template <int W> __device__ __forceinline__ int row_run_from(const u64 (&a)[W], int p) {
+  int len = 0;
+  for (int q = p; q < 64 * W; q += 64) {
+    const int wq = q >> 6, b = q & 63;
+    const u64 lo = row_word<W>(a, wq), hi = row_word<W>(a, wq + 1);
+    const u64 x = (b == 0) ? lo : ((lo >> b) | (hi << (64 - b)));  // slots [q, q + 64): bit 0 = slot q
+    const int c = (x == ~0ull) ? 64 : (int)__builtin_ctzll(~x);
+    len += c;
+    if (c < 64) break;
+  }
+  return len;
+}
+// the longest run of free slots of the row (runs continue across word boundaries; the non-cached branch of row_stat_lane)
+template <int W> __device__ __forceinline__ int row_longest_free(const u64 (&a)[W]) {
+  int best = 0, c = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) {
+    if (a[w] == ~0ull) {
+      c += 64;
+    } else {
+      const int lead = (int)__builtin_ctzll(~a[w]), trail = (int)__builtin_clzll(~a[w]);
+      const int inner = word_longest_run_flat((a[w] & (a[w] + 1ull)) & (~0ull >> trail));  // the word without its boundary runs
+      const int cand = (c + lead) > inner ? (c + lead) : inner;
+      best = cand > best ? cand : best;
+      c = trail;
+    }
+  }
+  return c > best ? c : best;
+}
+// the mask [s0, s0 + n) applied to the row (a provision clears free slots, a release sets taken ones) and the summary brought up to date
+template <int W>
+__device__ __forceinline__ void row_inc_apply(u64 (&a)[W], int S, int s0, int n, bool prov, RowInc& s) {
+  const int l = row_run_below<W>(a, s0), r = row_run_from<W>(a, s0 + n);  // (the slots next to the mask do not change)
+  const int joins = ((s0 > 0 && l == 0) ? 1 : 0) + ((s0 + n < S && r == 0) ? 1 : 0);  // used slots directly next to the mask
+  const Mask2 mm = mask2(s0, n);
+#pragma unroll
+  for (int w = 0; w < W; w++) a[w] ^= mask2_word(mm, w);
+  if (prov) {
+    s.free_ -= n;
+    s.nu += 1 - joins;
+    s.lo = s0 < s.lo ? s0 : s.lo;
+    s.hi = s0 + n > s.hi ? s0 + n : s.hi;
+    if (l + n + r == s.me) s.me = row_longest_free<W>(a);  // (the run it split was the longest, or as long)
+  } else {
+    s.free_ += n;
+    s.nu -= 1 - joins;
+    const int m = l + n + r;
+    s.me = m > s.me ? m : s.me;
+    if (s.nu == 0) { s.lo = 1 << 20; s.hi = 0; }
+    else {
+      if (s0 == s.lo) s.lo = s0 + n + r;       // the first used block began with these slots: the next used slot lies behind the merged run
+      if (s0 + n == s.hi) s.hi = s0 - l;       // the last used block ended with them
+    }
+  }
+}
+
 // the cache word of a row, from scratch
 template <int W>
 __device__ __forceinline__ u32 row_inner_cache(const u64* row) {
@@ -1878,7 +1973,7 @@ __device__ __forceinline__ void row_item_lane1(const DevParams& P, const Wmem& M
 #pragma unroll
       for (int w = 0; w < W; w++) a[w] |= mask2_word(mm, w);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (LDS executes a wavefront's instructions in order)
+    rw_release_lds();  // (this lane's reads of the row, the mask table and the clocks are done: workgroup-scope release on LDS only)
     if (sig) __hip_atomic_store(sig, sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     ORL_PROFR(9);
   }

@@ -14,6 +14,8 @@
 //   -DORL_DIAG -DORL_X_SKIP_F64     no float64 running averages
 //   -DORL_DIAG -DORL_X_NOMINI       (correct results) the control phase's record words stay in the global records
 //   -DORL_DIAG -DORL_X_NOOCG        (correct results) cache level 1 recomputes a row's contribution to the compactness sums
+//   -DORL_DIAG -DORL_X_JITTER       (correct results) the two wavefronts of the pair form sleep a pseudo-random time before every
+//                                   signal and after every wait of their hand-over: a stress of its ordering (tests)
 #pragma once
 #ifdef ORL_DIAG
 #ifdef ORL_X_SKIP_SVC
@@ -48,7 +50,13 @@
 #ifdef ORL_X_NOOCG
 #define ORL_DIAG_NO_OCG 1
 #endif
+#ifdef ORL_X_JITTER
+#define ORL_DIAG_JITTER() do { const int n_ = (int)((clock64() >> 5) & 31); for (int i_ = 0; i_ < n_; i_++) __builtin_amdgcn_s_sleep(3); } while (0)
+#endif
 #ifdef ORL_X_WAVESYNC
 #define ORL_DIAG_WAVE_SYNC 1
 #endif
 #endif  // ORL_DIAG
+#ifndef ORL_DIAG_JITTER
+#define ORL_DIAG_JITTER() do { } while (0)
+#endif

@@ -35,6 +35,9 @@ __global__ void __launch_bounds__(64) k_reset(DevParams P, int full, const unsig
   if (mask && !mask[env]) return;
   // (services the persistent kernel drew ahead for a run that was abandoned — an overflow error — are dropped with the reset)
   if (lane < 8) P.svc_cnt[(env >> 3) * 64 + (env & 7) * 8 + lane] = 0;
+#ifndef ORL_X_NO_STAMP
+  if (full && lane == 8 && P.row_cache_stamp) P.row_cache_stamp[env >> 3] = 0;  // (the slot maps change: stored row caches are stale)
+#endif
   Env e;
   env_load(P, e, env, lane);
   if (!full) {
@@ -106,6 +109,9 @@ template <int ENV, int W, bool EVL>
 __global__ void __launch_bounds__(64, ORL_STEP_WAVES) k_step(DevParams P, int auto_reset, int want_info, int pol) {
   const i64 env = blockIdx.x;
   const int lane = lane_id();
+#ifndef ORL_X_NO_STAMP
+  if (lane == 0 && P.row_cache_stamp) P.row_cache_stamp[env >> 3] = 0;  // (as k_agent: the persistent kernel's row caches of these envs are stale)
+#endif
   Env e;
   // Round trip 1: everything addressed by the env index alone is requested before anything is waited for — the
   // scalar record, the action, the slot map / link statistics / per-core sums (into LDS), the source-node table.
@@ -360,9 +366,12 @@ template <int ENV, int LDS> struct PersistDeferred {
 // slower, 143 us instead of 90 us behind a 128-step launch of 65 536 envs: the replay is bound by memory requests, and a
 // request of 16 lanes carries a quarter of the bytes)
 #define ORL_STATS_LANES 64
-// rd: the launch ran a rows-deferred form — the compactness sums come from DevParams::ssum (k_rowstats), (occ << 16) | fb per step
-template <int ENV>
-__global__ void __launch_bounds__(64) k_stats(DevParams P, int rd) {
+// RD: the launch ran a rows-deferred form — the compactness sums come from DevParams::ssum (k_rowstats), (occ << 16) | fb per step.
+// (A template parameter: as a run-time switch the conditional loads of ssum among the unrolled log loads changed the results of the
+// other forms in a few wavefronts per 4 096-env Germany50 batch — tools/pair_diff2.py — with nothing of ssum reaching a result.)
+template <int ENV, bool RD = false>
+__global__ void __launch_bounds__(64) k_stats(DevParams P) {
+  constexpr bool rd = RD;
   if (threadIdx.x >= ORL_STATS_LANES) return;
   const i64 env = (i64)blockIdx.x * ORL_STATS_LANES + (i64)threadIdx.x;
   if (env >= P.B) return;
@@ -398,7 +407,8 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P, int rd) {
       w0[k] = lg[(size_t)(3 * t) * st];
       w1[k] = lg[(size_t)(3 * t + 1) * st];
       w2[k] = lg[(size_t)(3 * t + 2) * st];
-      w3[k] = (rd && ENV != ENV_RWA) ? P.ssum[(size_t)t * st + (size_t)env] : 0u;
+      if constexpr (rd && ENV != ENV_RWA) w3[k] = P.ssum[(size_t)t * st + (size_t)env];
+      else w3[k] = 0u;
     }
 #pragma unroll
     for (int k = 0; k < ORL_STATS_BATCH; k++) {
@@ -477,10 +487,15 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P, int rd) {
   }
   if (fin && ENV != ENV_RWA && ((u32)acc & 2u)) {
     // the run ends here: the update the last step left pending, from the sums after its row phase (k_finish2's expressions)
-    const u64 a1 = rd ? 0ull : lg[(size_t)(3 * n + 1) * st];
-    const u32 a3 = rd ? P.ssum[(size_t)n * st + (size_t)env] : 0u;
+    int occ, fb;
+    if constexpr (rd) {
+      const u32 a3 = P.ssum[(size_t)n * st + (size_t)env];
+      occ = (int)(a3 >> 16); fb = (int)(a3 & 0xffffu);
+    } else {
+      const u64 a1 = lg[(size_t)(3 * n + 1) * st];
+      occ = (int)((a1 >> 25) & 0x1ffffu); fb = (int)((a1 >> 42) & 0xffffu);
+    }
     const i64 s_nh_prov = (i64)(acc >> 37);
-    const int occ = rd ? (int)(a3 >> 16) : (int)((a1 >> 25) & 0x1ffffu), fb = rd ? (int)(a3 & 0xffffu) : (int)((a1 >> 42) & 0xffffu);
     const double cmp = (fb > 0) ? ((double)occ / (double)s_nh_prov) * ((double)P.E / (double)fb) : 1.0;
     g_comp = (gc_a + (cmp * gc_td)) / now_a;
     acc &= ~2ull;
@@ -599,7 +614,8 @@ k_rowstats(DevParams P, int G) {
   for (int w = 0; w < W; w++) a[w] = 0ull;
   double util = 0.0, frag = 0.0, comp = 0.0, last_update = 0.0;
   int occ0 = 0, fb0 = 0;
-  u32 cw = 0u;
+  sp::RowInc ri;
+  ri.free_ = 0; ri.nu = 0; ri.lo = 1 << 20; ri.hi = 0; ri.me = 0;
   double* ls = nullptr;
   ORL_RSP(0);
   for (int j0 = 0; j0 < nev_max; j0 += ORL_RS_WIN) {
@@ -665,9 +681,18 @@ k_rowstats(DevParams P, int G) {
         ls = P.lstat + env * 4 * E + 4 * link;
         const double2 ls01 = *(const double2*)ls, ls23 = *(const double2*)(ls + 2);
         util = ls01.x; frag = ls01.y; comp = ls23.x; last_update = ls23.y;
-        if (!RWA) sp::row_occ_fb<W>(a, S, occ0, fb0);
+        if (!RWA) {  // the row's summary as the launch found it: once per row and launch
+          RowStat st0;
+          int me0 = 0, edge0 = 0;
+          sp::row_stat_lane<W>(a, S, st0, me0, edge0);
+          ri.free_ = st0.free_; ri.nu = st0.nu; ri.lo = st0.lo; ri.hi = st0.hi; ri.me = me0;
+          occ0 = st0.occ; fb0 = st0.fb;
+        } else {
+          int f = 0;
 #pragma unroll
-        for (int w = 0; w < (W <= 5 ? W : 0); w++) cw |= 63u << (6 * w);  // inner-run cache of the row: nothing known yet
+          for (int w = 0; w < W; w++) f += __popcll(a[w]);
+          ri.free_ = f;
+        }
       }
     }
     ORL_RSP(3);
@@ -688,19 +713,21 @@ k_rowstats(DevParams P, int G) {
         const u32 meta = meta_g[k];
         const double clock = clk_g[k];
         const int s0 = (int)(meta & 0x1ffu), n = (int)((meta >> 9) & 63u);
-        const sp::Mask2 mm = sp::mask2(s0, n);
-#pragma unroll
-        for (int w = 0; w < W; w++) a[w] ^= sp::mask2_word(mm, w);  // (a provision clears free slots, a release sets taken ones)
+        const bool prov = ((meta >> 24) & 1u) != 0u;
         RowStat after;
         int max_empty = 0, edge = 0;
         if (!RWA) {
-          if (W >= 3 && W <= 5) sp::row_stat_lane<W, (W >= 3 && W <= 5)>(a, S, after, max_empty, edge, &cw, sp::mask_words(s0, n), true);
-          else sp::row_stat_lane<W>(a, S, after, max_empty, edge);
+          // (incremental: the two free runs next to the mask give everything the summary changes by, sp::row_inc_apply)
+          sp::row_inc_apply<W>(a, S, s0, n, prov, ri);
+          const int tw = (S - 1) >> 6, tb = (S - 1) & 63;
+          edge = (int)(a[0] & 1ull) + (int)((sp::row_word<W>(a, tw) >> tb) & 1ull);
+          const bool two = ri.nu > 1;
+          after.free_ = ri.free_; after.nu = ri.nu; after.lo = ri.lo; after.hi = ri.hi; after.nf = ri.nu - 1 + edge;
+          after.occ = two ? ri.hi - ri.lo : 0; after.fb = two ? ri.nu - 1 : 0;
+          max_empty = ri.me;
         } else {
-          int f = 0;
-#pragma unroll
-          for (int w = 0; w < W; w++) f += __popcll(a[w]);
-          after.free_ = f;
+          ri.free_ += prov ? -n : n;  // (RWA: the utilization is all a link keeps)
+          after.free_ = ri.free_;
         }
         // the values _update_link_stats derives from the row (rmsa_env.py:464-543), as sp::row_item_lane1
         const int free_ = after.free_;
@@ -817,16 +844,20 @@ k_rowstats(DevParams P, int G) {
 #define ORL_RW_STAGE_BYTES (2 * 64 * 24)  // two batches: the one asked for a step ahead, and one asked for on the spot
 #define ORL_RW_EXTRA_BYTES (ORL_RW_SYNC_WORDS * 4 + ORL_RW_STAGE_BYTES)
 __device__ __forceinline__ u32 rw_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// (Everything the pair shares is in LDS, and a CU's LDS executes a wavefront's instructions in the order they were issued: data
-// written before a counter is visible before it.  The fences are therefore wavefront-scope — compiler ordering only: a
-// workgroup-scope release would also wait for every global store the wavefront has in flight, log words and event records that
-// nobody in the pair reads, a global round trip in the step's chain.)
+// (Everything the pair shares is in LDS.  Round 6: the hand-over is a workgroup-scope release / acquire on the LOCAL address space
+// only — sp::rw_release_lds / rw_acquire_lds: the release drains the wavefront's LDS operations (s_waitcnt lgkmcnt(0)) before the
+// counter is stored and orders the compiler, inside the memory model.  A plain workgroup-scope release would also wait for every
+// global store the wavefront has in flight — log words and event records that nobody in the pair reads, a global round trip in the
+// step's chain — which is what round 5 avoided with wavefront-scope fences and the assumption that a CU's LDS executes a wavefront's
+// instructions in issue order.)
 __device__ __forceinline__ void rw_wait(const u32* p, u32 want) {
   while ((u32)__builtin_amdgcn_readfirstlane((int)rw_load(p)) < want) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  sp::rw_acquire_lds();
+  ORL_DIAG_JITTER();
 }
 __device__ __forceinline__ void rw_signal(u32* p, u32 v, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  ORL_DIAG_JITTER();
+  sp::rw_release_lds();
   if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 template <int ENV, int W, int LDS>
@@ -869,7 +900,7 @@ __device__ __forceinline__ void persist_row_wave(const DevParams& P, const Persi
       {
         const int ch = (asked1 > drawn1) ? 1 : 0;
         u32* chan = sync + 4 + 4 * ch;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sp::rw_acquire_lds();
         const int n_want = __builtin_amdgcn_readfirstlane((int)rw_load(chan + 2));
         const u32 groups = (u32)__builtin_amdgcn_readfirstlane((int)rw_load(chan + 3));
         double* stg_q = (double*)((char*)(sync + ORL_RW_SYNC_WORDS) + ch * (ORL_RW_STAGE_BYTES / 2));
@@ -893,7 +924,7 @@ __device__ __forceinline__ void persist_row_wave(const DevParams& P, const Persi
       __builtin_amdgcn_s_sleep(2);
       continue;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    sp::rw_acquire_lds();
     ORL_PROFR(8);  // (idle)
     k++;
     // the step's work items, from the sink table the control wavefront filled (its own ctrl_d skips this in the pair form)
@@ -1352,7 +1383,12 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       }
     }
     if (threadIdx.x == 0) P.log_n[blockIdx.x] = (step - first_step) | (finished_run ? (1 << 16) : 0);
-    if (RD && valid && (lane & 7) == 0) P.elog_n[env] = ecur;
+    if constexpr (RD) {
+      int tid_e = (int)threadIdx.x;
+      asm volatile("" : "+v"(tid_e));
+      const i64 env_e = env0 + (tid_e >> 3);
+      if (env_e < P.B && (tid_e & 7) == 0) P.elog_n[env_e] = ecur;
+    }
   } else if (PersistDeferred<ENV, 0>::value && threadIdx.x == 0) {
     P.log_n[blockIdx.x] = 0;  // (a form that keeps the bookkeeping in the loop: nothing for k_stats)
   }
@@ -1443,39 +1479,45 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     const double2* ls = (const double2*)M.ls0;
     for (int i = lane; i < nenv * 2 * P.E; i += 64) gs[i] = ls[i];
   }
-  if (MINI && step > first_step && valid) {
+  // (the env index of the write-backs below recomputed from the thread index behind an opaque copy: kept live across the step loop —
+  // 64 bits that nothing in the loop reads — it was the one value the 128-VGPR specialisations spilled, 2 VGPRs / 12 B of scratch)
+  int tid_w = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_w));
+  const i64 env_w = env0 + (tid_w >> 3);
+  const bool valid_w = env_w < P.B;
+  if (MINI && step > first_step && valid_w) {
     // the record words the control phase kept in the window go back to the records (SC_AT: the pending service arrived at the clock)
     wave_fence();
     const int k = lane & 7;
     if (k < ORL_MINI_WORDS) {
       const u64 v = M.mini[(lane >> 3) * ORL_MINI_STRIDE + k];
-      P.scal[env * ORL_SCAL_WORDS + sp::mini_slot(k)] = v;
-      if (k == 0) P.scal[env * ORL_SCAL_WORDS + SC_AT] = v;
+      P.scal[env_w * ORL_SCAL_WORDS + sp::mini_slot(k)] = v;
+      if (k == 0) P.scal[env_w * ORL_SCAL_WORDS + SC_AT] = v;
     } else if (k == ORL_MINI_WORDS) {
       u64 sd, br;
       sp::svc_words<ENV>(P, desc, sd, br);
-      P.scal[env * ORL_SCAL_WORDS + SC_SRC_DST] = sd;
-      P.scal[env * ORL_SCAL_WORDS + SC_BR_IDX] = br;
+      P.scal[env_w * ORL_SCAL_WORDS + SC_SRC_DST] = sd;
+      P.scal[env_w * ORL_SCAL_WORDS + SC_BR_IDX] = br;
     }
   }
-  if (SVC && step > first_step && valid) {
+  if (SVC && step > first_step && valid_w) {
     // what the group drew ahead and did not use: nothing when the loop ran to the launch's target; a wavefront that left early
     // (releases to be done in place) parks it for its next launch
     const size_t sl = (size_t)blockIdx.x * 64 + (size_t)lane;
     P.svc_cnt[sl] = svb.cnt;
     if (!sp::svc_empty(svb)) { P.svc_q[sl] = svb.q; P.svc_ht[sl] = svb.ht; P.svc_pk[sl] = svb.pk; }
   }
-  if (SR && step > first_step && valid) {
+  if (SR && step > first_step && valid_w) {
 #pragma unroll
     for (int k = 0; k < ORL_SOON_PER_LANE; k++) {
-      P.soon_t[env * ORL_SOON + (lane & 7) + 8 * k] = soon_c.t[k];
-      P.soon_i[env * ORL_SOON + (lane & 7) + 8 * k] = (u32)soon_c.i[k];
+      P.soon_t[env_w * ORL_SOON + (lane & 7) + 8 * k] = soon_c.t[k];
+      P.soon_i[env_w * ORL_SOON + (lane & 7) + 8 * k] = (u32)soon_c.i[k];
     }
   }
-  if (step > first_step && step < target && valid) {
+  if (step > first_step && step < target && valid_w) {
     // leaving early (deferred releases): the descriptor the next launch / the stand-alone scan reads; action, reward and done
     // of an unfinished run are not host-visible
-    if ((lane & 7) == 0) P.svc_desc[env] = desc;
+    if ((lane & 7) == 0) P.svc_desc[env_w] = desc;
   }
   if (threadIdx.x == 0) {
     wg_step[blockIdx.x] = step;
@@ -1596,6 +1638,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
       ((orl_i32x4*)M.cs0)[i] = ((const orl_i32x4*)(P.core_sums + (env0 + i / q) * P.cs_words))[i % q];
   }
   if (threadIdx.x == 0) s_deferred[0] = 0;
+  // (this launch changes slot maps outside the persistent kernel: the row caches that kernel left with the state — keyed by a host
+  // counter the launch of a captured graph does not advance — no longer describe them)
+#ifndef ORL_X_NO_STAMP
+  if (threadIdx.x == 0 && P.row_cache_stamp) P.row_cache_stamp[blockIdx.x] = 0;
+#endif
   wave_fence();
   sp::CtrlOpts O;
   O.persistent = true; O.write_io = true; O.trusted = false; O.emit_queue = false; O.prefetch = true; O.auto_reset = auto_reset != 0;
@@ -2271,12 +2318,18 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   // on its stream; the forms that keep it in the loop logged nothing
   if (orl_persist_deferred(VP.env_type) && VP.slog) {
     dim3 gs((unsigned)((VP.B + ORL_STATS_LANES - 1) / ORL_STATS_LANES));
-    const int rd = persist_rd_state(kPersistForms[v].lds) ? 1 : 0;
+    const bool rd = persist_rd_state(kPersistForms[v].lds);
     switch (VP.env_type) {
-      case ENV_RMSA: hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP, rd); break;
-      case ENV_DEEPRMSA: hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP, rd); break;
-      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, 0, st, VP, rd); break;
-      default: hipLaunchKernelGGL((k_stats<ENV_RWA>), gs, blk, 0, st, VP, rd); break;
+      case ENV_RMSA:
+        if (rd) hipLaunchKernelGGL((k_stats<ENV_RMSA, true>), gs, blk, 0, st, VP);
+        else hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP);
+        break;
+      case ENV_DEEPRMSA:
+        if (rd) hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA, true>), gs, blk, 0, st, VP);
+        else hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP);
+        break;
+      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, 0, st, VP); break;
+      default: hipLaunchKernelGGL((k_stats<ENV_RWA>), gs, blk, 0, st, VP); break;
     }
   }
 }

@@ -402,6 +402,41 @@ def test_pair_form_early_exits_parked_and_ordered_services(workload, monkeypatch
         chk(k, "item", x, y)
 
 
+def test_pair_form_hand_over_under_jitter(monkeypatch):
+    """The pair form's hand-over (LDS counters, workgroup-scope release / acquire on the local address space) with both wavefronts
+    sleeping a pseudo-random time before every signal and after every wait (-DORL_DIAG -DORL_X_JITTER: a library and a specialisation
+    of their own), one release per step allowed so that wavefronts also leave early: every env against the one-wavefront-per-env
+    kernel of the product library."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    fam, topo, kw, policy = WORKLOADS["cfg2"]
+    kw = dict(kw, episode_length=70)
+    batch = 4096
+    seeds = [9 + 5 * i for i in range(batch)]
+    out = {}
+    for name in ("wave64", "persist"):
+        force_impl(monkeypatch, name)
+        if name == "persist":
+            monkeypatch.setenv("ORL_ITEM_MASKS", "2")
+            monkeypatch.setenv("ORL_JIT_SPEC", "1")
+            monkeypatch.setenv("ORL_HIPCC_EXTRA", "-DORL_DIAG -DORL_X_JITTER")
+            monkeypatch.setenv("ORL_LIB_VARIANT", "exp")
+        else:
+            monkeypatch.delenv("ORL_ITEM_MASKS", raising=False)
+        env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+        for chunk in (140, 61):
+            env.run(policy, chunk)
+        if name == "persist":
+            assert _ran_pair_form(env)
+        out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy(),
+                     env.net_stats_all().copy(), env.link_stats_all().copy(), env.slots_packed().copy()]
+        env.close()
+    chk = _exact("cfg2 pair form under jitter")
+    for k, (x, y) in enumerate(zip(out["persist"], out["wave64"])):
+        chk(k, "item", x, y)
+
+
 @pytest.mark.parametrize("workload,batch", [("cfg2", 4096), ("cfg2", 20000), ("cfg3", 4096), ("cfg5", 2048)])
 def test_short_statistics_log_and_early_exits(workload, batch, monkeypatch):
     """The statistics log of a launch shortened to 12 steps (ORL_LOG_CAP; launches are then 6 steps long) and the item form limited
@@ -707,6 +742,80 @@ def test_zero_copy_device_tensors_drive_the_batch():
         assert np.array_equal(info.cpu().numpy(), i), t
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("B", [4096, 1024])
+def test_agent_rollout_in_a_captured_graph_equals_the_eager_loop(B):
+    """What the reference's examples/stable_baselines3/DeepRMSA.ipynb:272-302 does through SB3, on the GPU: T = 32 steps of policy
+    network forward + sampling + `step(None, fetch=False)` captured ONCE in a torch.cuda.CUDAGraph on the batch's own stream
+    (orl_batch_stream: the step call must neither synchronise nor allocate) and replayed, against the same loop queued eagerly:
+    the whole batch state — counters, pending services, slot maps, link and network statistics, observation, reward — bit for bit.
+    (4 096 envs: k_agent; 1 024: k_step.  The samples come from Gumbel noise drawn beforehand, indexed by a device-side step
+    counter, so that both loops consume the same random numbers.)"""
+    import torch
+
+    import optical_rl_gym_amd as orl
+
+    T, REPLAYS, WARM = 32, 2, 3
+    kw = dict(topology="nsfnet_chen", mean_service_holding_time=7.5, mean_service_inter_arrival_time=1 / 12.0, j=1,
+              episode_length=50, num_spectrum_resources=100)
+    out = {}
+    for mode in ("eager", "graph"):
+        env = orl.make("DeepRMSA-v0", num_envs=B, seeds=[3 + 7 * i for i in range(B)], **kw)
+        dev = "cuda:%d" % env.device_id
+        obs, rew, act = (env.device_tensor(n) for n in ("obs", "reward", "actions"))
+        n_actions = env.k_paths * env.j + (1 if env.allow_rejection else 0)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234)
+        net = torch.nn.Sequential(torch.nn.Linear(env.obs_dim, 64), torch.nn.ELU(), torch.nn.Linear(64, n_actions)).to(dev)
+        with torch.no_grad():
+            for k, prm in enumerate(net.parameters()):
+                prm.copy_(torch.randn(prm.shape, generator=gen, device=dev) * 0.3)
+        n_steps = WARM + T * REPLAYS
+        u = torch.rand((n_steps, B, n_actions), generator=gen, device=dev).clamp_(1e-6, 1 - 1e-6)
+        gumbel = -torch.log(-torch.log(u))
+        tcount = torch.zeros(1, dtype=torch.long, device=dev)
+        env.reset()
+        env.observation()
+        stream = env.torch_stream()
+
+        def rollout_step():
+            with torch.no_grad():
+                logits = net(obs.float())
+                a = (logits + gumbel.index_select(0, tcount)[0]).argmax(dim=1)
+                act[:, 0] = a.int()
+                env.step(None, auto_reset=True, fetch=False)
+                tcount.add_(1)
+
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for _ in range(WARM):
+                rollout_step()
+            if mode == "eager":
+                for _ in range(T * REPLAYS):
+                    rollout_step()
+        torch.cuda.synchronize()
+        if mode == "graph":
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                for _ in range(T):
+                    rollout_step()
+            with torch.cuda.stream(stream):
+                for _ in range(REPLAYS):
+                    g.replay()
+            torch.cuda.synchronize()
+        env.check()
+        assert int(tcount.item()) == n_steps
+        out[mode] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy(), env.net_stats_all().copy(),
+                     env.link_stats_all().copy(), env.slots_packed().copy(), obs.cpu().numpy().copy(), rew.cpu().numpy().copy()]
+        # (a device-resident run on top: the persistent kernel must not trust row caches from before the replays)
+        env.run("SAP", 40)
+        out[mode] += [env.counters().copy(), env.link_stats_all().copy(), env.slots_packed().copy()]
+        env.close()
+    assert out["eager"][0][:, 0].min() > 0  # (services were processed)
+    chk = _exact("captured rollout, %d envs" % B)
+    for k, (x, y) in enumerate(zip(out["graph"], out["eager"])):
+        chk(k, "item", x, y)
 
 
 @pytest.mark.parametrize("workload,B", [("cfg2", 65536), ("cfg3", 65536), ("cfg1", 32768), ("cfg4", 16384)])
