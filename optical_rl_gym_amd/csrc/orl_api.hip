@@ -1222,6 +1222,7 @@ static int ensure_logs(orl_batch* b, int64_t n_steps, int* chunk_io) {
       size_t ecap = 3 * want + 40, emost = ((size_t)1 << 30) / (32 * B);
       if (emost < 80) emost = 80;
       if (ecap > emost) ecap = emost;
+      if (const char* ev = getenv("ORL_ELOG_CAP")) { const int v = atoi(ev); if (v >= 34 && v <= 4096) ecap = (size_t)v; }  // tests: wavefronts stop for a full event log
       rc = dalloc(b, &P.elog, 2 * ecap * B);
       if (rc) return rc;
       if (!P.elog_n) {

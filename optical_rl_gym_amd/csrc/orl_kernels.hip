@@ -445,9 +445,11 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
           sp += 1; esp += 1;
           // actions_output marginals (rwa_env.py:103): the scan's action is never out of range
           const int path0 = (int)((a1 >> 25) & 15u), slot0 = (int)((a1 >> 29) & 1023u), rej = P.allow_rejection ? 1 : 0;
-          i64* h = P.act_hist + env * ((P.K + 1) + (P.S + 1));
-          if (path0 < P.K + rej) h[path0] += 1;
-          if (slot0 < P.S + rej) h[(P.K + 1) + slot0] += 1;
+          // (atomics without a return value: a read-modify-write per marginal made the replay a chain of 2 n dependent global round
+          // trips per lane — 80 us behind a 20-step launch of 65 536 RWA envs, three times the other families' replay)
+          unsigned long long* h = (unsigned long long*)(P.act_hist + env * ((P.K + 1) + (P.S + 1)));
+          if (path0 < P.K + rej) atomicAdd(h + path0, 1ull);
+          if (slot0 < P.S + rej) atomicAdd(h + (P.K + 1) + slot0, 1ull);
         }
         acc = pack2(accepted ? 1 : 0, core);
         now_a = now;
@@ -549,6 +551,71 @@ __device__ unsigned long long g_rs_prof[ORL_RSP_WAVES * 16];  // (a slot per wav
 #ifndef ORL_RS_WAVES
 #define ORL_RS_WAVES 5  // waves per SIMD the register allocator leaves room for
 #endif
+// one touch of a row in the replay: the event's mask applied, the summary brought up to date (sp::row_inc_apply), the link's running
+// averages updated at the event's clock (_update_link_stats, rmsa_env.py:464-543; the expressions of sp::row_item_lane1); returns what
+// the row's contribution to the compactness sums changed by, (occupied range << 16) + free blocks inside
+struct RsLink { double util, frag, comp, last_update; };
+template <bool RWA, int W>
+__device__ __forceinline__ void rs_row_init(const u64 (&a)[W], int S, sp::RowInc& ri, int& occ0, int& fb0) {
+  if (!RWA) {  // the row's summary as the launch found it: once per row and launch
+    RowStat st0;
+    int me0 = 0, edge0 = 0;
+    sp::row_stat_lane<W>(a, S, st0, me0, edge0);
+    ri.free_ = st0.free_; ri.nu = st0.nu; ri.lo = st0.lo; ri.hi = st0.hi; ri.me = me0;
+    occ0 = st0.occ; fb0 = st0.fb;
+  } else {
+    int f = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) f += __popcll(a[w]);
+    ri.free_ = f; ri.nu = 0; ri.lo = 1 << 20; ri.hi = 0; ri.me = 0;
+    occ0 = 0; fb0 = 0;
+  }
+}
+template <bool RWA, int W>
+__device__ __forceinline__ int rs_touch(u64 (&a)[W], sp::RowInc& ri, RsLink& rl, int& occ0, int& fb0, u32 meta, double clock, int S) {
+  const int s0 = (int)(meta & 0x1ffu), n = (int)((meta >> 9) & 63u);
+  const bool prov = ((meta >> 24) & 1u) != 0u;
+  int nu = 0, lo = 0, hi = 0, nf = 0, occ = 0, fb = 0, max_empty = 0, edge = 0;
+  if (!RWA) {
+    // (incremental: the two free runs next to the mask give everything the summary changes by)
+    sp::row_inc_apply<W>(a, S, s0, n, prov, ri);
+    const int tw = (S - 1) >> 6, tb = (S - 1) & 63;
+    edge = (int)(a[0] & 1ull) + (int)((sp::row_word<W>(a, tw) >> tb) & 1ull);
+    const bool two = ri.nu > 1;
+    nu = ri.nu; lo = ri.lo; hi = ri.hi; nf = ri.nu - 1 + edge;
+    occ = two ? ri.hi - ri.lo : 0; fb = two ? ri.nu - 1 : 0;
+    max_empty = ri.me;
+  } else {
+    ri.free_ += prov ? -n : n;  // (RWA: the utilization is all a link keeps)
+  }
+  const int free_ = ri.free_;
+  const double cur_util = sp::div_pos((double)(S - free_), (double)S);
+  double cur_frag = 0.0, cur_comp = 0.0;
+  if (!RWA && free_ > 0) {
+    const int me = (nf > 1 && !(nf == 2 && edge == 2)) ? max_empty : 0;
+    cur_frag = 1.0 - sp::div_pos((double)me, (double)free_);
+    if (nu > 1) cur_comp = sp::div_pos((double)(hi - lo), (double)(S - free_)) * sp::div_pos(1.0, (double)nu);
+    else cur_comp = 1.0;
+  }
+  if (clock > 0) {
+    // (a link touched again at the same clock: time_diff == 0, i.e. new = ((old * now) + (cur * 0.0)) / now with a finite
+    // cur >= 0 — the reference's own expression, and what the in-loop row phase computes for the further releases of a step)
+    const double time_diff = clock - rl.last_update;
+    const sp::Recip rc = sp::recip_of(clock);
+    rl.util = sp::div_by((rl.util * rl.last_update) + (cur_util * time_diff), rc);
+    if (!RWA) {
+      rl.frag = sp::div_by((rl.frag * rl.last_update) + (cur_frag * time_diff), rc);
+      rl.comp = sp::div_by((rl.comp * rl.last_update) + (cur_comp * time_diff), rc);
+    }
+  }
+  rl.last_update = clock;
+  int d = 0;
+  if (!RWA) {
+    d = ((occ - occ0) << 16) + (fb - fb0);
+    occ0 = occ; fb0 = fb;
+  }
+  return d;
+}
 struct RowstatsLds { int bits, meta, clk, delta, hist, perm, nev, total; };
 __host__ __device__ inline RowstatsLds rowstats_lds_layout(int G) {
   RowstatsLds L;
@@ -612,7 +679,8 @@ k_rowstats(DevParams P, int G) {
   u64 a[W];
 #pragma unroll
   for (int w = 0; w < W; w++) a[w] = 0ull;
-  double util = 0.0, frag = 0.0, comp = 0.0, last_update = 0.0;
+  RsLink rl;
+  rl.util = 0.0; rl.frag = 0.0; rl.comp = 0.0; rl.last_update = 0.0;
   int occ0 = 0, fb0 = 0;
   sp::RowInc ri;
   ri.free_ = 0; ri.nu = 0; ri.lo = 1 << 20; ri.hi = 0; ri.me = 0;
@@ -680,19 +748,8 @@ k_rowstats(DevParams P, int G) {
         for (int w = 0; w < W; w++) a[w] = row[w];
         ls = P.lstat + env * 4 * E + 4 * link;
         const double2 ls01 = *(const double2*)ls, ls23 = *(const double2*)(ls + 2);
-        util = ls01.x; frag = ls01.y; comp = ls23.x; last_update = ls23.y;
-        if (!RWA) {  // the row's summary as the launch found it: once per row and launch
-          RowStat st0;
-          int me0 = 0, edge0 = 0;
-          sp::row_stat_lane<W>(a, S, st0, me0, edge0);
-          ri.free_ = st0.free_; ri.nu = st0.nu; ri.lo = st0.lo; ri.hi = st0.hi; ri.me = me0;
-          occ0 = st0.occ; fb0 = st0.fb;
-        } else {
-          int f = 0;
-#pragma unroll
-          for (int w = 0; w < W; w++) f += __popcll(a[w]);
-          ri.free_ = f;
-        }
+        rl.util = ls01.x; rl.frag = ls01.y; rl.comp = ls23.x; rl.last_update = ls23.y;
+        rs_row_init<RWA, W>(a, S, ri, occ0, fb0);
       }
     }
     ORL_RSP(3);
@@ -710,52 +767,8 @@ k_rowstats(DevParams P, int G) {
         word &= word - 1u;
         touched_any = true;
         rounds_++;
-        const u32 meta = meta_g[k];
-        const double clock = clk_g[k];
-        const int s0 = (int)(meta & 0x1ffu), n = (int)((meta >> 9) & 63u);
-        const bool prov = ((meta >> 24) & 1u) != 0u;
-        RowStat after;
-        int max_empty = 0, edge = 0;
-        if (!RWA) {
-          // (incremental: the two free runs next to the mask give everything the summary changes by, sp::row_inc_apply)
-          sp::row_inc_apply<W>(a, S, s0, n, prov, ri);
-          const int tw = (S - 1) >> 6, tb = (S - 1) & 63;
-          edge = (int)(a[0] & 1ull) + (int)((sp::row_word<W>(a, tw) >> tb) & 1ull);
-          const bool two = ri.nu > 1;
-          after.free_ = ri.free_; after.nu = ri.nu; after.lo = ri.lo; after.hi = ri.hi; after.nf = ri.nu - 1 + edge;
-          after.occ = two ? ri.hi - ri.lo : 0; after.fb = two ? ri.nu - 1 : 0;
-          max_empty = ri.me;
-        } else {
-          ri.free_ += prov ? -n : n;  // (RWA: the utilization is all a link keeps)
-          after.free_ = ri.free_;
-        }
-        // the values _update_link_stats derives from the row (rmsa_env.py:464-543), as sp::row_item_lane1
-        const int free_ = after.free_;
-        const double cur_util = sp::div_pos((double)(S - free_), (double)S);
-        double cur_frag = 0.0, cur_comp = 0.0;
-        if (!RWA && free_ > 0) {
-          const int me = (after.nf > 1 && !(after.nf == 2 && edge == 2)) ? max_empty : 0;
-          cur_frag = 1.0 - sp::div_pos((double)me, (double)free_);
-          if (after.nu > 1) cur_comp = sp::div_pos((double)(after.hi - after.lo), (double)(S - free_)) * sp::div_pos(1.0, (double)after.nu);
-          else cur_comp = 1.0;
-        }
-        if (clock > 0) {
-          // (a link touched again at the same clock: time_diff == 0, i.e. new = ((old * now) + (cur * 0.0)) / now with a finite
-          // cur >= 0 — the reference's own expression, and what the in-loop row phase computes for the further releases of a step)
-          const double time_diff = clock - last_update;
-          const sp::Recip rc = sp::recip_of(clock);
-          util = sp::div_by((util * last_update) + (cur_util * time_diff), rc);
-          if (!RWA) {
-            frag = sp::div_by((frag * last_update) + (cur_frag * time_diff), rc);
-            comp = sp::div_by((comp * last_update) + (cur_comp * time_diff), rc);
-          }
-        }
-        last_update = clock;
-        if (!RWA) {
-          const int d = ((after.occ - occ0) << 16) + (after.fb - fb0);
-          occ0 = after.occ; fb0 = after.fb;
-          if (d) atomicAdd(&s_delta[g_r * ORL_RS_WIN + k], d);
-        }
+        const int d = rs_touch<RWA, W>(a, ri, rl, occ0, fb0, meta_g[k], clk_g[k], S);
+        if (!RWA && d) atomicAdd(&s_delta[g_r * ORL_RS_WIN + k], d);
       }
     }
     ORL_RSP(4);
@@ -793,8 +806,8 @@ k_rowstats(DevParams P, int G) {
     ORL_RSP(7);
   }
   if (have && touched_any) {
-    *(double2*)ls = make_double2(util, frag);
-    *(double2*)(ls + 2) = make_double2(comp, last_update);
+    *(double2*)ls = make_double2(rl.util, rl.frag);
+    *(double2*)(ls + 2) = make_double2(rl.comp, rl.last_update);
   }
   if (sc_on) {
     // the steps behind the last event, the slot behind the last step (k_stats finishes the run's last pending update from it), and
@@ -2302,11 +2315,7 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     G = G > ORL_RS_GMAX ? ORL_RS_GMAX : G;
     const size_t lds_r = (size_t)rowstats_lds_layout(G).total;
     dim3 gr((unsigned)((VP.B + G - 1) / G)), br(ORL_ROWSTATS_THREADS);
-#define ROWSTATS(E_)                                                                                                                    \
-  do {                                                                                                                                 \
-    if (lds_r > 48 * 1024) hipFuncSetAttribute((const void*)k_rowstats<E_, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r); \
-    hipLaunchKernelGGL((k_rowstats<E_, W>), gr, br, lds_r, st, VP, G);                                                             \
-  } while (0)
+#define ROWSTATS(E_) hipLaunchKernelGGL((k_rowstats<E_, W>), gr, br, lds_r, st, VP, G)
     switch (VP.env_type) {
       case ENV_RMSA: ROWSTATS(ENV_RMSA); break;
       case ENV_DEEPRMSA: ROWSTATS(ENV_DEEPRMSA); break;

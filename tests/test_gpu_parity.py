@@ -348,7 +348,7 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
         seeds = [5 + 11 * i for i in range(batch)]
         for name, v, masks in (("wave64", "wave64", None), ("two", "split2", "1"), ("two2", "split2", "2"),
                                ("persist", "persist", "1"), ("persist2", "persist", "2"), ("persist_g", "persist_global", "1"),
-                               ("persist_l", "persist_lds", "1")):
+                               ("persist_l", "persist_lds", "1"), ("persist_rd", "persist_rd", "1"), ("persist_rd2", "persist_rd", "2")):
             force_impl(monkeypatch, v)
             if masks:
                 monkeypatch.setenv("ORL_ITEM_MASKS", masks)
@@ -362,7 +362,7 @@ def test_split_pipeline_serial_tail_and_tally_pass(monkeypatch):
             assert not env.flags().any()
             env.close()
         chk = _exact(workload)
-        for name in ("two", "two2", "persist", "persist2", "persist_g", "persist_l"):
+        for name in ("two", "two2", "persist", "persist2", "persist_g", "persist_l", "persist_rd", "persist_rd2"):
             for key in ("counters", "services", "active", "slots", "link", "net"):
                 chk(0, name + " " + key, out[name][key], out["wave64"][key])
         assert out["two"]["serial"] > 100 and out["two2"]["serial"] > 0 and out["persist"]["serial"] > 100
@@ -451,12 +451,19 @@ def test_short_statistics_log_and_early_exits(workload, batch, monkeypatch):
     kw = dict(kw, episode_length=70)
     seeds = [5 + 11 * i for i in range(batch)]
     out = {}
-    for name in ("wave64", "persist"):
-        force_impl(monkeypatch, name)
-        if name == "persist":
+    # (persist_rd: the rows-deferred form with the same short statistics log; persist_rd_ev: its EVENT log shortened to 40 events per
+    # env and launch instead, so that wavefronts stop because that one is full — Germany50 has more links than an event's link bits:
+    # the library's own form runs there)
+    for name in ("wave64", "persist", "persist_rd", "persist_rd_ev"):
+        force_impl(monkeypatch, "persist_rd" if name.startswith("persist_rd") else name)
+        monkeypatch.delenv("ORL_ELOG_CAP", raising=False)
+        if name != "wave64":
             monkeypatch.setenv("ORL_ITEM_MASKS", "1")
             monkeypatch.setenv("ORL_LOG_CAP", "12")
             monkeypatch.setenv("ORL_JIT_SPEC", "1")
+            if name == "persist_rd_ev":
+                monkeypatch.setenv("ORL_LOG_CAP", "64")
+                monkeypatch.setenv("ORL_ELOG_CAP", "40")
         else:
             monkeypatch.delenv("ORL_ITEM_MASKS", raising=False)
             monkeypatch.delenv("ORL_LOG_CAP", raising=False)
@@ -465,12 +472,15 @@ def test_short_statistics_log_and_early_exits(workload, batch, monkeypatch):
             env.run(policy, chunk)
         if name == "persist":
             assert _ran_pair_form(env) == (batch <= 12288)
+        if name.startswith("persist_rd"):
+            assert int(env.lib.orl_batch_debug_persist_form(env._h)) == (7 if workload != "cfg5" else 4 if batch <= 12288 else 0)
         out[name] = [env.counters().copy(), env.services().copy(), env.active().copy(), env.flags().copy(),
                      env.net_stats_all().copy(), env.link_stats_all().copy(), env.slots_packed().copy()]
         env.close()
-    chk = _exact("%s %d, short log" % (workload, batch))
-    for k, (x, y) in enumerate(zip(out["persist"], out["wave64"])):
-        chk(k, "item", x, y)
+    for name in ("persist", "persist_rd", "persist_rd_ev"):
+        chk = _exact("%s %d, short log, %s" % (workload, batch, name))
+        for k, (x, y) in enumerate(zip(out[name], out["wave64"])):
+            chk(k, "item", x, y)
 
 
 def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkeypatch):
