@@ -2194,6 +2194,14 @@ static PersistChoice persist_choose(const DevParams& VP, bool tuned = false) {
       c.inner = (st >= 1 && st <= 3 && persist_inner(VP.env_type, ORL_W, st)) ? level(st, 4 * kPersistForms[f].waves) : 0;
     }
   }
+  // RMCSA (24-byte sink entries, a core per mask, the general row loop) does not fit the 128-VGPR budget of the 4-wave forms — 25-32
+  // spilled VGPRs, measured slower than its 3-wave forms wherever both fit — and is not built in them: routed to the 3-wave form
+  // with the same state (global: 1; maps + records in LDS: 4, where that window fits a workgroup; else global)
+  if (VP.env_type == ENV_RMCSA && kPersistForms[c.form].waves == 4) {
+    const bool lds_ok = kPersistForms[c.form].lds != 0 && persist_window(VP, 1, 0) <= 64 * 1024 && lds_wgs_per_cu(persist_window(VP, 1, 0)) >= 4;
+    c.form = lds_ok ? 4 : 1;
+    c.inner = 0;
+  }
   if (const char* e = getenv("ORL_PERSIST_INNER")) {  // A/B and cross-checks: 0 = no row caches, 1 = inner runs, 2 = + occ / free blocks
     const int v = atoi(e);
     c.inner = (v >= 0 && v <= 2 && !persist_rd_state(kPersistForms[c.form].lds) && persist_inner(VP.env_type, ORL_W, kPersistForms[c.form].lds)) ? v : 0;
@@ -2290,14 +2298,14 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   } else {
 #define PER_ENV(E_)                                                                                                          \
   switch (v) {                                                                                                               \
-    case 0: LAUNCH(E_, 0, 4); break;                                                                                         \
+    case 0: if constexpr (E_ != ENV_RMCSA) LAUNCH(E_, 0, 4); break;                                                          \
     case 1: LAUNCH(E_, 0, 3); break;                                                                                         \
     ORL_FULL_LDS_CASES(E_)                                                                                                   \
     case 4: LAUNCH(E_, 1, 3); break;                                                                                         \
-    case 6: LAUNCH(E_, 3, 4); break;                                                                                         \
+    case 6: if constexpr (E_ != ENV_RMCSA) LAUNCH(E_, 3, 4); break;                                                          \
     case 7: if constexpr (E_ != ENV_RMCSA) LAUNCH(E_, 4, 4); break;                                                          \
     case 8: if constexpr (E_ != ENV_RMCSA) LAUNCH(E_, 5, 4); break;                                                          \
-    default: LAUNCH(E_, 1, 4); break;                                                                                        \
+    default: if constexpr (E_ != ENV_RMCSA) LAUNCH(E_, 1, 4); break;                                                         \
   }
     ORL_FOR_ENV(b, PER_ENV)
 #undef PER_ENV

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """QoSConstrainedRA with an agent in the loop: policy(fetch=False) + step(None, auto_reset=True, fetch=False) on the device, one
-sync at the end — through the 8-lanes-per-env kernel (k_agent_qos, the library's choice from 2 048 envs) and through the
+sync at the end — through the 8-lanes-per-env kernel (k_agent_qos, the library's choice from 20 480 envs) and through the
 one-wavefront-per-env kernel (ORL_AGENT_STEP=0), on the same seeds; and the two must leave the same state.
 
     python3 tools/qos_step_rate.py [batch]        (on the GPU box)
