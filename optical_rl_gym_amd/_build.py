@@ -142,7 +142,8 @@ SPEC_TUNING = ["-mllvm", "-disable-machine-licm", "-DORL_PF_WAVES=4"]
 def spec_tuning(flags):
     if "-DORL_SPEC_ENV=3" in flags.split() or "-DORL_PF_WAVES" in flags or os.environ.get("ORL_SPEC_TUNING", "1") == "0":
         return []
-    return list(SPEC_TUNING)
+    # (ORL_SPEC_PF_WAVES: experiments with the soon list back in memory in the 4-wave forms)
+    return SPEC_TUNING[:2] + ["-DORL_PF_WAVES=%s" % os.environ.get("ORL_SPEC_PF_WAVES", "4")]
 
 
 def spec_path(flags):
