@@ -91,7 +91,8 @@ def build(force=False, verbose=False, variant="default"):
     lib = lib_path(variant)
     if not force and not stale(variant):
         return lib
-    with open(lib + ".lock", "w") as lock:
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", os.path.basename(lib) + ".lock"), "w") as lock:  # (not beside the library: the package directory holds sources and the built .so only)
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and not stale(variant):  # another process built it while we waited

@@ -39,9 +39,15 @@ for case in range(n_cases):
     seeds = [int(s) for s in rng.randint(0, 2**31 - 1, B)]
     out = {}
     try:
-        for v in ("64", "1", "2"):
-            os.environ["ORL_STEP_IMPL"] = v
-            os.environ["ORL_AGENT_STEP"] = "1" if v == "2" else "0"
+        for v in ("64", "1", "2", "rd"):  # ("rd": the rows-deferred form of the persistent kernel where it applies, round 6)
+            os.environ["ORL_STEP_IMPL"] = "2" if v == "rd" else v
+            os.environ["ORL_AGENT_STEP"] = "1" if v in ("2", "rd") else "0"
+            if v == "rd":
+                os.environ["ORL_PERSIST_VARIANT"] = str(7 + int(rng.randint(2)))
+                os.environ["ORL_PERSIST_RW"] = "0"
+            else:
+                os.environ.pop("ORL_PERSIST_VARIANT", None)
+                os.environ.pop("ORL_PERSIST_RW", None)
             env = orl.make(fam, topology=topo, num_envs=B, seeds=seeds, **kw)
             env.run(policy, steps // 2)
             n_host = 12 if fam in ("RMSA", "DeepRMSA") else 0  # in the middle: host- / agent-driven steps (v == "2": k_agent)
@@ -57,7 +63,7 @@ for case in range(n_cases):
         print("case", case, fam, topo, kw, "->", type(exc).__name__, exc)
         continue
     ok = all(np.array_equal(out["64"][k], out[v][k], equal_nan=True) if out["64"][k].dtype.kind == "f" else np.array_equal(out["64"][k], out[v][k])
-             for v in ("1", "2") for k in range(7))
+             for v in ("1", "2", "rd") for k in range(7))
     bad += 0 if ok else 1
     print("case", case, fam, topo, B, steps, policy, kw, "OK" if ok else "MISMATCH", "flags", int(out["64"][3].any()))
 print("mismatches:", bad)
