@@ -369,16 +369,29 @@ template <int ENV, int LDS> struct PersistDeferred {
 // RD: the launch ran a rows-deferred form — the compactness sums come from DevParams::ssum (k_rowstats), (occ << 16) | fb per step.
 // (A template parameter: as a run-time switch the conditional loads of ssum among the unrolled log loads changed the results of the
 // other forms in a few wavefronts per 4 096-env Germany50 batch — tools/pair_diff2.py — with nothing of ssum reaching a result.)
+// hist_lds (RWA): the marginals of actions_output (rwa_env.py:103) are counted in LDS for the launch — one row of (k + 1) + (S + 1)
+// counters per lane — and added to the env's histogram once at the end, with coalesced requests.  Two scattered 8-byte global updates
+// per env-step (read-modify-writes until round 6, then atomics) ran at ~10 G updates/s: 0.83 ms behind a 128-step launch of 32 768
+// envs, a quarter of cfg1's GPU time, where the other families' replay takes a tenth of that.
 template <int ENV, bool RD = false>
-__global__ void __launch_bounds__(64) k_stats(DevParams P) {
+__global__ void __launch_bounds__(64) k_stats(DevParams P, int hist_lds) {
   constexpr bool rd = RD;
   if (threadIdx.x >= ORL_STATS_LANES) return;
-  const i64 env = (i64)blockIdx.x * ORL_STATS_LANES + (i64)threadIdx.x;
-  if (env >= P.B) return;
-  const int ln = P.log_n[env >> 3];
+  const i64 env_raw = (i64)blockIdx.x * ORL_STATS_LANES + (i64)threadIdx.x;
+  const int ln = env_raw < P.B ? P.log_n[env_raw >> 3] : 0;
   const int n = ln & 0xffff;
   const bool fin = ((ln >> 16) & 1) != 0;
-  if (n == 0) return;
+  const bool lds_hist = ENV == ENV_RWA && hist_lds != 0;
+  const int HW = (P.K + 1) + (P.S + 1);
+  u32* s_h = (u32*)orl_lds_raw;  // [64][HW] (lds_hist)
+  if (lds_hist) {
+    for (int i = (int)threadIdx.x; i < ORL_STATS_LANES * HW; i += ORL_STATS_LANES) s_h[i] = 0u;
+    wave_fence();
+  }
+  // (lanes without an env or without logged steps: the other families' leave here; RWA's stay for the cooperative flush below)
+  if (!(ENV == ENV_RWA && lds_hist) && n == 0) return;
+  const bool live = n > 0;
+  const i64 env = live ? env_raw : 0;
   u64* s = P.scal + env * ORL_SCAL_WORDS;
 #define F64(slot) __longlong_as_double((i64)s[slot])
   double g_thr = F64(SC_GTHR), g_comp = F64(SC_GCOMP), g_last = F64(SC_GLAST);
@@ -447,9 +460,15 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
           const int path0 = (int)((a1 >> 25) & 15u), slot0 = (int)((a1 >> 29) & 1023u), rej = P.allow_rejection ? 1 : 0;
           // (atomics without a return value: a read-modify-write per marginal made the replay a chain of 2 n dependent global round
           // trips per lane — 80 us behind a 20-step launch of 65 536 RWA envs, three times the other families' replay)
-          unsigned long long* h = (unsigned long long*)(P.act_hist + env * ((P.K + 1) + (P.S + 1)));
-          if (path0 < P.K + rej) atomicAdd(h + path0, 1ull);
-          if (slot0 < P.S + rej) atomicAdd(h + (P.K + 1) + slot0, 1ull);
+          if (lds_hist) {
+            u32* hl = s_h + (int)threadIdx.x * HW;
+            if (path0 < P.K + rej) atomicAdd(hl + path0, 1u);
+            if (slot0 < P.S + rej) atomicAdd(hl + (P.K + 1) + slot0, 1u);
+          } else {
+            unsigned long long* h = (unsigned long long*)(P.act_hist + env * ((P.K + 1) + (P.S + 1)));
+            if (path0 < P.K + rej) atomicAdd(h + path0, 1ull);
+            if (slot0 < P.S + rej) atomicAdd(h + (P.K + 1) + slot0, 1ull);
+          }
         }
         acc = pack2(accepted ? 1 : 0, core);
         now_a = now;
@@ -502,15 +521,32 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P) {
     g_comp = (gc_a + (cmp * gc_td)) / now_a;
     acc &= ~2ull;
   }
+  if (live) {
 #define PF(slot, x) s[slot] = (u64)__double_as_longlong(x);
-  PF(SC_GTHR, g_thr) PF(SC_GCOMP, g_comp) PF(SC_GLAST, g_last) PF(SC_GC_A, gc_a) PF(SC_GC_TD, gc_td) PF(SC_NOWA, now_a)
+    PF(SC_GTHR, g_thr) PF(SC_GCOMP, g_comp) PF(SC_GLAST, g_last) PF(SC_GC_A, gc_a) PF(SC_GC_TD, gc_td) PF(SC_NOWA, now_a)
 #undef PF
-  s[SC_SP] = (u64)sp; s[SC_SA] = (u64)sa; s[SC_ESP] = (u64)esp; s[SC_ESA] = (u64)esa;
-  s[SC_BRQ] = (u64)brq; s[SC_BRP] = (u64)brp; s[SC_EBRQ] = (u64)ebrq; s[SC_EBRP] = (u64)ebrp;
-  s[SC_SBR] = (u64)s_br; s[SC_SNH] = (u64)s_nh;
-  s[SC_ACC] = acc | acc_keep;
-  ((u32*)(s + SC_ID_MTPOS))[0] = (u32)id;
+    s[SC_SP] = (u64)sp; s[SC_SA] = (u64)sa; s[SC_ESP] = (u64)esp; s[SC_ESA] = (u64)esa;
+    s[SC_BRQ] = (u64)brq; s[SC_BRP] = (u64)brp; s[SC_EBRQ] = (u64)ebrq; s[SC_EBRP] = (u64)ebrp;
+    s[SC_SBR] = (u64)s_br; s[SC_SNH] = (u64)s_nh;
+    s[SC_ACC] = acc | acc_keep;
+    ((u32*)(s + SC_ID_MTPOS))[0] = (u32)id;
+  }
   (void)now; (void)br_idx;
+  if (lds_hist) {
+    // the launch's counts to the envs' histograms: the 64 lanes walk one env's row together (consecutive 8-byte counters)
+    wave_fence();
+    for (int e = 0; e < ORL_STATS_LANES; e++) {
+      const i64 env_e = (i64)blockIdx.x * ORL_STATS_LANES + e;
+      if (env_e >= P.B) break;
+      // (atomics without a return value on consecutive counters: nothing waits for them — as read-modify-writes the 128 rounds
+      // of this loop were a chain of dependent global round trips, 60 us per launch)
+      unsigned long long* h = (unsigned long long*)(P.act_hist + env_e * HW);
+      for (int i = (int)threadIdx.x; i < HW; i += ORL_STATS_LANES) {
+        const u32 c = s_h[e * HW + i];
+        if (c) atomicAdd(h + i, (unsigned long long)c);
+      }
+    }
+  }
 }
 
 // ---- rows-deferred form: the replay of the row statistics (round 6) ----------------------------------------------------------
@@ -2338,15 +2374,20 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
     const bool rd = persist_rd_state(kPersistForms[v].lds);
     switch (VP.env_type) {
       case ENV_RMSA:
-        if (rd) hipLaunchKernelGGL((k_stats<ENV_RMSA, true>), gs, blk, 0, st, VP);
-        else hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP);
+        if (rd) hipLaunchKernelGGL((k_stats<ENV_RMSA, true>), gs, blk, 0, st, VP, 0);
+        else hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP, 0);
         break;
       case ENV_DEEPRMSA:
-        if (rd) hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA, true>), gs, blk, 0, st, VP);
-        else hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP);
+        if (rd) hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA, true>), gs, blk, 0, st, VP, 0);
+        else hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP, 0);
         break;
-      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, 0, st, VP); break;
-      default: hipLaunchKernelGGL((k_stats<ENV_RWA>), gs, blk, 0, st, VP); break;
+      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, 0, st, VP, 0); break;
+      default: {
+        // (RWA: the action marginals of the launch counted in LDS while the row of counters per lane fits 48 KiB)
+        const size_t hb = (size_t)ORL_STATS_LANES * (size_t)((VP.K + 1) + (VP.S + 1)) * 4;
+        const int hist_lds = (hb <= 48 * 1024 && VP.act_hist) ? 1 : 0;
+        hipLaunchKernelGGL((k_stats<ENV_RWA>), gs, blk, hist_lds ? hb : 0, st, VP, hist_lds);
+      } break;
     }
   }
 }

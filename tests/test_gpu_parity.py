@@ -1977,6 +1977,7 @@ def test_info_mode_rates_only_changes_nothing_but_the_skipped_entries(fam, kw, p
         o_a, r_a, d_a, i_a = a.step(act, auto_reset=True)
         o_b, r_b, d_b, i_b = b.step(act, auto_reset=True)
         chk(t, "reward", r_a, r_b); chk(t, "done", d_a, d_b); chk(t, "rates", i_a[:, :4], i_b[:, :4])
+        assert np.isnan(i_a[:, 4:8]).all(), "the skipped info columns read NaN in the rates-only mode, not stale values"
         if o_b is not None:
             chk(t, "obs", o_a, o_b)
     a.set_info_mode(False)
@@ -1988,4 +1989,22 @@ def test_info_mode_rates_only_changes_nothing_but_the_skipped_entries(fam, kw, p
     for e in (0, n // 2, n - 1):
         chk(e, "link_stats", a.link_stats(e), b.link_stats(e))
         chk(e, "net_stats", a.net_stats(e), b.net_stats(e))
+    # the VecEnv face: full info unless the caller opts in (the reference's step() always fills every entry, rmsa_env.py:228-264);
+    # with rates_only_info the batch goes back to the full mode when the VecEnv is closed
+    from optical_rl_gym_amd.vec_env import OpticalVecEnv
+
+    width = a.N_ACTION
+    v = OpticalVecEnv(a)
+    v.reset()
+    v.step(b.policy(policy)[:, :width].copy())
+    assert np.isfinite(v.device_tensors()["info"].cpu().numpy()[:, 4:8]).all()
+    v2 = OpticalVecEnv(b, rates_only_info=True)
+    v2.reset()
+    v2.step(a.policy(policy)[:, :width].copy())
+    i_v = v2.device_tensors()["info"].cpu().numpy()
+    assert np.isnan(i_v[:, 4:8]).all() and np.isfinite(i_v[:, :4]).all()
+    v2._rates_only and v2.batch.set_info_mode(False)  # (what close() does before it closes the batch)
+    v2._rates_only = False
+    _, _, _, i_b = b.step(a.policy(policy), auto_reset=True)
+    assert np.isfinite(i_b[:, 4:8]).all()
     a.close(); b.close()
