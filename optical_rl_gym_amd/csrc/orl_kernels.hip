@@ -590,10 +590,18 @@ __device__ unsigned long long g_rs_prof[ORL_RSP_WAVES * 16];  // (a slot per wav
 // one touch of a row in the replay: the event's mask applied, the summary brought up to date (sp::row_inc_apply), the link's running
 // averages updated at the event's clock (_update_link_stats, rmsa_env.py:464-543; the expressions of sp::row_item_lane1); returns what
 // the row's contribution to the compactness sums changed by, (occupied range << 16) + free blocks inside
-struct RsLink { double util, frag, comp, last_update; };
+struct RsLink { double util, frag, comp, last_update; u32 cw; };  // (cw: rows of 3-5 words — the per-word cache of inner free runs, 63 = unknown)
+// Rows of 3-5 words (cfg2) are summarised word by word with that cache, as the in-loop row phase does (sp::row_stat_lane): the
+// incremental summary issues MORE instructions there — 1.37 against 1.15e8 VALU wavefront-instructions per 20-step replay — because
+// some lane of a wavefront re-searches the longest run at almost every touch; rows of one or two words take the incremental one
+// (cfg3's replay 286 -> 188 us).
+template <int W> struct RsIncremental { static constexpr bool value = !(W >= 3 && W <= 5); };
 template <bool RWA, int W>
 __device__ __forceinline__ void rs_row_init(const u64 (&a)[W], int S, sp::RowInc& ri, int& occ0, int& fb0) {
-  if (!RWA) {  // the row's summary as the launch found it: once per row and launch
+  if (!RWA && !RsIncremental<W>::value) {
+    sp::row_occ_fb<W>(a, S, occ0, fb0);  // (the word-by-word summary needs the row's contribution to the sums only)
+    ri.free_ = 0; ri.nu = 0; ri.lo = 1 << 20; ri.hi = 0; ri.me = 0;
+  } else if (!RWA) {  // the row's summary as the launch found it: once per row and launch
     RowStat st0;
     int me0 = 0, edge0 = 0;
     sp::row_stat_lane<W>(a, S, st0, me0, edge0);
@@ -612,7 +620,15 @@ __device__ __forceinline__ int rs_touch(u64 (&a)[W], sp::RowInc& ri, RsLink& rl,
   const int s0 = (int)(meta & 0x1ffu), n = (int)((meta >> 9) & 63u);
   const bool prov = ((meta >> 24) & 1u) != 0u;
   int nu = 0, lo = 0, hi = 0, nf = 0, occ = 0, fb = 0, max_empty = 0, edge = 0;
-  if (!RWA) {
+  if (!RWA && !RsIncremental<W>::value) {
+    const sp::Mask2 mm = sp::mask2(s0, n);
+#pragma unroll
+    for (int w = 0; w < W; w++) a[w] ^= sp::mask2_word(mm, w);  // (a provision clears free slots, a release sets taken ones)
+    RowStat after;
+    sp::row_stat_lane<W, !RsIncremental<W>::value>(a, S, after, max_empty, edge, &rl.cw, sp::mask_words(s0, n), true);
+    ri.free_ = after.free_;
+    nu = after.nu; lo = after.lo; hi = after.hi; nf = after.nf; occ = after.occ; fb = after.fb;
+  } else if (!RWA) {
     // (incremental: the two free runs next to the mask give everything the summary changes by)
     sp::row_inc_apply<W>(a, S, s0, n, prov, ri);
     const int tw = (S - 1) >> 6, tb = (S - 1) & 63;
@@ -716,7 +732,9 @@ k_rowstats(DevParams P, int G) {
 #pragma unroll
   for (int w = 0; w < W; w++) a[w] = 0ull;
   RsLink rl;
-  rl.util = 0.0; rl.frag = 0.0; rl.comp = 0.0; rl.last_update = 0.0;
+  rl.util = 0.0; rl.frag = 0.0; rl.comp = 0.0; rl.last_update = 0.0; rl.cw = 0u;
+#pragma unroll
+  for (int w = 0; w < (W <= 5 ? W : 0); w++) rl.cw |= 63u << (6 * w);  // (nothing known about the row's inner runs yet)
   int occ0 = 0, fb0 = 0;
   sp::RowInc ri;
   ri.free_ = 0; ri.nu = 0; ri.lo = 1 << 20; ri.hi = 0; ri.me = 0;
