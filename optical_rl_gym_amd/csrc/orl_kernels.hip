@@ -668,7 +668,7 @@ __device__ __forceinline__ int rs_touch(u64 (&a)[W], sp::RowInc& ri, RsLink& rl,
   }
   return d;
 }
-struct RowstatsLds { int bits, meta, clk, delta, hist, perm, nev, total; };
+struct RowstatsLds { int bits, meta, clk, delta, hist, perm, nev, sc, total; };
 __host__ __device__ inline RowstatsLds rowstats_lds_layout(int G) {
   RowstatsLds L;
   int o = 0;
@@ -679,6 +679,7 @@ __host__ __device__ inline RowstatsLds rowstats_lds_layout(int G) {
   L.hist = o; o += 2 * 16 * 4;
   L.perm = o; o += ORL_ROWSTATS_THREADS * 2;
   L.nev = o; o += ORL_RS_GMAX * 4;
+  L.sc = o; o += (ORL_RS_GMAX * 8 + 4) * 4;
   L.total = (o + 15) & ~15;
   return L;
 }
@@ -701,17 +702,18 @@ k_rowstats(DevParams P, int G) {
 #ifdef ORL_RS_PROF
   long long rsp_t = clock64();
 #endif
-  // the env scan of phase D (lanes tid < G): running totals, the sums pending for the step after the last event's, that step
-  int sc_occ = 0, sc_fb = 0, sp_occ = 0, sp_fb = 0, sc_t = -1, sc_ns = 0;
-  bool sc_fin = false, sc_on = false;
+  // the env scan of phase D keeps its state in LDS (whichever wavefront finishes the workgroup's last window runs it): per env the
+  // running totals, the sums pending for the step after the last event's, that step, the steps logged, finished-the-run, on / off
+  int* s_sc = (int*)(orl_lds_raw + L.sc);  // [GMAX][8]
+  int* s_done = s_sc + ORL_RS_GMAX * 8;
   if (tid < ORL_RS_GMAX) {
-    int n = 0;
+    int n = 0, sc_occ = 0, sc_fb = 0, sp_occ = 0, sp_fb = 0, sc_ns = 0, sc_fin = 0, sc_on = 0;
     if (tid < G && envb + tid < P.B) {
       const int ln = P.log_n[(envb + tid) >> 3];
       sc_ns = ln & 0xffff;
-      sc_fin = ((ln >> 16) & 1) != 0;
+      sc_fin = (ln >> 16) & 1;
       n = sc_ns ? P.elog_n[envb + tid] : 0;
-      sc_on = !RWA && sc_ns > 0;
+      sc_on = (!RWA && sc_ns > 0) ? 1 : 0;
       if (sc_on) {
         const int* cs = P.core_sums + (envb + tid) * P.cs_words;
         sc_occ = cs[0]; sc_fb = cs[1];
@@ -719,6 +721,9 @@ k_rowstats(DevParams P, int G) {
       }
     }
     s_nev[tid] = n;
+    int* q = s_sc + 8 * tid;
+    q[0] = sc_occ; q[1] = sc_fb; q[2] = sp_occ; q[3] = sp_fb; q[4] = -1; q[5] = sc_ns; q[6] = sc_fin; q[7] = sc_on;
+    if (tid == 0) *s_done = 0;
   }
   if (tid >= 32 && tid < 64) s_hist[tid - 32] = 0;
   __syncthreads();
@@ -739,6 +744,26 @@ k_rowstats(DevParams P, int G) {
   sp::RowInc ri;
   ri.free_ = 0; ri.nu = 0; ri.lo = 1 << 20; ri.hi = 0; ri.me = 0;
   double* ls = nullptr;
+  // the steps behind the last event, the slot behind the last step (k_stats finishes the run's last pending update from it), and
+  // core_sums as the in-loop row phase leaves them: the totals, and what the last step's releases added (cleared when the
+  // wavefront finished the run's state: DevParams::persist_finish)
+  auto finish_envs = [&](int l) {
+    if (l >= G) return;
+    const int* q = s_sc + 8 * l;
+    if (!q[7]) return;
+    const int sc_occ = q[0], sc_fb = q[1], sp_occ = q[2], sp_fb = q[3], sc_t = q[4], sc_ns = q[5];
+    u32* out = P.ssum + (size_t)(envb + l);
+    const size_t st = (size_t)P.log_stride;
+    out[(size_t)(sc_t + 1) * st] = ((u32)sp_occ << 16) | (u32)sp_fb;
+    for (int s2 = sc_t + 2; s2 <= sc_ns; s2++) out[(size_t)s2 * st] = ((u32)sc_occ << 16) | (u32)sc_fb;
+    // (the sums of slot ns: after the last step's provision — the pending ones when that step had events, else the totals)
+    const bool last_had = sc_t == sc_ns - 1;
+    const int e_occ = last_had ? sp_occ : sc_occ, e_fb = last_had ? sp_fb : sc_fb;
+    int* cs = P.core_sums + (envb + l) * P.cs_words;
+    cs[0] = sc_occ; cs[1] = sc_fb;
+    cs[2 * P.C] = q[6] ? 0 : sc_occ - e_occ;
+    cs[2 * P.C + 1] = q[6] ? 0 : sc_fb - e_fb;
+  };
   ORL_RSP(0);
   for (int j0 = 0; j0 < nev_max; j0 += ORL_RS_WIN) {
     // ---- A: the window's events ------------------------------------------------------------------------------------------------
@@ -832,15 +857,17 @@ k_rowstats(DevParams P, int G) {
       ORL_RSP_CNT(8, mx); ORL_RSP_CNT(9, sm); ORL_RSP_CNT(10, 1); }
 #endif
     (void)rounds_;
-    __syncthreads();
-    ORL_RSP(5);
     // ---- D: the sums after each step's provision, one lane per env ------------------------------------------------------------------
-    if (sc_on) {
-      const int nk = s_nev[tid] - j0 < ORL_RS_WIN ? s_nev[tid] - j0 : ORL_RS_WIN;
-      u32* out = P.ssum + (size_t)(envb + tid);
+    // (lane l < G of the wavefront that runs it; state in LDS)
+    auto scan_window = [&](int l) {
+      int* q = s_sc + 8 * l;
+      if (!q[7]) return;
+      int sc_occ = q[0], sc_fb = q[1], sp_occ = q[2], sp_fb = q[3], sc_t = q[4];
+      const int nk = s_nev[l] - j0 < ORL_RS_WIN ? s_nev[l] - j0 : ORL_RS_WIN;
+      u32* out = P.ssum + (size_t)(envb + l);
       const size_t st = (size_t)P.log_stride;
       for (int k = 0; k < nk; k++) {
-        const u32 meta = s_meta[tid * ORL_RS_WIN + k];
+        const u32 meta = s_meta[l * ORL_RS_WIN + k];
         const int t = (int)((meta >> 15) & 0x1ffu);
         if (t != sc_t) {
           // the step before is complete: its pending sums are those of step sc_t + 1; steps without events in between see the totals
@@ -849,36 +876,42 @@ k_rowstats(DevParams P, int G) {
           sc_t = t;
           sp_occ = sc_occ; sp_fb = sc_fb;
         }
-        const int d = s_delta[tid * ORL_RS_WIN + k];
+        const int d = s_delta[l * ORL_RS_WIN + k];
         const int d_fb = (int)(short)(d & 0xffff);
         sc_occ += (d - d_fb) >> 16; sc_fb += d_fb;
         if ((meta >> 24) & 1u) { sp_occ = sc_occ; sp_fb = sc_fb; }  // (right after the provision)
       }
+      q[0] = sc_occ; q[1] = sc_fb; q[2] = sp_occ; q[3] = sp_fb; q[4] = sc_t;
+    };
+    if (j0 + ORL_RS_WIN < nev_max) {  // (more windows follow: the tables are overwritten, everybody waits)
+      __syncthreads();
+      ORL_RSP(5);
+      if (tid < G) scan_window(tid);
+      ORL_RSP(6);
+      __syncthreads();
+      ORL_RSP(7);
+    } else {
+      // The workgroup's last window: a wavefront whose rows are done stores their link records and LEAVES — no barrier: the four
+      // wavefronts take sorted quarters of the rows, and the lighter three waited a quarter of their lifetime for the heaviest
+      // (tools/rs_prof.py) while holding registers another workgroup could use.  The last one to get here runs the env scan.
+      if (have && touched_any) {
+        *(double2*)ls = make_double2(rl.util, rl.frag);
+        *(double2*)(ls + 2) = make_double2(rl.comp, rl.last_update);
+      }
+      int arrived = 0;
+      if ((tid & 63) == 0) arrived = __hip_atomic_fetch_add(s_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      arrived = __builtin_amdgcn_readfirstlane(arrived);
+      ORL_RSP(5);
+      if (arrived != ORL_ROWSTATS_THREADS / 64 - 1) return;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if ((tid & 63) < G) scan_window(tid & 63);
+      ORL_RSP(6);
+      finish_envs(tid & 63);
+      return;
     }
-    ORL_RSP(6);
-    if (j0 + ORL_RS_WIN < nev_max) __syncthreads();  // (the next window overwrites the tables)
-    ORL_RSP(7);
   }
-  if (have && touched_any) {
-    *(double2*)ls = make_double2(rl.util, rl.frag);
-    *(double2*)(ls + 2) = make_double2(rl.comp, rl.last_update);
-  }
-  if (sc_on) {
-    // the steps behind the last event, the slot behind the last step (k_stats finishes the run's last pending update from it), and
-    // core_sums as the in-loop row phase leaves them: the totals, and what the last step's releases added (cleared when the
-    // wavefront finished the run's state: DevParams::persist_finish)
-    u32* out = P.ssum + (size_t)(envb + tid);
-    const size_t st = (size_t)P.log_stride;
-    out[(size_t)(sc_t + 1) * st] = ((u32)sp_occ << 16) | (u32)sp_fb;
-    for (int s2 = sc_t + 2; s2 <= sc_ns; s2++) out[(size_t)s2 * st] = ((u32)sc_occ << 16) | (u32)sc_fb;
-    // (the sums of slot ns: after the last step's provision — the pending ones when that step had events, else the totals)
-    const bool last_had = sc_t == sc_ns - 1;
-    const int e_occ = last_had ? sp_occ : sc_occ, e_fb = last_had ? sp_fb : sc_fb;
-    int* cs = P.core_sums + (envb + tid) * P.cs_words;
-    cs[0] = sc_occ; cs[1] = sc_fb;
-    cs[2 * P.C] = sc_fin ? 0 : sc_occ - e_occ;
-    cs[2 * P.C + 1] = sc_fin ? 0 : sc_fb - e_fb;
-  }
+  // (no events at all in this workgroup's envs: the steps they logged still get their sums)
+  if (tid < ORL_RS_GMAX) finish_envs(tid);
 }
 
 // LDS: 0 = the state stays in global memory, 1 = slot maps + per-core sums + env records in LDS, 2 = + link statistics,
