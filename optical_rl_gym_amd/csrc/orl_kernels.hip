@@ -390,6 +390,12 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P, int hist_lds) {
   }
   // (lanes without an env or without logged steps: the other families' leave here; RWA's stay for the cooperative flush below)
   if (!(ENV == ENV_RWA && lds_hist) && n == 0) return;
+  // discrete bit rates (rmsa_env.py:217-227: requested / provisioned counts per rate): the same for the 2 n_br counters of a lane's
+  // env — counted in the lane's own LDS row, added once per launch
+  const bool br_lds = ENV != ENV_RWA && P.bit_rate_mode == 1 && hist_lds != 0;
+  const int HB = 2 * P.n_br;
+  if (br_lds)
+    for (int i = 0; i < HB; i++) s_h[(int)threadIdx.x * HB + i] = 0u;
   const bool live = n > 0;
   const i64 env = live ? env_raw : 0;
   u64* s = P.scal + env * ORL_SCAL_WORDS;
@@ -445,7 +451,10 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P, int hist_lds) {
           if (ENV != ENV_RWA) {
             brp += bit_rate;
             ebrp += bit_rate;
-            if (P.bit_rate_mode == 1) P.br_hist[env * 2 * P.n_br + P.n_br + br_idx] += 1;
+            if (P.bit_rate_mode == 1) {
+              if (br_lds) s_h[(int)threadIdx.x * HB + P.n_br + br_idx] += 1u;
+              else P.br_hist[env * 2 * P.n_br + P.n_br + br_idx] += 1;
+            }
           }
           sa += 1;
           esa += 1;
@@ -492,7 +501,10 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P, int hist_lds) {
         if (ENV != ENV_RWA) {
           brq += bit_rate;
           ebrq += bit_rate;
-          if (P.bit_rate_mode == 1) P.br_hist[env * 2 * P.n_br + br_idx] += 1;
+          if (P.bit_rate_mode == 1) {
+            if (br_lds) s_h[(int)threadIdx.x * HB + br_idx] += 1u;
+            else P.br_hist[env * 2 * P.n_br + br_idx] += 1;
+          }
         }
         done = (esp == (i64)P.episode_length);
         if (done) {
@@ -532,6 +544,13 @@ __global__ void __launch_bounds__(64) k_stats(DevParams P, int hist_lds) {
     ((u32*)(s + SC_ID_MTPOS))[0] = (u32)id;
   }
   (void)now; (void)br_idx;
+  if (br_lds && live) {
+    unsigned long long* hb = (unsigned long long*)(P.br_hist + env * HB);
+    for (int i = 0; i < HB; i++) {
+      const u32 c = s_h[(int)threadIdx.x * HB + i];
+      if (c) atomicAdd(hb + i, (unsigned long long)c);
+    }
+  }
   if (lds_hist) {
     // the launch's counts to the envs' histograms: the 64 lanes walk one env's row together (consecutive 8-byte counters)
     wave_fence();
@@ -2423,16 +2442,19 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   if (orl_persist_deferred(VP.env_type) && VP.slog) {
     dim3 gs((unsigned)((VP.B + ORL_STATS_LANES - 1) / ORL_STATS_LANES));
     const bool rd = persist_rd_state(kPersistForms[v].lds);
+    // (discrete bit rates: the per-rate counts of a launch in LDS, 2 n_br counters per lane)
+    const int br_lds = (VP.bit_rate_mode == 1 && VP.br_hist && (size_t)ORL_STATS_LANES * 2 * VP.n_br * 4 <= 48 * 1024) ? 1 : 0;
+    const size_t brb = br_lds ? (size_t)ORL_STATS_LANES * 2 * VP.n_br * 4 : 0;
     switch (VP.env_type) {
       case ENV_RMSA:
-        if (rd) hipLaunchKernelGGL((k_stats<ENV_RMSA, true>), gs, blk, 0, st, VP, 0);
-        else hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, 0, st, VP, 0);
+        if (rd) hipLaunchKernelGGL((k_stats<ENV_RMSA, true>), gs, blk, brb, st, VP, br_lds);
+        else hipLaunchKernelGGL((k_stats<ENV_RMSA>), gs, blk, brb, st, VP, br_lds);
         break;
       case ENV_DEEPRMSA:
-        if (rd) hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA, true>), gs, blk, 0, st, VP, 0);
-        else hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, 0, st, VP, 0);
+        if (rd) hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA, true>), gs, blk, brb, st, VP, br_lds);
+        else hipLaunchKernelGGL((k_stats<ENV_DEEPRMSA>), gs, blk, brb, st, VP, br_lds);
         break;
-      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, 0, st, VP, 0); break;
+      case ENV_RMCSA: hipLaunchKernelGGL((k_stats<ENV_RMCSA>), gs, blk, brb, st, VP, br_lds); break;
       default: {
         // (RWA: the action marginals of the launch counted in LDS while the row of counters per lane fits 48 KiB)
         const size_t hb = (size_t)ORL_STATS_LANES * (size_t)((VP.K + 1) + (VP.S + 1)) * 4;
