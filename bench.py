@@ -147,6 +147,24 @@ def launch_ranks(args, argv):
         raise SystemExit("bench: rank(s) %s failed (exit codes %s)" % ([r for r, _ in bad], [c for _, c in bad]))
 
 
+def _hip_clock_khz(device):
+    """hipDeviceAttributeClockRate (peak engine clock, kHz) from the HIP runtime this process already uses (the copy torch
+    bundles — the same file path, so no second runtime is loaded); 0 when it cannot be asked."""
+    try:
+        import ctypes
+
+        import torch
+
+        lib = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        hip = ctypes.CDLL(lib if os.path.exists(lib) else "libamdhip64.so")
+        v = ctypes.c_int(0)
+        if hip.hipDeviceGetAttribute(ctypes.byref(v), 5, int(device)) == 0:  # 5 = hipDeviceAttributeClockRate
+            return int(v.value)
+    except Exception:
+        pass
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,7 +342,7 @@ def main():
                 n_simd = 4 * torch.cuda.get_device_properties(dev_index).multi_processor_count
                 # the engine clock the runtime reports for this device (hipDeviceProp_t::clockRate, kHz); the MI355X peak of
                 # MI355X_MICROARCH.md only where the property is missing
-                clock_khz = getattr(torch.cuda.get_device_properties(dev_index), "clock_rate", 0) or 0
+                clock_khz = getattr(torch.cuda.get_device_properties(dev_index), "clock_rate", 0) or _hip_clock_khz(dev_index)
                 clock_hz = clock_khz * 1e3 if clock_khz > 0 else 2.4e9
                 clock_src = "hipDeviceProp_t.clockRate" if clock_khz > 0 else "assumed (MI355X peak engine clock)"
                 per_step_c = {c: v / k["steps_per_launch"] for c, v in sq.items()}
