@@ -118,6 +118,7 @@ struct DevParams {
   int q_wave;       // item slots per wavefront region
   int persist_ic;   // persistent kernel: keep the per-row cache of inner free runs in LDS (set per launch by the host)
   int persist_evl;  // two-wavefront form: the 8 envs' pending release times in LDS behind the pair's areas (set per launch by the host)
+  int persist_fair;    // persistent kernel: rotate the wavefronts' issue priority (s_setprio) over the slots of their SIMD, period 2^persist_fair x 10 ns per level; 0: off
   int persist_finish;  // this launch ends a run: every wavefront that reaches the target finishes its envs' pending
                        // network-compactness update and reports their flags itself (what k_finish2 does in a launch of its own)
   // the row caches of the persistent kernel travel with the state from launch to launch instead of being rebuilt from the

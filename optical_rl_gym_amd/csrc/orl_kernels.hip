@@ -1069,6 +1069,24 @@ __device__ __forceinline__ void persist_row_wave(const DevParams& P, const Persi
 // RW: the two-wavefront form above (128 threads per workgroup)
 // LDS_ 4 / 5: the rows-deferred forms (round 6) — the window of state 3 / 1 without everything the row phase needed; the loop is
 // slot scan + ctrl_d<..., RD> (which changes the slot maps itself and logs events), k_rowstats replays the rest after the launch
+#ifdef ORL_TIMING
+// (diagnostic builds) per wavefront of the last launch: the constant 100 MHz clock at entry, at the first step, behind the last step and
+// at the end of the write-back, HW_ID, XCC_ID — tools/wave_timeline.py reads them through the profile call (mode 2; mode 3: the
+// per-wavefront phase sums, unsummed)
+static __device__ unsigned long long g_wts[16384 * 8];
+#endif
+// Fair issue priority.  A SIMD's arbiter picks the OLDEST ready wavefront first: of the four wavefronts of this kernel that share a
+// SIMD for a whole launch, the one in slot 0 ran 7 % faster than the mean and the one in slot 3 8 % slower (tools/wave_timeline.py,
+// cfg2: 2 227 / 2 325 / 2 443 / 2 599 us for the same 80 steps) — and a launch ends when its slowest wavefront does.  Each wavefront
+// therefore sets its user priority (which the arbiter looks at before the age) to (its slot + the constant 100 MHz clock >> shift)
+// mod 4 at a few points of every step: the four take turns at each level, and they finish together.
+__device__ __forceinline__ void wave_prio_rotate(int slot, int shift) {
+  const int p = (slot + (int)(wall_clock64() >> shift)) & 3;
+  if (p == 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
 template <int ENV, int W, int LDS_, bool PF, bool RW = false>
 __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int target, int* wg_step, u32* n_unfinished) {
   constexpr bool RD = (LDS_ == 4 || LDS_ == 5);
@@ -1132,7 +1150,12 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
   const i64 env = env0 + (threadIdx.x >> 3);
   const int nenv = (int)(P.B - env0 < 8 ? P.B - env0 : 8);
   int step = wg_step[blockIdx.x];
+  const int fair = RW ? 0 : P.persist_fair;  // (the pair form's two wavefronts depend on each other: left to the arbiter)
+  const int wslot = (int)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_ID.WAVE_ID: the wavefront's slot on its SIMD
   sp::Prof prof;
+#ifdef ORL_TIMING
+  unsigned long long wts0 = wall_clock64(), wts1 = 0, wts2 = 0;
+#endif
   // An env whose releases did not fit the item form in the last step of the previous launch (flag in its record; the
   // wavefront left its loop right after that step's row phase): they are released in place, by the wavefront that owns
   // the env, before anything of this launch uses the state.  (A kernel of its own after every launch — round 1, and
@@ -1331,6 +1354,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     M.evl0 = s_ev;
   }
   ORL_PROF_BEGIN();
+#ifdef ORL_TIMING
+  wts1 = wall_clock64();
+#endif
   // (DS: a wavefront that caught up over more steps than a launch can log stops there and counts as unfinished)
   while (step < target && (!DS || step - first_step < P.log_cap)) {
     ORL_SYNC();  // (one wavefront: an ordering point) the previous row phase's writes are done
@@ -1341,6 +1367,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     asm volatile("" : "+v"(env_lo), "+v"(lane_i));
     const i64 env_i = (i64)env_lo;
     const bool valid_i = env_i < P.B;
+    if (fair) wave_prio_rotate(wslot, fair);
     // (ORL_DIAG_*: hook points of the diagnostic builds, orl_diag.h)
     if (SVC) {  // a group whose batch of services is used up draws the next one: as many as the launch has steps left, 8 at most
       const bool need = valid_i && sp::svc_empty(svb);
@@ -1410,6 +1437,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
 #endif
       const int4 av = make_int4(a[0], a[1], a[2], a[3]);
       ORL_PROFA(1);
+      if (fair) wave_prio_rotate(wslot, fair);
       if constexpr (DS) {
         u64* slog_s = P.slog + (size_t)(step - first_step) * ORL_SLOG_WORDS * (size_t)P.log_stride + (size_t)(valid_i ? env_i : 0);
         desc = sp::ctrl_d<ENV, W, CP, MINI, RW, RD>(P, M, O, env_i, valid_i, lane_i, prof, av, desc, s_tab, s_tally, L.tw, &s_deferred[step & 1], &done_i,
@@ -1421,6 +1449,7 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
       }
     }
     ORL_SYNC();  // sink table + item list, clocks, env records
+    if (fair) wave_prio_rotate(wslot, fair);
     if constexpr (RW) {  // the row wavefront takes the items (the slot maps are up to date: ctrl_d applied the masks); this one goes on
       rw_k++;
       rw_signal(rw_sync + 0, rw_k, lane_i);
@@ -1474,6 +1503,9 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     if constexpr (RD) { if (__ballot(valid_i && ecur + 1 + P.rel_limit > P.elog_cap) != 0ull) break; }
   }
   ORL_PROF_END();
+#ifdef ORL_TIMING
+  wts2 = wall_clock64();
+#endif
   if constexpr (RW) {
     rw_wait(rw_sync + 2, rw_k);
     if (SVC && rw_early != 0u) {  // a batch on order: its groups' own are used up (see above); parked below like any other
@@ -1642,6 +1674,14 @@ __device__ __forceinline__ void persist_body(const DevParams& P, int pol, int ta
     wg_step[blockIdx.x] = step;
     if (step < target || left_pending) atomicAdd(n_unfinished, 1u);  // (pending releases: the next launch starts with them)
   }
+#ifdef ORL_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 16384) {
+    __builtin_amdgcn_s_waitcnt(0);
+    g_wts[blockIdx.x * 8 + 0] = wts0; g_wts[blockIdx.x * 8 + 1] = wts1; g_wts[blockIdx.x * 8 + 2] = wts2; g_wts[blockIdx.x * 8 + 3] = wall_clock64();
+    g_wts[blockIdx.x * 8 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+    g_wts[blockIdx.x * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+  }
+#endif
 }
 #undef ORL_SYNC
 #undef ORL_RW_TAKE
@@ -2126,6 +2166,10 @@ extern "C" void orl_spec_launch(const DevParams* VP, unsigned grid, size_t lds, 
 }
 // (diagnostic builds, -DORL_TIMING: the per-phase cycle sums of this library's kernel — tools/pair_prof.py)
 extern "C" int orl_spec_prof(unsigned long long* out48, int reset) {
+#ifdef ORL_TIMING
+  if (reset == 2) return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_wts), 16384 * 8 * 8) == hipSuccess ? 0 : -1;
+  if (reset == 3) return hipMemcpyFromSymbol(out48, HIP_SYMBOL(sp::g_prof), (size_t)ORL_PROF_WAVES * ORL_PROF_SLOTS * 8) == hipSuccess ? 0 : -1;
+#endif
   for (int k = 0; k < ORL_PROF_SLOTS; k++) out48[k] = 0;
 #ifdef ORL_TIMING
   std::vector<unsigned long long> h((size_t)ORL_PROF_WAVES * ORL_PROF_SLOTS);
@@ -2386,6 +2430,8 @@ template <int W> void persist(orl_batch* b, const DevParams& VP0, hipStream_t st
   const int v = ch.form;
   VP.persist_ic = ch.inner;
   VP.persist_evl = ch.evl;
+  VP.persist_fair = 11;  // (20 us per priority level: about one step)
+  if (const char* e = getenv("ORL_PERSIST_FAIR")) { const int f = atoi(e); if (f >= 0 && f <= 30) VP.persist_fair = f; }  // A/B: 0 = the arbiter's oldest-first
   VP.row_cache_key = VP.row_cache ? ((b->cache_epoch << 8) | (v << 4) | ch.inner) : 0;
   if (const char* e = getenv("ORL_ROW_CACHE_KEEP")) { if (atoi(e) == 0) VP.row_cache_key = 0; }  // A/B: rebuild at every launch
   size_t lds_a = persist_tuned_lds(v, ch.lds);
@@ -2533,6 +2579,10 @@ template <int W> void step2(orl_batch* b, int pol) {
 
 // diagnostic builds (-DORL_TIMING): per-phase cycle sums of this unit's persistent kernels; zeros otherwise
 template <int W> int prof_read(unsigned long long* out48, int reset) {
+#ifdef ORL_TIMING
+  if (reset == 2) return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_wts), 16384 * 8 * 8) == hipSuccess ? 0 : -1;
+  if (reset == 3) return hipMemcpyFromSymbol(out48, HIP_SYMBOL(sp::g_prof), (size_t)ORL_PROF_WAVES * ORL_PROF_SLOTS * 8) == hipSuccess ? 0 : -1;
+#endif
   for (int k = 0; k < ORL_PROF_SLOTS; k++) out48[k] = 0;
 #ifdef ORL_TIMING
   std::vector<unsigned long long> h((size_t)ORL_PROF_WAVES * ORL_PROF_SLOTS);
