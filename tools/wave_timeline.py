@@ -74,11 +74,15 @@ print("end                  %s" % q(t[:, 3]))
 print("load  (entry->first) %s" % q(t[:, 1] - t[:, 0]))
 print("loop                 %s" % q(t[:, 2] - t[:, 1]))
 print("store (loop->end)    %s" % q(t[:, 3] - t[:, 2]))
-gen2 = t[:, 0] > np.percentile(t[:, 0], 50) - 1e-9
 first = t[:, 0] < 30.0
+
+
+def ms(a):
+    return (a.mean(), a.std()) if a.size else (0.0, 0.0)
+
+
 print("wavefronts entering in the first 30 us: %d; loop time of those %.1f (sd %.1f), of the others %.1f (sd %.1f)" %
-      (first.sum(), (t[first, 2] - t[first, 1]).mean(), (t[first, 2] - t[first, 1]).std(), (t[~first, 2] - t[~first, 1]).mean(),
-       (t[~first, 2] - t[~first, 1]).std()))
+      ((first.sum(),) + ms(t[first, 2] - t[first, 1]) + ms(t[~first, 2] - t[~first, 1])))
 # how many wavefronts are in their loop at time x
 edges = np.arange(0, t[:, 3].max() + 20, 20.0)
 print("time us: wavefronts loading / in the loop / storing")
@@ -109,6 +113,8 @@ for nm, v in (("wave slot", wave_id), ("simd", simd), ("cu", cu), ("sh", sh), ("
 key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
 for gname, gm in (("first", g1), ("second", ~g1)):
     ks = np.unique(key[gm])
+    if not ks.size:
+        continue
     means = np.array([loop[gm & (key == k)].mean() for k in ks])
     within = np.array([loop[gm & (key == k)].std() for k in ks])
     print("%s generation: %d SIMDs; sd of the SIMD means %.1f, mean sd within a SIMD %.1f" % (gname, ks.size, means.std(), within.mean()))
