@@ -14,7 +14,10 @@ The policy is a small MLP trained with a plain policy-gradient update over the s
 entropy bonus; log-probabilities recomputed with gradients from the stored observations and actions, as PPO does); the point of the
 example is the data path, not the learning algorithm — the SAP-FF heuristic's acceptance on the same traffic is printed beside it.
 
-    python examples/deeprmsa_agent_on_gpu.py [num_envs] [updates] [--eager]
+`--halves`: the envs as TWO batches of num_envs / 2, each with its own stream and its own captured rollout, replayed side by side:
+the step kernel of one half (bound by memory latency, half of the vector ALU idle) overlaps the network's GEMMs of the other.
+
+    python examples/deeprmsa_agent_on_gpu.py [num_envs] [updates] [--eager] [--halves]
 """
 import os
 import sys
@@ -28,6 +31,7 @@ import optical_rl_gym_amd as orl  # noqa: E402
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 EAGER = "--eager" in sys.argv
+HALVES = "--halves" in sys.argv and not EAGER
 B = int(args[0]) if len(args) > 0 else 4096
 UPDATES = int(args[1]) if len(args) > 1 else 60
 T = 32  # steps per rollout
@@ -41,67 +45,89 @@ processed, accepted = ref.totals()
 print("SAP-FF heuristic: %.4f of the requests accepted" % (accepted / processed))
 ref.close()
 
-env = orl.make("DeepRMSA-v0", num_envs=B, seeds=1, **kw)
+# one batch, or two halves with a stream each (env i of the second half is env B/2 + i of the whole: seed 1 + B/2 + i)
+parts = [(0, B)] if not HALVES else [(0, B // 2), (B // 2, B - B // 2)]
+envs = [orl.make("DeepRMSA-v0", num_envs=n, seeds=1 + lo, **kw) for lo, n in parts]
+env = envs[0]
 dev = "cuda:%d" % env.device_id
-obs, rew, done, act = (env.device_tensor(n) for n in ("obs", "reward", "done", "actions"))  # views of the batch's arrays
 n_actions = env.k_paths * env.j + (1 if env.allow_rejection else 0)
 net = torch.nn.Sequential(torch.nn.Linear(env.obs_dim, 128), torch.nn.ELU(), torch.nn.Linear(128, 128), torch.nn.ELU(),
                           torch.nn.Linear(128, n_actions)).to(dev)
 opt = torch.optim.Adam(net.parameters(), lr=3e-4)
-obs_buf = torch.zeros((T, B, env.obs_dim), device=dev)
+obs_buf = torch.zeros((T, B, env.obs_dim), device=dev)  # the rollout of all envs; each part writes its columns
 act_buf = torch.zeros((T, B), dtype=torch.long, device=dev)
 rew_buf = torch.zeros((T, B), device=dev)
-env.reset()
-env.observation()  # the kernels keep `obs` current from here on
-stream = env.torch_stream()
 
 
-def policy_part(t):
-    """observation -> action of step t, stored for the update (no gradients: the update recomputes the log-probabilities)"""
-    with torch.no_grad():
-        x = obs.float()
-        obs_buf[t].copy_(x)
-        logits = net(x)
-        u = torch.rand_like(logits).clamp_(1e-7, 1 - 1e-7)
-        a = (logits - torch.log(-torch.log(u))).argmax(dim=1)  # Gumbel-max = a sample of Categorical(logits)
-        act_buf[t].copy_(a)
-        act[:, 0] = a.int()
+class Part:
+    """one batch of envs: views of its device arrays, its columns of the rollout buffers, its stream and its captured rollout"""
+
+    def __init__(self, e, lo, n):
+        self.env, self.lo, self.hi = e, lo, lo + n
+        self.obs, self.rew, self.done, self.act = (e.device_tensor(k) for k in ("obs", "reward", "done", "actions"))
+        e.reset()
+        e.observation()  # the kernels keep `obs` current from here on
+        self.stream = e.torch_stream()
+        self.graph = None
+
+    def policy_part(self, t):
+        """observation -> action of step t, stored for the update (no gradients: the update recomputes the log-probabilities)"""
+        with torch.no_grad():
+            x = self.obs.float()
+            obs_buf[t, self.lo:self.hi].copy_(x)
+            logits = net(x)
+            u = torch.rand_like(logits).clamp_(1e-7, 1 - 1e-7)
+            a = (logits - torch.log(-torch.log(u))).argmax(dim=1)  # Gumbel-max = a sample of Categorical(logits)
+            act_buf[t, self.lo:self.hi].copy_(a)
+            self.act[:, 0] = a.int()
+
+    def env_part(self, t):
+        self.env.step(None, auto_reset=True, fetch=False)  # one launch; reward / done / obs are rewritten in place
+        rew_buf[t, self.lo:self.hi].copy_(self.rew)
+
+    def rollout(self):
+        for t in range(T):
+            self.policy_part(t)
+            self.env_part(t)
+
+    def capture(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            fn()
+        return g
 
 
-def env_part(t):
-    env.step(None, auto_reset=True, fetch=False)  # one launch; reward / done / obs are rewritten in place
-    rew_buf[t].copy_(rew)
-
-
-def rollout():
-    for t in range(T):
-        policy_part(t)
-        env_part(t)
-
-
-def capture(fn):
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=stream):
-        fn()
-    return g
-
-
-with torch.cuda.stream(stream):  # (libraries' workspaces are set up outside the capture)
-    rollout()
+P = [Part(e, lo, n) for e, (lo, n) in zip(envs, parts)]
+for p in P:
+    with torch.cuda.stream(p.stream):  # (libraries' workspaces are set up outside the capture)
+        p.rollout()
 torch.cuda.synchronize()
-g_roll = None
 if not EAGER:
-    g_roll = capture(rollout)
-    g_net = capture(lambda: [policy_part(t) for t in range(T)])
-    g_env = capture(lambda: [env_part(t) for t in range(T)])
+    for p in P:
+        p.graph = p.capture(p.rollout)
+        p.g_net = p.capture(lambda: [p.policy_part(t) for t in range(T)])
+        p.g_env = p.capture(lambda: [p.env_part(t) for t in range(T)])
+main = torch.cuda.current_stream()
+
+
+def rollouts(which="graph"):
+    """the parts' rollouts side by side, each on its own stream; the caller's stream continues when all are done"""
+    for p in P:
+        p.stream.wait_stream(main)
+        with torch.cuda.stream(p.stream):
+            if EAGER:
+                p.rollout()
+            else:
+                getattr(p, which).replay()
+    for p in P:
+        main.wait_stream(p.stream)
 
 
 def timed(fn, n=5):
     torch.cuda.synchronize()
     t0 = time.time()
-    with torch.cuda.stream(stream):
-        for _ in range(n):
-            fn()
+    for _ in range(n):
+        fn()
     torch.cuda.synchronize()
     return (time.time() - t0) / n
 
@@ -127,25 +153,22 @@ def update():
 torch.cuda.synchronize()
 t0 = time.time()
 steps = 0
-with torch.cuda.stream(stream):  # everything below is queued on the stream the step kernel runs on
-    for u_ in range(UPDATES):
-        if g_roll is not None:
-            g_roll.replay()
-        else:
-            rollout()
-        steps += T * B
-        update()
-        if u_ % 10 == 9 or u_ == UPDATES - 1:
-            mean_r = rew_buf.mean().item()  # (.item() waits) +1 accepted, -1 blocked (deeprmsa_env.py:123-124)
-            print("update %3d: accepted %.4f of the requests of its rollout, %.2f M env-steps/s incl. the network and the update"
-                  % (u_ + 1, 0.5 + 0.5 * mean_r, steps / (time.time() - t0) / 1e6))
+for u_ in range(UPDATES):
+    rollouts()
+    steps += T * B
+    update()
+    if u_ % 10 == 9 or u_ == UPDATES - 1:
+        mean_r = rew_buf.mean().item()  # (.item() waits) +1 accepted, -1 blocked (deeprmsa_env.py:123-124)
+        print("update %3d: accepted %.4f of the requests of its rollout, %.2f M env-steps/s incl. the network and the update"
+              % (u_ + 1, 0.5 + 0.5 * mean_r, steps / (time.time() - t0) / 1e6))
 torch.cuda.synchronize()
-if g_roll is not None:
-    # where a rollout's time goes (graphs of the two halves on their own; the env half steps on whatever actions are in the array)
-    t_roll, t_net, t_env = timed(g_roll.replay), timed(g_net.replay), timed(g_env.replay)
+if not EAGER:
+    # where a rollout's time goes (graphs of the two halves of a step on their own; the env half steps on whatever actions are in the array)
+    t_roll, t_net, t_env = timed(rollouts), timed(lambda: rollouts("g_net")), timed(lambda: rollouts("g_env"))
     t_upd = timed(update, 3)
-    print("rollout of %d steps x %d envs: %.2f ms = %.1f M env-steps/s (network forward + sampling %.2f ms = %.0f %%, env steps %.2f ms = %.0f %%); "
-          "update %.2f ms" % (T, B, 1e3 * t_roll, T * B / t_roll / 1e6, 1e3 * t_net, 100 * t_net / t_roll, 1e3 * t_env, 100 * t_env / t_roll,
+    print("rollout of %d steps x %d envs%s: %.2f ms = %.1f M env-steps/s (network forward + sampling alone %.2f ms, env steps alone %.2f ms); "
+          "update %.2f ms" % (T, B, " as two halves side by side" if HALVES else "", 1e3 * t_roll, T * B / t_roll / 1e6, 1e3 * t_net, 1e3 * t_env,
                               1e3 * t_upd))
-env.check()
-env.close()
+for e in envs:
+    e.check()
+    e.close()
