@@ -483,6 +483,36 @@ def test_short_statistics_log_and_early_exits(workload, batch, monkeypatch):
             chk(k, "item", x, y)
 
 
+@pytest.mark.parametrize("workload,batch", [("cfg2", 16384), ("cfg4", 2048), ("cfg5", 4096)])
+def test_issue_priority_rotation_changes_no_result(workload, batch, monkeypatch):
+    """Round 6: the wavefronts of the persistent kernel rotate their issue priority (`s_setprio` by the constant clock) so that
+    the four wavefronts of a SIMD finish together.  It orders instructions, nothing else: the arbiter's own order (ORL_PERSIST_FAIR=0), the
+    default period and a fast one leave every env in the same state."""
+    import optical_rl_gym_amd as orl
+    from bench import WORKLOADS
+
+    fam, topo, kw, policy = WORKLOADS[workload]
+    kw = dict(kw, episode_length=45)
+    seeds = [5 + 11 * i for i in range(batch)]
+    force_impl(monkeypatch, "persist")
+    out = {}
+    for fair in ("0", "11", "6"):
+        monkeypatch.setenv("ORL_PERSIST_FAIR", fair)
+        env = orl.make(fam, topology=topo, num_envs=batch, seeds=seeds, **kw)
+        env.run(policy, 130)
+        env.run(policy, 57)
+        out[fair] = dict(counters=env.counters().copy(), services=env.services().copy(), active=env.active().copy(), flags=env.flags().copy(),
+                         link=env.link_stats_all().copy(), net=[env.net_stats(i).copy() for i in (0, batch // 2, batch - 1)],
+                         slots=env.slots_packed().copy())
+        env.close()
+    chk = _exact(workload)
+    for fair in ("11", "6"):
+        for key in ("counters", "services", "active", "flags", "link", "slots"):
+            chk(0, "fair=%s %s" % (fair, key), out[fair][key], out["0"][key])
+        for j in range(3):
+            chk(j, "fair=%s net_stats" % fair, out[fair]["net"][j], out["0"]["net"][j])
+
+
 def test_specialised_instantiations_are_used_and_equal_the_generic_kernel(monkeypatch):
     """Any configuration gets the persistent kernel with ITS sizes as compile-time constants: a small library built on first
     use from the flags the main library writes for the batch (orl_batch_spec_flags -> _build.build_spec -> orl_batch_load_spec),
