@@ -1781,6 +1781,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
   const bool valid = env < P.B;
   const int nenv = (int)(P.B - env0 < 8 ? P.B - env0 : 8);
   sp::Prof prof;
+#ifdef ORL_TIMING  // (tools/agent_timeline.py: the wavefront's clocks at entry and end, its cycles in the rebuild scan and in the release loop)
+  const unsigned long long ag_t0 = wall_clock64();
+  ORL_PROF_BEGIN_();
+#endif
   sp::Wmem M = sp::wmem_global(P);
   M.clk = (double*)(orl_lds_raw + L.clk);
   M.clk_env0 = env0;
@@ -1970,6 +1974,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORL_AGE
       obs8_env<W>(P, P.bitmap + env * P.bm_words, rec, env, lane, done_i);
     }
   }
+#ifdef ORL_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 16384) {
+    __builtin_amdgcn_s_waitcnt(0);
+    g_wts[blockIdx.x * 8 + 0] = ag_t0; g_wts[blockIdx.x * 8 + 1] = wall_clock64(); g_wts[blockIdx.x * 8 + 2] = prof.acc[16 + 5];
+    g_wts[blockIdx.x * 8 + 3] = prof.acc[16 + 6] + prof.acc[16 + 7];
+    g_wts[blockIdx.x * 8 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+  }
+#endif
 }
 
 // serial tail, one small workgroup per launch: the envs whose releases of this step did not fit the item form (about
