@@ -1299,6 +1299,18 @@ __device__ __forceinline__ bool service_part(const DevParams& P, EnvG& e, i64 en
 // only when the clock passes t_soon the list is rebuilt from a full scan.  Pushes keep the invariant (g8::ev_push).
 // ---------------------------------------------------------------------------------------------------------------
 // The list is returned in registers: the caller writes it back (when dirty) after everything that still loads.
+// an opaque use of every value of a batch of requests at one point: the requests are all issued before it, one wait covers them
+template <int N> __device__ __forceinline__ void scan_batch_fence(double (&t)[N]) {
+  if constexpr (N == 4) asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+  else if constexpr (N == 6) asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+  else if constexpr (N == 8) asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+  else if constexpr (N == 12) {
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]));
+  } else if constexpr (N == 16) {
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]),
+                 "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]));
+  }
+}
 template <int ENV, int W, bool CP, bool RD>
 // `pre_idx / pre_info`: a release slot of this LANE's list whose info word the caller requested at the start of the step.
 // `extra`: masks this step already put on links (its provision, two-kernel pipeline); `pushed_idx / pushed_info`: the
@@ -1342,8 +1354,16 @@ __device__ __forceinline__ void release_soon(const DevParams& P, EnvG& e, int la
 #pragma unroll
         for (int k = 0; k < ORL_SCAN_BATCH; k++) {
           const int i = base + 8 * k;
-          const double v = e.ev_time[i < hwm ? i : hwm - 1];
-          tt[k] = (i < hwm) ? v : INF;
+          tt[k] = e.ev_time[i < hwm ? i : hwm - 1];
+        }
+        // (all of the batch's requests in flight before the first result is looked at: left to the register allocator, the
+        // 128-VGPR forms came out as load - wait - load - wait, one dependent round trip per release time instead of one per batch —
+        // 44 instead of 6 for an env's ~350 pending releases, the 26 us a rebuilding wavefront of k_agent spent in this scan)
+        scan_batch_fence(tt);
+#pragma unroll
+        for (int k = 0; k < ORL_SCAN_BATCH; k++) {
+          const int i = base + 8 * k;
+          tt[k] = (i < hwm) ? tt[k] : INF;
         }
 #pragma unroll
         for (int k = 0; k < ORL_SCAN_BATCH; k++) {
