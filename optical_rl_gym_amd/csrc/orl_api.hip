@@ -654,6 +654,7 @@ static int batch_create_impl(const orl_env_config* c, const orl_topology* t, int
   HIPCHK_B(hipHostMalloc((void**)&b->h_tail, 32 * sizeof(unsigned int), hipHostMallocPortable));
   HIPCHK_B(hipEventCreate(&b->ev0));
   HIPCHK_B(hipEventCreate(&b->ev1));
+  HIPCHK_B(hipDeviceSynchronize());  // (the null-stream memsets above are not ordered with the batch's non-blocking stream)
   // everything below is ordered on the batch's own stream
   HIPCHK_B(hipMemsetAsync(P.q_def, 0, 2 * (size_t)P.q_def_stride * sizeof(u32), b->stream));
   HIPCHK_B(hipMemsetAsync(P.q_stat, 0, 16 * sizeof(u32), b->stream));
@@ -1211,7 +1212,10 @@ static int ensure_logs(orl_batch* b, int64_t n_steps, int* chunk_io) {
     if (!P.log_n) {
       rc = dalloc(b, &P.log_n, (B + 7) / 8 + 16);
       if (rc) return rc;
-      HIPCHK(hipMemset(P.log_n, 0, ((B + 7) / 8 + 16) * sizeof(int)));
+      // (on the batch's stream: it is non-blocking, so a memset on the null stream is NOT ordered in front of the launch that writes
+      // log_n — the first run of a batch could have its first launch's step counts zeroed behind the kernel and its replay skipped:
+      // seen once in ~5 runs of the three-thread shard test)
+      HIPCHK(hipMemsetAsync(P.log_n, 0, ((B + 7) / 8 + 16) * sizeof(int), b->stream));
     }
     P.log_cap = (int)want;
     P.log_stride = (i64)B;
@@ -1877,7 +1881,7 @@ extern "C" int orl_batch_set_state(orl_batch* b, const void* in) try {
   for (auto& s : state_sections(b)) { HIPCHK(hipMemcpy(s.ptr, o, s.bytes, hipMemcpyHostToDevice)); o += s.bytes; }
   // services the persistent kernel drew ahead and parked when a run was abandoned mid-launch (a HIP error) belong to the
   // generator state that has just been replaced: a snapshot is always taken between runs, where nothing is parked
-  if (b->P.svc_cnt) HIPCHK(hipMemset(b->P.svc_cnt, 0, (size_t)((b->P.B + 7) / 8) * 64 * sizeof(int)));
+  if (b->P.svc_cnt) HIPCHK(hipMemsetAsync(b->P.svc_cnt, 0, (size_t)((b->P.B + 7) / 8) * 64 * sizeof(int), b->stream));
   b->run_abandoned = false;  // (the step counters of an abandoned run are cleared by the next run: wg_dirty stays set)
   slot_maps_change(b);
   if (b->P.obs_dim) launch_obs(b, 0);
