@@ -141,7 +141,13 @@ SPEC_TUNING = ["-mllvm", "-disable-machine-licm", "-DORL_PF_WAVES=4"]
 
 
 def spec_tuning(flags):
-    if "-DORL_SPEC_ENV=3" in flags.split() or "-DORL_PF_WAVES" in flags or os.environ.get("ORL_SPEC_TUNING", "1") == "0":
+    if os.environ.get("ORL_SPEC_TUNING", "1") == "0":
+        return []
+    if "-DORL_SPEC_ENV=3" in flags.split():
+        # RMCSA (168-VGPR form): room for 12 release times per round of the rebuild scan — its envs hold ~1 500 pending releases, 24
+        # rounds of 8 (round 6, once the rounds really were rounds: cfg4 7.3 -> 7.6e8; the 128-VGPR forms gain nothing and spill at 16)
+        return [] if "-DORL_SCAN_BATCH" in flags else ["-DORL_SCAN_BATCH=12"]
+    if "-DORL_PF_WAVES" in flags:
         return []
     # (ORL_SPEC_PF_WAVES: experiments with the soon list back in memory in the 4-wave forms)
     return SPEC_TUNING[:2] + ["-DORL_PF_WAVES=%s" % os.environ.get("ORL_SPEC_PF_WAVES", "4")]
